@@ -1,0 +1,354 @@
+"""
+oracle/ref_cpu.py -- TEST INFRASTRUCTURE ONLY (CPU oracle).
+
+A functional, torch-fp32, CPU restatement of the HS-Pose hybrid-scope feature extractor, written
+from the behaviour of the reference (all paths relative to /root/reference).  It works on a flat
+``state`` dict (reference state_dict key names -> tensors) instead of nn.Modules, so the same
+tensors can be leaf variables for autograd-derived oracle gradients.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file; the
+product path (hs_pose_amd/) never does.
+
+Parity status: PINNED.  oracle/gen_golden.py imports the reference in the build container, checks
+every function here against it (bit-equal for indices, exact/allclose(0) for floats where the op
+sequence is identical) and writes the fixtures under tests/golden/ that
+tests/test_oracle_golden.py re-checks everywhere.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+# ---------------------------------------------------------------------------------------------
+# neighbour search                                                   gcn3d.py:15-36
+# ---------------------------------------------------------------------------------------------
+
+def knn_index(x: Tensor, k: int) -> Tensor:
+    """k nearest rows of ``x`` (B,N,C) to each row, expanded-form fp32 distance, rank 0 dropped.
+
+    Follows gcn3d.py:19-23: ``inner*(-2) + quad[:,None,:] + quad[:,:,None]`` evaluated left to
+    right, ``topk(k+1, smallest)`` then ``[:, :, 1:]``.  Returns int64 (B,N,k), ascending distance.
+    """
+    inner = torch.bmm(x, x.transpose(1, 2))
+    quad = (x ** 2).sum(dim=2)
+    dist = inner * (-2) + quad.unsqueeze(1) + quad.unsqueeze(2)
+    return torch.topk(dist, k + 1, dim=-1, largest=False)[1][:, :, 1:]
+
+
+def knn_dist(x: Tensor) -> Tensor:
+    """The (B,N,N) distance matrix knn_index ranks by (for near-tie diagnostics in tests)."""
+    inner = torch.bmm(x, x.transpose(1, 2))
+    quad = (x ** 2).sum(dim=2)
+    return inner * (-2) + quad.unsqueeze(1) + quad.unsqueeze(2)
+
+
+def nearest_index(target: Tensor, source: Tensor) -> Tensor:
+    """Index (B,Nt,1) of the closest ``source`` row per ``target`` row (gcn3d.py:31-35).
+
+    Note the association differs from knn_index: ``s_norm[j] + t_norm[i] - 2*inner``.
+    """
+    inner = torch.bmm(target, source.transpose(1, 2))
+    s2 = (source ** 2).sum(dim=2)
+    t2 = (target ** 2).sum(dim=2)
+    d = s2.unsqueeze(1) + t2.unsqueeze(2) - 2 * inner
+    return torch.topk(d, 1, dim=-1, largest=False)[1]
+
+
+def gather_rows(t: Tensor, index: Tensor) -> Tensor:
+    """rows of ``t`` (B,Np,D) picked per batch by ``index`` (B,No,n) -> (B,No,n,D)  (gcn3d.py:39-47)."""
+    B, Np, D = t.shape
+    flat = (index + torch.arange(B, device=t.device).view(B, 1, 1) * Np).reshape(-1)
+    return t.reshape(B * Np, D)[flat].view(B, index.shape[1], index.shape[2], D)
+
+
+def neighbor_dirs(xyz: Tensor, index: Tensor) -> Tensor:
+    """unit vectors from each point to its listed neighbours, (B,N,k,3) fp32  (gcn3d.py:49-59)."""
+    rel = gather_rows(xyz, index) - xyz.unsqueeze(2)
+    return F.normalize(rel, dim=-1).float()
+
+
+# ---------------------------------------------------------------------------------------------
+# HS layers                                                           gcn3d.py:61-218
+# ---------------------------------------------------------------------------------------------
+
+def _conv1x1(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
+    """nn.Conv1d(kernel_size=1) applied to a (B,N,Cin) tensor the way the reference does it:
+    transpose -> conv1d -> transpose (gcn3d.py:85,112,149,186)."""
+    return F.conv1d(x.transpose(-1, -2), w, b).transpose(-1, -2).contiguous()
+
+
+def orl_global(feature: Tensor, xyz: Tensor, k: int) -> Tensor:
+    """outlier-robust global feature, (B,N,C) constant along N   (gcn3d.py:211-218)."""
+    idx = knn_index(xyz, k)
+    g = gather_rows(feature, idx).max(dim=2)[0]
+    return g.mean(dim=1, keepdim=True).repeat(1, feature.shape[1], 1)
+
+
+def orl_forward(feature: Tensor, xyz: Tensor, k: int, conv2_w: Tensor) -> Tensor:
+    """conv2(cat[feature, f_global]) + feature     (gcn3d.py:109-113, :183-187)."""
+    fg = orl_global(feature, xyz, k)
+    return _conv1x1(torch.cat([feature, fg], dim=-1), conv2_w) + feature
+
+
+def surface_graph_conv(rf: Tensor, directions: Tensor, S: int, K: int) -> Tensor:
+    """gcn3d.py:92-107: relu(rf @ normalize(D, dim=0)) -> max over neighbours -> mean over supports."""
+    B, N, k, _ = rf.shape
+    theta = torch.relu(rf @ F.normalize(directions, dim=0))
+    theta = theta.reshape(B, N, k, S, K).max(dim=2)[0]
+    return theta.mean(dim=2)
+
+
+def surface_layer(p: Dict[str, Tensor], prefix: str, xyz: Tensor, k: int, S: int) -> Tensor:
+    """HSlayer_surface.forward (gcn3d.py:79-90).  Keys: directions, STE_layer.weight, conv2.weight."""
+    D = p[prefix + "directions"]
+    K = D.shape[1] // S
+    ste = _conv1x1(xyz, p[prefix + "STE_layer.weight"])
+    idx = knn_index(xyz, k)                                   # RF-P
+    feat = surface_graph_conv(neighbor_dirs(xyz, idx), D, S, K)
+    feat = orl_forward(feat, xyz, k, p[prefix + "conv2.weight"])
+    return feat + ste
+
+
+def hs_graph_conv(rf: Tensor, idx: Tensor, x: Tensor, weights: Tensor, bias: Tensor,
+                  directions: Tensor, S: int) -> Tensor:
+    """HS_layer.graph_conv (gcn3d.py:158-181)."""
+    B, N, k, _ = rf.shape
+    Cout = directions.shape[1] // S
+    theta = torch.relu(rf @ F.normalize(directions, dim=0))            # (B,N,k,S*Cout)
+    fm = x @ weights + bias                                           # (B,N,(S+1)*Cout)
+    center, support = fm[:, :, :Cout], fm[:, :, Cout:]
+    act = theta * gather_rows(support, idx)
+    act = act.view(B, N, k, S, Cout).max(dim=2)[0].mean(dim=2)
+    return center + act
+
+
+def hs_layer(p: Dict[str, Tensor], prefix: str, xyz: Tensor, x: Tensor, k: int, S: int,
+             return_idx: bool = False):
+    """HS_layer.forward (gcn3d.py:143-156): feature-space KNN (RF-F), directions in xyz space."""
+    ste = _conv1x1(x, p[prefix + "STE_layer.weight"])
+    idx = knn_index(x, k)                                            # RF-F: neighbours in feature space
+    rf = neighbor_dirs(xyz, idx)
+    feat = hs_graph_conv(rf, idx, x, p[prefix + "weights"], p[prefix + "bias"], p[prefix + "directions"], S)
+    feat = orl_forward(feat, xyz, k, p[prefix + "conv2.weight"])
+    out = feat + ste
+    return (out, idx) if return_idx else out
+
+
+def pool_layer(xyz: Tensor, x: Tensor, sample_idx: Tensor, k: int = 4) -> Tuple[Tensor, Tensor]:
+    """Pool_layer.forward (gcn3d.py:226-246) with the randperm draw passed in explicitly
+    (``sample_idx = torch.randperm(N)[:int(N/rate)]``, one draw shared by the whole batch)."""
+    idx = knn_index(xyz, k)
+    pooled = gather_rows(x, idx).max(dim=2)[0]
+    return xyz[:, sample_idx, :], pooled[:, sample_idx, :]
+
+
+def draw_pool_indices(n_points: int, rate: int = 4, levels: int = 2) -> List[Tensor]:
+    """Consume the CPU default generator exactly like FaceRecon's two Pool_layers do
+    (gcn3d.py:242-243 called from FaceRecon.py:91 then :96)."""
+    out, n = [], n_points
+    for _ in range(levels):
+        m = int(n / rate)
+        out.append(torch.randperm(n)[:m])
+        n = m
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# HS stack wiring                                                     FaceRecon.py:70-128
+# ---------------------------------------------------------------------------------------------
+
+def _bn(p, prefix, x, training, momentum=0.1, eps=1e-5):
+    """nn.BatchNorm1d over the channel dim of a (B,N,C) tensor (FaceRecon.py:90: transpose,bn,transpose)."""
+    y = F.batch_norm(x.transpose(1, 2), p.get(prefix + "running_mean"), p.get(prefix + "running_var"),
+                     p[prefix + "weight"], p[prefix + "bias"], training, momentum, eps)
+    return y.transpose(1, 2)
+
+
+def _bn_cn(p, prefix, x, training, momentum=0.1, eps=1e-5):
+    """BatchNorm1d on a (B,C,N) or (B,C) tensor."""
+    return F.batch_norm(x, p.get(prefix + "running_mean"), p.get(prefix + "running_var"),
+                        p[prefix + "weight"], p[prefix + "bias"], training, momentum, eps)
+
+
+def face_recon(p: Dict[str, Tensor], xyz: Tensor, cat_id: Tensor, pool_idx: Sequence[Tensor], *,
+               k: int = 20, S: int = 7, obj_c: int = 6, train_heads: bool = False,
+               bn_training: bool = True, prefix: str = "") -> Dict[str, Tensor]:
+    """FaceRecon.forward (FaceRecon.py:70-128).  ``pool_idx`` = the two randperm slices.
+
+    Returns a dict with feat (B,N,1286) and, when ``train_heads`` (FLAGS.train), recon/face, plus the
+    intermediate feature maps (handy for layer-by-layer parity)."""
+    B, N, _ = xyz.shape
+    one_hot = torch.zeros(B, obj_c, device=xyz.device).scatter_(1, cat_id.view(-1, 1).long(), 1)
+    fm0 = torch.relu(surface_layer(p, prefix + "conv_0.", xyz, k, S))
+    fm1 = torch.relu(_bn(p, prefix + "bn1.", hs_layer(p, prefix + "conv_1.", xyz, fm0, k, S), bn_training))
+    v1, fp1 = pool_layer(xyz, fm1, pool_idx[0])
+    k1 = min(k, v1.shape[1] // 8)
+    fm2 = torch.relu(_bn(p, prefix + "bn2.", hs_layer(p, prefix + "conv_2.", v1, fp1, k1, S), bn_training))
+    fm3 = torch.relu(_bn(p, prefix + "bn3.", hs_layer(p, prefix + "conv_3.", v1, fm2, k1, S), bn_training))
+    v2, fp2 = pool_layer(v1, fm3, pool_idx[1])
+    k2 = min(k, v2.shape[1] // 8)
+    fm4 = hs_layer(p, prefix + "conv_4.", v2, fp2, k2, S)
+    f_global = fm4.max(dim=1)[0]
+    near1 = nearest_index(xyz, v1)
+    near2 = nearest_index(xyz, v2)
+    up2 = gather_rows(fm2, near1).squeeze(2)
+    up3 = gather_rows(fm3, near1).squeeze(2)
+    up4 = gather_rows(fm4, near2).squeeze(2)
+    feat = torch.cat([fm0, fm1, up2, up3, up4, one_hot.unsqueeze(1).repeat(1, N, 1)], dim=2)
+    out = {"feat": feat, "fm0": fm0, "fm1": fm1, "fm2": fm2, "fm3": fm3, "fm4": fm4,
+           "v1": v1, "v2": v2, "near1": near1, "near2": near2, "recon": None, "face": None}
+    if train_heads:
+        x = feat.permute(0, 2, 1)
+        h = _seq_conv_bn_relu(p, prefix + "conv1d_block.", x, 3, bn_training)
+        recon = _seq_conv_bn_relu(p, prefix + "recon_head.", h, 1, bn_training)
+        recon = F.conv1d(recon, p[prefix + "recon_head.3.weight"], p[prefix + "recon_head.3.bias"])
+        face_in = torch.cat([f_global.view(B, -1, 1).repeat(1, 1, N), h, xyz.permute(0, 2, 1)], dim=1)
+        face = _seq_conv_bn_relu(p, prefix + "face_head.", face_in, 3, bn_training)
+        face = F.conv1d(face, p[prefix + "face_head.9.weight"], p[prefix + "face_head.9.bias"])
+        out["recon"], out["face"] = recon.permute(0, 2, 1), face.permute(0, 2, 1)
+    return out
+
+
+def _seq_conv_bn_relu(p, prefix, x, n_blocks, bn_training):
+    """n_blocks x (Conv1d, BatchNorm1d, ReLU) laid out as an nn.Sequential with indices 3i,3i+1,3i+2
+    (FaceRecon.py:38-66)."""
+    for i in range(n_blocks):
+        x = F.conv1d(x, p[f"{prefix}{3 * i}.weight"], p[f"{prefix}{3 * i}.bias"])
+        x = torch.relu(_bn_cn(p, f"{prefix}{3 * i + 1}.", x, bn_training))
+    return x
+
+
+# ---------------------------------------------------------------------------------------------
+# pose heads + PoseNet9D                                    PoseR.py:10-70, PoseTs.py:12-45, PoseNet9D.py:23-52
+# ---------------------------------------------------------------------------------------------
+
+def pose_head(p: Dict[str, Tensor], prefix: str, x: Tensor, bn_training: bool, dropout_p: float = 0.0) -> Tensor:
+    """Rot_green / Rot_red / Pose_Ts trunk: x (B,Cin,N) -> (B,k).  Dropout(0.2) sits before conv4
+    (PoseR.py:33); parity runs use p=0 / eval mode since device RNG cannot match a CPU oracle."""
+    x = torch.relu(_bn_cn(p, prefix + "bn1.", F.conv1d(x, p[prefix + "conv1.weight"], p[prefix + "conv1.bias"]), bn_training))
+    x = torch.relu(_bn_cn(p, prefix + "bn2.", F.conv1d(x, p[prefix + "conv2.weight"], p[prefix + "conv2.bias"]), bn_training))
+    x = x.max(dim=2, keepdim=True)[0]
+    x = torch.relu(_bn_cn(p, prefix + "bn3.", F.conv1d(x, p[prefix + "conv3.weight"], p[prefix + "conv3.bias"]), bn_training))
+    if dropout_p > 0:
+        x = F.dropout(x, dropout_p, training=True)
+    x = F.conv1d(x, p[prefix + "conv4.weight"], p[prefix + "conv4.bias"])
+    return x.squeeze(2).contiguous()
+
+
+def posenet9d(p: Dict[str, Tensor], points: Tensor, obj_id: Tensor, pool_idx: Sequence[Tensor], *,
+              train_heads: bool, bn_training: bool, k: int = 20, S: int = 7, obj_c: int = 6,
+              prefix: str = "") -> Dict[str, Tensor]:
+    """PoseNet9D.forward (PoseNet9D.py:23-52); returns the 10 outputs by name."""
+    B, N, _ = points.shape
+    mean = points.mean(dim=1, keepdim=True)
+    fr = face_recon(p, points - mean, obj_id, pool_idx, k=k, S=S, obj_c=obj_c, train_heads=train_heads,
+                    bn_training=bn_training, prefix=prefix + "face_recon.")
+    feat = fr["feat"]
+    out: Dict[str, Optional[Tensor]] = {"feat": feat, "recon": None, "face_normal": None, "face_dis": None, "face_f": None}
+    if train_heads:
+        face = fr["face"]
+        out["recon"] = fr["recon"] + mean
+        fn = face[:, :, :18].view(B, N, 6, 3)
+        out["face_normal"] = fn / torch.norm(fn, dim=-1, keepdim=True)
+        out["face_dis"] = face[:, :, 18:24]
+        out["face_f"] = torch.sigmoid(face[:, :, 24:])
+    x = feat.permute(0, 2, 1)
+    green = pose_head(p, prefix + "rot_green.", x, bn_training)
+    red = pose_head(p, prefix + "rot_red.", x, bn_training)
+    out["p_green_R"] = green[:, 1:] / (torch.norm(green[:, 1:], dim=1, keepdim=True) + 1e-6)
+    out["p_red_R"] = red[:, 1:] / (torch.norm(red[:, 1:], dim=1, keepdim=True) + 1e-6)
+    out["f_green_R"] = torch.sigmoid(green[:, 0])
+    out["f_red_R"] = torch.sigmoid(red[:, 0])
+    ts_in = torch.cat([feat, points - mean], dim=2).permute(0, 2, 1)
+    ts = pose_head(p, prefix + "ts.", ts_in, bn_training)
+    out["Pred_T"] = ts[:, 0:3] + points.mean(dim=1)
+    out["Pred_s"] = ts[:, 3:6]
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Chamfer + FPS (float side; index rules live in hsp_oracle.c)
+# ---------------------------------------------------------------------------------------------
+
+def chamfer(x1: Tensor, x2: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """ChamferDistanceFunction.forward semantics (chamfer_distance.cpp:59-111): squared distances from
+    differences, first minimum wins.  Differentiable (autograd reproduces the +-2g(p-q) backward of
+    chamfer_distance.cpp:141-175 because min() routes the gradient to the arg-min pair)."""
+    d = ((x1.unsqueeze(2) - x2.unsqueeze(1)) ** 2)
+    d = (d[..., 0] + d[..., 1]) + d[..., 2]
+    dist1, idx1 = d.min(dim=2)
+    dist2, idx2 = d.min(dim=1)
+    return dist1, dist2, idx1, idx2
+
+
+# ---------------------------------------------------------------------------------------------
+# deterministic closed-form parameter fill shared by the golden generator and the tests
+# ---------------------------------------------------------------------------------------------
+
+def hash_unit(n: int, seed: int):
+    """n reproducible pseudo-random numbers in [0,1) with 24 significant bits (exact in fp32):
+    splitmix64 of (index, seed) in wrapping uint64 arithmetic -- no RNG state, no libm, identical on
+    every machine.  Returned as a float64 numpy array."""
+    import numpy as np
+    with np.errstate(over="ignore"):
+        z = np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64((seed * 0xD1B54A32D192ED03 + 0x632BE59BD9B4E019) % (1 << 64))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+
+
+def hash_fill_(t: Tensor, seed: int, scale: float) -> Tensor:
+    """t.flat[i] = (hash_unit(i, seed) - 0.5) * 2 * scale, computed in fp64 and rounded once to fp32."""
+    v = (hash_unit(t.numel(), seed) - 0.5) * (2.0 * scale)
+    with torch.no_grad():
+        t.copy_(torch.from_numpy(v).to(torch.float32).view_as(t))
+    return t
+
+
+def hash_tensor(shape, seed: int, scale: float = 1.0, offset: float = 0.0) -> Tensor:
+    """fresh fp32 tensor filled by hash_fill_ (+ offset)."""
+    t = torch.empty(*shape, dtype=torch.float32)
+    hash_fill_(t, seed, scale)
+    if offset:
+        t += offset
+    return t
+
+
+def fill_state_closed_form(state: Dict[str, Tensor]) -> None:
+    """Fill every tensor of a (reference-shaped) state dict in place: weights by hash_fill_ with a
+    fan-in scale, BN affine near (1, 0), running stats (0, 1).  Key order = sorted(), so the fill is
+    independent of module construction order."""
+    for n, key in enumerate(sorted(state.keys())):
+        t = state[key]
+        if key.endswith("num_batches_tracked"):
+            t.zero_()
+        elif key.endswith("running_mean"):
+            t.zero_()
+        elif key.endswith("running_var"):
+            t.fill_(1.0)
+        elif ".bn" in key or _is_seq_bn(key, state):
+            if key.endswith("weight"):
+                hash_fill_(t, n, 0.25); t.add_(1.0)
+            else:
+                hash_fill_(t, n, 0.1)
+        else:
+            fan = t.shape[1] if t.dim() >= 2 else t.shape[0]
+            if key.endswith("directions"):
+                hash_fill_(t, n, 1.0)
+            elif key.endswith(".weights"):
+                hash_fill_(t, n, 1.0 / math.sqrt(t.shape[0]))
+            else:
+                hash_fill_(t, n, 1.0 / math.sqrt(max(fan, 1)))
+
+
+def _is_seq_bn(key: str, state: Dict[str, Tensor]) -> bool:
+    """BatchNorm layers inside nn.Sequential blocks have numeric names; spot them by their sibling
+    running_mean entry."""
+    stem = key.rsplit(".", 1)[0]
+    return (stem + ".running_mean") in state
