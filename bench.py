@@ -1,0 +1,176 @@
+"""bench.py -- HS-layer stack forward+backward throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of unit U1 over one per-GPU batch of synthetic clouds, all inputs
+already resident in HBM: FaceRecon backbone (5 HS layers, 2 pools, nearest up-sample, concat; train-mode
+BatchNorm, reference init under torch.manual_seed(0)) forward to feat (B,N,1286), then backward from a
+given dfeat to every HS-stack parameter; for N>1 ranks the gradient mean over RCCL is inside the step.
+Workload at N=1: BASELINE.json configs[1] shape, B=16 N=1028 fp32.  Weak scaling: 16 clouds per GPU.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the dominant libhsp kernel of the step: algorithmic bytes per launch / live HIP-event
+                  average duration over the timed region vs the 8 TB/s HBM peak;
+  cpu_baseline -- (rank 0, N=1 only) the CPU oracle restatement (oracle/ref_cpu.py, kind "port") timed on
+                  the host cores on a bounded sample of the same workload.  Reported, never a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+
+
+def make_inputs(B, N, device, seed=0):
+    """SURVEY 8d synthetic inputs: PC = randn*0.05 + [0,0,0.8] (centred like PoseNet9D.py:25 does),
+    obj_id = randint(0,6), dfeat = randn."""
+    g = torch.Generator().manual_seed(seed)
+    pc = torch.randn(B, N, 3, generator=g) * 0.05 + torch.tensor([0.0, 0.0, 0.8])
+    obj = torch.randint(0, 6, (B, 1), generator=g).float()
+    dfeat = torch.randn(B, N, 1286, generator=g)
+    centred = pc - pc.mean(dim=1, keepdim=True)
+    return centred.to(device), obj.to(device), dfeat.to(device)
+
+
+def cpu_baseline(n_points, sample_clouds):
+    """time the CPU oracle (restatement of the reference, oracle/ref_cpu.py) on the host cores:
+    same unit (HS stack fwd + bwd, train-mode BN, reference-shaped params), bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_cpu as oc                                      # checker / baseline only
+    from hs_pose_amd.config import FLAGS
+    from hs_pose_amd.FaceRecon import FaceRecon
+    FLAGS.reset(); FLAGS.train = 0
+    torch.manual_seed(0)
+    sd = FaceRecon().state_dict()
+    p = {k: v.detach().clone() for k, v in sd.items()}
+    for k in p:
+        if p[k].is_floating_point() and "running" not in k:
+            p[k].requires_grad_(True)
+    centred, obj, dfeat = make_inputs(sample_clouds, n_points, torch.device("cpu"))
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(1)
+    t0 = time.perf_counter()
+    feat = oc.face_recon(p, centred, obj, oc.draw_pool_indices(n_points), train_heads=False, bn_training=True)["feat"]
+    feat.backward(dfeat)
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_clouds / dt, 4), "unit": "point-clouds/sec", "cores": cores, "kind": "port",
+            "sample": f"1 fwd+bwd of the HS stack on {sample_clouds} clouds x N={n_points} fp32 "
+                      f"(oracle/ref_cpu.py, torch CPU, {cores} threads), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="clouds per GPU")
+    ap.add_argument("--points", type=int, default=1028)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4, help="clouds in the CPU-baseline sample")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
+    args = ap.parse_args()
+
+    from hs_pose_amd import ops
+    from hs_pose_amd.config import FLAGS
+    from hs_pose_amd.FaceRecon import FaceRecon
+    from hs_pose_amd.parallel import GradReducer, init_distributed
+
+    rank, world, device = init_distributed()
+    assert device.type == "cuda", "bench.py measures the HIP path; it needs a GPU"
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    B, N = args.batch, args.points
+
+    FLAGS.reset(); FLAGS.train = 0                      # U1: backbone only (feat), no train-only heads
+    torch.manual_seed(0)
+    net = FaceRecon().to(device).train()
+    params = [p for p in net.parameters()]
+    reducer = GradReducer(params) if world > 1 else None
+    centred, obj, dfeat = make_inputs(B, N, device, seed=rank)
+    torch.manual_seed(1 + rank)                         # Pool_layer randperm stream (per rank)
+
+    def step():
+        for p in params:
+            p.grad = None
+        _, _, feat = net(centred, obj)
+        feat.backward(dfeat)
+        if reducer is not None:
+            reducer.finish()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    timer = ops.KernelTimer() if rank == 0 else None
+    ops.set_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    ops.set_timer(None)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+
+    if rank == 0:
+        summ = timer.summary()
+        # dominant kernel = the C-ABI call with the largest total time in the timed region
+        (kname, kkey), kd = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
+        achieved = kd["abytes"] / (kd["avg_us"] * 1e-6) / 1e9
+        hsp_ms = sum(d["total_ms"] for d in summ.values()) / args.steps
+        if args.breakdown:
+            for (n_, k_), d in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
+                print(f"{n_:22s} {k_:28s} calls/step {d['calls'] / args.steps:4.1f}  avg {d['avg_us']:9.1f} us  "
+                      f"{d['total_ms'] / args.steps:8.3f} ms/step  alg {d['abytes'] / 1e6:8.2f} MB "
+                      f"-> {d['abytes'] / (d['avg_us'] * 1e-6) / 1e9:8.1f} GB/s", file=sys.stderr)
+            print(f"libhsp kernels {hsp_ms:.3f} ms/step of {1e3 * dt / args.steps:.3f} ms/step", file=sys.stderr)
+        line = {
+            "metric": "point-clouds/sec (N=1028) HS-layer fwd+bwd",
+            "value": round(world * B * args.steps / dt, 2),
+            "unit": "point-clouds/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"HS stack (FaceRecon backbone -> feat) fwd+bwd, B={B}/GPU N={N} fp32, "
+                                   f"train-mode BN, random-init weights (BASELINE configs[1] shape)",
+                       "global_batch": world * B, "points": N, "parallelism": f"dp{world}",
+                       "libhsp_ms_per_step": round(hsp_ms, 4)},
+            "roofline": {"bound": "hbm", "kernel": f"{kname}[{kkey}]", "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "avg_us": round(kd["avg_us"], 2), "algorithmic_bytes_per_launch": kd["abytes"],
+                         "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(N, args.cpu_sample)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,100 @@
+"""Drop-in mirror of the reference's ``network/fs_net_repo/FaceRecon.py`` (HS-layer stack wiring).
+
+Module / parameter names match the reference (conv_0..conv_4, pool_1/2, bn1..3, and -- when
+FLAGS.train -- conv1d_block / recon_head / face_head as nn.Sequential with the same indices), so its
+state_dict loads here with strict=True.  Execution differs: point-major (B,N,C) tensors end to end
+(BatchNorm and the 1x1 convolutions run on the flattened (B*N, C) view: same statistics, no
+transposes), one shared xyz-KNN per resolution, fused graph-conv kernels.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import gcn3d, ops
+from .config import FLAGS
+
+
+def _bn_rows(bn, x):
+    """BatchNorm1d over channels of a (B,N,C) tensor == reference's transpose->bn->transpose (FaceRecon.py:90)."""
+    b, n, c = x.shape
+    return bn(x.reshape(b * n, c)).view(b, n, c)
+
+
+def _conv_bn_relu_rows(seq, x, n_blocks):
+    """Apply n_blocks x (Conv1d k=1, BatchNorm1d, ReLU) of an nn.Sequential to (R, C) rows."""
+    for i in range(n_blocks):
+        conv, bn = seq[3 * i], seq[3 * i + 1]
+        x = torch.relu(bn(F.linear(x, conv.weight.squeeze(-1), conv.bias)))
+    return x
+
+
+class FaceRecon(nn.Module):
+    """reference FaceRecon.py:12-128."""
+
+    def __init__(self):
+        super(FaceRecon, self).__init__()
+        self.neighbor_num = FLAGS.gcn_n_num
+        self.support_num = FLAGS.gcn_sup_num
+
+        self.conv_0 = gcn3d.HSlayer_surface(kernel_num=128, support_num=self.support_num)
+        self.conv_1 = gcn3d.HS_layer(128, 128, support_num=self.support_num)
+        self.pool_1 = gcn3d.Pool_layer(pooling_rate=4, neighbor_num=4)
+        self.conv_2 = gcn3d.HS_layer(128, 256, support_num=self.support_num)
+        self.conv_3 = gcn3d.HS_layer(256, 256, support_num=self.support_num)
+        self.pool_2 = gcn3d.Pool_layer(pooling_rate=4, neighbor_num=4)
+        self.conv_4 = gcn3d.HS_layer(256, 512, support_num=self.support_num)
+
+        self.bn1 = nn.BatchNorm1d(128)
+        self.bn2 = nn.BatchNorm1d(256)
+        self.bn3 = nn.BatchNorm1d(256)
+
+        self.recon_num = 3
+        self.face_recon_num = FLAGS.face_recon_c
+        dim_fuse = sum([128, 128, 256, 256, 512, FLAGS.obj_c])
+
+        if FLAGS.train:
+            def cbr(i, o):
+                return [nn.Conv1d(i, o, 1), nn.BatchNorm1d(o), nn.ReLU(inplace=True)]
+
+            self.conv1d_block = nn.Sequential(*cbr(dim_fuse, 512), *cbr(512, 512), *cbr(512, 256))
+            self.recon_head = nn.Sequential(*cbr(256, 128), nn.Conv1d(128, self.recon_num, 1))
+            self.face_head = nn.Sequential(*cbr(FLAGS.feat_face + 3, 512), *cbr(512, 256), *cbr(256, 128),
+                                           nn.Conv1d(128, self.face_recon_num, 1))
+
+    def forward(self, vertices: "tensor (bs, vetice_num, 3)", cat_id: "tensor (bs, 1)"):
+        """-> (recon (bs,N,3) | None, face (bs,N,face_recon_c) | None, feat (bs,N,1286))"""
+        bs, vertice_num, _ = vertices.size()
+        one_hot = torch.zeros(bs, FLAGS.obj_c, device=vertices.device).scatter_(1, cat_id.view(-1, 1).long(), 1)
+        k = self.neighbor_num
+        with gcn3d.knn_scope():
+            fm_0 = F.relu(self.conv_0(vertices, k), inplace=True)
+            fm_1 = F.relu(_bn_rows(self.bn1, self.conv_1(vertices, fm_0, k)), inplace=True)
+            v_pool_1, fm_pool_1 = self.pool_1(vertices, fm_1)
+            k1 = min(k, v_pool_1.shape[1] // 8)
+            fm_2 = F.relu(_bn_rows(self.bn2, self.conv_2(v_pool_1, fm_pool_1, k1)), inplace=True)
+            fm_3 = F.relu(_bn_rows(self.bn3, self.conv_3(v_pool_1, fm_2, k1)), inplace=True)
+            v_pool_2, fm_pool_2 = self.pool_2(v_pool_1, fm_3)
+            k2 = min(k, v_pool_2.shape[1] // 8)
+            fm_4 = self.conv_4(v_pool_2, fm_pool_2, k2)
+        f_global = fm_4.max(1)[0]
+
+        nearest_pool_1 = ops.nn1(vertices, v_pool_1)
+        nearest_pool_2 = ops.nn1(vertices, v_pool_2)
+        up_2 = ops.gather_rows(fm_2, nearest_pool_1)
+        up_3 = ops.gather_rows(fm_3, nearest_pool_1)
+        up_4 = ops.gather_rows(fm_4, nearest_pool_2)
+        feat = torch.cat([fm_0, fm_1, up_2, up_3, up_4, one_hot.unsqueeze(1).expand(-1, vertice_num, -1)], dim=2)
+
+        if FLAGS.train:
+            rows = feat.reshape(bs * vertice_num, -1)
+            h = _conv_bn_relu_rows(self.conv1d_block, rows, 3)                       # (B*N, 256)
+            r = _conv_bn_relu_rows(self.recon_head, h, 1)
+            last = self.recon_head[3]
+            recon = F.linear(r, last.weight.squeeze(-1), last.bias).view(bs, vertice_num, -1)
+            face_in = torch.cat([f_global.unsqueeze(1).expand(-1, vertice_num, -1).reshape(bs * vertice_num, -1), h,
+                                 vertices.reshape(bs * vertice_num, 3)], dim=1)
+            f = _conv_bn_relu_rows(self.face_head, face_in, 3)
+            last = self.face_head[9]
+            face = F.linear(f, last.weight.squeeze(-1), last.bias).view(bs, vertice_num, -1)
+            return recon, face, feat
+        return None, None, feat

@@ -1,0 +1,56 @@
+"""Drop-in mirror of the reference's ``network/fs_net_repo/PoseR.py`` (rotation heads).
+
+Same parameter names (conv1..4, bn1..3).  The reference feeds (B,C,N) into Conv1d(k=1); here the
+trunk runs point-major as (B*N,C) GEMMs (hipBLASLt through torch), which is the layout the HS stack
+already produces -- ``forward`` still accepts the reference's (B,C,N), ``forward_rows`` takes (B,N,C).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .config import FLAGS
+
+
+class _PointMLPHead(nn.Module):
+    """Conv1d(f,1024)-BN-ReLU, Conv1d(1024,256)-BN-ReLU, max over points, Conv1d(256,256)-BN-ReLU,
+    Dropout(0.2), Conv1d(256,k)   (reference PoseR.py:16-39, PoseTs.py:18-45)."""
+
+    def __init__(self, f, k):
+        super().__init__()
+        self.f = f
+        self.k = k
+        self.conv1 = torch.nn.Conv1d(self.f, 1024, 1)
+        self.conv2 = torch.nn.Conv1d(1024, 256, 1)
+        self.conv3 = torch.nn.Conv1d(256, 256, 1)
+        self.conv4 = torch.nn.Conv1d(256, self.k, 1)
+        self.drop1 = nn.Dropout(0.2)
+        self.bn1 = nn.BatchNorm1d(1024)
+        self.bn2 = nn.BatchNorm1d(256)
+        self.bn3 = nn.BatchNorm1d(256)
+
+    def forward_rows(self, x: "(B, N, f)"):
+        b, n, c = x.shape
+        h = x.reshape(b * n, c)
+        h = F.relu(self.bn1(F.linear(h, self.conv1.weight.squeeze(-1), self.conv1.bias)))
+        h = F.relu(self.bn2(F.linear(h, self.conv2.weight.squeeze(-1), self.conv2.bias)))
+        h = h.view(b, n, -1).max(dim=1)[0]                                       # (B,256)
+        h = F.relu(self.bn3(F.linear(h, self.conv3.weight.squeeze(-1), self.conv3.bias)))
+        h = self.drop1(h)
+        return F.linear(h, self.conv4.weight.squeeze(-1), self.conv4.bias).contiguous()
+
+    def forward(self, x: "(B, f, N)"):
+        return self.forward_rows(x.transpose(1, 2))
+
+
+class Rot_green(_PointMLPHead):
+    """reference PoseR.py:10-39"""
+
+    def __init__(self):
+        super().__init__(FLAGS.feat_c_R, FLAGS.R_c)
+
+
+class Rot_red(_PointMLPHead):
+    """reference PoseR.py:42-70"""
+
+    def __init__(self):
+        super().__init__(FLAGS.feat_c_R, FLAGS.R_c)

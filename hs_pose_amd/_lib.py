@@ -1,0 +1,63 @@
+"""ctypes binding of libhsp.so (include/hsp.h).  Loaded lazily on the first device op; a missing
+library is a hard error -- there is no fallback path."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhsp.so")
+_lib = None
+
+_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol declared in include/hsp.h
+SIGNATURES = {
+    "hsp_version": (_i, []),
+    "hsp_error_string": (ctypes.c_char_p, [_i]),
+    "hsp_last_hip_error": (ctypes.c_char_p, []),
+    "hsp_knn_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "hsp_knn_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "hsp_nn1_f32": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
+    "hsp_rf_surface_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "hsp_rf_bwd_workspace_bytes": (_sz, [_i]),
+    "hsp_rf_surface_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "hsp_rf_conv_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "hsp_rf_conv_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "hsp_gather_max_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "hsp_gather_max_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "hsp_gather_rows_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "hsp_gather_rows_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "hsp_chamfer_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "hsp_chamfer_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "hsp_fps_workspace_bytes": (_sz, [_i, _i]),
+    "hsp_fps_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+}
+
+
+class HspError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded libhsp.so with argtypes set.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HspError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C hs_pose_amd/csrc`). "
+                "hs_pose_amd has no CPU / eager fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        L = lib()
+        msg = L.hsp_error_string(rc).decode()
+        hip = L.hsp_last_hip_error().decode()
+        raise HspError(f"{what} failed: {msg} (code {rc})" + (f" [hip: {hip}]" if hip and rc == -4 else ""))

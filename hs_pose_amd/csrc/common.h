@@ -1,0 +1,60 @@
+// common.h -- shared helpers for the libhsp.so HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <limits.h>
+#include <math.h>
+
+#include "hsp.h"
+
+#define HSP_WAVE 64
+#define HSP_NUM_XCD 8            // MI355X: 8 XCDs, block b is dispatched to XCD b % 8 (speed only)
+#define HSP_NUM_CU 256
+
+namespace hsp {
+
+void set_last_hip_error(hipError_t e);
+
+inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_hip_error(e);
+        return HSP_ERR_LAUNCH;
+    }
+    return HSP_OK;
+}
+
+inline hipStream_t as_stream(hspStream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// persistent grid: a multiple of the XCD count so that block % 8 == XCD for every block
+inline int persistent_blocks(long long work_items, int blocks_per_cu) {
+    long long g = (long long)HSP_NUM_CU * blocks_per_cu;
+    if (work_items < g) g = ((work_items + HSP_NUM_XCD - 1) / HSP_NUM_XCD) * HSP_NUM_XCD;
+    if (g < HSP_NUM_XCD) g = HSP_NUM_XCD;
+    return (int)g;
+}
+
+// exact fp32 helpers that the compiler may not contract into fma
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+
+// |v|^2 of an xyz row in ATen's order for C == 3: (x*x + y*y) + z*z, products rounded separately
+__device__ __forceinline__ float quad3(float x, float y, float z) {
+    return add_rn(add_rn(mul_rn(x, x), mul_rn(y, y)), mul_rn(z, z));
+}
+
+// k-ordered fma chain == torch.bmm (MKL sgemm) for K = 3
+__device__ __forceinline__ float dot3_chain(float ax, float ay, float az, float bx, float by, float bz) {
+    return __fmaf_rn(az, bz, __fmaf_rn(ay, by, mul_rn(ax, bx)));
+}
+
+// unit vector from p to q the way F.normalize does it: v / max(|v|, 1e-12), |v| = sqrt(sum of squares)
+__device__ __forceinline__ float3 unit_dir(float px, float py, float pz, float qx, float qy, float qz) {
+    float dx = sub_rn(qx, px), dy = sub_rn(qy, py), dz = sub_rn(qz, pz);
+    float n2 = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
+    float nrm = fmaxf(__fsqrt_rn(n2), 1e-12f);
+    return make_float3(__fdiv_rn(dx, nrm), __fdiv_rn(dy, nrm), __fdiv_rn(dz, nrm));
+}
+
+}  // namespace hsp

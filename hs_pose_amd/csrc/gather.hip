@@ -1,0 +1,191 @@
+// gather.hip -- neighbourhood max-pool and row gather/scatter kernels for gfx950.
+//
+// gather_max: replaces indexing_neighbor_new(...) + torch.max(dim=2) of the ORL branch and of
+//             Pool_layer (reference network/fs_net_repo/gcn3d.py:214-216, :236-240); with `qsel`
+//             only the rows Pool_layer keeps after its randperm (gcn3d.py:243-245) are computed.
+// gather_rows: replaces the nearest-neighbour up-sampling gathers (FaceRecon.py:102-104) and
+//             vertices[:, sample_idx] (gcn3d.py:244); can write directly into a column slice of
+//             the concatenated feature tensor (FaceRecon.py:107).
+// All are pure HBM/L2 streaming kernels: one lane per float4 of a row, 16-byte accesses.
+#include "common.h"
+
+namespace hsp {
+
+// one thread per (query row, float4 column group); grid-stride
+__global__ __launch_bounds__(256) void gather_max_fwd_kernel(const float* __restrict__ feat,
+                                                             const int32_t* __restrict__ idx,
+                                                             const int32_t* __restrict__ qsel, int B, int Nsrc,
+                                                             int Nidx, int Nq, int k, int kstride, int C,
+                                                             float* __restrict__ out,
+                                                             uint8_t* __restrict__ argmax) {
+    const int cq = C >> 2;
+    const long long total = (long long)B * Nq * cq;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int g = (int)(e % cq);
+        const long long row = e / cq;            // b*Nq + q
+        const int q = (int)(row % Nq);
+        const int b = (int)(row / Nq);
+        const int qi = qsel ? qsel[q] : q;
+        const int32_t* nb = idx + ((size_t)b * Nidx + qi) * kstride;
+        const float* fb = feat + (size_t)b * Nsrc * C + (g << 2);
+        float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll 4
+        for (int n = 0; n < k; ++n) {
+            const float4 f = *reinterpret_cast<const float4*>(fb + (size_t)nb[n] * C);
+            if (f.x > best.x) { best.x = f.x; a0 = n; }
+            if (f.y > best.y) { best.y = f.y; a1 = n; }
+            if (f.z > best.z) { best.z = f.z; a2 = n; }
+            if (f.w > best.w) { best.w = f.w; a3 = n; }
+        }
+        *reinterpret_cast<float4*>(out + row * C + (g << 2)) = best;
+        *reinterpret_cast<uchar4*>(argmax + row * C + (g << 2)) =
+            make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
+    }
+}
+
+// scatter-add of the pooled gradient to the winning source rows (grad_feat pre-zeroed)
+__global__ __launch_bounds__(256) void gather_max_bwd_kernel(const float* __restrict__ gout, int gbcast,
+                                                             const int32_t* __restrict__ idx,
+                                                             const int32_t* __restrict__ qsel,
+                                                             const uint8_t* __restrict__ argmax, int B, int Nsrc,
+                                                             int Nidx, int Nq, int kstride, int C,
+                                                             float* __restrict__ gfeat) {
+    const int cq = C >> 2;
+    const long long total = (long long)B * Nq * cq;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int g = (int)(e % cq);
+        const long long row = e / cq;
+        const int q = (int)(row % Nq);
+        const int b = (int)(row / Nq);
+        const int qi = qsel ? qsel[q] : q;
+        const int32_t* nb = idx + ((size_t)b * Nidx + qi) * kstride;
+        const float4 gv = *reinterpret_cast<const float4*>(gout + (gbcast ? (size_t)b * C : (size_t)row * C) + (g << 2));
+        const uchar4 am = *reinterpret_cast<const uchar4*>(argmax + row * C + (g << 2));
+        float* gb = gfeat + (size_t)b * Nsrc * C + (g << 2);
+        if (gv.x != 0.f) atomicAdd(gb + (size_t)nb[am.x] * C + 0, gv.x);
+        if (gv.y != 0.f) atomicAdd(gb + (size_t)nb[am.y] * C + 1, gv.y);
+        if (gv.z != 0.f) atomicAdd(gb + (size_t)nb[am.z] * C + 2, gv.z);
+        if (gv.w != 0.f) atomicAdd(gb + (size_t)nb[am.w] * C + 3, gv.w);
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_fwd_kernel(const float* __restrict__ feat,
+                                                              const int32_t* __restrict__ idx, int idx_shared,
+                                                              int B, int Nsrc, int Nq, int C,
+                                                              float* __restrict__ out, int out_stride) {
+    const int cq = C >> 2;
+    const long long total = (long long)B * Nq * cq;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int g = (int)(e % cq);
+        const long long row = e / cq;
+        const int q = (int)(row % Nq);
+        const int b = (int)(row / Nq);
+        const int m = idx_shared ? idx[q] : idx[row];
+        const float4 f = *reinterpret_cast<const float4*>(feat + ((size_t)b * Nsrc + m) * C + (g << 2));
+        float* o = out + (size_t)row * out_stride + (g << 2);
+        o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = f.w;   // out_stride need not be a multiple of 4
+    }
+}
+
+// rows of 3 floats (xyz): scalar variant
+__global__ __launch_bounds__(256) void gather_rows_fwd_scalar_kernel(const float* __restrict__ feat,
+                                                                     const int32_t* __restrict__ idx,
+                                                                     int idx_shared, int B, int Nsrc, int Nq, int C,
+                                                                     float* __restrict__ out, int out_stride) {
+    const long long total = (long long)B * Nq * C;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const long long row = e / C;
+        const int q = (int)(row % Nq);
+        const int b = (int)(row / Nq);
+        const int m = idx_shared ? idx[q] : idx[row];
+        out[(size_t)row * out_stride + c] = feat[((size_t)b * Nsrc + m) * C + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float* __restrict__ gout, int gstride,
+                                                              const int32_t* __restrict__ idx, int idx_shared,
+                                                              int B, int Nsrc, int Nq, int C,
+                                                              float* __restrict__ gfeat) {
+    const long long total = (long long)B * Nq * C;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const long long row = e / C;
+        const int q = (int)(row % Nq);
+        const int b = (int)(row / Nq);
+        const int m = idx_shared ? idx[q] : idx[row];
+        const float g = gout[(size_t)row * gstride + c];
+        if (g != 0.f) atomicAdd(gfeat + ((size_t)b * Nsrc + m) * C + c, g);
+    }
+}
+
+static int stream_grid(long long threads) {
+    long long g = (threads + 255) / 256;
+    const long long cap = (long long)HSP_NUM_CU * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace hsp
+
+using namespace hsp;
+
+extern "C" int hsp_gather_max_fwd(const float* feat, const int32_t* idx, const int32_t* qsel, int B, int Nsrc,
+                                  int Nidx, int Nq, int k, int kstride, int C, float* out, uint8_t* argmax,
+                                  hspStream_t stream) {
+    if (!feat || !idx || !out || !argmax || B <= 0 || Nsrc <= 0 || Nidx <= 0 || Nq <= 0 || k <= 0 || kstride < k || C <= 0)
+        return HSP_ERR_BAD_ARG;
+    if (!qsel && Nq != Nidx) return HSP_ERR_BAD_ARG;
+    if ((C & 3) || k > 255) return HSP_ERR_UNSUPPORTED;
+    const long long total = (long long)B * Nq * (C >> 2);
+    hipLaunchKernelGGL(gather_max_fwd_kernel, dim3(stream_grid(total)), dim3(256), 0, as_stream(stream), feat, idx,
+                       qsel, B, Nsrc, Nidx, Nq, k, kstride, C, out, argmax);
+    return check_launch();
+}
+
+extern "C" int hsp_gather_max_bwd(const float* grad_out, int grad_bcast, const int32_t* idx, const int32_t* qsel,
+                                  const uint8_t* argmax, int B, int Nsrc, int Nidx, int Nq, int kstride, int C,
+                                  float* grad_feat, hspStream_t stream) {
+    if (!grad_out || !idx || !argmax || !grad_feat || B <= 0 || Nsrc <= 0 || Nidx <= 0 || Nq <= 0 || kstride <= 0 || C <= 0)
+        return HSP_ERR_BAD_ARG;
+    if (!qsel && Nq != Nidx) return HSP_ERR_BAD_ARG;
+    if (C & 3) return HSP_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    hipError_t e = hipMemsetAsync(grad_feat, 0, (size_t)B * Nsrc * C * sizeof(float), st);
+    if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
+    const long long total = (long long)B * Nq * (C >> 2);
+    hipLaunchKernelGGL(gather_max_bwd_kernel, dim3(stream_grid(total)), dim3(256), 0, st, grad_out, grad_bcast, idx,
+                       qsel, argmax, B, Nsrc, Nidx, Nq, kstride, C, grad_feat);
+    return check_launch();
+}
+
+extern "C" int hsp_gather_rows_fwd(const float* feat, const int32_t* idx, int idx_shared, int B, int Nsrc, int Nq,
+                                   int C, float* out, int out_stride, hspStream_t stream) {
+    if (!feat || !idx || !out || B <= 0 || Nsrc <= 0 || Nq <= 0 || C <= 0 || out_stride < C) return HSP_ERR_BAD_ARG;
+    hipStream_t st = as_stream(stream);
+    if ((C & 3) == 0) {
+        const long long total = (long long)B * Nq * (C >> 2);
+        hipLaunchKernelGGL(gather_rows_fwd_kernel, dim3(stream_grid(total)), dim3(256), 0, st, feat, idx, idx_shared, B,
+                           Nsrc, Nq, C, out, out_stride);
+    } else {
+        const long long total = (long long)B * Nq * C;
+        hipLaunchKernelGGL(gather_rows_fwd_scalar_kernel, dim3(stream_grid(total)), dim3(256), 0, st, feat, idx,
+                           idx_shared, B, Nsrc, Nq, C, out, out_stride);
+    }
+    return check_launch();
+}
+
+extern "C" int hsp_gather_rows_bwd(const float* grad_out, int grad_stride, const int32_t* idx, int idx_shared, int B,
+                                   int Nsrc, int Nq, int C, float* grad_feat, hspStream_t stream) {
+    if (!grad_out || !idx || !grad_feat || B <= 0 || Nsrc <= 0 || Nq <= 0 || C <= 0 || grad_stride < C)
+        return HSP_ERR_BAD_ARG;
+    hipStream_t st = as_stream(stream);
+    hipError_t e = hipMemsetAsync(grad_feat, 0, (size_t)B * Nsrc * C * sizeof(float), st);
+    if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
+    const long long total = (long long)B * Nq * C;
+    hipLaunchKernelGGL(gather_rows_bwd_kernel, dim3(stream_grid(total)), dim3(256), 0, st, grad_out, grad_stride, idx,
+                       idx_shared, B, Nsrc, Nq, C, grad_feat);
+    return check_launch();
+}

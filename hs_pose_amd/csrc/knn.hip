@@ -1,0 +1,507 @@
+// knn.hip -- brute-force k-nearest-neighbour search for gfx950.
+//
+// Replaces get_neighbor_index / get_nearest_index (reference network/fs_net_repo/gcn3d.py:15-36).
+// The (B,N,N) distance matrix of the reference is never written: distances live in registers
+// (xyz path) or in f32-MFMA accumulators (feature path) and go straight into per-lane sorted lists.
+//
+// Bit-exactness contract (pinned by oracle/hsp_oracle.c against the reference's CPU path):
+//   inner  = k-ordered fp32 fma chain from 0.  v_mfma_f32_32x32x2_f32 IS such a chain, so the
+//            feature-space tiles reproduce torch.bmm bit for bit; the xyz path spells it out.
+//   quad   = ATen row-sum order (quad_kernel below), dist = ((inner*-2)+quad[j])+quad[i]
+//   select = ascending (distance, index); strict '<' keeps the lower index on exact ties.
+#include "common.h"
+
+namespace hsp {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// ------------------------------------------------------------------------------------------------
+// per-lane sorted list of the K1 smallest (distance, index) pairs seen so far
+// ------------------------------------------------------------------------------------------------
+template <int K1>
+struct TopList {
+    float d[K1];
+    int i[K1];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int p = 0; p < K1; ++p) { d[p] = INFINITY; i[p] = INT_MAX; }
+    }
+    // candidates arrive in ascending index order per lane, so strict '<' == lowest index first
+    __device__ __forceinline__ void insert(float v, int idx) {
+        if (v < d[K1 - 1]) {
+#pragma unroll
+            for (int p = K1 - 1; p > 0; --p) {
+                const bool lt_prev = v < d[p - 1];
+                const bool lt_cur = v < d[p];
+                d[p] = lt_prev ? d[p - 1] : (lt_cur ? v : d[p]);
+                i[p] = lt_prev ? i[p - 1] : (lt_cur ? idx : i[p]);
+            }
+            const bool lt0 = v < d[0];
+            d[0] = lt0 ? v : d[0];
+            i[0] = lt0 ? idx : i[0];
+        }
+    }
+    __device__ __forceinline__ void store(int2* dst) const {
+#pragma unroll
+        for (int p = 0; p < K1; ++p) dst[p] = make_int2(__float_as_int(d[p]), i[p]);
+    }
+};
+
+// T-way tournament merge of sorted lists held in LDS.  The T lanes of one query are adjacent
+// lanes of a wave; lane `sub` walks list `my_list`.  Writes ranks [drop, drop+k) of the union.
+template <int K1, int T>
+__device__ __forceinline__ void merge_write(const int2* __restrict__ lists, int my_list, int sub, int k,
+                                            int drop, bool valid, int32_t* __restrict__ out_row) {
+    const int2* mine = lists + (size_t)my_list * K1;
+    int ptr = 0;
+    int2 h = mine[0];
+    float hd = __int_as_float(h.x);
+    int hi = h.y;
+    const int m = k + drop;
+    for (int r = 0; r < m; ++r) {
+        float bd = hd;
+        int bi = hi;
+#pragma unroll
+        for (int s = 1; s < T; s <<= 1) {
+            const float od = __shfl_xor(bd, s, T);
+            const int oi = __shfl_xor(bi, s, T);
+            const bool take = (od < bd) || (od == bd && oi < bi);
+            bd = take ? od : bd;
+            bi = take ? oi : bi;
+        }
+        if (hi == bi) {  // this lane owned the winner: advance its head
+            ++ptr;
+            if (ptr < K1) {
+                h = mine[ptr];
+                hd = __int_as_float(h.x);
+                hi = h.y;
+            } else {
+                hd = INFINITY;
+                hi = INT_MAX;
+            }
+        }
+        if (valid && sub == 0 && r >= drop) out_row[r - drop] = bi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// xyz path (C == 3): the cloud (x,y,z,|p|^2) sits in LDS; T lanes share one query, each scanning
+// every T-th candidate (one broadcast ds_read_b128 per candidate); lists are merged by tournament.
+// grid (ceil(N / (256/T)), B), block 256, dynamic LDS = chunk*16 + 256*K1*8
+// ------------------------------------------------------------------------------------------------
+template <int K1, int T>
+__global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ x, int N, int k, int drop,
+                                                   int32_t* __restrict__ idx, int chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* pts = reinterpret_cast<float4*>(smem);
+    int2* lists = reinterpret_cast<int2*>(smem + (size_t)chunk * sizeof(float4));
+    constexpr int Q = 256 / T;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x * Q + tid / T;
+    const int t = tid % T;
+    const float* xb = x + (size_t)b * N * 3;
+    const bool valid = q < N;
+
+    TopList<K1> top;
+    top.init();
+    float qx = 0.f, qy = 0.f, qz = 0.f, qq = 0.f;
+    if (valid) {
+        qx = xb[q * 3 + 0]; qy = xb[q * 3 + 1]; qz = xb[q * 3 + 2];
+        qq = quad3(qx, qy, qz);
+    }
+    for (int c0 = 0; c0 < N; c0 += chunk) {
+        const int cn = min(chunk, N - c0);
+        __syncthreads();
+        for (int j = tid; j < cn; j += 256) {
+            const float px = xb[(c0 + j) * 3 + 0], py = xb[(c0 + j) * 3 + 1], pz = xb[(c0 + j) * 3 + 2];
+            pts[j] = make_float4(px, py, pz, quad3(px, py, pz));
+        }
+        __syncthreads();
+        if (valid) {
+            for (int j = t; j < cn; j += T) {
+                const float4 c = pts[j];
+                const float inner = dot3_chain(qx, qy, qz, c.x, c.y, c.z);
+                const float d = add_rn(add_rn(mul_rn(inner, -2.0f), c.w), qq);
+                top.insert(d, c0 + j);
+            }
+        }
+    }
+    top.store(lists + (size_t)tid * K1);   // each lane re-reads only its own list: no barrier needed
+    merge_write<K1, T>(lists, tid, t, k, drop, valid, idx + ((size_t)b * N + (valid ? q : 0)) * k);
+}
+
+// ------------------------------------------------------------------------------------------------
+// quad[r] = sum_c x[r][c]^2 in ATen's CPU order (oracle/hsp_oracle.c aten_row_sum): 8-lane vector
+// partials with 4-way ILP, then a sequential horizontal sum.  One thread per row.
+// C < 8 : 4 interleaved scalar partials.  Cascade levels (only reached when C >= 512) included.
+// ------------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void multi_row_sum(const float* __restrict__ row, long long size, float (&out)[4][W]) {
+    // size < 2^20 => level_step == 16
+    int lp = 0;
+    {
+        long long v = 1; int r = 0;
+        while (v < size) { v <<= 1; ++r; }
+        lp = r / 4;
+        if (lp < 4) lp = 4;
+    }
+    const long long level_step = 1ll << lp, level_mask = level_step - 1;
+    float acc[4][4][W];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int l = 0; l < W; ++l) acc[a][k][l] = 0.f;
+    long long i = 0;
+    for (; i + level_step <= size;) {
+        for (long long j = 0; j < level_step; ++j, ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int l = 0; l < W; ++l) {
+                    const float v = row[(i * 4 + k) * W + l];
+                    acc[0][k][l] = add_rn(acc[0][k][l], mul_rn(v, v));
+                }
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int l = 0; l < W; ++l) { acc[j][k][l] = add_rn(acc[j][k][l], acc[j - 1][k][l]); acc[j - 1][k][l] = 0.f; }
+            const long long mask = level_mask << (j * lp);
+            if ((i & mask) != 0) break;
+        }
+    }
+    for (; i < size; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int l = 0; l < W; ++l) {
+                const float v = row[(i * 4 + k) * W + l];
+                acc[0][k][l] = add_rn(acc[0][k][l], mul_rn(v, v));
+            }
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int l = 0; l < W; ++l) acc[0][k][l] = add_rn(acc[0][k][l], acc[j][k][l]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int l = 0; l < W; ++l) out[k][l] = acc[0][k][l];
+}
+
+__global__ __launch_bounds__(256) void quad_kernel(const float* __restrict__ x, long long rows, int C,
+                                                   float* __restrict__ quad) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float* row = x + r * C;
+    if (C < 8) {
+        float ps[4][1];
+        const long long size_ilp = C / 4;
+        multi_row_sum<1>(row, size_ilp, ps);
+        for (long long i = size_ilp * 4; i < C; ++i) ps[0][0] = add_rn(ps[0][0], mul_rn(row[i], row[i]));
+        for (int k = 1; k < 4; ++k) ps[0][0] = add_rn(ps[0][0], ps[k][0]);
+        quad[r] = ps[0][0];
+        return;
+    }
+    constexpr int W = 8;
+    float ps[4][W];
+    const long long vec_size = C / W, size_ilp = vec_size / 4;
+    multi_row_sum<W>(row, size_ilp, ps);
+    for (long long m = size_ilp * 4; m < vec_size; ++m)
+#pragma unroll
+        for (int l = 0; l < W; ++l) { const float v = row[m * W + l]; ps[0][l] = add_rn(ps[0][l], mul_rn(v, v)); }
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+#pragma unroll
+        for (int l = 0; l < W; ++l) ps[0][l] = add_rn(ps[0][l], ps[k][l]);
+    float fin = 0.f;
+    for (long long c = vec_size * W; c < C; ++c) fin = add_rn(fin, mul_rn(row[c], row[c]));
+#pragma unroll
+    for (int l = 0; l < W; ++l) fin = add_rn(fin, ps[0][l]);
+    quad[r] = fin;
+}
+
+// ------------------------------------------------------------------------------------------------
+// feature path (any C that is a multiple of 64, or any even C via zero padding of the last chunk):
+// one block = 32 queries of one cloud, 4 waves; wave w takes candidate tiles w, w+4, ... (32 rows
+// each).  Distances of a 32x32 (candidate x query) tile come from v_mfma_f32_32x32x2_f32 over
+// K-chunks of 64 staged through wave-private LDS (k de-interleaved into even|odd halves so every
+// lane fetches its operands for 4 consecutive MFMA steps with one ds_read_b128).
+//   lane l: query column j = l & 31, half h = l >> 5; acc[r] = inner(query j, candidate row
+//   (r&3) + 8*(r>>2) + 4*h of the tile).
+// Each lane keeps a sorted list for (query j, its half of the rows); the 8 lists per query
+// (4 waves x 2 halves) are merged by tournament at the end.
+// grid (ceil(N/32), B), block 256.
+// ------------------------------------------------------------------------------------------------
+#define KF_CT_STRIDE 68   // candidate chunk row stride in floats (64 + 4: 16B aligned, odd # of 16B slots)
+
+template <int K1>
+__global__ __launch_bounds__(256) void knn_feat_kernel(const float* __restrict__ x,
+                                                       const float* __restrict__ quad, int N, int C, int k,
+                                                       int drop, int32_t* __restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int Cp = (C + 63) & ~63;          // K padded to a multiple of 64 with zeros (adds exact 0s)
+    const int QS = Cp + 4;                  // query row stride (floats)
+    float* qtile = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int col = lane & 31, h = lane >> 5;
+    float* ctile = qtile + 32 * QS + wave * 32 * KF_CT_STRIDE;
+    const int b = blockIdx.y;
+    const int q0 = blockIdx.x * 32;
+    const float* xb = x + (size_t)b * N * C;
+    const float* quadb = quad + (size_t)b * N;
+
+    // ---- stage the 32 query rows, de-interleaved per 64-chunk: [chunk][even 32 | odd 32]
+    const int halfC = Cp >> 1;
+    for (int e = tid; e < 32 * halfC; e += 256) {
+        const int row = e / halfC, pair = e - row * halfC;
+        const int kk = pair * 2;
+        float2 v = make_float2(0.f, 0.f);
+        if (q0 + row < N) {
+            if (kk + 1 < C) v = *reinterpret_cast<const float2*>(xb + (size_t)(q0 + row) * C + kk);
+            else if (kk < C) v.x = xb[(size_t)(q0 + row) * C + kk];
+        }
+        const int chunk = kk >> 6, within = pair & 31;
+        qtile[row * QS + chunk * 64 + within] = v.x;
+        qtile[row * QS + chunk * 64 + 32 + within] = v.y;
+    }
+    __syncthreads();
+
+    const int q = q0 + col;
+    const bool qvalid = q < N;
+    const float qq = qvalid ? quadb[q] : 0.f;
+    TopList<K1> top;
+    top.init();
+
+    const int ntiles = (N + 31) >> 5;
+    const int nchunks = Cp >> 6;
+    // register prefetch of one candidate chunk: 32 rows x 32 float2 = 16 float2 per lane
+    float2 pre[16];
+    auto prefetch = [&](int tile, int chunk) {
+        const int c0 = tile * 32, kc = chunk * 64;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int e = it * 64 + lane;
+            const int row = e >> 5, pair = e & 31;
+            const int kk = kc + pair * 2;
+            float2 v = make_float2(0.f, 0.f);
+            if (c0 + row < N) {
+                if (kk + 1 < C) v = *reinterpret_cast<const float2*>(xb + (size_t)(c0 + row) * C + kk);
+                else if (kk < C) v.x = xb[(size_t)(c0 + row) * C + kk];
+            }
+            pre[it] = v;
+        }
+    };
+
+    int tile = wave, chunk = 0;
+    if (tile < ntiles) prefetch(tile, 0);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    while (tile < ntiles) {
+        // registers -> wave-private LDS chunk (in-order LDS ops of one wave: no barrier required)
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int e = it * 64 + lane;
+            const int row = e >> 5, pair = e & 31;
+            ctile[row * KF_CT_STRIDE + pair] = pre[it].x;
+            ctile[row * KF_CT_STRIDE + 32 + pair] = pre[it].y;
+        }
+        // next (tile, chunk) of this wave
+        int ntile = tile, nchunk = chunk + 1;
+        if (nchunk == nchunks) { nchunk = 0; ntile = tile + 4; }
+        if (ntile < ntiles) prefetch(ntile, nchunk);
+        __builtin_amdgcn_wave_barrier();
+
+        const float* arow = ctile + col * KF_CT_STRIDE + h * 32;
+        const float* brow = qtile + col * QS + chunk * 64 + h * 32;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 a4 = *reinterpret_cast<const float4*>(arow + 4 * g);
+            const float4 b4 = *reinterpret_cast<const float4*>(brow + 4 * g);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        if (chunk == nchunks - 1) {
+            // tile finished: fold the 16 distances of this lane into its list (rows ascend with r)
+            const int c0 = tile * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cand = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (cand < N) {
+                    const float d = add_rn(add_rn(mul_rn(acc[r], -2.0f), quadb[cand]), qq);
+                    top.insert(d, cand);
+                }
+                acc[r] = 0.f;
+            }
+        }
+        tile = ntile;
+        chunk = nchunk;
+    }
+
+    // ---- merge the 8 lists of every query
+    __syncthreads();                                   // tiles are dead: alias the region with the lists
+    int2* lists = reinterpret_cast<int2*>(smem);
+    top.store(lists + (size_t)tid * K1);
+    __syncthreads();
+    const int mq = tid >> 3, ml = tid & 7;             // merge thread -> (query, list)
+    const int src = (ml >> 1) * 64 + (ml & 1) * 32 + mq;
+    const int oq = q0 + mq;
+    const bool ovalid = oq < N;
+    merge_write<K1, 8>(lists, src, ml, k, drop, ovalid, idx + ((size_t)b * N + (ovalid ? oq : 0)) * k);
+}
+
+// ------------------------------------------------------------------------------------------------
+// top-1 nearest source row per target row (C == 3); d = (s2[j] + t2[i]) - 2*inner   (gcn3d.py:34)
+// grid (ceil(Nt/256), B), block 256, dynamic LDS = Ns*16
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nn1_kernel(const float* __restrict__ tgt, int Nt,
+                                                  const float* __restrict__ src, int Ns,
+                                                  int32_t* __restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* pts = reinterpret_cast<float4*>(smem);
+    const int b = blockIdx.y;
+    const float* sb = src + (size_t)b * Ns * 3;
+    for (int j = threadIdx.x; j < Ns; j += 256) {
+        const float px = sb[j * 3], py = sb[j * 3 + 1], pz = sb[j * 3 + 2];
+        pts[j] = make_float4(px, py, pz, quad3(px, py, pz));
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Nt) return;
+    const float* tp = tgt + ((size_t)b * Nt + i) * 3;
+    const float tx = tp[0], ty = tp[1], tz = tp[2];
+    const float t2 = quad3(tx, ty, tz);
+    float best = INFINITY;
+    int bi = 0;
+    for (int j = 0; j < Ns; ++j) {
+        const float4 c = pts[j];
+        const float inner = dot3_chain(tx, ty, tz, c.x, c.y, c.z);
+        const float d = sub_rn(add_rn(c.w, t2), mul_rn(2.0f, inner));
+        if (j == 0 || d < best) { best = d; bi = j; }
+    }
+    idx[(size_t)b * Nt + i] = bi;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int pick_k1(int m) {
+    if (m <= 3) return 3;
+    if (m <= 5) return 5;
+    if (m <= 9) return 9;
+    if (m <= 17) return 17;
+    if (m <= 21) return 21;
+    if (m <= 33) return 33;
+    return 0;
+}
+
+template <int K1, int T>
+static int launch_knn3(const float* x, int B, int N, int k, int drop, int32_t* idx, hipStream_t st) {
+    const int chunk = N < 4096 ? N : 4096;
+    const size_t lds = (size_t)chunk * 16 + (size_t)256 * K1 * 8;
+    auto kern = knn3_kernel<K1, T>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
+    }
+    constexpr int Q = 256 / T;
+    dim3 grid((N + Q - 1) / Q, B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, N, k, drop, idx, chunk);
+    return check_launch();
+}
+
+template <int K1>
+static int launch_knn3_t(const float* x, int B, int N, int k, int drop, int32_t* idx, hipStream_t st) {
+    const long long nq = (long long)B * N;
+    if (nq >= 131072) return launch_knn3<K1, 1>(x, B, N, k, drop, idx, st);
+    if (nq >= 32768) return launch_knn3<K1, 4>(x, B, N, k, drop, idx, st);
+    return launch_knn3<K1, 16>(x, B, N, k, drop, idx, st);
+}
+
+template <int K1>
+static int launch_knn_feat(const float* x, const float* quad, int B, int N, int C, int k, int drop,
+                           int32_t* idx, hipStream_t st) {
+    const int Cp = (C + 63) & ~63;
+    size_t lds = (size_t)(32 * (Cp + 4) + 4 * 32 * KF_CT_STRIDE) * 4;
+    const size_t lds_lists = (size_t)256 * K1 * 8;
+    if (lds_lists > lds) lds = lds_lists;
+    auto kern = knn_feat_kernel<K1>;
+    if (lds > 64 * 1024) {
+        if (lds > 160 * 1024) return HSP_ERR_UNSUPPORTED;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
+    }
+    dim3 grid((N + 31) / 32, B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, quad, N, C, k, drop, idx);
+    return check_launch();
+}
+
+}  // namespace hsp
+
+using namespace hsp;
+
+extern "C" size_t hsp_knn_workspace_bytes(int B, int N, int C, int k) {
+    (void)k;
+    if (C == 3) return 0;
+    return (size_t)B * N * sizeof(float);   // quad
+}
+
+extern "C" int hsp_knn_f32(const float* x, int B, int N, int C, int k, int drop_first, int32_t* idx, void* ws,
+                           size_t ws_bytes, hspStream_t stream) {
+    if (!x || !idx || B <= 0 || N <= 0 || C <= 0 || k <= 0) return HSP_ERR_BAD_ARG;
+    const int drop = drop_first ? 1 : 0;
+    const int m = k + drop;
+    if (m > N || k > HSP_MAX_K) return HSP_ERR_BAD_ARG;
+    const int K1 = pick_k1(m);
+    if (!K1) return HSP_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+#define HSP_K1_SWITCH(CALL)                                  \
+    switch (K1) {                                            \
+        case 3: return CALL(3);                              \
+        case 5: return CALL(5);                              \
+        case 9: return CALL(9);                              \
+        case 17: return CALL(17);                            \
+        case 21: return CALL(21);                            \
+        default: return CALL(33);                            \
+    }
+    if (C == 3) {
+#define CALL3(K) launch_knn3_t<K>(x, B, N, k, drop, idx, st)
+        HSP_K1_SWITCH(CALL3)
+#undef CALL3
+    }
+    if (hsp_knn_workspace_bytes(B, N, C, k) > ws_bytes || !ws) return HSP_ERR_WORKSPACE;
+    float* quad = reinterpret_cast<float*>(ws);
+    const long long rows = (long long)B * N;
+    hipLaunchKernelGGL(quad_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, x, rows, C, quad);
+    int rc = check_launch();
+    if (rc) return rc;
+#define CALLF(K) launch_knn_feat<K>(x, quad, B, N, C, k, drop, idx, st)
+    HSP_K1_SWITCH(CALLF)
+#undef CALLF
+#undef HSP_K1_SWITCH
+}
+
+extern "C" int hsp_nn1_f32(const float* tgt, int Nt, const float* src, int Ns, int B, int32_t* idx,
+                           hspStream_t stream) {
+    if (!tgt || !src || !idx || B <= 0 || Nt <= 0 || Ns <= 0) return HSP_ERR_BAD_ARG;
+    const size_t lds = (size_t)Ns * 16;
+    if (lds > 160 * 1024) return HSP_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nn1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
+    }
+    hipLaunchKernelGGL(nn1_kernel, dim3((Nt + 255) / 256, B), dim3(256), lds, as_stream(stream), tgt, Nt, src, Ns, idx);
+    return check_launch();
+}

@@ -1,0 +1,359 @@
+"""Device ops of the hot path: thin autograd wrappers over the libhsp.so C-ABI (include/hsp.h).
+
+Each function checks device / dtype / contiguity, allocates outputs with torch (PyTorch owns every
+buffer), passes raw device pointers + the current HIP stream through ctypes and raises on a non-zero
+return code.  No CPU fallback: a non-GPU tensor is an error.
+"""
+import ctypes
+
+import torch
+
+from ._lib import HspError, check, lib
+
+_vp = ctypes.c_void_p
+
+
+def _p(t):
+    return _vp(t.data_ptr()) if t is not None else _vp(0)
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise HspError(f"{name}: expected a GPU tensor (hs_pose_amd has no CPU path), got "
+                       f"{getattr(t, 'device', type(t))}")
+    if t.dtype != dtype:
+        raise HspError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+class KernelTimer:
+    """Optional per-call timing of the C-ABI entry points with HIP events recorded on the stream the
+    kernels are launched on (torch's current stream).  bench.py installs one over its timed region to
+    get the live average duration of the dominant kernel for the roofline line; ``abytes`` is the
+    call's ALGORITHMIC byte count (every input read once, every output written once -- DESIGN.md)."""
+
+    def __init__(self, only=None):
+        self.only = set(only) if only else None
+        self.records = []          # (name, key, abytes, ev0, ev1)
+
+    def summary(self):
+        """{(name, key): dict(calls, total_ms, avg_us, abytes)} -- call after torch.cuda.synchronize()."""
+        out = {}
+        for name, key, ab, e0, e1 in self.records:
+            d = out.setdefault((name, key), dict(calls=0, total_ms=0.0, abytes=ab))
+            d["calls"] += 1
+            d["total_ms"] += e0.elapsed_time(e1)
+        for d in out.values():
+            d["avg_us"] = 1e3 * d["total_ms"] / d["calls"]
+        return out
+
+
+_timer = None
+
+
+def set_timer(t):
+    """install (or with None remove) a KernelTimer; returns the previous one."""
+    global _timer
+    prev, _timer = _timer, t
+    return prev
+
+
+def _run(name, args, key="", abytes=0):
+    """call libhsp entry point ``name``; raise on a non-zero return code."""
+    fn = getattr(lib(), name)
+    t = _timer
+    if t is not None and (t.only is None or name in t.only):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        t.records.append((name, key, abytes, e0, e1))
+    else:
+        rc = fn(*args)
+    check(rc, name)
+
+
+# ------------------------------------------------------------------------------------------------
+# neighbour search (no gradient: indices)
+# ------------------------------------------------------------------------------------------------
+
+def knn(x, k, drop_first=True):
+    """int32 (B,N,k) nearest rows of x (B,N,C) per row; semantics of gcn3d.get_neighbor_index."""
+    x = _req(x.detach(), torch.float32, "knn.x")
+    B, N, C = x.shape
+    idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
+    L = lib()
+    wsb = L.hsp_knn_workspace_bytes(B, N, C, k)
+    ws = _ws(wsb, x.device)
+    _run("hsp_knn_f32", (_p(x), B, N, C, k, 1 if drop_first else 0, _p(idx), _p(ws), wsb, _stream()),
+         key=f"B{B}N{N}C{C}k{k}", abytes=B * N * (4 * C + 4 * k + (8 if C != 3 else 0)))
+    return idx
+
+
+def nn1(target, source):
+    """int32 (B,Nt) closest source row per target row; semantics of gcn3d.get_nearest_index."""
+    t = _req(target.detach(), torch.float32, "nn1.target")
+    s = _req(source.detach(), torch.float32, "nn1.source")
+    B, Nt, C = t.shape
+    if C != 3 or s.shape[2] != 3 or s.shape[0] != B:
+        raise HspError("nn1: expects (B,Nt,3) and (B,Ns,3)")
+    idx = torch.empty(B, Nt, dtype=torch.int32, device=t.device)
+    _run("hsp_nn1_f32", (_p(t), Nt, _p(s), s.shape[1], B, _p(idx), _stream()),
+         key=f"B{B}Nt{Nt}Ns{s.shape[1]}", abytes=B * (16 * Nt + 12 * s.shape[1]))
+    return idx
+
+
+# ------------------------------------------------------------------------------------------------
+# receptive-field graph convolution
+# ------------------------------------------------------------------------------------------------
+
+class _RFSurface(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, idx, dirs_n, S):
+        xyz = _req(xyz, torch.float32, "rf_surface.xyz")
+        idx = _req(idx, torch.int32, "rf_surface.idx")
+        dirs_n = _req(dirs_n, torch.float32, "rf_surface.dirs")
+        B, N, k = idx.shape
+        SC = dirs_n.shape[1]
+        K = SC // S
+        out = torch.empty(B, N, K, dtype=torch.float32, device=xyz.device)
+        arg = torch.empty(B, N, SC, dtype=torch.uint8, device=xyz.device)
+        _run("hsp_rf_surface_fwd", (_p(xyz), _p(idx), _p(dirs_n), B, N, k, S, K, _p(out), _p(arg), _stream()),
+             key=f"B{B}N{N}k{k}S{S}C{K}", abytes=B * N * (12 + 4 * k + 4 * K + SC) + 12 * SC)
+        ctx.save_for_backward(xyz, idx, dirs_n, arg)
+        ctx.S = S
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xyz, idx, dirs_n, arg = ctx.saved_tensors
+        g = _req(g, torch.float32, "rf_surface.grad")
+        B, N, k = idx.shape
+        SC = dirs_n.shape[1]
+        gd = torch.empty_like(dirs_n)
+        L = lib()
+        wsb = L.hsp_rf_bwd_workspace_bytes(SC)
+        ws = _ws(wsb, g.device)
+        _run("hsp_rf_surface_bwd", (_p(xyz), _p(idx), _p(dirs_n), _p(arg), _p(g), B, N, k, ctx.S, SC // ctx.S,
+                                    _p(gd), _p(ws), wsb, _stream()),
+             key=f"B{B}N{N}k{k}S{ctx.S}C{SC // ctx.S}", abytes=B * N * (12 + 4 * k + 4 * (SC // ctx.S) + SC) + 24 * SC)
+        return None, None, gd, None
+
+
+class _RFConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, idx, dirs_n, fm, S):
+        xyz = _req(xyz, torch.float32, "rf_conv.xyz")
+        idx = _req(idx, torch.int32, "rf_conv.idx")
+        dirs_n = _req(dirs_n, torch.float32, "rf_conv.dirs")
+        fm = _req(fm, torch.float32, "rf_conv.fm")
+        B, N, k = idx.shape
+        SC = dirs_n.shape[1]
+        C = SC // S
+        if fm.shape[-1] != (S + 1) * C:
+            raise HspError("rf_conv: fm must have (S+1)*C columns")
+        out = torch.empty(B, N, C, dtype=torch.float32, device=xyz.device)
+        arg = torch.empty(B, N, SC, dtype=torch.uint8, device=xyz.device)
+        _run("hsp_rf_conv_fwd", (_p(xyz), _p(idx), _p(dirs_n), _p(fm), B, N, k, S, C, _p(out), _p(arg), _stream()),
+             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 4 * k + 4 * (S + 1) * C + 4 * C + SC) + 12 * SC)
+        ctx.save_for_backward(xyz, idx, dirs_n, fm, arg)
+        ctx.S = S
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xyz, idx, dirs_n, fm, arg = ctx.saved_tensors
+        g = _req(g, torch.float32, "rf_conv.grad")
+        B, N, k = idx.shape
+        SC = dirs_n.shape[1]
+        C = SC // ctx.S
+        gfm = torch.empty_like(fm)
+        gd = torch.empty_like(dirs_n)
+        L = lib()
+        wsb = L.hsp_rf_bwd_workspace_bytes(SC)
+        ws = _ws(wsb, g.device)
+        _run("hsp_rf_conv_bwd", (_p(xyz), _p(idx), _p(dirs_n), _p(fm), _p(arg), _p(g), B, N, k, ctx.S, C, _p(gfm),
+                                 _p(gd), _p(ws), wsb, _stream()),
+             key=f"B{B}N{N}k{k}S{ctx.S}C{C}",
+             abytes=B * N * (12 + 4 * k + 4 * SC + SC + 4 * C + 4 * (ctx.S + 1) * C) + 24 * SC)
+        return None, None, gd, gfm, None
+
+
+def rf_surface(xyz, idx, dirs_n, S):
+    """mean_s max_n relu(R . dirs_n): HSlayer_surface.graph_conv (gcn3d.py:92-107) -> (B,N,K)."""
+    return _RFSurface.apply(xyz, idx, dirs_n, S)
+
+
+def rf_conv(xyz, idx, dirs_n, fm, S):
+    """HS_layer.graph_conv after the fm GEMM (gcn3d.py:166-181) -> (B,N,C)."""
+    return _RFConv.apply(xyz, idx, dirs_n, fm, S)
+
+
+# ------------------------------------------------------------------------------------------------
+# neighbourhood max-pool
+# ------------------------------------------------------------------------------------------------
+
+class _GatherMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, idx, qsel, k):
+        feat = _req(feat, torch.float32, "gather_max.feat")
+        idx = _req(idx, torch.int32, "gather_max.idx")
+        if qsel is not None:
+            qsel = _req(qsel, torch.int32, "gather_max.qsel")
+        B, Nsrc, C = feat.shape
+        Nidx, kstride = idx.shape[1], idx.shape[2]
+        Nq = qsel.numel() if qsel is not None else Nidx
+        out = torch.empty(B, Nq, C, dtype=torch.float32, device=feat.device)
+        arg = torch.empty(B, Nq, C, dtype=torch.uint8, device=feat.device)
+        _run("hsp_gather_max_fwd", (_p(feat), _p(idx), _p(qsel), B, Nsrc, Nidx, Nq, k, kstride, C, _p(out), _p(arg),
+                                    _stream()),
+             key=f"B{B}Ns{Nsrc}Nq{Nq}k{k}C{C}", abytes=B * (4 * Nsrc * C + Nq * (4 * k + 5 * C)))
+        ctx.save_for_backward(idx, qsel, arg)
+        ctx.dims = (B, Nsrc, Nidx, Nq, kstride, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, qsel, arg = ctx.saved_tensors
+        B, Nsrc, Nidx, Nq, kstride, C = ctx.dims
+        g = _req(g, torch.float32, "gather_max.grad")
+        gfeat = torch.empty(B, Nsrc, C, dtype=torch.float32, device=g.device)
+        _run("hsp_gather_max_bwd", (_p(g), 0, _p(idx), _p(qsel), _p(arg), B, Nsrc, Nidx, Nq, kstride, C, _p(gfeat),
+                                    _stream()),
+             key=f"B{B}Ns{Nsrc}Nq{Nq}C{C}", abytes=B * (4 * Nsrc * C + Nq * (4 * kstride + 5 * C)))
+        return gfeat, None, None, None
+
+
+class _OrlGlobal(torch.autograd.Function):
+    """fg[b,c] = mean_i max_n feat[b, idx[b,i,n], c]  (get_ORL_global, gcn3d.py:211-218, before the repeat)."""
+
+    @staticmethod
+    def forward(ctx, feat, idx, k):
+        feat = _req(feat, torch.float32, "orl.feat")
+        idx = _req(idx, torch.int32, "orl.idx")
+        B, N, C = feat.shape
+        kstride = idx.shape[2]
+        G = torch.empty(B, N, C, dtype=torch.float32, device=feat.device)
+        arg = torch.empty(B, N, C, dtype=torch.uint8, device=feat.device)
+        _run("hsp_gather_max_fwd", (_p(feat), _p(idx), _vp(0), B, N, N, N, k, kstride, C, _p(G), _p(arg), _stream()),
+             key=f"B{B}Ns{N}Nq{N}k{k}C{C}", abytes=B * N * (4 * C + 4 * k + 5 * C))
+        ctx.save_for_backward(idx, arg)
+        ctx.dims = (B, N, kstride, C)
+        return G.mean(dim=1)
+
+    @staticmethod
+    def backward(ctx, gfg):
+        idx, arg = ctx.saved_tensors
+        B, N, kstride, C = ctx.dims
+        g = _req(gfg / N, torch.float32, "orl.grad")
+        gfeat = torch.empty(B, N, C, dtype=torch.float32, device=g.device)
+        _run("hsp_gather_max_bwd", (_p(g), 1, _p(idx), _vp(0), _p(arg), B, N, N, N, kstride, C, _p(gfeat), _stream()),
+             key=f"B{B}Ns{N}Nq{N}C{C}bc", abytes=B * N * (4 * C + 4 * kstride + C))
+        return gfeat, None, None
+
+
+def gather_max(feat, idx, k, qsel=None):
+    """max over the first k listed neighbours of each (selected) row -> (B,Nq,C)."""
+    return _GatherMax.apply(feat, idx, qsel, k)
+
+
+def orl_global(feat, idx, k):
+    """(B,C) outlier-robust global feature (mean over points of the neighbourhood max)."""
+    return _OrlGlobal.apply(feat, idx, k)
+
+
+# ------------------------------------------------------------------------------------------------
+# row gather
+# ------------------------------------------------------------------------------------------------
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, idx):
+        feat = _req(feat, torch.float32, "gather_rows.feat")
+        idx = _req(idx, torch.int32, "gather_rows.idx")
+        B, Nsrc, C = feat.shape
+        shared = 1 if idx.dim() == 1 else 0
+        Nq = idx.shape[-1]
+        out = torch.empty(B, Nq, C, dtype=torch.float32, device=feat.device)
+        _run("hsp_gather_rows_fwd", (_p(feat), _p(idx), shared, B, Nsrc, Nq, C, _p(out), C, _stream()),
+             key=f"B{B}Ns{Nsrc}Nq{Nq}C{C}", abytes=B * (4 * Nsrc * C + Nq * (4 + 4 * C)))
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, Nsrc, Nq, C, shared)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        B, Nsrc, Nq, C, shared = ctx.dims
+        g = _req(g, torch.float32, "gather_rows.grad")
+        gfeat = torch.empty(B, Nsrc, C, dtype=torch.float32, device=g.device)
+        _run("hsp_gather_rows_bwd", (_p(g), C, _p(idx), shared, B, Nsrc, Nq, C, _p(gfeat), _stream()),
+             key=f"B{B}Ns{Nsrc}Nq{Nq}C{C}", abytes=B * (4 * Nsrc * C + Nq * (4 + 4 * C)))
+        return gfeat, None
+
+
+def gather_rows(feat, idx):
+    """feat (B,Nsrc,C), idx int32 (B,Nq) or shared (Nq,) -> (B,Nq,C)."""
+    return _GatherRows.apply(feat, idx)
+
+
+# ------------------------------------------------------------------------------------------------
+# Chamfer / FPS
+# ------------------------------------------------------------------------------------------------
+
+class _Chamfer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        xyz1 = _req(xyz1, torch.float32, "chamfer.xyz1")
+        xyz2 = _req(xyz2, torch.float32, "chamfer.xyz2")
+        B, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        d1 = torch.empty(B, n, dtype=torch.float32, device=xyz1.device)
+        d2 = torch.empty(B, m, dtype=torch.float32, device=xyz1.device)
+        i1 = torch.empty(B, n, dtype=torch.int32, device=xyz1.device)
+        i2 = torch.empty(B, m, dtype=torch.int32, device=xyz1.device)
+        _run("hsp_chamfer_fwd", (_p(xyz1), _p(xyz2), B, n, m, _p(d1), _p(d2), _p(i1), _p(i2), _stream()),
+             key=f"B{B}n{n}m{m}", abytes=B * (n + m) * 20)
+        ctx.save_for_backward(xyz1, xyz2, i1, i2)
+        ctx.mark_non_differentiable(i1, i2)
+        return d1, d2, i1, i2
+
+    @staticmethod
+    def backward(ctx, g1, g2, _gi1, _gi2):
+        xyz1, xyz2, i1, i2 = ctx.saved_tensors
+        B, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        g1 = _req(g1 if g1 is not None else torch.zeros(B, n, device=xyz1.device), torch.float32, "chamfer.g1")
+        g2 = _req(g2 if g2 is not None else torch.zeros(B, m, device=xyz1.device), torch.float32, "chamfer.g2")
+        gx1 = torch.empty_like(xyz1)
+        gx2 = torch.empty_like(xyz2)
+        _run("hsp_chamfer_bwd", (_p(xyz1), _p(xyz2), _p(i1), _p(i2), _p(g1), _p(g2), B, n, m, _p(gx1), _p(gx2),
+                                 _stream()), key=f"B{B}n{n}m{m}", abytes=B * (n + m) * 32)
+        return gx1, gx2
+
+
+def chamfer(xyz1, xyz2):
+    """(dist1, dist2, idx1, idx2): squared NN distances both ways + int32 arg-mins."""
+    return _Chamfer.apply(xyz1, xyz2)
+
+
+def fps(xyz, n_samples):
+    """int32 (B,n_samples) farthest-point-sampling indices per cloud (first pick = index 0)."""
+    xyz = _req(xyz.detach(), torch.float32, "fps.xyz")
+    B, N, _ = xyz.shape
+    sel = torch.empty(B, n_samples, dtype=torch.int32, device=xyz.device)
+    L = lib()
+    wsb = L.hsp_fps_workspace_bytes(B, N)
+    ws = _ws(wsb, xyz.device)
+    _run("hsp_fps_f32", (_p(xyz), B, N, n_samples, _p(sel), _p(ws), wsb, _stream()),
+         key=f"B{B}N{N}n{n_samples}", abytes=B * (12 * N + 4 * n_samples))
+    return sel

@@ -1,0 +1,143 @@
+/*
+ * hsp.h -- C-ABI of libhsp.so: the MI355X (gfx950) hybrid-scope point-cloud feature-extractor kernels.
+ *
+ * This is the drop-in boundary for the HS-Pose hot path.  The reference has no
+ * C/FFI boundary for its live path -- the boundary there is the Python module API of
+ * network/fs_net_repo/gcn3d.py -- so every entry point below cites the reference Python function
+ * whose device work it replaces.  The only FFI the reference does have is the pybind module of its
+ * (dead) Chamfer extension, tools/pyTorchChamferDistance/chamfer_distance.cpp:180-185; hsp_chamfer_*
+ * keep that module's argument roles.
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory, row-major contiguous, fp32 / int32 / uint8 as typed;
+ *   - the caller owns every buffer; kernels allocate nothing.  Ops that need scratch take a
+ *     caller-supplied workspace (`ws`, `ws_bytes`) sized by the matching *_workspace_bytes() query;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is stream-ordered
+ *     and re-entrant, safe to capture into a hipGraph;
+ *   - return value: 0 = HSP_OK, negative = error code (see hsp_error_string); nothing throws;
+ *   - index tensors are int32 (the Python mirror widens to int64 at its edge because the reference
+ *     API returns int64, gcn3d.py:22-23);
+ *   - "cloud" = one (N,3) point set of the batch; B clouds are independent in every op.
+ */
+#ifndef HSP_H_
+#define HSP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HSP_OK 0
+#define HSP_ERR_BAD_ARG (-1)      /* null pointer, non-positive size, k out of range ...       */
+#define HSP_ERR_UNSUPPORTED (-2)  /* shape outside what the kernels were built for             */
+#define HSP_ERR_WORKSPACE (-3)    /* ws == NULL or ws_bytes too small                          */
+#define HSP_ERR_LAUNCH (-4)       /* hipLaunch / hipMemsetAsync reported an error              */
+
+#define HSP_MAX_K 32              /* largest neighbour count (k + drop_first <= 33)            */
+
+typedef void *hspStream_t;
+
+int hsp_version(void);
+const char *hsp_error_string(int code);
+/* last HIP error text recorded by a failing launch on this thread ("" if none) */
+const char *hsp_last_hip_error(void);
+
+/* ---- neighbour search ------------------------------------------------------------------------
+ * replaces get_neighbor_index(vertices, k)            network/fs_net_repo/gcn3d.py:15-24
+ * x (B,N,C) -> idx (B,N,k): the k rows nearest to each row under the reference's expanded fp32
+ * distance ((inner*-2)+quad[j])+quad[i], inner = k-ordered fma chain (== torch.bmm on CPU), quad in
+ * ATen's row-sum order; ascending distance, lowest index first on exact ties; with drop_first=1 the
+ * rank-0 entry of the (k+1) nearest is dropped (the reference's [:, :, 1:]), which is NOT "exclude
+ * self".  C==3 runs the LDS-resident xyz kernel, any other C the f32-MFMA distance-tile kernel.
+ */
+size_t hsp_knn_workspace_bytes(int B, int N, int C, int k);
+int hsp_knn_f32(const float *x, int B, int N, int C, int k, int drop_first, int32_t *idx,
+                void *ws, size_t ws_bytes, hspStream_t stream);
+
+/* replaces get_nearest_index(target, source)          network/fs_net_repo/gcn3d.py:27-36
+ * tgt (B,Nt,3), src (B,Ns,3) -> idx (B,Nt): top-1 source row, d = (s2[j]+t2[i]) - 2*inner. */
+int hsp_nn1_f32(const float *tgt, int Nt, const float *src, int Ns, int B, int32_t *idx,
+                hspStream_t stream);
+
+/* ---- receptive-field graph convolution -------------------------------------------------------
+ * replaces HSlayer_surface.graph_conv                 gcn3d.py:92-107   (+ directions of :49-59)
+ * xyz (B,N,3), idx (B,N,k), dirs_n (3, S*K) = column-normalised support directions
+ * out (B,N,K) = mean_s max_n relu(R[b,i,n,:] . dirs_n[:, s*K+c]),  argmax (B,N,S*K) uint8 = winning n.
+ * R = normalize(xyz[idx]-xyz) is recomputed in-kernel, never materialised.
+ */
+int hsp_rf_surface_fwd(const float *xyz, const int32_t *idx, const float *dirs_n, int B, int N, int k,
+                       int S, int K, float *out, uint8_t *argmax, hspStream_t stream);
+/* grad_dirs_n (3,S*K) is OVERWRITTEN with d(loss)/d(dirs_n) (the column-normalisation Jacobian is
+ * applied by the caller).  ws: hsp_rf_bwd_workspace_bytes(S*K). */
+size_t hsp_rf_bwd_workspace_bytes(int SC);
+int hsp_rf_surface_bwd(const float *xyz, const int32_t *idx, const float *dirs_n, const uint8_t *argmax,
+                       const float *grad_out, int B, int N, int k, int S, int K, float *grad_dirs_n,
+                       void *ws, size_t ws_bytes, hspStream_t stream);
+
+/* replaces HS_layer.graph_conv after its fm GEMM      gcn3d.py:158-181  (gather of :39-47 fused)
+ * fm (B,N,(S+1)*C) = feature_map @ weights + bias: columns [0,C) centre, [C+s*C+c] support s.
+ * out (B,N,C) = fm[b,i,c] + mean_s max_n relu(R.dirs_n[:,sC+c]) * fm[b, idx[b,i,n], C+sC+c]
+ * argmax (B,N,S*C) uint8.  The (B,N,k,S*C) tensors of the reference are never formed.
+ */
+int hsp_rf_conv_fwd(const float *xyz, const int32_t *idx, const float *dirs_n, const float *fm, int B,
+                    int N, int k, int S, int C, float *out, uint8_t *argmax, hspStream_t stream);
+/* grad_fm (B,N,(S+1)*C) and grad_dirs_n (3,S*C) are OVERWRITTEN. */
+int hsp_rf_conv_bwd(const float *xyz, const int32_t *idx, const float *dirs_n, const float *fm,
+                    const uint8_t *argmax, const float *grad_out, int B, int N, int k, int S, int C,
+                    float *grad_fm, float *grad_dirs_n, void *ws, size_t ws_bytes, hspStream_t stream);
+
+/* ---- neighbourhood max-pool (ORL global branch, Pool_layer) ----------------------------------
+ * replaces indexing_neighbor_new(...) + max(dim=2)    gcn3d.py:214-216, :236-240
+ * feat (B,Nsrc,C); idx (B,Nidx,kstride) of which the first k columns are used; qsel (Nq) optional
+ * row selector shared by the batch (Pool_layer's randperm slice, gcn3d.py:243-245; NULL = identity,
+ * then Nq must equal Nidx).  out (B,Nq,C) = max_{n<k} feat[b, idx[b, q', n], :], q' = qsel ? qsel[q] : q;
+ * argmax (B,Nq,C) uint8.
+ */
+int hsp_gather_max_fwd(const float *feat, const int32_t *idx, const int32_t *qsel, int B, int Nsrc,
+                       int Nidx, int Nq, int k, int kstride, int C, float *out, uint8_t *argmax,
+                       hspStream_t stream);
+/* grad_feat (B,Nsrc,C) is OVERWRITTEN (zeroed, then scatter-added).  grad_out is (B,Nq,C), or (B,C)
+ * broadcast over q when grad_bcast != 0 (the ORL mean-over-points branch). */
+int hsp_gather_max_bwd(const float *grad_out, int grad_bcast, const int32_t *idx, const int32_t *qsel,
+                       const uint8_t *argmax, int B, int Nsrc, int Nidx, int Nq, int kstride, int C,
+                       float *grad_feat, hspStream_t stream);
+
+/* ---- row gather (nearest up-sample, vertex select) -------------------------------------------
+ * replaces indexing_neighbor_new(t, nearest).squeeze(2)    FaceRecon.py:102-104 ; vertices[:, sample_idx]
+ * feat (B,Nsrc,C); idx (B,Nq) or, when idx_shared != 0, (Nq) shared by the batch.
+ * out rows are written at out + (b*Nq+q)*out_stride (out_stride >= C lets the caller write straight
+ * into a slice of the concatenated feature tensor, FaceRecon.py:107).
+ */
+int hsp_gather_rows_fwd(const float *feat, const int32_t *idx, int idx_shared, int B, int Nsrc, int Nq,
+                        int C, float *out, int out_stride, hspStream_t stream);
+/* grad_feat (B,Nsrc,C) OVERWRITTEN; grad_out rows at grad_out + (b*Nq+q)*grad_stride. */
+int hsp_gather_rows_bwd(const float *grad_out, int grad_stride, const int32_t *idx, int idx_shared, int B,
+                        int Nsrc, int Nq, int C, float *grad_feat, hspStream_t stream);
+
+/* ---- Chamfer distance -------------------------------------------------------------------------
+ * replaces cd.forward_cuda / cd.backward_cuda    tools/pyTorchChamferDistance/chamfer_distance.cpp:27-56
+ * xyz1 (B,n,3), xyz2 (B,m,3) -> dist1 (B,n), dist2 (B,m) squared NN distances, idx1/idx2 int32 arg-min
+ * (first minimum wins, chamfer_distance.cpp:78).  bwd: gx1/gx2 OVERWRITTEN with +-2g(p-q) sums
+ * (chamfer_distance.cpp:141-175).
+ */
+int hsp_chamfer_fwd(const float *xyz1, const float *xyz2, int B, int n, int m, float *dist1, float *dist2,
+                    int32_t *idx1, int32_t *idx2, hspStream_t stream);
+int hsp_chamfer_bwd(const float *xyz1, const float *xyz2, const int32_t *idx1, const int32_t *idx2,
+                    const float *gd1, const float *gd2, int B, int n, int m, float *gx1, float *gx2,
+                    hspStream_t stream);
+
+/* ---- farthest point sampling -----------------------------------------------------------------
+ * replaces farthest_point_sampling(points, n)         tools/eval_utils.py:107-119 (per cloud)
+ * xyz (B,N,3) -> sel (B,n_samples): start at 0, running min of squared fp32 distances, first maximum wins.
+ * ws: hsp_fps_workspace_bytes(B,N).
+ */
+size_t hsp_fps_workspace_bytes(int B, int N);
+int hsp_fps_f32(const float *xyz, int B, int N, int n_samples, int32_t *sel, void *ws, size_t ws_bytes,
+                hspStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSP_H_ */

@@ -266,6 +266,28 @@ save("pool_1028", perm_seed1_a=perm_a.numpy().astype(np.int16), perm_seed1_b=per
 print("[stack]")
 
 
+class KnnRecorder:
+    """records the reference's internal get_neighbor_index results (feature-space calls only) so the
+    GPU stack can be teacher-forced with the very same neighbour sets ("selection
+    discontinuity")."""
+
+    def __init__(self):
+        self.feat_idx = []
+        self._orig = rg.get_neighbor_index
+
+    def __enter__(self):
+        def rec(vertices, neighbor_num):
+            out = self._orig(vertices, neighbor_num)
+            if vertices.shape[-1] != 3:
+                self.feat_idx.append(out.clone())
+            return out
+        rg.get_neighbor_index = rec
+        return self
+
+    def __exit__(self, *a):
+        rg.get_neighbor_index = self._orig
+
+
 def run_stack(train_flag, B, N, seed, name, bn_training, with_grads):
     FLAGS.train = train_flag
     net = RefPoseNet9D()
@@ -278,12 +300,12 @@ def run_stack(train_flag, B, N, seed, name, bn_training, with_grads):
     pts = oc.hash_tensor((B, N, 3), seed, 0.05)
     pts[:, :, 2] += 0.8
     obj = torch.from_numpy((oc.hash_unit(B, seed + 1) * 6).astype(np.int64)).float().view(B, 1)
+    centred = pts - pts.mean(dim=1, keepdim=True)
     torch.manual_seed(1)
-    outs = net(pts, obj)
+    with KnnRecorder() as rec:
+        outs = net(pts, obj)
     names = ["recon", "face_normal", "face_dis", "face_f", "p_green_R", "p_red_R", "f_green_R", "f_red_R", "Pred_T", "Pred_s"]
     outs = dict(zip(names, outs))
-    torch.manual_seed(1)
-    recon_r, face_r, feat_r = net.face_recon(pts - pts.mean(dim=1, keepdim=True), obj)
     # oracle restatement on a copy of the (pre-step) state
     sd0 = fill_module(RefPoseNet9D())
     p = {k_: v.detach().clone() for k_, v in sd0.items()}
@@ -296,7 +318,11 @@ def run_stack(train_flag, B, N, seed, name, bn_training, with_grads):
     for n_ in names[4:]:
         assert torch.equal(o[n_], outs[n_]), (name, n_)
     arrs = {"meta": np.array([train_flag, B, N, seed, int(bn_training)], np.int64),
+            "centred": centred.numpy(),        # bit-exact stack input (the GPU mean may round differently)
             "pool_idx0": pidx[0].numpy().astype(np.int16), "pool_idx1": pidx[1].numpy().astype(np.int16)}
+    assert len(rec.feat_idx) == 4
+    for li, fi in enumerate(rec.feat_idx):
+        arrs[f"featknn{li + 1}"] = fi.numpy().astype(np.int16)
     for n_ in names[4:]:
         arrs["out." + n_] = outs[n_].detach().numpy()
     if train_flag:
@@ -311,7 +337,7 @@ def run_stack(train_flag, B, N, seed, name, bn_training, with_grads):
         # backward of the HS stack alone from a closed-form dfeat (unit U1 of SURVEY 8d)
         net2 = RefPoseNet9D(); fill_module(net2); net2.train(bn_training)
         torch.manual_seed(1)
-        _, _, f2 = net2.face_recon(pts - pts.mean(dim=1, keepdim=True), obj)
+        _, _, f2 = net2.face_recon(centred, obj)
         dfeat = oc.hash_tensor(tuple(f2.shape), seed + 5, 1.0)
         (f2 * dfeat).sum().backward()
         for k_, prm in net2.face_recon.named_parameters():
@@ -332,8 +358,9 @@ def run_stack(train_flag, B, N, seed, name, bn_training, with_grads):
 
 
 keys_eval = run_stack(0, 2, 256, 71, "stack_eval_256", False, False)
-run_stack(0, 2, 1028, 72, "stack_evalflags_trainbn_1028", True, True)
-keys_train = run_stack(1, 2, 256, 73, "stack_train_256", True, True)
+run_stack(0, 2, 1028, 74, "stack_eval_1028", False, False)
+run_stack(0, 4, 1028, 72, "stack_evalflags_trainbn_1028", True, True)     # B >= 4: train-mode BN on (B,256) head rows
+keys_train = run_stack(1, 4, 256, 73, "stack_train_256", True, True)
 with open(os.path.join(GOLD, "state_keys.json"), "w") as f:
     json.dump({"train": keys_train, "eval": keys_eval}, f, indent=0, sort_keys=True)
 assert len(keys_train) == 160 and len(keys_eval) == 107, (len(keys_train), len(keys_eval))

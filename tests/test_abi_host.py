@@ -1,0 +1,110 @@
+"""CPU: the C-ABI library loads and exports every symbol include/hsp.h declares; argument validation
+returns error codes (no compute without a GPU); host-side mirror of the reference surface."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "hsp.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(hsp_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from hs_pose_amd import _lib
+    syms = _header_symbols()
+    assert len(syms) >= 19
+    L = _lib.lib()
+    for s in syms:
+        assert hasattr(L, s), f"libhsp.so lacks {s}"
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes table and include/hsp.h disagree"
+    assert L.hsp_version() >= 100
+    assert L.hsp_error_string(-3) == b"workspace missing or too small"
+
+
+def test_argument_validation_without_gpu():
+    from hs_pose_amd._lib import lib
+    L = lib()
+    null, one = ctypes.c_void_p(0), ctypes.c_void_p(16)
+    assert L.hsp_knn_f32(null, 1, 8, 3, 2, 1, null, null, 0, null) == -1          # null pointers
+    assert L.hsp_knn_f32(one, 1, 8, 3, 8, 1, one, null, 0, null) == -1            # k + 1 > N
+    assert L.hsp_knn_f32(one, 1, 100, 3, 40, 1, one, null, 0, null) == -1         # k > HSP_MAX_K
+    assert L.hsp_knn_f32(one, 1, 100, 64, 4, 1, one, null, 0, null) == -3         # feature path needs workspace
+    assert L.hsp_knn_workspace_bytes(2, 100, 3, 4) == 0
+    assert L.hsp_knn_workspace_bytes(2, 100, 128, 4) == 2 * 100 * 4
+    assert L.hsp_rf_conv_fwd(one, one, one, one, 1, 8, 300, 7, 128, one, one, null) == -2   # k > 255
+    assert L.hsp_rf_conv_fwd(one, one, one, one, 1, 8, 4, 7, 126, one, one, null) == -2     # C % 4
+    assert L.hsp_rf_conv_bwd(one, one, one, one, one, one, 1, 8, 4, 7, 128, one, one, null, 0, null) == -3
+    assert L.hsp_gather_max_fwd(one, one, null, 1, 8, 8, 4, 2, 2, 16, one, one, null) == -1  # Nq != Nidx w/o qsel
+    assert L.hsp_gather_rows_fwd(one, one, 0, 1, 8, 8, 16, one, 8, null) == -1               # out_stride < C
+    assert L.hsp_fps_f32(one, 1, 8, 9, one, one, 1024, null) == -1
+    assert L.hsp_fps_workspace_bytes(2, 100) == 800
+    assert L.hsp_rf_bwd_workspace_bytes(896) > 0
+
+
+def test_state_dict_surface_matches_reference(flags, state_keys):
+    """parameter names / shapes == the reference's (SURVEY 5 'checkpoint': 160 tensors train, 107 eval)."""
+    from hs_pose_amd.PoseNet9D import PoseNet9D
+    flags.train = 1
+    sd = PoseNet9D().state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == state_keys["train"] and len(sd) == 160
+    flags.train = 0
+    sd = PoseNet9D().state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == state_keys["eval"] and len(sd) == 107
+    assert sum(p.numel() for p in PoseNet9D().parameters()) < 9709871
+    flags.train = 1
+    assert sum(p.numel() for p in PoseNet9D().parameters()) == 9709871      # SURVEY 8c known answer
+
+
+def test_layer_constructors_and_init(flags):
+    """ctor signatures and init ranges of gcn3d.py:64-77, :117-141."""
+    import math
+    from hs_pose_amd import gcn3d
+    s = gcn3d.HSlayer_surface(kernel_num=32, support_num=3)
+    assert s.directions.shape == (3, 96) and s.STE_layer.weight.shape == (32, 3, 1) and s.conv2.weight.shape == (32, 64, 1)
+    assert s.directions.abs().max().item() <= 1 / math.sqrt(96) + 1e-7
+    h = gcn3d.HS_layer(in_channel=16, out_channel=32, support_num=3)
+    assert h.weights.shape == (16, 128) and h.bias.shape == (128,) and h.directions.shape == (3, 96)
+    bound = 1 / math.sqrt(32 * 4)
+    for p in (h.weights, h.bias, h.directions):
+        assert p.abs().max().item() <= bound + 1e-7
+    pl = gcn3d.Pool_layer(pooling_rate=4, neighbor_num=4)
+    assert pl.pooling_rate == 4 and pl.neighbor_num == 4 and len(list(pl.parameters())) == 0
+
+
+def test_no_cpu_fallback(flags):
+    """the product path fails loudly off-GPU instead of degrading to eager torch."""
+    from hs_pose_amd import gcn3d, ops
+    from hs_pose_amd._lib import HspError
+    from hs_pose_amd.FaceRecon import FaceRecon
+    with pytest.raises(HspError):
+        gcn3d.get_neighbor_index(torch.zeros(1, 32, 3), 4)
+    with pytest.raises(HspError):
+        ops.gather_rows(torch.zeros(1, 8, 4), torch.zeros(1, 3, dtype=torch.int32))
+    flags.train = 0
+    with pytest.raises(HspError):
+        FaceRecon()(torch.zeros(1, 64, 3), torch.zeros(1, 1))
+
+
+def test_missing_library_is_an_error(monkeypatch, tmp_path):
+    from hs_pose_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.HspError, match="not built"):
+        _lib.lib()
+
+
+def test_product_never_imports_oracle():
+    """hs_pose_amd/ must not reference oracle/ (the oracle is the checker, never the thing shipped)."""
+    pkg = os.path.join(ROOT, "hs_pose_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "ref_cpu" not in txt and "hsp_oracle" not in txt.replace("oracle/hsp_oracle.c", ""), f

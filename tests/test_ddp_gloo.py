@@ -1,0 +1,80 @@
+"""CPU, world_size 2, gloo: the N>1 path -- batch sharding and the bucketed gradient mean -- without any
+device compute (all-reduced grad == mean of per-rank grads)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from hs_pose_amd.parallel import GradReducer, init_distributed, shard_range
+    r, w, dev = init_distributed()
+    assert (r, w) == (rank, world) and dev.type == "cpu"
+    torch.manual_seed(0)                                   # identical replicas
+    model = torch.nn.Sequential(torch.nn.Linear(64, 300), torch.nn.ReLU(), torch.nn.Linear(300, 300),
+                                torch.nn.ReLU(), torch.nn.Linear(300, 8))
+    unused = torch.nn.Parameter(torch.ones(5))             # never receives a gradient
+    params = list(model.parameters()) + [unused]
+    red = GradReducer(params, bucket_bytes=100_000)        # several buckets
+    assert len(red.buckets) >= 3
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(10, 64, generator=g)                   # the GLOBAL batch, split across ranks
+    lo, hi = shard_range(10, rank, world)
+    for step in range(2):                                  # twice: state resets between steps
+        for p in params:
+            p.grad = None
+        model(x[lo:hi]).pow(2).sum().backward()
+        local = [p.grad.clone() for p in model.parameters()]
+        red.finish()
+        gathered = [[torch.zeros_like(t) for _ in range(world)] for t in local]
+        for t, outl in zip(local, gathered):
+            dist.all_gather(outl, t)
+        for p, outl in zip(model.parameters(), gathered):
+            assert torch.allclose(p.grad, sum(outl) / world, rtol=1e-6, atol=1e-7)
+        assert torch.equal(unused.grad, torch.zeros(5))
+    # mean-of-shards == gradient of the summed loss over the global batch / world
+    # (autograd.grad does not accumulate into .grad, so the reducer's hooks stay quiet)
+    full = [g_ / world for g_ in torch.autograd.grad(model(x).pow(2).sum(), list(model.parameters()))]
+    for p in params:
+        p.grad = None
+    model(x[lo:hi]).pow(2).sum().backward()
+    red.finish()
+    for p, f in zip(model.parameters(), full):
+        assert torch.allclose(p.grad, f, rtol=1e-4, atol=1e-5)
+    red.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, "ok"))
+
+
+def test_grad_reducer_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got == [(0, "ok"), (1, "ok")]
+
+
+def test_shard_range_covers_batch():
+    from hs_pose_amd.parallel import shard_range
+    for n in (1, 7, 16, 128, 129):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1

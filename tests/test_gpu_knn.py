@@ -1,0 +1,119 @@
+"""GPU parity: neighbour search through the C-ABI vs the reference's golden indices and the C oracle.
+Bar: bit-exact indices (SURVEY 8c / BASELINE north_star "KNN indices bit-exact")."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+KNN_CASES = ["knn_xyz_1028", "knn_xyz_257", "knn_xyz_64_k8", "knn_xyz_1028_k4", "knn_feat128_1028",
+             "knn_feat128_257", "knn_feat256_257", "knn_feat256_64_k8", "knn_feat16_128_k8", "knn_feat32_16_k2",
+             "knn_relu_feat128_257"]
+
+
+def _case_input(ref, g):
+    meta = g["meta"]
+    shape, seed, k = tuple(int(v) for v in meta[:3]), int(meta[3]), int(meta[4])
+    scale, off = (float(v) for v in g["scale_off"])
+    return ref.hash_tensor(shape, seed, scale, off), k
+
+
+def test_config1_known_answer(dev, ref):
+    """BASELINE.json configs[0]: B=1 N=256 C=3 cloud, KNN-index parity with the reference CPU path."""
+    from hs_pose_amd import gcn3d
+    g = golden("knn_cfg1")
+    x = torch.from_numpy(g["x"]).to(dev)
+    idx = gcn3d.get_neighbor_index(x, 20)
+    assert idx.dtype == torch.int64 and idx.shape == (1, 256, 20)
+    assert idx[0, 0, :5].tolist() == [121, 239, 166, 46, 230]
+    assert np.array_equal(idx.cpu().numpy(), g["idx"].astype(np.int64))
+
+
+@pytest.mark.parametrize("name", KNN_CASES)
+def test_knn_golden_bit_exact(dev, ref, name):
+    from hs_pose_amd import ops
+    g = golden(name)
+    x, k = _case_input(ref, g)
+    if "relu" in name:
+        x = torch.relu(x)
+    idx = ops.knn(x.to(dev), k).cpu().numpy()
+    assert np.array_equal(idx, g["idx"].astype(np.int32)), f"{name}: {(idx != g['idx']).sum()} mismatching entries"
+
+
+def test_knn_ties_value_equal(dev, ref, oc):
+    """uncentred cloud with exact fp32 distance ties: the kernel equals the C oracle (lowest index first)
+    bit for bit, and equals the reference's picks up to permutations inside equal-distance groups."""
+    from hs_pose_amd import ops
+    g = golden("knn_xyz_offset")
+    x, k = _case_input(ref, g)
+    idx = ops.knn(x.to(dev), k).cpu().numpy()
+    assert np.array_equal(idx, oc.knn(x.numpy(), k))
+    d = ref.knn_dist(x)
+    dv_ref = torch.gather(d, 2, torch.from_numpy(g["idx"].astype(np.int64))).numpy()
+    dv_gpu = torch.gather(d, 2, torch.from_numpy(idx.astype(np.int64))).numpy()
+    assert np.array_equal(dv_ref, dv_gpu)
+
+
+@pytest.mark.parametrize("B,N,C,k,drop", [
+    (1, 21, 3, 20, 1),        # N == k+1: every other point is a neighbour
+    (3, 33, 3, 8, 1), (2, 100, 3, 1, 1), (2, 100, 3, 1, 0), (2, 300, 3, 32, 1), (1, 64, 3, 16, 0),
+    (40, 1028, 3, 20, 1),     # B*N >= 32768 -> 4 lanes per query
+    (130, 1028, 3, 4, 1),     # B*N >= 131072 -> 1 lane per query
+    (1, 4100, 3, 20, 1),      # more points than one LDS chunk
+    (2, 40, 8, 4, 1), (2, 70, 100, 8, 1), (1, 33, 64, 2, 1), (2, 130, 192, 20, 0), (1, 500, 128, 32, 1),
+    (1, 31, 6, 3, 1),
+])
+def test_knn_vs_c_oracle(dev, ref, oc, B, N, C, k, drop):
+    from hs_pose_amd import ops
+    x = ref.hash_tensor((B, N, C), 1000 + N + C + k, 0.3)
+    idx = ops.knn(x.to(dev), k, drop_first=bool(drop)).cpu().numpy()
+    want = oc.knn(x.numpy(), k, drop)
+    assert np.array_equal(idx, want), f"{(idx != want).sum()} of {idx.size} differ"
+
+
+def test_knn_duplicate_points(dev, ref, oc):
+    """tiled clouds (the dataset pads short clouds by repetition, SURVEY 7 hard part 2): heavy exact ties;
+    'drop rank 0' is not 'exclude self'.  Kernel == C oracle exactly."""
+    from hs_pose_amd import ops
+    base = ref.hash_tensor((2, 300, 3), 77, 0.1)
+    x = torch.cat([base, base[:, :212]], dim=1).contiguous()      # 512 points, 212 duplicated
+    idx = ops.knn(x.to(dev), 20).cpu().numpy()
+    assert np.array_equal(idx, oc.knn(x.numpy(), 20))
+    xf = torch.relu(ref.hash_tensor((1, 200, 32), 78, 1.0))
+    xf = torch.cat([xf, xf[:, :56]], dim=1).contiguous()
+    idx = ops.knn(xf.to(dev), 8).cpu().numpy()
+    assert np.array_equal(idx, oc.knn(xf.numpy(), 8))
+
+
+@pytest.mark.parametrize("name", ["nn1_1028_257", "nn1_1028_64"])
+def test_nn1_golden(dev, ref, name):
+    from hs_pose_amd import gcn3d
+    g = golden(name)
+    tgt = ref.hash_tensor((2, 1028, 3), 31, 0.1)
+    src = tgt[:, torch.from_numpy(g["perm"].astype(np.int64)), :].contiguous()
+    idx = gcn3d.get_nearest_index(tgt.to(dev), src.to(dev))
+    assert idx.shape == (2, 1028, 1) and idx.dtype == torch.int64
+    assert np.array_equal(idx.squeeze(-1).cpu().numpy(), g["idx"].astype(np.int64))
+
+
+def test_knn_full_size_properties(dev, ref):
+    """BASELINE configs[1] size (B=16, N=1028): size-independent properties instead of a CPU oracle run:
+    ascending distances, no duplicates in a row, k=4 list == prefix of k=20 list, permutation
+    equivariance (renumbering the points renumbers the neighbours)."""
+    from hs_pose_amd import ops
+    x = ref.hash_tensor((16, 1028, 3), 5, 0.05).to(dev)
+    idx = ops.knn(x, 20).long()
+    d = ((x.unsqueeze(2) - torch.gather(x.unsqueeze(1).expand(-1, 1028, -1, -1), 2, idx.unsqueeze(-1).expand(-1, -1, -1, 3))) ** 2).sum(-1)
+    assert (d[:, :, 1:] - d[:, :, :-1] >= -1e-9).all()
+    s = idx.sort(dim=2)[0]
+    assert (s[:, :, 1:] != s[:, :, :-1]).all()
+    assert torch.equal(ops.knn(x, 4).long(), idx[:, :, :4])
+    perm = torch.randperm(1028, generator=torch.Generator().manual_seed(3)).to(dev)
+    inv = torch.empty_like(perm); inv[perm] = torch.arange(1028, device=dev)
+    idx_p = ops.knn(x[:, perm].contiguous(), 20).long()
+    # neighbour sets must agree (order too, barring exact ties whose index order changes with numbering)
+    back = perm[idx_p][:, inv]
+    same = (back.sort(dim=2)[0] == idx.sort(dim=2)[0]).all(dim=2).float().mean().item()
+    assert same > 0.999

@@ -1,0 +1,159 @@
+"""CPU: the oracle (oracle/hsp_oracle.c + oracle/ref_cpu.py) against the reference's golden vectors
+(tests/golden/*.npz, produced by oracle/gen_golden.py from the imported reference)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+KNN_CASES = ["knn_xyz_1028", "knn_xyz_257", "knn_xyz_64_k8", "knn_xyz_1028_k4", "knn_feat128_1028",
+             "knn_feat128_257", "knn_feat256_257", "knn_feat256_64_k8", "knn_feat16_128_k8", "knn_feat32_16_k2",
+             "knn_relu_feat128_257"]
+
+
+def _case_input(ref, g):
+    meta = g["meta"]
+    shape, seed, k = tuple(int(v) for v in meta[:3]), int(meta[3]), int(meta[4])
+    scale, off = (float(v) for v in g["scale_off"])
+    return ref.hash_tensor(shape, seed, scale, off), k
+
+
+def test_config1_known_answer(ref, oc):
+    g = golden("knn_cfg1")
+    x = torch.from_numpy(g["x"])
+    assert ref.knn_index(x, 20)[0, 0, :5].tolist() == [121, 239, 166, 46, 230]
+    assert np.array_equal(ref.knn_index(x, 20).numpy(), g["idx"].astype(np.int64))
+    assert np.array_equal(oc.knn(g["x"], 20), g["idx"].astype(np.int32))
+
+
+@pytest.mark.parametrize("name", KNN_CASES)
+def test_knn_oracles_match_reference(ref, oc, name):
+    g = golden(name)
+    x, k = _case_input(ref, g)
+    if "relu" in name:
+        x = torch.relu(x)
+    want = g["idx"].astype(np.int32)
+    assert np.array_equal(oc.knn(x.numpy(), k), want)                # C oracle: bit-exact indices
+    assert np.array_equal(ref.knn_index(x, k).numpy(), want)         # torch restatement
+
+
+def test_knn_tie_case(ref, oc):
+    """exact ties: torch.topk's order is unspecified, so only the selected distance VALUES are pinned."""
+    g = golden("knn_xyz_offset")
+    x, k = _case_input(ref, g)
+    assert int(g["meta"][5]) == 0
+    d = ref.knn_dist(x)
+    ci = oc.knn(x.numpy(), k)
+    dv_ref = torch.gather(d, 2, torch.from_numpy(g["idx"].astype(np.int64))).numpy()
+    dv_c = torch.gather(d, 2, torch.from_numpy(ci.astype(np.int64))).numpy()
+    assert np.array_equal(dv_ref, dv_c)
+    # lowest index first inside every equal-distance run of the C oracle's rows
+    same = dv_c[:, :, 1:] == dv_c[:, :, :-1]
+    assert (ci[:, :, 1:][same] > ci[:, :, :-1][same]).all()
+
+
+def test_quad_matches_aten_order(ref, oc):
+    for C in (3, 6, 16, 33, 128, 256, 700):
+        x = ref.hash_tensor((50, C), C, 1.0)
+        want = (x ** 2).sum(dim=1).numpy()
+        assert np.array_equal(oc.quad(x.numpy()).view(np.uint32), want.view(np.uint32)), C
+
+
+@pytest.mark.parametrize("name,m", [("nn1_1028_257", 257), ("nn1_1028_64", 64)])
+def test_nearest(ref, oc, name, m):
+    g = golden(name)
+    tgt = ref.hash_tensor((2, 1028, 3), 31, 0.1)
+    src = tgt[:, torch.from_numpy(g["perm"].astype(np.int64)), :].contiguous()
+    assert np.array_equal(oc.nn1(tgt.numpy(), src.numpy()), g["idx"].astype(np.int32))
+    assert np.array_equal(ref.nearest_index(tgt, src).squeeze(-1).numpy(), g["idx"].astype(np.int64))
+
+
+def _fill(ref, keys_shapes):
+    sd = {k: torch.empty(*shape) if shape else torch.zeros((), dtype=torch.long) for k, shape in keys_shapes.items()}
+    for k in sd:
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros((), dtype=torch.long)
+    ref.fill_state_closed_form(sd)
+    return sd
+
+
+def test_surface_and_hs_layers(ref):
+    g = golden("surface_small")
+    K, S, N, k, B, seed = (int(v) for v in g["meta"])
+    sd = _fill(ref, {"directions": (3, S * K), "STE_layer.weight": (K, 3, 1), "conv2.weight": (K, 2 * K, 1)})
+    p = {k_: v.requires_grad_(True) for k_, v in sd.items()}
+    xyz = ref.hash_tensor((B, N, 3), seed, 0.1)
+    up = ref.hash_tensor((B, N, K), seed + 1, 1.0)
+    out = ref.surface_layer(p, "", xyz, k, S)
+    assert np.array_equal(out.detach().numpy(), g["out"])
+    (out * up).sum().backward()
+    for k_ in p:
+        assert np.allclose(p[k_].grad.numpy(), g["grad." + k_], rtol=1e-5, atol=1e-5 * np.abs(g["grad." + k_]).max())
+
+    g = golden("hs_small")
+    Cin, Cout, S, N, k, B, seed = (int(v) for v in g["meta"])
+    sd = _fill(ref, {"weights": (Cin, (S + 1) * Cout), "bias": ((S + 1) * Cout,), "directions": (3, S * Cout),
+                     "STE_layer.weight": (Cout, Cin, 1), "conv2.weight": (Cout, 2 * Cout, 1)})
+    p = {k_: v.requires_grad_(True) for k_, v in sd.items()}
+    xyz = ref.hash_tensor((B, N, 3), seed, 0.1)
+    fmap = torch.relu(ref.hash_tensor((B, N, Cin), seed + 2, 1.0)).requires_grad_(True)
+    up = ref.hash_tensor((B, N, Cout), seed + 1, 1.0)
+    out, idx = ref.hs_layer(p, "", xyz, fmap, k, S, return_idx=True)
+    assert np.array_equal(idx.numpy(), g["knn_idx"].astype(np.int64))
+    assert np.array_equal(out.detach().numpy(), g["out"])
+    (out * up).sum().backward()
+    assert np.allclose(fmap.grad.numpy(), g["grad_fmap"], rtol=1e-5, atol=1e-5 * np.abs(g["grad_fmap"]).max())
+    for k_ in p:
+        assert np.allclose(p[k_].grad.numpy(), g["grad." + k_], rtol=1e-5, atol=1e-5 * np.abs(g["grad." + k_]).max())
+
+
+def test_pool_and_generator_consumption(ref):
+    g = golden("pool_1028")
+    torch.manual_seed(1)
+    a, b = ref.draw_pool_indices(1028)
+    assert np.array_equal(a.numpy(), g["perm_seed1_a"].astype(np.int64))
+    assert np.array_equal(b.numpy(), g["perm_seed1_b"].astype(np.int64))
+    xyz = ref.hash_tensor((2, 1028, 3), 61, 0.1)
+    fmap = ref.hash_tensor((2, 1028, 32), 62, 1.0)
+    vp, fp = ref.pool_layer(xyz, fmap, a)
+    assert np.array_equal(vp.numpy(), g["v_pool"]) and np.array_equal(fp.numpy(), g["f_pool"])
+
+
+@pytest.mark.parametrize("name", ["stack_eval_256", "stack_train_256"])
+def test_posenet9d_oracle_vs_reference(ref, state_keys, name):
+    """whole-model restatement == reference outputs (bit-equal here: same ATen ops, same order)."""
+    g = golden(name)
+    train_flag, B, N, seed, bn_training = (int(v) for v in g["meta"])
+    sd = _fill(ref, state_keys["train" if train_flag else "eval"])
+    pts = ref.hash_tensor((B, N, 3), seed, 0.05)
+    pts[:, :, 2] += 0.8
+    obj = torch.from_numpy((ref.hash_unit(B, seed + 1) * 6).astype(np.int64)).float().view(B, 1)
+    pidx = [torch.from_numpy(g["pool_idx0"].astype(np.int64)), torch.from_numpy(g["pool_idx1"].astype(np.int64))]
+    with torch.no_grad():
+        o = ref.posenet9d(sd, pts, obj, pidx, train_heads=bool(train_flag), bn_training=bool(bn_training))
+    assert np.array_equal((pts - pts.mean(dim=1, keepdim=True)).numpy(), g["centred"])
+    for n_ in ("p_green_R", "p_red_R", "f_green_R", "f_red_R", "Pred_T", "Pred_s"):
+        assert np.allclose(o[n_].numpy(), g["out." + n_], rtol=0, atol=1e-6), n_
+    assert np.allclose(o["feat"].reshape(-1)[::1009].numpy(), g["feat_sample"], rtol=0, atol=1e-6)
+
+
+def test_fps_oracles(ref, oc):
+    g = golden("fps_512_64")
+    pts = ref.hash_tensor((512, 3), 81, 1.0)
+    assert np.array_equal(oc.fps_f64(pts.double().numpy()[None], 64)[0], g["sel"].astype(np.int32))
+    assert np.array_equal(oc.fps_f32(pts.numpy()[None], 64)[0], g["sel"].astype(np.int32))
+
+
+def test_chamfer_oracle_vs_bruteforce(ref, oc):
+    """the C restatement of chamfer_distance.cpp:59-177 against an independent torch formulation
+    (the reference extension itself needs nvcc for its .cu half -- see DESIGN.md)."""
+    x1 = ref.hash_tensor((2, 100, 3), 91, 0.5).requires_grad_(True)
+    x2 = ref.hash_tensor((2, 50, 3), 92, 0.5).requires_grad_(True)
+    d1, d2, i1, i2 = oc.chamfer_fwd(x1.detach().numpy(), x2.detach().numpy())
+    w1, w2, j1, j2 = ref.chamfer(x1, x2)
+    assert np.array_equal(i1, j1.numpy()) and np.array_equal(i2, j2.numpy())
+    assert np.allclose(d1, w1.detach().numpy(), atol=1e-7) and np.allclose(d2, w2.detach().numpy(), atol=1e-7)
+    u1, u2 = ref.hash_tensor((2, 100), 93, 1.0), ref.hash_tensor((2, 50), 94, 1.0)
+    ((w1 * u1).sum() + (w2 * u2).sum()).backward()
+    gx1, gx2 = oc.chamfer_bwd(x1.detach().numpy(), x2.detach().numpy(), i1, i2, u1.numpy(), u2.numpy())
+    assert np.allclose(gx1, x1.grad.numpy(), atol=1e-5) and np.allclose(gx2, x2.grad.numpy(), atol=1e-5)
