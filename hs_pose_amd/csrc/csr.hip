@@ -1,0 +1,103 @@
+// csr.hip -- reverse-edge (CSR) index of a KNN graph, for atomic-free gather-form backward passes.
+//
+// A neighbour index idx (B,Nq,k) says "query i lists source row m = idx[i][n] at slot n".  Every
+// backward of the hot path scatters gradient from (i,n) to m (reference: the _index_put_impl_
+// accumulate of the gather in network/fs_net_repo/gcn3d.py:39-47).  Instead of fp32 atomics
+// (measured ~20 G atomics/s on MI355X: 0.6 ms for one N=1028 layer), the backward kernels walk, for
+// each source row m, the list of edges e = i*k + n that point at it, and write each gradient row once.
+//
+//   rev_off  (B, Nsrc+1) int32 : list of row m = rev_edge[b][rev_off[m] .. rev_off[m+1])
+//   rev_edge (B, Nq*k)   int32 : edge ids e = i*k + n, ASCENDING within each list -> the summation
+//                                order of every backward is fixed: bit-reproducible gradients.
+//
+// One 1024-thread workgroup per cloud: LDS histogram -> workgroup exclusive scan -> chunk-ordered fill
+// (edges are taken 1024 at a time, so a list is sorted up to swaps inside one chunk) -> per-row
+// insertion sort, O(length + inversions).
+#include "common.h"
+
+namespace hsp {
+
+#define REV_THREADS 1024
+
+__global__ __launch_bounds__(REV_THREADS) void rev_build_kernel(const int32_t* __restrict__ idx, int Nq, int Nsrc,
+                                                                int k, int kstride, int32_t* __restrict__ rev_off,
+                                                                int32_t* __restrict__ rev_edge) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* cnt = reinterpret_cast<int*>(smem);            // Nsrc + 1 (histogram, then cursor)
+    __shared__ int part[REV_THREADS];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int32_t* ib = idx + (size_t)b * Nq * kstride;
+    int32_t* off = rev_off + (size_t)b * (Nsrc + 1);
+    int32_t* edge = rev_edge + (size_t)b * Nq * k;
+    const int E = Nq * k;
+
+    for (int m = tid; m <= Nsrc; m += REV_THREADS) cnt[m] = 0;
+    __syncthreads();
+    for (int e = tid; e < E; e += REV_THREADS) {
+        const int i = e / k, n = e - i * k;
+        atomicAdd(&cnt[ib[(size_t)i * kstride + n]], 1);
+    }
+    __syncthreads();
+    // exclusive scan of cnt[0..Nsrc): thread t owns a contiguous slice
+    const int per = (Nsrc + REV_THREADS - 1) / REV_THREADS;
+    const int lo = min(tid * per, Nsrc), hi = min(lo + per, Nsrc);
+    int s = 0;
+    for (int m = lo; m < hi; ++m) s += cnt[m];
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < REV_THREADS; d <<= 1) {          // Hillis-Steele inclusive scan of the partials
+        const int v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = tid ? part[tid - 1] : 0;
+    for (int m = lo; m < hi; ++m) {
+        const int c = cnt[m];
+        cnt[m] = run;                                    // becomes the fill cursor
+        off[m] = run;
+        run += c;
+    }
+    if (tid == 0) off[Nsrc] = E;
+    __syncthreads();
+    // chunk-ordered fill
+    for (int e0 = 0; e0 < E; e0 += REV_THREADS) {
+        const int e = e0 + tid;
+        if (e < E) {
+            const int i = e / k, n = e - i * k;
+            const int pos = atomicAdd(&cnt[ib[(size_t)i * kstride + n]], 1);
+            edge[pos] = e;
+        }
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    // nearly sorted lists -> insertion sort per row (global memory, L2 resident)
+    for (int m = tid; m < Nsrc; m += REV_THREADS) {
+        const int a = off[m], z = (m + 1 < Nsrc) ? off[m + 1] : E;
+        for (int p = a + 1; p < z; ++p) {
+            const int v = edge[p];
+            int q = p - 1;
+            while (q >= a && edge[q] > v) { edge[q + 1] = edge[q]; --q; }
+            edge[q + 1] = v;
+        }
+    }
+}
+
+}  // namespace hsp
+
+using namespace hsp;
+
+extern "C" int hsp_rev_build(const int32_t* idx, int B, int Nq, int Nsrc, int k, int kstride, int32_t* rev_off,
+                             int32_t* rev_edge, hspStream_t stream) {
+    if (!idx || !rev_off || !rev_edge || B <= 0 || Nq <= 0 || Nsrc <= 0 || k <= 0 || kstride < k) return HSP_ERR_BAD_ARG;
+    const size_t lds = (size_t)(Nsrc + 1) * sizeof(int);
+    if (lds > 140 * 1024) return HSP_ERR_UNSUPPORTED;
+    if (lds > 60 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rev_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
+    }
+    hipLaunchKernelGGL(rev_build_kernel, dim3(B), dim3(REV_THREADS), lds, as_stream(stream), idx, Nq, Nsrc, k, kstride,
+                       rev_off, rev_edge);
+    return check_launch();
+}

@@ -70,6 +70,152 @@ __global__ __launch_bounds__(256) void gather_max_bwd_kernel(const float* __rest
     }
 }
 
+// COLUMN-TILE LDS-SCATTER form of the pooling backward (default): one workgroup per (cloud, TC columns)
+// keeps acc[Nsrc][TC] in LDS, sweeps the queries and adds into the winning source row with LDS atomics,
+// then writes every grad_feat row segment once -- no memset, no global atomics.  With a broadcast
+// gradient (ORL: d fg / N for every query) the accumulated quantity is an integer COUNT, so that
+// branch is exactly reproducible.  MODE 0: arg-max routed (gather_max), MODE 1: plain row scatter
+// (gather_rows: nearest-neighbour up-sampling backward, many queries per source row).
+// grid (C/TC, B), block 256, dynamic LDS = Nsrc*TC*4
+template <int TC, int MODE>
+__global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const float* __restrict__ gout, int gstride,
+                                                               int gbcast, const int32_t* __restrict__ idx,
+                                                               int idx_shared, const int32_t* __restrict__ qsel,
+                                                               const uint8_t* __restrict__ argmax, int Nsrc,
+                                                               int Nidx, int Nq, int kstride, int C,
+                                                               float* __restrict__ gfeat) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* acc = reinterpret_cast<float*>(smem);
+    int* cnt = reinterpret_cast<int*>(smem);
+    constexpr int G = TC / 4;
+    constexpr int PL = 256 / G;
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int j0 = blockIdx.x * TC;
+    const int cg = tid % G, pl = tid / G;
+    const int j = j0 + cg * 4;
+    for (int q = tid; q < Nsrc * G; q += 256) *reinterpret_cast<float4*>(acc + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    for (int q = pl; q < Nq; q += PL) {
+        const size_t row = (size_t)b * Nq + q;
+        if (MODE == 1) {
+            const int m = idx_shared ? idx[q] : idx[row];
+            const float4 gv = *reinterpret_cast<const float4*>(gout + row * gstride + j);
+            float* a = acc + m * TC + cg * 4;
+            if (gv.x != 0.f) atomicAdd(a + 0, gv.x);
+            if (gv.y != 0.f) atomicAdd(a + 1, gv.y);
+            if (gv.z != 0.f) atomicAdd(a + 2, gv.z);
+            if (gv.w != 0.f) atomicAdd(a + 3, gv.w);
+        } else {
+            const int qi = qsel ? qsel[q] : q;
+            const int32_t* nb = idx + ((size_t)b * Nidx + qi) * kstride;
+            const uchar4 am = *reinterpret_cast<const uchar4*>(argmax + row * C + j);
+            const int m0 = nb[am.x], m1 = nb[am.y], m2 = nb[am.z], m3 = nb[am.w];
+            if (gbcast) {
+                atomicAdd(cnt + m0 * TC + cg * 4 + 0, 1);
+                atomicAdd(cnt + m1 * TC + cg * 4 + 1, 1);
+                atomicAdd(cnt + m2 * TC + cg * 4 + 2, 1);
+                atomicAdd(cnt + m3 * TC + cg * 4 + 3, 1);
+            } else {
+                const float4 gv = *reinterpret_cast<const float4*>(gout + row * gstride + j);
+                if (gv.x != 0.f) atomicAdd(acc + m0 * TC + cg * 4 + 0, gv.x);
+                if (gv.y != 0.f) atomicAdd(acc + m1 * TC + cg * 4 + 1, gv.y);
+                if (gv.z != 0.f) atomicAdd(acc + m2 * TC + cg * 4 + 2, gv.z);
+                if (gv.w != 0.f) atomicAdd(acc + m3 * TC + cg * 4 + 3, gv.w);
+            }
+        }
+    }
+    __syncthreads();
+    float4 gb = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = tid; q < Nsrc * G; q += 256) {
+        const int m = q / G, g4 = q - m * G;
+        float4 v;
+        if (MODE == 0 && gbcast) {
+            gb = *reinterpret_cast<const float4*>(gout + (size_t)b * C + j0 + g4 * 4);
+            const int4 cv = *reinterpret_cast<const int4*>(cnt + m * TC + g4 * 4);
+            v = make_float4(gb.x * cv.x, gb.y * cv.y, gb.z * cv.z, gb.w * cv.w);
+        } else {
+            v = *reinterpret_cast<const float4*>(acc + m * TC + g4 * 4);
+        }
+        *reinterpret_cast<float4*>(gfeat + ((size_t)b * Nsrc + m) * C + j0 + g4 * 4) = v;
+    }
+}
+
+static int pick_scatter_cols(int Nsrc, int C) {
+    for (int tc = 16; tc >= 4; tc >>= 1)
+        if (C % tc == 0 && (size_t)Nsrc * tc * 4 <= 144 * 1024) return tc;
+    return 0;
+}
+
+template <int MODE>
+static int launch_scatter_tile(int tc, const float* gout, int gstride, int gbcast, const int32_t* idx, int idx_shared,
+                               const int32_t* qsel, const uint8_t* argmax, int B, int Nsrc, int Nidx, int Nq,
+                               int kstride, int C, float* gfeat, hipStream_t st) {
+    const size_t lds = (size_t)Nsrc * tc * 4;
+    dim3 grid(C / tc, B);
+#define SC_LAUNCH(TC)                                                                                              \
+    {                                                                                                              \
+        auto kern = scatter_tile_bwd_kernel<TC, MODE>;                                                             \
+        if (lds > 64 * 1024) {                                                                                     \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+            if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }                                 \
+        }                                                                                                          \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, gout, gstride, gbcast, idx, idx_shared, qsel, argmax, Nsrc, \
+                           Nidx, Nq, kstride, C, gfeat);                                                           \
+    }
+    if (tc == 16) SC_LAUNCH(16) else if (tc == 8) SC_LAUNCH(8) else SC_LAUNCH(4)
+#undef SC_LAUNCH
+    return check_launch();
+}
+
+// gather form of the same backward over the reverse-edge index (csr.hip): one thread per
+// (source row m, float4 column group) walks the edges e = i*k + n pointing at m and adds
+// grad_out[b,i,c] (or the per-cloud broadcast row) where argmax[b,i,c] == n.  No atomics.
+__global__ __launch_bounds__(256) void gather_max_bwd_csr_kernel(const float* __restrict__ gout, int gbcast,
+                                                                 const uint8_t* __restrict__ argmax,
+                                                                 const int32_t* __restrict__ rev_off,
+                                                                 const int32_t* __restrict__ rev_edge, int B,
+                                                                 int Nsrc, int Nq, int k, int C,
+                                                                 float* __restrict__ gfeat) {
+    const int cq = C >> 2;
+    const long long total = (long long)B * Nsrc * cq;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int g = (int)(e % cq);
+        const long long row = e / cq;            // b*Nsrc + m
+        const int m = (int)(row % Nsrc);
+        const int b = (int)(row / Nsrc);
+        const int32_t* off = rev_off + (size_t)b * (Nsrc + 1);
+        const int32_t* edge = rev_edge + (size_t)b * Nq * k;
+        const int o0 = off[m], o1 = off[m + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gbcast) {
+            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            for (int p = o0; p < o1; ++p) {
+                const int ed = edge[p];
+                const int i = ed / k, n = ed - i * k;
+                const uchar4 am = *reinterpret_cast<const uchar4*>(argmax + ((size_t)b * Nq + i) * C + (g << 2));
+                c0 += am.x == n; c1 += am.y == n; c2 += am.z == n; c3 += am.w == n;
+            }
+            const float4 gv = *reinterpret_cast<const float4*>(gout + (size_t)b * C + (g << 2));
+            // (count * g): equals the serial sum of count copies of g up to one rounding
+            acc = make_float4(gv.x * c0, gv.y * c1, gv.z * c2, gv.w * c3);
+        } else {
+            for (int p = o0; p < o1; ++p) {
+                const int ed = edge[p];
+                const int i = ed / k, n = ed - i * k;
+                const size_t qrow = (size_t)b * Nq + i;
+                const uchar4 am = *reinterpret_cast<const uchar4*>(argmax + qrow * C + (g << 2));
+                const float4 gv = *reinterpret_cast<const float4*>(gout + qrow * C + (g << 2));
+                if (am.x == n) acc.x += gv.x;
+                if (am.y == n) acc.y += gv.y;
+                if (am.z == n) acc.z += gv.z;
+                if (am.w == n) acc.w += gv.w;
+            }
+        }
+        *reinterpret_cast<float4*>(gfeat + row * C + (g << 2)) = acc;
+    }
+}
+
 __global__ __launch_bounds__(256) void gather_rows_fwd_kernel(const float* __restrict__ feat,
                                                               const int32_t* __restrict__ idx, int idx_shared,
                                                               int B, int Nsrc, int Nq, int C,
@@ -153,6 +299,9 @@ extern "C" int hsp_gather_max_bwd(const float* grad_out, int grad_bcast, const i
     if (!qsel && Nq != Nidx) return HSP_ERR_BAD_ARG;
     if (C & 3) return HSP_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);
+    if (const int tc = pick_scatter_cols(Nsrc, C))
+        return launch_scatter_tile<0>(tc, grad_out, C, grad_bcast, idx, 0, qsel, argmax, B, Nsrc, Nidx, Nq, kstride, C,
+                                      grad_feat, st);
     hipError_t e = hipMemsetAsync(grad_feat, 0, (size_t)B * Nsrc * C * sizeof(float), st);
     if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
     const long long total = (long long)B * Nq * (C >> 2);
@@ -182,10 +331,26 @@ extern "C" int hsp_gather_rows_bwd(const float* grad_out, int grad_stride, const
     if (!grad_out || !idx || !grad_feat || B <= 0 || Nsrc <= 0 || Nq <= 0 || C <= 0 || grad_stride < C)
         return HSP_ERR_BAD_ARG;
     hipStream_t st = as_stream(stream);
+    if ((C & 3) == 0 && (grad_stride & 3) == 0)
+        if (const int tc = pick_scatter_cols(Nsrc, C))
+            return launch_scatter_tile<1>(tc, grad_out, grad_stride, 0, idx, idx_shared, nullptr, nullptr, B, Nsrc, Nq,
+                                          Nq, 1, C, grad_feat, st);
     hipError_t e = hipMemsetAsync(grad_feat, 0, (size_t)B * Nsrc * C * sizeof(float), st);
     if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
     const long long total = (long long)B * Nq * C;
     hipLaunchKernelGGL(gather_rows_bwd_kernel, dim3(stream_grid(total)), dim3(256), 0, st, grad_out, grad_stride, idx,
                        idx_shared, B, Nsrc, Nq, C, grad_feat);
+    return check_launch();
+}
+
+extern "C" int hsp_gather_max_bwd_csr(const float* grad_out, int grad_bcast, const uint8_t* argmax,
+                                      const int32_t* rev_off, const int32_t* rev_edge, int B, int Nsrc, int Nq, int k,
+                                      int C, float* grad_feat, hspStream_t stream) {
+    if (!grad_out || !argmax || !rev_off || !rev_edge || !grad_feat || B <= 0 || Nsrc <= 0 || Nq <= 0 || k <= 0 || C <= 0)
+        return HSP_ERR_BAD_ARG;
+    if (C & 3) return HSP_ERR_UNSUPPORTED;
+    const long long total = (long long)B * Nsrc * (C >> 2);
+    hipLaunchKernelGGL(gather_max_bwd_csr_kernel, dim3(stream_grid(total)), dim3(256), 0, as_stream(stream), grad_out,
+                       grad_bcast, argmax, rev_off, rev_edge, B, Nsrc, Nq, k, C, grad_feat);
     return check_launch();
 }

@@ -215,14 +215,251 @@ __global__ __launch_bounds__(RF_THREADS) void rf_bwd_kernel(const float* __restr
     }
 }
 
-// out[e] = sum over blocks of ws[blk][e], e in [0, 3*SC): fixed order => deterministic
-__global__ __launch_bounds__(256) void rf_dirs_reduce_kernel(const float* __restrict__ ws, int nblk, int n3,
-                                                             float* __restrict__ out) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= n3) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += ws[(size_t)b * n3 + e];
-    out[e] = s;
+// ------------------------------------------------------------------------------------------------
+// backward of HS_layer.graph_conv, GATHER form (no atomics, fixed summation order).
+// A workgroup owns one SOURCE row m at a time and walks the reverse-edge list of m (csr.hip):
+// for every edge e = i*k + n with idx[b,i,n] == m and every column j
+//     hit = (argmax[b,i,j] == n);  z = R(i->m) . dirs[:,j];  ga = g[b,i,j%C] / S
+//     grad_fm[b,m,C+j] += hit ? ga * relu(z) : 0
+//     gD[d][j]         += hit && z>0 ? ga * fm[b,m,C+j] * R[d] : 0        (registers -> ws partials)
+// grad_fm[b,m,c] = g[b,m,c] (centre).  Edges are staged EB at a time in LDS (unit direction, slot n,
+// the query's g row pre-scaled by 1/S) so the EB arg-max loads of a thread are independent.
+// dynamic LDS: EB*(C + 8) floats
+// ------------------------------------------------------------------------------------------------
+#define RF_EB 8
+
+template <int NCH>
+__global__ __launch_bounds__(RF_THREADS) void rf_conv_bwd_csr_kernel(
+    const float* __restrict__ xyz, const float* __restrict__ dirs, const float* __restrict__ fm,
+    const uint8_t* __restrict__ argmax, const float* __restrict__ gout, const int32_t* __restrict__ rev_off,
+    const int32_t* __restrict__ rev_edge, int B, int N, int k, int S, int C, float* __restrict__ gfm,
+    float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int SC = S * C;
+    float* sg = reinterpret_cast<float*>(smem);                       // RF_EB x C   (g[i] / S)
+    float4* sR = reinterpret_cast<float4*>(sg + RF_EB * C);           // RF_EB       (R.xyz, w = slot n as int bits)
+    int* sI = reinterpret_cast<int*>(sR + RF_EB);                     // RF_EB       query row i
+    const int tid = threadIdx.x;
+    const int nq = SC >> 2;
+    const int fstride = (S + 1) * C;
+    const float invS = 1.0f / (float)S;
+    const int cq4 = C >> 2;
+
+    float4 d0[NCH], d1[NCH], d2[NCH], gd0[NCH], gd1[NCH], gd2[NCH];
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+        const int cq = tid + u * RF_THREADS;
+        const int j = (cq < nq ? cq : 0) << 2;
+        d0[u] = *reinterpret_cast<const float4*>(dirs + j);
+        d1[u] = *reinterpret_cast<const float4*>(dirs + SC + j);
+        d2[u] = *reinterpret_cast<const float4*>(dirs + 2 * SC + j);
+        gd0[u] = gd1[u] = gd2[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const PointIter it(B);
+    for (int b = it.b0; b < B; b += it.bstep) {
+        const float* xb = xyz + (size_t)b * N * 3;
+        const int32_t* offb = rev_off + (size_t)b * (N + 1);
+        const int32_t* edgeb = rev_edge + (size_t)b * N * k;
+        for (int m = it.i0; m < N; m += it.istep) {
+            const size_t pm = (size_t)b * N + m;
+            const int o0 = offb[m], o1 = offb[m + 1];
+            const float mx = xb[m * 3], my = xb[m * 3 + 1], mz = xb[m * 3 + 2];
+            float4 fv[NCH], acc[NCH];
+#pragma unroll
+            for (int u = 0; u < NCH; ++u) {
+                const int cq = tid + u * RF_THREADS;
+                acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                fv[u] = cq < nq ? *reinterpret_cast<const float4*>(fm + pm * fstride + C + (cq << 2)) : acc[u];
+            }
+            for (int c = tid; c < C; c += RF_THREADS) gfm[pm * fstride + c] = gout[pm * C + c];   // centre
+            for (int e0 = o0; e0 < o1; e0 += RF_EB) {
+                const int ne = min(RF_EB, o1 - e0);
+                __syncthreads();                                   // previous batch consumed
+                if (tid < ne) {
+                    const int e = edgeb[e0 + tid];
+                    const int i = e / k, n = e - i * k;
+                    const float3 r = unit_dir(xb[i * 3], xb[i * 3 + 1], xb[i * 3 + 2], mx, my, mz);
+                    sR[tid] = make_float4(r.x, r.y, r.z, __int_as_float(n));
+                    sI[tid] = i;
+                }
+                __syncthreads();
+                for (int q = tid; q < ne * cq4; q += RF_THREADS) {   // stage the g rows, scaled by 1/S
+                    const int t = q / cq4, c4 = q - t * cq4;
+                    float4 g = *reinterpret_cast<const float4*>(gout + ((size_t)b * N + sI[t]) * C + (c4 << 2));
+                    g.x *= invS; g.y *= invS; g.z *= invS; g.w *= invS;
+                    *reinterpret_cast<float4*>(sg + t * C + (c4 << 2)) = g;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < NCH; ++u) {
+                    const int cq = tid + u * RF_THREADS;
+                    if (cq < nq) {
+                        const int j = cq << 2;
+                        const int c = j % C;
+                        uchar4 am[RF_EB];
+#pragma unroll
+                        for (int t = 0; t < RF_EB; ++t)
+                            if (t < ne) am[t] = *reinterpret_cast<const uchar4*>(argmax + ((size_t)b * N + sI[t]) * SC + j);
+#pragma unroll
+                        for (int t = 0; t < RF_EB; ++t) {
+                            if (t < ne) {
+                                const float4 r = sR[t];
+                                const int n = __float_as_int(r.w);
+                                const float4 ga = *reinterpret_cast<const float4*>(sg + t * C + c);
+#define RF_ONE(X)                                                                                         \
+    if (am[t].X == n) {                                                                                   \
+        const float z = __fmaf_rn(r.z, d2[u].X, __fmaf_rn(r.y, d1[u].X, mul_rn(r.x, d0[u].X)));           \
+        if (z > 0.f) {                                                                                    \
+            acc[u].X += ga.X * z;                                                                         \
+            const float w = ga.X * fv[u].X;                                                               \
+            gd0[u].X += w * r.x; gd1[u].X += w * r.y; gd2[u].X += w * r.z;                                \
+        }                                                                                                 \
+    }
+                                RF_ONE(x) RF_ONE(y) RF_ONE(z) RF_ONE(w)
+#undef RF_ONE
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NCH; ++u) {
+                const int cq = tid + u * RF_THREADS;
+                if (cq < nq) *reinterpret_cast<float4*>(gfm + pm * fstride + C + (cq << 2)) = acc[u];
+            }
+        }
+    }
+    float* wsb = ws + (size_t)blockIdx.x * 3 * SC;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+        const int cq = tid + u * RF_THREADS;
+        if (cq < nq) {
+            const int j = cq << 2;
+            *reinterpret_cast<float4*>(wsb + j) = gd0[u];
+            *reinterpret_cast<float4*>(wsb + SC + j) = gd1[u];
+            *reinterpret_cast<float4*>(wsb + 2 * SC + j) = gd2[u];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of HS_layer.graph_conv, COLUMN-TILE LDS-SCATTER form (default).
+// One workgroup per (cloud b, tile of TC support columns).  The tile of grad_fm, acc[N][TC] fp32, lives
+// in LDS (66 KB at N=1028, TC=16); the workgroup sweeps the cloud's points i, and for each column j of
+// the tile routes  ga*relu(z)  to row m = idx[b,i,argmax[b,i,j]] with an LDS atomic add (ds_add_f32:
+// no L2 round trip, hub rows only serialise inside one wave), then writes every grad_fm row segment
+// once with 16-byte stores.  In-degree hubs of feature-space KNN graphs (hundreds of edges into one row)
+// cannot unbalance it, and no reverse index is needed.  The direction gradient is accumulated in
+// registers, folded across the workgroup's point lanes in LDS in a fixed order and written to
+// gd_part[b][3][SC] (exactly one writer per element); rf_dirs_reduce_kernel then sums the B clouds.
+// Only the LDS float adds are order-dependent; hsp_rf_conv_bwd (CSR form) is the bit-reproducible twin.
+// grid (SC/TC, B), block 256, dynamic LDS = max(N*TC, 256*12) floats
+// ------------------------------------------------------------------------------------------------
+template <int TC>
+__global__ __launch_bounds__(RF_THREADS) void rf_conv_bwd_tile_kernel(
+    const float* __restrict__ xyz, const int32_t* __restrict__ idx, const float* __restrict__ dirs,
+    const float* __restrict__ fm, const uint8_t* __restrict__ argmax, const float* __restrict__ gout, int B, int N,
+    int k, int S, int C, float* __restrict__ gfm, float* __restrict__ gd_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* acc = reinterpret_cast<float*>(smem);
+    constexpr int G = TC / 4;                 // float4 groups per tile
+    constexpr int PL = RF_THREADS / G;        // point lanes
+    const int SC = S * C;
+    const int fstride = (S + 1) * C;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int j0 = blockIdx.x * TC;
+    const int cg = tid % G, pl = tid / G;
+    const int j = j0 + cg * 4;
+    const int c = j % C;
+    const float invS = 1.0f / (float)S;
+    for (int q = tid; q < N * G; q += RF_THREADS) *reinterpret_cast<float4*>(acc + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 d0 = *reinterpret_cast<const float4*>(dirs + j);
+    const float4 d1 = *reinterpret_cast<const float4*>(dirs + SC + j);
+    const float4 d2 = *reinterpret_cast<const float4*>(dirs + 2 * SC + j);
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
+    const float* xb = xyz + (size_t)b * N * 3;
+    const float* fsup = fm + (size_t)b * N * fstride + C + j;
+    __syncthreads();
+    for (int p = pl; p < N; p += PL) {
+        const size_t pt = (size_t)b * N + p;
+        const uchar4 am = *reinterpret_cast<const uchar4*>(argmax + pt * SC + j);
+        float4 ga = *reinterpret_cast<const float4*>(gout + pt * C + c);
+        ga.x *= invS; ga.y *= invS; ga.z *= invS; ga.w *= invS;
+        const float px = xb[p * 3], py = xb[p * 3 + 1], pz = xb[p * 3 + 2];
+        const int32_t* nb = idx + pt * k;
+#define RF_T1(X, E)                                                                                  \
+        {                                                                                            \
+            const int m = nb[am.X];                                                                  \
+            const float3 r = unit_dir(px, py, pz, xb[m * 3], xb[m * 3 + 1], xb[m * 3 + 2]);          \
+            const float z = __fmaf_rn(r.z, d2.X, __fmaf_rn(r.y, d1.X, mul_rn(r.x, d0.X)));           \
+            if (z > 0.f) {                                                                           \
+                atomicAdd(acc + m * TC + cg * 4 + E, ga.X * z);                                      \
+                const float w = ga.X * fsup[(size_t)m * fstride + E];                                \
+                g0.X += w * r.x; g1.X += w * r.y; g2.X += w * r.z;                                   \
+            }                                                                                        \
+        }
+        RF_T1(x, 0) RF_T1(y, 1) RF_T1(z, 2) RF_T1(w, 3)
+#undef RF_T1
+    }
+    __syncthreads();
+    // flush the tile: one 16-byte store per (row, group)
+    for (int q = tid; q < N * G; q += RF_THREADS) {
+        const int m = q / G, g4 = q - m * G;
+        *reinterpret_cast<float4*>(gfm + ((size_t)b * N + m) * fstride + C + j0 + g4 * 4) =
+            *reinterpret_cast<const float4*>(acc + m * TC + g4 * 4);
+    }
+    if (j0 < C) {   // the first C/TC tiles also copy the centre columns grad_fm[b,m,c] = g[b,m,c]
+        for (int q = tid; q < N * G; q += RF_THREADS) {
+            const int m = q / G, g4 = q - m * G;
+            *reinterpret_cast<float4*>(gfm + ((size_t)b * N + m) * fstride + j0 + g4 * 4) =
+                *reinterpret_cast<const float4*>(gout + ((size_t)b * N + m) * C + j0 + g4 * 4);
+        }
+    }
+    __syncthreads();
+    // fold the direction gradient across the PL point lanes (fixed order) -> gd_part[b][d][j]
+    float* red = acc;                                  // 256 x 12 floats
+    float* mine = red + tid * 12;
+    mine[0] = g0.x; mine[1] = g0.y; mine[2] = g0.z; mine[3] = g0.w;
+    mine[4] = g1.x; mine[5] = g1.y; mine[6] = g1.z; mine[7] = g1.w;
+    mine[8] = g2.x; mine[9] = g2.y; mine[10] = g2.z; mine[11] = g2.w;
+    __syncthreads();
+    if (tid < G * 12) {
+        const int gg = tid / 12, w = tid - gg * 12;    // group, (d*4 + e)
+        float sacc = 0.f;
+        for (int l = 0; l < PL; ++l) sacc += red[(l * G + gg) * 12 + w];
+        const int d = w >> 2, e = w & 3;
+        gd_part[((size_t)b * 3 + d) * SC + j0 + gg * 4 + e] = sacc;
+    }
+}
+
+// out[e] = sum over blocks of ws[blk][e], e in [0, n3).  Workgroup = 64 elements x 16 block-slices;
+// every thread sums its slice with 4 independent accumulators (loads stay in flight), the 16 slices are
+// folded through LDS in a fixed order => deterministic.
+__global__ __launch_bounds__(1024) void rf_dirs_reduce_kernel(const float* __restrict__ ws, int nblk, int n3,
+                                                              float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int le = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + le;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (e < n3) {
+        int b = sl;
+        for (; b + 48 < nblk; b += 64) {
+            a0 += ws[(size_t)b * n3 + e];
+            a1 += ws[(size_t)(b + 16) * n3 + e];
+            a2 += ws[(size_t)(b + 32) * n3 + e];
+            a3 += ws[(size_t)(b + 48) * n3 + e];
+        }
+        for (; b < nblk; b += 16) a0 += ws[(size_t)b * n3 + e];
+    }
+    red[sl][le] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sl == 0 && e < n3) {
+        float s = red[0][le];
+#pragma unroll
+        for (int t = 1; t < 16; ++t) s += red[t][le];
+        out[e] = s;
+    }
 }
 
 // backward grid: persistent, capped so that the per-block direction-gradient partials stay <= 8 MiB
@@ -311,7 +548,7 @@ static int rf_bwd(const float* xyz, const int32_t* idx, const float* dirs, const
     rc = check_launch();
     if (rc) return rc;
     const int n3 = 3 * SC;
-    hipLaunchKernelGGL(rf_dirs_reduce_kernel, dim3((n3 + 255) / 256), dim3(256), 0, st, wsf, grid, n3, gdirs);
+    hipLaunchKernelGGL(rf_dirs_reduce_kernel, dim3((n3 + 63) / 64), dim3(1024), 0, st, wsf, grid, n3, gdirs);
     return check_launch();
 }
 
@@ -319,12 +556,86 @@ extern "C" int hsp_rf_surface_bwd(const float* xyz, const int32_t* idx, const fl
                                   const float* grad_out, int B, int N, int k, int S, int K, float* grad_dirs_n,
                                   void* ws, size_t ws_bytes, hspStream_t stream) {
     return rf_bwd<true>(xyz, idx, dirs_n, nullptr, argmax, grad_out, B, N, k, S, K, nullptr, grad_dirs_n, ws,
-                        ws_bytes, stream);
+                        ws_bytes, stream);   // no scatter in the surface layer: only the direction gradient
 }
 
-extern "C" int hsp_rf_conv_bwd(const float* xyz, const int32_t* idx, const float* dirs_n, const float* fm,
-                               const uint8_t* argmax, const float* grad_out, int B, int N, int k, int S, int C,
-                               float* grad_fm, float* grad_dirs_n, void* ws, size_t ws_bytes, hspStream_t stream) {
-    return rf_bwd<false>(xyz, idx, dirs_n, fm, argmax, grad_out, B, N, k, S, C, grad_fm, grad_dirs_n, ws, ws_bytes,
-                         stream);
+extern "C" int hsp_rf_conv_bwd(const float* xyz, const float* dirs_n, const float* fm, const uint8_t* argmax,
+                               const float* grad_out, const int32_t* rev_off, const int32_t* rev_edge, int B, int N,
+                               int k, int S, int C, float* grad_fm, float* grad_dirs_n, void* ws, size_t ws_bytes,
+                               hspStream_t stream) {
+    int rc = rf_check(xyz, dirs_n, fm, B, N, k, S, C);
+    if (rc) return rc;
+    if (!argmax || !grad_out || !rev_off || !rev_edge || !grad_fm || !grad_dirs_n) return HSP_ERR_BAD_ARG;
+    const int SC = S * C;
+    if (!ws || ws_bytes < hsp_rf_bwd_workspace_bytes(SC)) return HSP_ERR_WORKSPACE;
+    const int nq = SC >> 2;
+    const int nch = (nq + RF_THREADS - 1) / RF_THREADS;
+    if (nch > 4) return HSP_ERR_UNSUPPORTED;              // S*C <= 4096
+    hipStream_t st = as_stream(stream);
+    const int grid = rf_bwd_grid((long long)B * N, SC);
+    const size_t lds = (size_t)(RF_EB * (C + 8)) * 4;
+    if (lds > 64 * 1024) return HSP_ERR_UNSUPPORTED;
+    float* wsf = reinterpret_cast<float*>(ws);
+#define RF_CSR_LAUNCH(NCH)                                                                                        \
+    hipLaunchKernelGGL((rf_conv_bwd_csr_kernel<NCH>), dim3(grid), dim3(RF_THREADS), lds, st, xyz, dirs_n, fm, argmax, \
+                       grad_out, rev_off, rev_edge, B, N, k, S, C, grad_fm, wsf)
+    switch (nch) {
+        case 1: RF_CSR_LAUNCH(1); break;
+        case 2: RF_CSR_LAUNCH(2); break;
+        case 3: RF_CSR_LAUNCH(3); break;
+        default: RF_CSR_LAUNCH(4); break;
+    }
+#undef RF_CSR_LAUNCH
+    rc = check_launch();
+    if (rc) return rc;
+    const int n3 = 3 * SC;
+    hipLaunchKernelGGL(rf_dirs_reduce_kernel, dim3((n3 + 63) / 64), dim3(1024), 0, st, wsf, grid, n3, grad_dirs_n);
+    return check_launch();
+}
+
+static int pick_tile_cols(int N, int C) {
+    for (int tc = 16; tc >= 4; tc >>= 1)
+        if (C % tc == 0 && (size_t)N * tc * 4 <= 144 * 1024) return tc;
+    return 0;
+}
+
+extern "C" size_t hsp_rf_conv_bwd_scatter_workspace_bytes(int B, int SC) {
+    if (B <= 0 || SC <= 0) return 0;
+    return (size_t)B * 3 * SC * sizeof(float);
+}
+
+extern "C" int hsp_rf_conv_bwd_scatter(const float* xyz, const int32_t* idx, const float* dirs_n, const float* fm,
+                                       const uint8_t* argmax, const float* grad_out, int B, int N, int k, int S, int C,
+                                       float* grad_fm, float* grad_dirs_n, void* ws, size_t ws_bytes,
+                                       hspStream_t stream) {
+    int rc = rf_check(xyz, idx, dirs_n, B, N, k, S, C);
+    if (rc) return rc;
+    if (!fm || !argmax || !grad_out || !grad_fm || !grad_dirs_n) return HSP_ERR_BAD_ARG;
+    const int SC = S * C;
+    if (!ws || ws_bytes < hsp_rf_conv_bwd_scatter_workspace_bytes(B, SC)) return HSP_ERR_WORKSPACE;
+    const int tc = pick_tile_cols(N, C);
+    if (!tc) return HSP_ERR_UNSUPPORTED;
+    size_t lds = (size_t)N * tc * 4;
+    if (lds < 256 * 12 * 4) lds = 256 * 12 * 4;
+    hipStream_t st = as_stream(stream);
+    float* part = reinterpret_cast<float*>(ws);
+    dim3 grid(SC / tc, B);
+#define RF_TILE_LAUNCH(TC)                                                                                          \
+    {                                                                                                               \
+        auto kern = rf_conv_bwd_tile_kernel<TC>;                                                                    \
+        if (lds > 64 * 1024) {                                                                                      \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+            if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }                                  \
+        }                                                                                                           \
+        hipLaunchKernelGGL(kern, grid, dim3(RF_THREADS), lds, st, xyz, idx, dirs_n, fm, argmax, grad_out, B, N, k, S, \
+                           C, grad_fm, part);                                                                       \
+    }
+    if (tc == 16) RF_TILE_LAUNCH(16) else if (tc == 8) RF_TILE_LAUNCH(8) else RF_TILE_LAUNCH(4)
+#undef RF_TILE_LAUNCH
+    rc = check_launch();
+    if (rc) return rc;
+    const int n3 = 3 * SC;
+    hipLaunchKernelGGL(rf_dirs_reduce_kernel, dim3((n3 + 63) / 64), dim3(1024), 0, st, part, B, n3, grad_dirs_n);
+    return check_launch();
 }

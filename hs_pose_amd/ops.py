@@ -5,12 +5,18 @@ buffer), passes raw device pointers + the current HIP stream through ctypes and 
 return code.  No CPU fallback: a non-GPU tensor is an error.
 """
 import ctypes
+import os
 
 import torch
 
 from ._lib import HspError, check, lib
 
 _vp = ctypes.c_void_p
+
+# HSP_DETERMINISTIC=1 (or ops.DETERMINISTIC = True): graph-conv backward runs in gather form over a
+# reverse-edge index (fixed summation order, bit-reproducible gradients) instead of the faster
+# column-tile LDS scatter, whose fp32 LDS adds are order-dependent in the last bits.
+DETERMINISTIC = os.environ.get("HSP_DETERMINISTIC", "0") == "1"
 
 
 def _p(t):
@@ -112,6 +118,26 @@ def nn1(target, source):
     return idx
 
 
+def rev_index(idx, k, n_src):
+    """reverse-edge (CSR) index (rev_off (B,n_src+1), rev_edge (B,Nq*k)) of the first k columns of the
+    int32 neighbour index idx (B,Nq,kstride); memoised on the idx tensor, so a graph shared by several
+    layers (the per-resolution xyz graph of the ORL branches) is inverted once per step."""
+    cache = getattr(idx, "_hsp_rev", None)
+    if cache is None:
+        cache = {}
+        idx._hsp_rev = cache
+    hit = cache.get((k, n_src))
+    if hit is not None:
+        return hit
+    B, Nq, kstride = idx.shape
+    off = torch.empty(B, n_src + 1, dtype=torch.int32, device=idx.device)
+    edge = torch.empty(B, Nq * k, dtype=torch.int32, device=idx.device)
+    _run("hsp_rev_build", (_p(idx), B, Nq, n_src, k, kstride, _p(off), _p(edge), _stream()),
+         key=f"B{B}Nq{Nq}k{k}", abytes=B * (8 * Nq * k + 4 * n_src))
+    cache[(k, n_src)] = (off, edge)
+    return off, edge
+
+
 # ------------------------------------------------------------------------------------------------
 # receptive-field graph convolution
 # ------------------------------------------------------------------------------------------------
@@ -179,12 +205,21 @@ class _RFConv(torch.autograd.Function):
         gfm = torch.empty_like(fm)
         gd = torch.empty_like(dirs_n)
         L = lib()
-        wsb = L.hsp_rf_bwd_workspace_bytes(SC)
-        ws = _ws(wsb, g.device)
-        _run("hsp_rf_conv_bwd", (_p(xyz), _p(idx), _p(dirs_n), _p(fm), _p(arg), _p(g), B, N, k, ctx.S, C, _p(gfm),
-                                 _p(gd), _p(ws), wsb, _stream()),
-             key=f"B{B}N{N}k{k}S{ctx.S}C{C}",
-             abytes=B * N * (12 + 4 * k + 4 * SC + SC + 4 * C + 4 * (ctx.S + 1) * C) + 24 * SC)
+        if DETERMINISTIC:
+            wsb = L.hsp_rf_bwd_workspace_bytes(SC)
+            ws = _ws(wsb, g.device)
+            off, edge = rev_index(idx, k, N)
+            _run("hsp_rf_conv_bwd", (_p(xyz), _p(dirs_n), _p(fm), _p(arg), _p(g), _p(off), _p(edge), B, N, k, ctx.S, C,
+                                     _p(gfm), _p(gd), _p(ws), wsb, _stream()),
+                 key=f"B{B}N{N}k{k}S{ctx.S}C{C}",
+                 abytes=B * N * (12 + 8 * k + 4 * SC + SC + 4 * C + 4 * (ctx.S + 1) * C) + 24 * SC)
+        else:
+            wsb = L.hsp_rf_conv_bwd_scatter_workspace_bytes(B, SC)
+            ws = _ws(wsb, g.device)
+            _run("hsp_rf_conv_bwd_scatter", (_p(xyz), _p(idx), _p(dirs_n), _p(fm), _p(arg), _p(g), B, N, k, ctx.S, C,
+                                             _p(gfm), _p(gd), _p(ws), wsb, _stream()),
+                 key=f"B{B}N{N}k{k}S{ctx.S}C{C}",
+                 abytes=B * N * (12 + 4 * k + 4 * SC + SC + 4 * C + 4 * (ctx.S + 1) * C) + 24 * SC)
         return None, None, gd, gfm, None
 
 
@@ -248,6 +283,7 @@ class _OrlGlobal(torch.autograd.Function):
              key=f"B{B}Ns{N}Nq{N}k{k}C{C}", abytes=B * N * (4 * C + 4 * k + 5 * C))
         ctx.save_for_backward(idx, arg)
         ctx.dims = (B, N, kstride, C)
+        ctx.k = k
         return G.mean(dim=1)
 
     @staticmethod
@@ -256,8 +292,13 @@ class _OrlGlobal(torch.autograd.Function):
         B, N, kstride, C = ctx.dims
         g = _req(gfg / N, torch.float32, "orl.grad")
         gfeat = torch.empty(B, N, C, dtype=torch.float32, device=g.device)
-        _run("hsp_gather_max_bwd", (_p(g), 1, _p(idx), _vp(0), _p(arg), B, N, N, N, kstride, C, _p(gfeat), _stream()),
-             key=f"B{B}Ns{N}Nq{N}C{C}bc", abytes=B * N * (4 * C + 4 * kstride + C))
+        if DETERMINISTIC:      # gather form over the reverse-edge index (shared by the layers of a resolution)
+            off, edge = rev_index(idx, ctx.k, N)
+            _run("hsp_gather_max_bwd_csr", (_p(g), 1, _p(arg), _p(off), _p(edge), B, N, N, ctx.k, C, _p(gfeat), _stream()),
+                 key=f"B{B}Ns{N}Nq{N}k{ctx.k}C{C}bc", abytes=B * N * (4 * C + 8 * ctx.k + C))
+        else:                  # LDS tile kernel; broadcast gradient => integer counts => reproducible as well
+            _run("hsp_gather_max_bwd", (_p(g), 1, _p(idx), _vp(0), _p(arg), B, N, N, N, kstride, C, _p(gfeat), _stream()),
+                 key=f"B{B}Ns{N}Nq{N}C{C}bc", abytes=B * N * (4 * C + 4 * kstride + C))
         return gfeat, None, None
 
 

@@ -83,10 +83,32 @@ int hsp_rf_surface_bwd(const float *xyz, const int32_t *idx, const float *dirs_n
  */
 int hsp_rf_conv_fwd(const float *xyz, const int32_t *idx, const float *dirs_n, const float *fm, int B,
                     int N, int k, int S, int C, float *out, uint8_t *argmax, hspStream_t stream);
-/* grad_fm (B,N,(S+1)*C) and grad_dirs_n (3,S*C) are OVERWRITTEN. */
-int hsp_rf_conv_bwd(const float *xyz, const int32_t *idx, const float *dirs_n, const float *fm,
-                    const uint8_t *argmax, const float *grad_out, int B, int N, int k, int S, int C,
-                    float *grad_fm, float *grad_dirs_n, void *ws, size_t ws_bytes, hspStream_t stream);
+/* Backward, GATHER form: rev_off/rev_edge = hsp_rev_build(idx) of the SAME idx the forward used.
+ * grad_fm (B,N,(S+1)*C) and grad_dirs_n (3,S*C) are OVERWRITTEN (every row written exactly once: no
+ * atomics, no memset, fixed summation order). */
+int hsp_rf_conv_bwd(const float *xyz, const float *dirs_n, const float *fm, const uint8_t *argmax,
+                    const float *grad_out, const int32_t *rev_off, const int32_t *rev_edge, int B, int N,
+                    int k, int S, int C, float *grad_fm, float *grad_dirs_n, void *ws, size_t ws_bytes,
+                    hspStream_t stream);
+
+/* Backward, COLUMN-TILE LDS-SCATTER form (the default of the Python mirror): same outputs as
+ * hsp_rf_conv_bwd from idx itself, no reverse index; a (cloud, 16-column) tile of grad_fm is
+ * accumulated in LDS with ds_add_f32 (immune to in-degree hubs of feature-space graphs) and written
+ * once.  The LDS adds make grad_fm order-dependent in the last bits; use hsp_rf_conv_bwd when
+ * bit-reproducible gradients are required.  ws: hsp_rf_conv_bwd_scatter_workspace_bytes(B, S*C). */
+size_t hsp_rf_conv_bwd_scatter_workspace_bytes(int B, int SC);
+int hsp_rf_conv_bwd_scatter(const float *xyz, const int32_t *idx, const float *dirs_n, const float *fm,
+                            const uint8_t *argmax, const float *grad_out, int B, int N, int k, int S, int C,
+                            float *grad_fm, float *grad_dirs_n, void *ws, size_t ws_bytes, hspStream_t stream);
+
+/* ---- reverse-edge (CSR) index of a neighbour graph --------------------------------------------
+ * replaces the accumulate-scatter (_index_put_impl_) that autograd runs for the gather of
+ * indexing_neighbor_new (gcn3d.py:39-47): idx (B,Nq,kstride), first k columns used ->
+ * rev_off (B,Nsrc+1), rev_edge (B,Nq*k): for source row m the ascending edge ids e = i*k + n with
+ * idx[b,i,n] == m are rev_edge[b][rev_off[b][m] .. rev_off[b][m+1]).
+ */
+int hsp_rev_build(const int32_t *idx, int B, int Nq, int Nsrc, int k, int kstride, int32_t *rev_off,
+                  int32_t *rev_edge, hspStream_t stream);
 
 /* ---- neighbourhood max-pool (ORL global branch, Pool_layer) ----------------------------------
  * replaces indexing_neighbor_new(...) + max(dim=2)    gcn3d.py:214-216, :236-240
@@ -98,11 +120,17 @@ int hsp_rf_conv_bwd(const float *xyz, const int32_t *idx, const float *dirs_n, c
 int hsp_gather_max_fwd(const float *feat, const int32_t *idx, const int32_t *qsel, int B, int Nsrc,
                        int Nidx, int Nq, int k, int kstride, int C, float *out, uint8_t *argmax,
                        hspStream_t stream);
-/* grad_feat (B,Nsrc,C) is OVERWRITTEN (zeroed, then scatter-added).  grad_out is (B,Nq,C), or (B,C)
- * broadcast over q when grad_bcast != 0 (the ORL mean-over-points branch). */
+/* grad_feat (B,Nsrc,C) is OVERWRITTEN.  grad_out is (B,Nq,C), or (B,C) broadcast over q when
+ * grad_bcast != 0 (the ORL mean-over-points branch; integer counts in LDS => exactly reproducible).
+ * Column-tile LDS scatter when a (Nsrc x 16-column) tile fits LDS, else memset + global atomics. */
 int hsp_gather_max_bwd(const float *grad_out, int grad_bcast, const int32_t *idx, const int32_t *qsel,
                        const uint8_t *argmax, int B, int Nsrc, int Nidx, int Nq, int kstride, int C,
                        float *grad_feat, hspStream_t stream);
+/* the same result in GATHER form over hsp_rev_build(idx, k) (qsel == NULL case, Nq rows of idx):
+ * each grad_feat row written once, no atomics. */
+int hsp_gather_max_bwd_csr(const float *grad_out, int grad_bcast, const uint8_t *argmax, const int32_t *rev_off,
+                           const int32_t *rev_edge, int B, int Nsrc, int Nq, int k, int C, float *grad_feat,
+                           hspStream_t stream);
 
 /* ---- row gather (nearest up-sample, vertex select) -------------------------------------------
  * replaces indexing_neighbor_new(t, nearest).squeeze(2)    FaceRecon.py:102-104 ; vertices[:, sample_idx]

@@ -19,7 +19,7 @@ def _header_symbols():
 def test_library_exports_every_declared_symbol():
     from hs_pose_amd import _lib
     syms = _header_symbols()
-    assert len(syms) >= 19
+    assert len(syms) >= 23
     L = _lib.lib()
     for s in syms:
         assert hasattr(L, s), f"libhsp.so lacks {s}"
@@ -40,7 +40,9 @@ def test_argument_validation_without_gpu():
     assert L.hsp_knn_workspace_bytes(2, 100, 128, 4) == 2 * 100 * 4
     assert L.hsp_rf_conv_fwd(one, one, one, one, 1, 8, 300, 7, 128, one, one, null) == -2   # k > 255
     assert L.hsp_rf_conv_fwd(one, one, one, one, 1, 8, 4, 7, 126, one, one, null) == -2     # C % 4
-    assert L.hsp_rf_conv_bwd(one, one, one, one, one, one, 1, 8, 4, 7, 128, one, one, null, 0, null) == -3
+    assert L.hsp_rf_conv_bwd(one, one, one, one, one, one, one, 1, 8, 4, 7, 128, one, one, null, 0, null) == -3
+    assert L.hsp_rev_build(one, 1, 8, 8, 4, 2, one, one, null) == -1                         # kstride < k
+    assert L.hsp_gather_max_bwd_csr(one, 0, one, one, one, 1, 8, 8, 4, 126, one, null) == -2  # C % 4
     assert L.hsp_gather_max_fwd(one, one, null, 1, 8, 8, 4, 2, 2, 16, one, one, null) == -1  # Nq != Nidx w/o qsel
     assert L.hsp_gather_rows_fwd(one, one, 0, 1, 8, 8, 16, one, 8, null) == -1               # out_stride < C
     assert L.hsp_fps_f32(one, 1, 8, 9, one, one, 1024, null) == -1

@@ -46,10 +46,13 @@ def test_rf_surface_fwd_bwd(dev, ref, B, N, k, S, K):
     gclose(Dg.grad, D.grad, "rf_surface dD")
 
 
+@pytest.mark.parametrize("deterministic", [False, True])
 @pytest.mark.parametrize("B,N,k,S,Cin,C", [(2, 128, 8, 3, 16, 32), (1, 257, 20, 7, 128, 128), (2, 64, 8, 7, 256, 512),
-                                           (10, 48, 5, 2, 8, 12)])
-def test_rf_conv_fwd_bwd(dev, ref, B, N, k, S, Cin, C):
+                                           (10, 48, 5, 2, 8, 12), (1, 1028, 20, 7, 32, 128)])
+def test_rf_conv_fwd_bwd(dev, ref, monkeypatch, B, N, k, S, Cin, C, deterministic):
+    """both backward forms: column-tile LDS scatter (default) and CSR gather (HSP_DETERMINISTIC=1)"""
     from hs_pose_amd import ops
+    monkeypatch.setattr(ops, "DETERMINISTIC", deterministic)
     xyz = ref.hash_tensor((B, N, 3), 11, 0.1)
     x = torch.relu(ref.hash_tensor((B, N, Cin), 12, 1.0))
     W = ref.hash_tensor((Cin, (S + 1) * C), 13, 1.0 / Cin ** 0.5)
@@ -94,8 +97,10 @@ def test_gather_max_fwd_bwd(dev, ref, B, N, C, k, kstride, nq):
     gclose(fg.grad, feat.grad, "gather_max dfeat")
 
 
-def test_orl_global_fwd_bwd(dev, ref):
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_orl_global_fwd_bwd(dev, ref, monkeypatch, deterministic):
     from hs_pose_amd import ops
+    monkeypatch.setattr(ops, "DETERMINISTIC", deterministic)
     B, N, C, k = 3, 257, 64, 20
     xyz = ref.hash_tensor((B, N, 3), 31, 0.1)
     feat = ref.hash_tensor((B, N, C), 32, 1.0).requires_grad_(True)
@@ -223,3 +228,45 @@ def test_reference_api_helpers(dev, ref):
     rf, ni = gcn3d.get_receptive_fields(k, xyz.to(dev), feature_map=feat.to(dev), mode='RF-F')
     assert np.array_equal(ni.cpu().numpy(), ref.knn_index(feat, k).numpy())
     assert rf.shape == (B, N, k, 3)
+
+
+@pytest.mark.parametrize("B,Nq,Nsrc,k,kstride", [(2, 100, 100, 8, 8), (3, 257, 257, 20, 20), (1, 1028, 1028, 4, 20), (2, 50, 300, 5, 6)])
+def test_rev_build(dev, ref, B, Nq, Nsrc, k, kstride):
+    """reverse-edge index: every edge appears exactly once, in its target's list, lists ascending."""
+    from hs_pose_amd import ops
+    idx = torch.from_numpy((ref.hash_unit(B * Nq * kstride, 7) * Nsrc).astype(np.int32)).view(B, Nq, kstride)
+    idx[:, :, 0] = 3                                   # a hub: every query lists row 3
+    off, edge = ops.rev_index(idx.to(dev), k, Nsrc)
+    off, edge = off.cpu().numpy(), edge.cpu().numpy()
+    inp = idx.numpy()
+    for b in range(B):
+        assert off[b, 0] == 0 and off[b, -1] == Nq * k and (np.diff(off[b]) >= 0).all()
+        assert np.array_equal(np.sort(edge[b]), np.arange(Nq * k))
+        tgt = inp[b, edge[b] // k, edge[b] % k]
+        assert np.array_equal(tgt, np.repeat(np.arange(Nsrc), np.diff(off[b])))
+        for m in (0, 3, Nsrc - 1):
+            lst = edge[b, off[b, m]:off[b, m + 1]]
+            assert (np.diff(lst) > 0).all()
+
+
+def test_backward_is_bit_reproducible(dev, ref, monkeypatch):
+    """HSP_DETERMINISTIC mode: gather-form backward has a fixed summation order -> identical bits."""
+    from hs_pose_amd import ops
+    monkeypatch.setattr(ops, "DETERMINISTIC", True)
+    B, N, k, S, C = 2, 257, 20, 7, 128
+    xyz = ref.hash_tensor((B, N, 3), 11, 0.1).to(dev)
+    fm = ref.hash_tensor((B, N, (S + 1) * C), 12, 1.0).to(dev)
+    D = F.normalize(ref.hash_tensor((3, S * C), 15, 1.0), dim=0).to(dev)
+    up = ref.hash_tensor((B, N, C), 16, 1.0).to(dev)
+    idx = ops.knn(xyz, k)
+    outs = []
+    for _ in range(2):
+        f = fm.clone().requires_grad_(True)
+        d = D.clone().requires_grad_(True)
+        (ops.rf_conv(xyz, idx, d, f, S) * up).sum().backward()
+        g2 = ref.hash_tensor((B, C), 17, 1.0).to(dev)
+        ff = fm[:, :, :C].clone().requires_grad_(True)
+        (ops.orl_global(ff, idx, k) * g2).sum().backward()
+        outs.append((f.grad.clone(), d.grad.clone(), ff.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
