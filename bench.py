@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4, help="clouds in the CPU-baseline sample")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying a hipGraph")
     args = ap.parse_args()
 
     from hs_pose_amd import ops
@@ -100,13 +101,25 @@ def main():
     centred, obj, dfeat = make_inputs(B, N, device, seed=rank)
     torch.manual_seed(1 + rank)                         # Pool_layer randperm stream (per rank)
 
-    def step():
+    def eager_step():
         for p in params:
             p.grad = None
         _, _, feat = net(centred, obj)
         feat.backward(dfeat)
         if reducer is not None:
             reducer.finish()
+
+    graphed = None
+    if not args.no_graph and world == 1:
+        # hipGraph replay of zero_grad+fwd+bwd (hs_pose_amd/graph.py); the Pool_layer randperm draws stay on
+        # the host, before each replay.  (N>1: eager, so the bucketed RCCL all-reduce overlaps backward.)
+        from hs_pose_amd.graph import GraphedStep
+        try:
+            graphed = GraphedStep(net, centred, obj, dfeat)
+        except Exception as exc:                           # capture unsupported -> measure eagerly, say so
+            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
+            graphed = None
+    step = graphed.run if graphed is not None else eager_step
 
     def fence():
         if world > 1:
@@ -117,13 +130,23 @@ def main():
         step()
     fence()
     timer = ops.KernelTimer() if rank == 0 else None
-    ops.set_timer(timer)
+    if graphed is None:
+        ops.set_timer(timer)                            # eager: per-kernel HIP events inside the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
     ops.set_timer(None)
+    if graphed is not None and rank == 0:
+        # HIP events cannot be recorded inside a graph replay: the per-kernel durations of the roofline
+        # line come from the same K steps issued eagerly right after the timed region (same kernels, same
+        # buffers); profiles/ holds the rocprofv3 trace of the graph replays themselves.
+        ops.set_timer(timer)
+        for _ in range(args.steps):
+            eager_step()
+        torch.cuda.synchronize()
+        ops.set_timer(None)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
@@ -157,7 +180,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"HS stack (FaceRecon backbone -> feat) fwd+bwd, B={B}/GPU N={N} fp32, "
                                    f"train-mode BN, random-init weights (BASELINE configs[1] shape)",
-                       "global_batch": world * B, "points": N, "parallelism": f"dp{world}",
+                       "global_batch": world * B, "points": N, "parallelism": f"dp{world}", "hipgraph": graphed is not None,
                        "libhsp_ms_per_step": round(hsp_ms, 4)},
             "roofline": {"bound": "hbm", "kernel": f"{kname}[{kkey}]", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),

@@ -53,6 +53,25 @@ def _xyz_knn(vertices, k):
 
 
 # ------------------------------------------------------------------------------------------------
+# Pool_layer sample indices supplied from outside (hipGraph replay: no host work inside the graph)
+# ------------------------------------------------------------------------------------------------
+_pool_feed = None
+
+
+@contextlib.contextmanager
+def pool_index_feed(device_indices):
+    """Within the scope, successive Pool_layer.forward calls take their kept-row indices (int32 device
+    tensors) from ``device_indices`` in call order instead of drawing torch.randperm themselves.  The
+    caller draws them exactly as the reference would (hs_pose_amd.graph.draw_pool_indices)."""
+    global _pool_feed
+    prev, _pool_feed = _pool_feed, iter(device_indices)
+    try:
+        yield
+    finally:
+        _pool_feed = prev
+
+
+# ------------------------------------------------------------------------------------------------
 # functional API (reference gcn3d.py:15-59, :189-218)
 # ------------------------------------------------------------------------------------------------
 
@@ -212,8 +231,12 @@ class Pool_layer(nn.Module):
         bs, vertice_num, _ = vertices.size()
         neighbor_index = _xyz_knn(vertices, self.neighbor_num)
         pool_num = int(vertice_num / self.pooling_rate)
-        sample_idx = torch.randperm(vertice_num)[:pool_num]
-        sel = sample_idx.to(device=vertices.device, dtype=torch.int32)
+        if _pool_feed is not None:
+            sel = next(_pool_feed)
+            assert sel.numel() == pool_num and sel.dtype == torch.int32
+        else:
+            sample_idx = torch.randperm(vertice_num)[:pool_num]
+            sel = sample_idx.to(device=vertices.device, dtype=torch.int32)
         # only the kept rows are pooled (the reference pools all N rows, then selects)
         feature_map_pool = ops.gather_max(feature_map, neighbor_index, self.neighbor_num, qsel=sel)
         vertices_pool = ops.gather_rows(vertices, sel)
