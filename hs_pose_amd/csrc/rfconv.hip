@@ -16,6 +16,24 @@ namespace hsp {
 
 #define RF_THREADS 256
 
+// F.normalize(directions, dim=0) for the 4 columns j..j+3 of the raw (3, S*C) parameter
+// (reference gcn3d.py:100,166): D / max(||D||_col, 1e-12).  Folded into every kernel so the normalised
+// copy is never materialised and its Jacobian is applied by rf_dirs_reduce_kernel.
+__device__ __forceinline__ void load_dirs_normed(const float* __restrict__ dirs, int SC, int j, float4& d0,
+                                                 float4& d1, float4& d2) {
+    d0 = *reinterpret_cast<const float4*>(dirs + j);
+    d1 = *reinterpret_cast<const float4*>(dirs + SC + j);
+    d2 = *reinterpret_cast<const float4*>(dirs + 2 * SC + j);
+#define RF_NRM(X)                                                                                    \
+    {                                                                                                \
+        const float n2 = add_rn(add_rn(mul_rn(d0.X, d0.X), mul_rn(d1.X, d1.X)), mul_rn(d2.X, d2.X)); \
+        const float nr = fmaxf(__fsqrt_rn(n2), 1e-12f);                                              \
+        d0.X = __fdiv_rn(d0.X, nr); d1.X = __fdiv_rn(d1.X, nr); d2.X = __fdiv_rn(d2.X, nr);          \
+    }
+    RF_NRM(x) RF_NRM(y) RF_NRM(z) RF_NRM(w)
+#undef RF_NRM
+}
+
 // point schedule shared by all rf kernels: blocks of XCD x handle clouds x, x+8, ... one cloud at a
 // time (keeps that cloud's fm rows resident in the XCD-private 4 MiB L2); purely a speed choice.
 struct PointIter {
@@ -39,7 +57,7 @@ struct PointIter {
 // forward.  SURFACE=true: out = mean_s max_n relu(z);  false: out = fm_c + mean_s max_n relu(z)*fm_support
 // dynamic LDS: (S*C + 4*k + k) floats
 // ------------------------------------------------------------------------------------------------
-template <bool SURFACE>
+template <bool SURFACE, int NCH>
 __global__ __launch_bounds__(RF_THREADS) void rf_fwd_kernel(const float* __restrict__ xyz,
                                                             const int32_t* __restrict__ idx,
                                                             const float* __restrict__ dirs,
@@ -55,6 +73,12 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_kernel(const float* __restr
     const int nq = SC >> 2;                                   // float4 columns
     const int fstride = (S + 1) * C;
     const float invS_div = (float)S;
+    float4 d0[NCH], d1[NCH], d2[NCH];
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+        const int cq = tid + u * RF_THREADS;
+        load_dirs_normed(dirs, SC, (cq < nq ? cq : 0) << 2, d0[u], d1[u], d2[u]);
+    }
     const PointIter it(B);
     for (int b = it.b0; b < B; b += it.bstep) {
         const float* xb = xyz + (size_t)b * N * 3;
@@ -68,35 +92,36 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_kernel(const float* __restr
                 sR[tid] = make_float4(r.x, r.y, r.z, 0.f);
             }
             __syncthreads();
-            for (int cq = tid; cq < nq; cq += RF_THREADS) {
-                const int j = cq << 2;
-                const float4 d0 = *reinterpret_cast<const float4*>(dirs + j);
-                const float4 d1 = *reinterpret_cast<const float4*>(dirs + SC + j);
-                const float4 d2 = *reinterpret_cast<const float4*>(dirs + 2 * SC + j);
-                float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-                int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-                const float* fsup = SURFACE ? nullptr : fm + (size_t)b * N * fstride + C + j;
+#pragma unroll
+            for (int u = 0; u < NCH; ++u) {
+                const int cq = tid + u * RF_THREADS;
+                if (cq < nq) {
+                    const int j = cq << 2;
+                    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                    int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                    const float* fsup = SURFACE ? nullptr : fm + (size_t)b * N * fstride + C + j;
 #pragma unroll 4
-                for (int n = 0; n < k; ++n) {
-                    const float4 r = sR[n];
-                    // theta = relu(R . D) with the k-ordered fma chain of the reference's matmul
-                    float4 th;
-                    th.x = fmaxf(__fmaf_rn(r.z, d2.x, __fmaf_rn(r.y, d1.x, mul_rn(r.x, d0.x))), 0.f);
-                    th.y = fmaxf(__fmaf_rn(r.z, d2.y, __fmaf_rn(r.y, d1.y, mul_rn(r.x, d0.y))), 0.f);
-                    th.z = fmaxf(__fmaf_rn(r.z, d2.z, __fmaf_rn(r.y, d1.z, mul_rn(r.x, d0.z))), 0.f);
-                    th.w = fmaxf(__fmaf_rn(r.z, d2.w, __fmaf_rn(r.y, d1.w, mul_rn(r.x, d0.w))), 0.f);
-                    if (!SURFACE) {
-                        const float4 f = *reinterpret_cast<const float4*>(fsup + (size_t)sIdx[n] * fstride);
-                        th.x = mul_rn(th.x, f.x); th.y = mul_rn(th.y, f.y);
-                        th.z = mul_rn(th.z, f.z); th.w = mul_rn(th.w, f.w);
+                    for (int n = 0; n < k; ++n) {
+                        const float4 r = sR[n];
+                        // theta = relu(R . D) with the k-ordered fma chain of the reference's matmul
+                        float4 th;
+                        th.x = fmaxf(__fmaf_rn(r.z, d2[u].x, __fmaf_rn(r.y, d1[u].x, mul_rn(r.x, d0[u].x))), 0.f);
+                        th.y = fmaxf(__fmaf_rn(r.z, d2[u].y, __fmaf_rn(r.y, d1[u].y, mul_rn(r.x, d0[u].y))), 0.f);
+                        th.z = fmaxf(__fmaf_rn(r.z, d2[u].z, __fmaf_rn(r.y, d1[u].z, mul_rn(r.x, d0[u].z))), 0.f);
+                        th.w = fmaxf(__fmaf_rn(r.z, d2[u].w, __fmaf_rn(r.y, d1[u].w, mul_rn(r.x, d0[u].w))), 0.f);
+                        if (!SURFACE) {
+                            const float4 f = *reinterpret_cast<const float4*>(fsup + (size_t)sIdx[n] * fstride);
+                            th.x = mul_rn(th.x, f.x); th.y = mul_rn(th.y, f.y);
+                            th.z = mul_rn(th.z, f.z); th.w = mul_rn(th.w, f.w);
+                        }
+                        if (th.x > best.x) { best.x = th.x; a0 = n; }
+                        if (th.y > best.y) { best.y = th.y; a1 = n; }
+                        if (th.z > best.z) { best.z = th.z; a2 = n; }
+                        if (th.w > best.w) { best.w = th.w; a3 = n; }
                     }
-                    if (th.x > best.x) { best.x = th.x; a0 = n; }
-                    if (th.y > best.y) { best.y = th.y; a1 = n; }
-                    if (th.z > best.z) { best.z = th.z; a2 = n; }
-                    if (th.w > best.w) { best.w = th.w; a3 = n; }
+                    *reinterpret_cast<float4*>(smax + j) = best;
+                    *reinterpret_cast<uchar4*>(argmax + pt * SC + j) = make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
                 }
-                *reinterpret_cast<float4*>(smax + j) = best;
-                *reinterpret_cast<uchar4*>(argmax + pt * SC + j) = make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
             }
             __syncthreads();
             for (int c = tid; c < C; c += RF_THREADS) {
@@ -138,9 +163,13 @@ __global__ __launch_bounds__(RF_THREADS) void rf_bwd_kernel(const float* __restr
     const int fstride = (S + 1) * C;
     const float Sdiv = (float)S;
     // per-thread direction-gradient accumulators for its (up to NCH) float4 column groups
-    float4 gd0[NCH], gd1[NCH], gd2[NCH];
+    float4 gd0[NCH], gd1[NCH], gd2[NCH], dn0[NCH], dn1[NCH], dn2[NCH];
 #pragma unroll
-    for (int u = 0; u < NCH; ++u) gd0[u] = gd1[u] = gd2[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < NCH; ++u) {
+        gd0[u] = gd1[u] = gd2[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int cq = tid + u * RF_THREADS;
+        load_dirs_normed(dirs, SC, (cq < nq ? cq : 0) << 2, dn0[u], dn1[u], dn2[u]);
+    }
     const PointIter it(B);
     for (int b = it.b0; b < B; b += it.bstep) {
         const float* xb = xyz + (size_t)b * N * 3;
@@ -166,9 +195,7 @@ __global__ __launch_bounds__(RF_THREADS) void rf_bwd_kernel(const float* __restr
                     const int j = cq << 2;
                     const uchar4 am = *reinterpret_cast<const uchar4*>(argmax + pt * SC + j);
                     const int c = j % C;                     // C % 4 == 0: the 4 columns share s
-                    const float4 d0 = *reinterpret_cast<const float4*>(dirs + j);
-                    const float4 d1 = *reinterpret_cast<const float4*>(dirs + SC + j);
-                    const float4 d2 = *reinterpret_cast<const float4*>(dirs + 2 * SC + j);
+                    const float4 d0 = dn0[u], d1 = dn1[u], d2 = dn2[u];
                     const float4 ga = *reinterpret_cast<const float4*>(sg + c);
                     const unsigned char an[4] = {am.x, am.y, am.z, am.w};
                     const float gav[4] = {ga.x, ga.y, ga.z, ga.w};
@@ -250,9 +277,7 @@ __global__ __launch_bounds__(RF_THREADS) void rf_conv_bwd_csr_kernel(
     for (int u = 0; u < NCH; ++u) {
         const int cq = tid + u * RF_THREADS;
         const int j = (cq < nq ? cq : 0) << 2;
-        d0[u] = *reinterpret_cast<const float4*>(dirs + j);
-        d1[u] = *reinterpret_cast<const float4*>(dirs + SC + j);
-        d2[u] = *reinterpret_cast<const float4*>(dirs + 2 * SC + j);
+        load_dirs_normed(dirs, SC, j, d0[u], d1[u], d2[u]);
         gd0[u] = gd1[u] = gd2[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const PointIter it(B);
@@ -374,9 +399,8 @@ __global__ __launch_bounds__(RF_THREADS) void rf_conv_bwd_tile_kernel(
     const int c = j % C;
     const float invS = 1.0f / (float)S;
     for (int q = tid; q < N * G; q += RF_THREADS) *reinterpret_cast<float4*>(acc + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 d0 = *reinterpret_cast<const float4*>(dirs + j);
-    const float4 d1 = *reinterpret_cast<const float4*>(dirs + SC + j);
-    const float4 d2 = *reinterpret_cast<const float4*>(dirs + 2 * SC + j);
+    float4 d0, d1, d2;
+    load_dirs_normed(dirs, SC, j, d0, d1, d2);
     float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
     const float* xb = xyz + (size_t)b * N * 3;
     const float* fsup = fm + (size_t)b * N * fstride + C + j;
@@ -433,32 +457,49 @@ __global__ __launch_bounds__(RF_THREADS) void rf_conv_bwd_tile_kernel(
     }
 }
 
-// out[e] = sum over blocks of ws[blk][e], e in [0, n3).  Workgroup = 64 elements x 16 block-slices;
-// every thread sums its slice with 4 independent accumulators (loads stay in flight), the 16 slices are
-// folded through LDS in a fixed order => deterministic.
-__global__ __launch_bounds__(1024) void rf_dirs_reduce_kernel(const float* __restrict__ ws, int nblk, int n3,
+// Direction-gradient epilogue.  ws[blk][3][SC] holds per-workgroup partials of d(loss)/d(D^) (D^ = the
+// column-normalised directions).  Workgroup = 64 columns x 16 block-slices: every thread sums its slice
+// for the 3 rows of its column (independent accumulators keep loads in flight), the 16 slices are folded
+// through LDS in a fixed order (deterministic), then the Jacobian of F.normalize(dim=0) is applied:
+//   n = max(||D||, 1e-12);  ||D|| > 1e-12:  gD = (gD^ - D^ (D^ . gD^)) / n ;  else gD = gD^ / 1e-12
+__global__ __launch_bounds__(1024) void rf_dirs_reduce_kernel(const float* __restrict__ ws, int nblk, int SC,
+                                                              const float* __restrict__ dirs,
                                                               float* __restrict__ out) {
-    __shared__ float red[16][64];
-    const int le = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + le;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (e < n3) {
+    __shared__ float red[16][3][64];
+    const int lj = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lj;
+    const int n3 = 3 * SC;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    if (j < SC) {
         int b = sl;
-        for (; b + 48 < nblk; b += 64) {
-            a0 += ws[(size_t)b * n3 + e];
-            a1 += ws[(size_t)(b + 16) * n3 + e];
-            a2 += ws[(size_t)(b + 32) * n3 + e];
-            a3 += ws[(size_t)(b + 48) * n3 + e];
+        for (; b + 16 < nblk; b += 32) {
+            const float* p = ws + (size_t)b * n3 + j;
+            const float* q = ws + (size_t)(b + 16) * n3 + j;
+            a0 += p[0]; a1 += p[SC]; a2 += p[2 * SC];
+            b0 += q[0]; b1 += q[SC]; b2 += q[2 * SC];
         }
-        for (; b < nblk; b += 16) a0 += ws[(size_t)b * n3 + e];
+        for (; b < nblk; b += 16) {
+            const float* p = ws + (size_t)b * n3 + j;
+            a0 += p[0]; a1 += p[SC]; a2 += p[2 * SC];
+        }
     }
-    red[sl][le] = (a0 + a1) + (a2 + a3);
+    red[sl][0][lj] = a0 + b0; red[sl][1][lj] = a1 + b1; red[sl][2][lj] = a2 + b2;
     __syncthreads();
-    if (sl == 0 && e < n3) {
-        float s = red[0][le];
+    if (sl == 0 && j < SC) {
+        float g0 = red[0][0][lj], g1 = red[0][1][lj], g2 = red[0][2][lj];
 #pragma unroll
-        for (int t = 1; t < 16; ++t) s += red[t][le];
-        out[e] = s;
+        for (int t = 1; t < 16; ++t) { g0 += red[t][0][lj]; g1 += red[t][1][lj]; g2 += red[t][2][lj]; }
+        const float x = dirs[j], y = dirs[SC + j], z = dirs[2 * SC + j];
+        const float nrm = __fsqrt_rn(add_rn(add_rn(mul_rn(x, x), mul_rn(y, y)), mul_rn(z, z)));
+        if (nrm > 1e-12f) {
+            const float hx = x / nrm, hy = y / nrm, hz = z / nrm;
+            const float dot = hx * g0 + hy * g1 + hz * g2;
+            out[j] = (g0 - hx * dot) / nrm;
+            out[SC + j] = (g1 - hy * dot) / nrm;
+            out[2 * SC + j] = (g2 - hz * dot) / nrm;
+        } else {
+            out[j] = g0 / 1e-12f; out[SC + j] = g1 / 1e-12f; out[2 * SC + j] = g2 / 1e-12f;
+        }
     }
 }
 
@@ -495,8 +536,18 @@ static int rf_fwd(const float* xyz, const int32_t* idx, const float* dirs, const
     const size_t lds = (size_t)(S * C + 5 * k) * 4;
     if (lds > 64 * 1024) return HSP_ERR_UNSUPPORTED;
     const int grid = persistent_blocks((long long)B * N, 8);
-    hipLaunchKernelGGL(rf_fwd_kernel<SURFACE>, dim3(grid), dim3(RF_THREADS), lds, as_stream(stream), xyz, idx, dirs,
-                       fm, B, N, k, S, C, out, argmax);
+    const int nch = ((S * C >> 2) + RF_THREADS - 1) / RF_THREADS;
+    if (nch > 4) return HSP_ERR_UNSUPPORTED;              // S*C <= 4096
+#define RF_FWD_LAUNCH(NCH)                                                                                        \
+    hipLaunchKernelGGL((rf_fwd_kernel<SURFACE, NCH>), dim3(grid), dim3(RF_THREADS), lds, as_stream(stream), xyz, idx, \
+                       dirs, fm, B, N, k, S, C, out, argmax)
+    switch (nch) {
+        case 1: RF_FWD_LAUNCH(1); break;
+        case 2: RF_FWD_LAUNCH(2); break;
+        case 3: RF_FWD_LAUNCH(3); break;
+        default: RF_FWD_LAUNCH(4); break;
+    }
+#undef RF_FWD_LAUNCH
     return check_launch();
 }
 
@@ -547,8 +598,7 @@ static int rf_bwd(const float* xyz, const int32_t* idx, const float* dirs, const
 #undef RF_BWD_LAUNCH
     rc = check_launch();
     if (rc) return rc;
-    const int n3 = 3 * SC;
-    hipLaunchKernelGGL(rf_dirs_reduce_kernel, dim3((n3 + 63) / 64), dim3(1024), 0, st, wsf, grid, n3, gdirs);
+    hipLaunchKernelGGL(rf_dirs_reduce_kernel, dim3((SC + 63) / 64), dim3(1024), 0, st, wsf, grid, SC, dirs, gdirs);
     return check_launch();
 }
 
@@ -588,8 +638,7 @@ extern "C" int hsp_rf_conv_bwd(const float* xyz, const float* dirs_n, const floa
 #undef RF_CSR_LAUNCH
     rc = check_launch();
     if (rc) return rc;
-    const int n3 = 3 * SC;
-    hipLaunchKernelGGL(rf_dirs_reduce_kernel, dim3((n3 + 63) / 64), dim3(1024), 0, st, wsf, grid, n3, grad_dirs_n);
+    hipLaunchKernelGGL(rf_dirs_reduce_kernel, dim3((SC + 63) / 64), dim3(1024), 0, st, wsf, grid, SC, dirs_n, grad_dirs_n);
     return check_launch();
 }
 
@@ -635,7 +684,6 @@ extern "C" int hsp_rf_conv_bwd_scatter(const float* xyz, const int32_t* idx, con
 #undef RF_TILE_LAUNCH
     rc = check_launch();
     if (rc) return rc;
-    const int n3 = 3 * SC;
-    hipLaunchKernelGGL(rf_dirs_reduce_kernel, dim3((n3 + 63) / 64), dim3(1024), 0, st, part, B, n3, grad_dirs_n);
+    hipLaunchKernelGGL(rf_dirs_reduce_kernel, dim3((SC + 63) / 64), dim3(1024), 0, st, part, B, SC, dirs_n, grad_dirs_n);
     return check_launch();
 }

@@ -164,9 +164,9 @@ class HSlayer_surface(nn.Module):
         """fused relu(R @ D^) -> max over neighbours -> mean over supports (reference :92-107).  Takes the
         int32 neighbour index (directions are recomputed in-kernel) instead of the reference's
         materialised (bs,N,k,3) receptive field."""
-        dirs_n = F.normalize(self.directions, dim=0)
         idx = neighbor_index[:, :, :neighbor_num] if neighbor_index.shape[2] != neighbor_num else neighbor_index
-        return ops.rf_surface(vertices, idx.to(torch.int32), dirs_n, self.support_num)
+        # F.normalize(self.directions, dim=0) and its Jacobian are applied inside the kernels
+        return ops.rf_surface(vertices, idx.to(torch.int32), self.directions, self.support_num)
 
     def ORL_forward(self, feature, vertices, neighbor_num):
         return _orl_fused(feature, vertices, neighbor_num, self.conv2.weight)
@@ -208,9 +208,8 @@ class HS_layer(nn.Module):
     def graph_conv(self, neighbor_index, feature_map, vertices, neighbor_num):
         """reference :158-181 with the gather, theta product, max and mean fused into one kernel."""
         bs, n, cin = feature_map.shape
-        dirs_n = F.normalize(self.directions, dim=0)
         fm = torch.addmm(self.bias, feature_map.reshape(bs * n, cin), self.weights).view(bs, n, -1)
-        return ops.rf_conv(vertices, neighbor_index.to(torch.int32), dirs_n, fm, self.support_num)
+        return ops.rf_conv(vertices, neighbor_index.to(torch.int32), self.directions, fm, self.support_num)
 
     def ORL_forward(self, feature_fuse, vertices, neighbor_num):
         return _orl_fused(feature_fuse, vertices, neighbor_num, self.conv2.weight)

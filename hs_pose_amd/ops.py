@@ -223,14 +223,15 @@ class _RFConv(torch.autograd.Function):
         return None, None, gd, gfm, None
 
 
-def rf_surface(xyz, idx, dirs_n, S):
-    """mean_s max_n relu(R . dirs_n): HSlayer_surface.graph_conv (gcn3d.py:92-107) -> (B,N,K)."""
-    return _RFSurface.apply(xyz, idx, dirs_n, S)
+def rf_surface(xyz, idx, directions, S):
+    """mean_s max_n relu(R . normalize(directions, dim=0)): HSlayer_surface.graph_conv (gcn3d.py:92-107)
+    -> (B,N,K).  ``directions`` is the RAW (3, S*K) parameter; its gradient includes the normalisation."""
+    return _RFSurface.apply(xyz, idx, directions, S)
 
 
-def rf_conv(xyz, idx, dirs_n, fm, S):
-    """HS_layer.graph_conv after the fm GEMM (gcn3d.py:166-181) -> (B,N,C)."""
-    return _RFConv.apply(xyz, idx, dirs_n, fm, S)
+def rf_conv(xyz, idx, directions, fm, S):
+    """HS_layer.graph_conv after the fm GEMM (gcn3d.py:166-181) -> (B,N,C); raw ``directions`` as above."""
+    return _RFConv.apply(xyz, idx, directions, fm, S)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -63,14 +63,15 @@ int hsp_nn1_f32(const float *tgt, int Nt, const float *src, int Ns, int B, int32
 
 /* ---- receptive-field graph convolution -------------------------------------------------------
  * replaces HSlayer_surface.graph_conv                 gcn3d.py:92-107   (+ directions of :49-59)
- * xyz (B,N,3), idx (B,N,k), dirs_n (3, S*K) = column-normalised support directions
- * out (B,N,K) = mean_s max_n relu(R[b,i,n,:] . dirs_n[:, s*K+c]),  argmax (B,N,S*K) uint8 = winning n.
+ * xyz (B,N,3), idx (B,N,k), dirs_n (3, S*K) = the RAW support-direction parameter; the kernels apply
+ * F.normalize(dim=0) (gcn3d.py:100,166: D / max(||D||_col, 1e-12)) themselves, and the backward entry
+ * points return the gradient w.r.t. the RAW parameter (normalisation Jacobian included).
+ * out (B,N,K) = mean_s max_n relu(R[b,i,n,:] . D^[:, s*K+c]),  argmax (B,N,S*K) uint8 = winning n.
  * R = normalize(xyz[idx]-xyz) is recomputed in-kernel, never materialised.
  */
 int hsp_rf_surface_fwd(const float *xyz, const int32_t *idx, const float *dirs_n, int B, int N, int k,
                        int S, int K, float *out, uint8_t *argmax, hspStream_t stream);
-/* grad_dirs_n (3,S*K) is OVERWRITTEN with d(loss)/d(dirs_n) (the column-normalisation Jacobian is
- * applied by the caller).  ws: hsp_rf_bwd_workspace_bytes(S*K). */
+/* grad_dirs_n (3,S*K) is OVERWRITTEN with d(loss)/d(raw directions).  ws: hsp_rf_bwd_workspace_bytes(S*K). */
 size_t hsp_rf_bwd_workspace_bytes(int SC);
 int hsp_rf_surface_bwd(const float *xyz, const int32_t *idx, const float *dirs_n, const uint8_t *argmax,
                        const float *grad_out, int B, int N, int k, int S, int K, float *grad_dirs_n,
