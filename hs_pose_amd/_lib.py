@@ -27,7 +27,7 @@ SIGNATURES = {
     "hsp_rev_build": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "hsp_gather_max_bwd_csr": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "hsp_gather_max_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "hsp_gather_max_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "hsp_gather_max_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "hsp_gather_rows_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "hsp_gather_rows_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "hsp_chamfer_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

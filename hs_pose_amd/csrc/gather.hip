@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const float* __re
                                                                int idx_shared, const int32_t* __restrict__ qsel,
                                                                const uint8_t* __restrict__ argmax, int Nsrc,
                                                                int Nidx, int Nq, int kstride, int C,
-                                                               float* __restrict__ gfeat) {
+                                                               float* __restrict__ gfeat, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* acc = reinterpret_cast<float*>(smem);
     int* cnt = reinterpret_cast<int*>(smem);
@@ -136,7 +136,9 @@ __global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const float* __re
         } else {
             v = *reinterpret_cast<const float4*>(acc + m * TC + g4 * 4);
         }
-        *reinterpret_cast<float4*>(gfeat + ((size_t)b * Nsrc + m) * C + j0 + g4 * 4) = v;
+        float4* dst = reinterpret_cast<float4*>(gfeat + ((size_t)b * Nsrc + m) * C + j0 + g4 * 4);
+        if (accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *dst = v;
     }
 }
 
@@ -149,7 +151,7 @@ static int pick_scatter_cols(int Nsrc, int C) {
 template <int MODE>
 static int launch_scatter_tile(int tc, const float* gout, int gstride, int gbcast, const int32_t* idx, int idx_shared,
                                const int32_t* qsel, const uint8_t* argmax, int B, int Nsrc, int Nidx, int Nq,
-                               int kstride, int C, float* gfeat, hipStream_t st) {
+                               int kstride, int C, float* gfeat, int accumulate, hipStream_t st) {
     const size_t lds = (size_t)Nsrc * tc * 4;
     dim3 grid(C / tc, B);
 #define SC_LAUNCH(TC)                                                                                              \
@@ -161,7 +163,7 @@ static int launch_scatter_tile(int tc, const float* gout, int gstride, int gbcas
             if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }                                 \
         }                                                                                                          \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, gout, gstride, gbcast, idx, idx_shared, qsel, argmax, Nsrc, \
-                           Nidx, Nq, kstride, C, gfeat);                                                           \
+                           Nidx, Nq, kstride, C, gfeat, accumulate);                                               \
     }
     if (tc == 16) SC_LAUNCH(16) else if (tc == 8) SC_LAUNCH(8) else SC_LAUNCH(4)
 #undef SC_LAUNCH
@@ -293,7 +295,7 @@ extern "C" int hsp_gather_max_fwd(const float* feat, const int32_t* idx, const i
 
 extern "C" int hsp_gather_max_bwd(const float* grad_out, int grad_bcast, const int32_t* idx, const int32_t* qsel,
                                   const uint8_t* argmax, int B, int Nsrc, int Nidx, int Nq, int kstride, int C,
-                                  float* grad_feat, hspStream_t stream) {
+                                  float* grad_feat, int accumulate, hspStream_t stream) {
     if (!grad_out || !idx || !argmax || !grad_feat || B <= 0 || Nsrc <= 0 || Nidx <= 0 || Nq <= 0 || kstride <= 0 || C <= 0)
         return HSP_ERR_BAD_ARG;
     if (!qsel && Nq != Nidx) return HSP_ERR_BAD_ARG;
@@ -301,9 +303,11 @@ extern "C" int hsp_gather_max_bwd(const float* grad_out, int grad_bcast, const i
     hipStream_t st = as_stream(stream);
     if (const int tc = pick_scatter_cols(Nsrc, C))
         return launch_scatter_tile<0>(tc, grad_out, C, grad_bcast, idx, 0, qsel, argmax, B, Nsrc, Nidx, Nq, kstride, C,
-                                      grad_feat, st);
-    hipError_t e = hipMemsetAsync(grad_feat, 0, (size_t)B * Nsrc * C * sizeof(float), st);
-    if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
+                                      grad_feat, accumulate, st);
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(grad_feat, 0, (size_t)B * Nsrc * C * sizeof(float), st);
+        if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
+    }
     const long long total = (long long)B * Nq * (C >> 2);
     hipLaunchKernelGGL(gather_max_bwd_kernel, dim3(stream_grid(total)), dim3(256), 0, st, grad_out, grad_bcast, idx,
                        qsel, argmax, B, Nsrc, Nidx, Nq, kstride, C, grad_feat);
@@ -334,7 +338,7 @@ extern "C" int hsp_gather_rows_bwd(const float* grad_out, int grad_stride, const
     if ((C & 3) == 0 && (grad_stride & 3) == 0)
         if (const int tc = pick_scatter_cols(Nsrc, C))
             return launch_scatter_tile<1>(tc, grad_out, grad_stride, 0, idx, idx_shared, nullptr, nullptr, B, Nsrc, Nq,
-                                          Nq, 1, C, grad_feat, st);
+                                          Nq, 1, C, grad_feat, 0, st);
     hipError_t e = hipMemsetAsync(grad_feat, 0, (size_t)B * Nsrc * C * sizeof(float), st);
     if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
     const long long total = (long long)B * Nq * C;

@@ -153,12 +153,12 @@ class HSlayer_surface(nn.Module):
         self.directions.data.uniform_(-stdv, stdv)
 
     def forward(self, vertices: "(bs, vertice_num, 3)", neighbor_num: int):
-        """(bs, vertice_num, kernel_num)"""
-        f_STE = F.linear(vertices, self.STE_layer.weight.squeeze(-1))
+        """(bs, vertice_num, kernel_num) -- STE + RF-P graph conv + ORL as one fused autograd node"""
         idx = _xyz_knn(vertices, neighbor_num)                       # RF-P
-        feature = self.graph_conv(idx, vertices, neighbor_num)
-        feature = self.ORL_forward(feature, vertices, neighbor_num)
-        return feature + f_STE
+        if idx.shape[2] != neighbor_num:
+            idx = idx[:, :, :neighbor_num].contiguous()
+        return ops.surface_layer(vertices, idx, neighbor_num, self.support_num, self.directions,
+                                 self.STE_layer.weight.squeeze(-1), self.conv2.weight.squeeze(-1))
 
     def graph_conv(self, neighbor_index, vertices, neighbor_num):
         """fused relu(R @ D^) -> max over neighbours -> mean over supports (reference :92-107).  Takes the
@@ -198,12 +198,11 @@ class HS_layer(nn.Module):
 
     def forward(self, vertices: "(bs, vertice_num, 3)", feature_map: "(bs, vertice_num, in_channel)",
                 neighbor_num: int):
-        """(bs, vertice_num, out_channel)"""
-        f_STE = F.linear(feature_map, self.STE_layer.weight.squeeze(-1))
+        """(bs, vertice_num, out_channel) -- STE + fm GEMM + RF-F graph conv + ORL as one fused autograd node"""
         neighbor_index = ops.knn(feature_map, neighbor_num)          # RF-F: neighbours in feature space
-        feature = self.graph_conv(neighbor_index, feature_map, vertices, neighbor_num)
-        feature_fuse = self.ORL_forward(feature, vertices, neighbor_num)
-        return feature_fuse + f_STE
+        return ops.hs_layer(vertices, feature_map, neighbor_index, _xyz_knn(vertices, neighbor_num), neighbor_num,
+                            self.support_num, self.weights, self.bias, self.directions,
+                            self.STE_layer.weight.squeeze(-1), self.conv2.weight.squeeze(-1))
 
     def graph_conv(self, neighbor_index, feature_map, vertices, neighbor_num):
         """reference :158-181 with the gather, theta product, max and mean fused into one kernel."""

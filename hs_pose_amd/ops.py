@@ -263,7 +263,7 @@ class _GatherMax(torch.autograd.Function):
         B, Nsrc, Nidx, Nq, kstride, C = ctx.dims
         g = _req(g, torch.float32, "gather_max.grad")
         gfeat = torch.empty(B, Nsrc, C, dtype=torch.float32, device=g.device)
-        _run("hsp_gather_max_bwd", (_p(g), 0, _p(idx), _p(qsel), _p(arg), B, Nsrc, Nidx, Nq, kstride, C, _p(gfeat),
+        _run("hsp_gather_max_bwd", (_p(g), 0, _p(idx), _p(qsel), _p(arg), B, Nsrc, Nidx, Nq, kstride, C, _p(gfeat), 0,
                                     _stream()),
              key=f"B{B}Ns{Nsrc}Nq{Nq}C{C}", abytes=B * (4 * Nsrc * C + Nq * (4 * kstride + 5 * C)))
         return gfeat, None, None, None
@@ -298,7 +298,7 @@ class _OrlGlobal(torch.autograd.Function):
             _run("hsp_gather_max_bwd_csr", (_p(g), 1, _p(arg), _p(off), _p(edge), B, N, N, ctx.k, C, _p(gfeat), _stream()),
                  key=f"B{B}Ns{N}Nq{N}k{ctx.k}C{C}bc", abytes=B * N * (4 * C + 8 * ctx.k + C))
         else:                  # LDS tile kernel; broadcast gradient => integer counts => reproducible as well
-            _run("hsp_gather_max_bwd", (_p(g), 1, _p(idx), _vp(0), _p(arg), B, N, N, N, kstride, C, _p(gfeat), _stream()),
+            _run("hsp_gather_max_bwd", (_p(g), 1, _p(idx), _vp(0), _p(arg), B, N, N, N, kstride, C, _p(gfeat), 0, _stream()),
                  key=f"B{B}Ns{N}Nq{N}C{C}bc", abytes=B * N * (4 * C + 4 * kstride + C))
         return gfeat, None, None
 
@@ -311,6 +311,189 @@ def gather_max(feat, idx, k, qsel=None):
 def orl_global(feat, idx, k):
     """(B,C) outlier-robust global feature (mean over points of the neighbourhood max)."""
     return _OrlGlobal.apply(feat, idx, k)
+
+
+# ------------------------------------------------------------------------------------------------
+# whole HS layers as ONE autograd node each (hand-written backward)
+#
+# Autograd over the small ops above costs ~25 tiny add / copy / reduce kernels per layer and step; here
+# the layer is laid out as its minimal kernel sequence and every gradient sum is an in-place GEMM
+# accumulation (addmm_) or a kernel epilogue:
+#   forward   fm = X W + b ; F = graph_conv(fm) ; fg = mean_i max_n F[idx_xyz] ; t = fg Wb^T
+#             out = F + F Wa^T + X Wste^T + t[b]                  (conv2 = [Wa | Wb], gcn3d.py:109-113,183-187)
+#   backward  gt = sum_i g ; gWb = gt^T fg ; gfg = gt Wb
+#             gF = g + g Wa  (+= ORL scatter of gfg/N, accumulated by the kernel) ; gWa = g^T F
+#             gfm, gD = graph_conv_bwd(gF) ; gW = X^T gfm ; gb = colsum(gfm)
+#             gX = g Wste + gfm W^T ; gWste = g^T X
+# ------------------------------------------------------------------------------------------------
+
+def _orl_fwd_raw(F3, idx_x, k):
+    B, N, C = F3.shape
+    G = torch.empty(B, N, C, dtype=torch.float32, device=F3.device)
+    arg = torch.empty(B, N, C, dtype=torch.uint8, device=F3.device)
+    _run("hsp_gather_max_fwd", (_p(F3), _p(idx_x), _vp(0), B, N, N, N, k, idx_x.shape[2], C, _p(G), _p(arg), _stream()),
+         key=f"B{B}Ns{N}Nq{N}k{k}C{C}", abytes=B * N * (4 * C + 4 * k + 5 * C))
+    return G.mean(dim=1), arg
+
+
+def _orl_bwd_accumulate_raw(gfg_over_n, idx_x, arg, k, gF3):
+    """gF3[b, idx_x[b,i,arg[b,i,c]], c] += gfg_over_n[b,c]   (in place)"""
+    B, N, C = gF3.shape
+    if DETERMINISTIC:
+        tmp = torch.empty_like(gF3)
+        off, edge = rev_index(idx_x, k, N)
+        _run("hsp_gather_max_bwd_csr", (_p(gfg_over_n), 1, _p(arg), _p(off), _p(edge), B, N, N, k, C, _p(tmp), _stream()),
+             key=f"B{B}Ns{N}Nq{N}k{k}C{C}bc", abytes=B * N * (4 * C + 8 * k + C))
+        gF3.add_(tmp)
+    else:
+        _run("hsp_gather_max_bwd", (_p(gfg_over_n), 1, _p(idx_x), _vp(0), _p(arg), B, N, N, N, idx_x.shape[2], C,
+                                    _p(gF3), 1, _stream()),
+             key=f"B{B}Ns{N}Nq{N}C{C}bc+", abytes=B * N * (8 * C + 4 * idx_x.shape[2] + C))
+
+
+def _rf_conv_bwd_raw(xyz, idx, directions, fm, arg, gF3, S):
+    B, N, k = idx.shape
+    SC = directions.shape[1]
+    C = SC // S
+    gfm = torch.empty_like(fm)
+    gd = torch.empty_like(directions)
+    L = lib()
+    if DETERMINISTIC:
+        wsb = L.hsp_rf_bwd_workspace_bytes(SC)
+        ws = _ws(wsb, gF3.device)
+        off, edge = rev_index(idx, k, N)
+        _run("hsp_rf_conv_bwd", (_p(xyz), _p(directions), _p(fm), _p(arg), _p(gF3), _p(off), _p(edge), B, N, k, S, C,
+                                 _p(gfm), _p(gd), _p(ws), wsb, _stream()),
+             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 8 * k + 4 * SC + SC + 4 * C + 4 * (S + 1) * C) + 24 * SC)
+    else:
+        wsb = L.hsp_rf_conv_bwd_scatter_workspace_bytes(B, SC)
+        ws = _ws(wsb, gF3.device)
+        _run("hsp_rf_conv_bwd_scatter", (_p(xyz), _p(idx), _p(directions), _p(fm), _p(arg), _p(gF3), B, N, k, S, C,
+                                         _p(gfm), _p(gd), _p(ws), wsb, _stream()),
+             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 4 * k + 4 * SC + SC + 4 * C + 4 * (S + 1) * C) + 24 * SC)
+    return gfm, gd
+
+
+class _HSLayer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste, w_conv2):
+        xyz = _req(xyz, torch.float32, "hs_layer.xyz")
+        X = _req(X, torch.float32, "hs_layer.X")
+        idx_f = _req(idx_f, torch.int32, "hs_layer.idx_f")
+        idx_x = _req(idx_x, torch.int32, "hs_layer.idx_x")
+        directions = _req(directions, torch.float32, "hs_layer.directions")
+        B, N, Cin = X.shape
+        SC = directions.shape[1]
+        C = SC // S
+        X2 = X.view(B * N, Cin)
+        fm = torch.addmm(bias, X2, weights)                                    # (BN, (S+1)C)
+        F3 = torch.empty(B, N, C, dtype=torch.float32, device=X.device)
+        arg = torch.empty(B, N, SC, dtype=torch.uint8, device=X.device)
+        _run("hsp_rf_conv_fwd", (_p(xyz), _p(idx_f), _p(directions), _p(fm), B, N, k, S, C, _p(F3), _p(arg), _stream()),
+             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 4 * k + 4 * (S + 1) * C + 4 * C + SC) + 12 * SC)
+        fg, arg_o = _orl_fwd_raw(F3, idx_x, k)                                 # (B,C)
+        F2 = F3.view(B * N, C)
+        out3 = torch.empty(B, N, C, dtype=torch.float32, device=X.device)      # (returned as is: not a view)
+        out = out3.view(B * N, C)
+        torch.addmm(F2, F2, w_conv2[:, :C].t(), out=out)                       # F + F Wa^T
+        out.addmm_(X2, w_ste.t())                                              # + X Wste^T
+        out3 += (fg @ w_conv2[:, C:].t()).unsqueeze(1)                         # + t[b]
+        ctx.save_for_backward(xyz, X, idx_f, idx_x, fm, arg, F3, arg_o, fg, weights, directions, w_ste, w_conv2)
+        ctx.k, ctx.S = k, S
+        return out3
+
+    @staticmethod
+    def backward(ctx, g):
+        xyz, X, idx_f, idx_x, fm, arg, F3, arg_o, fg, weights, directions, w_ste, w_conv2 = ctx.saved_tensors
+        k, S = ctx.k, ctx.S
+        g = _req(g, torch.float32, "hs_layer.grad")
+        B, N, Cin = X.shape
+        C = F3.shape[2]
+        g2, X2, F2 = g.view(B * N, C), X.view(B * N, Cin), F3.view(B * N, C)
+        Wa, Wb = w_conv2[:, :C], w_conv2[:, C:]
+        gt = g.sum(dim=1)                                                      # (B,C)
+        g_conv2 = torch.empty_like(w_conv2)
+        torch.mm(g2.t(), F2, out=g_conv2[:, :C])                               # gWa (strided out)
+        torch.mm(gt.t(), fg, out=g_conv2[:, C:])                               # gWb
+        gF = torch.addmm(g2, g2, Wa)                                           # g + g Wa
+        gF3 = gF.view(B, N, C)
+        _orl_bwd_accumulate_raw((gt @ Wb) / N, idx_x, arg_o, k, gF3)
+        gfm, gD = _rf_conv_bwd_raw(xyz, idx_f, directions, fm.view(B, N, -1), arg, gF3, S)
+        gfm2 = gfm.view(B * N, -1)
+        gW = X2.t() @ gfm2
+        gb = gfm2.sum(dim=0)
+        g_ste = g2.t() @ X2
+        gX3 = torch.empty(B, N, Cin, dtype=torch.float32, device=g.device)
+        gXv = gX3.view(B * N, Cin)
+        torch.mm(g2, w_ste, out=gXv)
+        gXv.addmm_(gfm2, weights.t())
+        return None, gX3, None, None, None, None, gW, gb, gD, g_ste, g_conv2
+
+
+class _SurfaceLayer(torch.autograd.Function):
+    """HSlayer_surface.forward (gcn3d.py:79-90) as one node; xyz carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, xyz, idx_x, k, S, directions, w_ste, w_conv2):
+        xyz = _req(xyz, torch.float32, "surface_layer.xyz")
+        idx_x = _req(idx_x, torch.int32, "surface_layer.idx")
+        directions = _req(directions, torch.float32, "surface_layer.directions")
+        B, N, _ = xyz.shape
+        SC = directions.shape[1]
+        C = SC // S
+        if idx_x.shape[2] != k:
+            raise HspError("surface_layer: idx must have exactly k columns")
+        F3 = torch.empty(B, N, C, dtype=torch.float32, device=xyz.device)
+        arg = torch.empty(B, N, SC, dtype=torch.uint8, device=xyz.device)
+        _run("hsp_rf_surface_fwd", (_p(xyz), _p(idx_x), _p(directions), B, N, k, S, C, _p(F3), _p(arg), _stream()),
+             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 4 * k + 4 * C + SC) + 12 * SC)
+        fg, arg_o = _orl_fwd_raw(F3, idx_x, k)
+        F2, x2 = F3.view(B * N, C), xyz.view(B * N, 3)
+        out3 = torch.empty(B, N, C, dtype=torch.float32, device=xyz.device)
+        out = out3.view(B * N, C)
+        torch.addmm(F2, F2, w_conv2[:, :C].t(), out=out)
+        out.addmm_(x2, w_ste.t())
+        out3 += (fg @ w_conv2[:, C:].t()).unsqueeze(1)
+        ctx.save_for_backward(xyz, idx_x, arg, F3, arg_o, fg, directions, w_conv2)
+        ctx.k, ctx.S = k, S
+        return out3
+
+    @staticmethod
+    def backward(ctx, g):
+        xyz, idx_x, arg, F3, arg_o, fg, directions, w_conv2 = ctx.saved_tensors
+        k, S = ctx.k, ctx.S
+        g = _req(g, torch.float32, "surface_layer.grad")
+        B, N, C = F3.shape
+        SC = directions.shape[1]
+        g2, F2, x2 = g.view(B * N, C), F3.view(B * N, C), xyz.view(B * N, 3)
+        Wa, Wb = w_conv2[:, :C], w_conv2[:, C:]
+        gt = g.sum(dim=1)
+        g_conv2 = torch.empty_like(w_conv2)
+        torch.mm(g2.t(), F2, out=g_conv2[:, :C])
+        torch.mm(gt.t(), fg, out=g_conv2[:, C:])
+        gF = torch.addmm(g2, g2, Wa)
+        gF3 = gF.view(B, N, C)
+        _orl_bwd_accumulate_raw((gt @ Wb) / N, idx_x, arg_o, k, gF3)
+        gD = torch.empty_like(directions)
+        L = lib()
+        wsb = L.hsp_rf_bwd_workspace_bytes(SC)
+        ws = _ws(wsb, g.device)
+        _run("hsp_rf_surface_bwd", (_p(xyz), _p(idx_x), _p(directions), _p(arg), _p(gF3), B, N, k, S, C, _p(gD), _p(ws),
+                                    wsb, _stream()),
+             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 4 * k + 4 * C + SC) + 24 * SC)
+        g_ste = g2.t() @ x2
+        return None, None, None, None, gD, g_ste, g_conv2
+
+
+def hs_layer(xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste, w_conv2):
+    """HS_layer.forward (gcn3d.py:143-156) given the feature-space (idx_f, exactly k columns) and xyz-space
+    (idx_x, >= k columns) neighbour indices; w_ste (Cout,Cin), w_conv2 (Cout,2*Cout)."""
+    return _HSLayer.apply(xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste, w_conv2)
+
+
+def surface_layer(xyz, idx_x, k, S, directions, w_ste, w_conv2):
+    """HSlayer_surface.forward (gcn3d.py:79-90) given the xyz neighbour index (exactly k columns)."""
+    return _SurfaceLayer.apply(xyz, idx_x, k, S, directions, w_ste, w_conv2)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -126,7 +126,8 @@ int hsp_gather_max_fwd(const float *feat, const int32_t *idx, const int32_t *qse
  * Column-tile LDS scatter when a (Nsrc x 16-column) tile fits LDS, else memset + global atomics. */
 int hsp_gather_max_bwd(const float *grad_out, int grad_bcast, const int32_t *idx, const int32_t *qsel,
                        const uint8_t *argmax, int B, int Nsrc, int Nidx, int Nq, int kstride, int C,
-                       float *grad_feat, hspStream_t stream);
+                       float *grad_feat, int accumulate /* !=0: add into grad_feat instead of overwriting */,
+                       hspStream_t stream);
 /* the same result in GATHER form over hsp_rev_build(idx, k) (qsel == NULL case, Nq rows of idx):
  * each grad_feat row written once, no atomics. */
 int hsp_gather_max_bwd_csr(const float *grad_out, int grad_bcast, const uint8_t *argmax, const int32_t *rev_off,
