@@ -26,19 +26,21 @@ struct TopList {
 #pragma unroll
         for (int p = 0; p < K1; ++p) { d[p] = INFINITY; i[p] = INT_MAX; }
     }
-    // candidates arrive in ascending index order per lane, so strict '<' == lowest index first
+    // candidates arrive in ascending index order per lane, so strict '<' == lowest index first.
+    // Sorted insert that drops the largest: new d[p] = clamp(v, d[p-1], d[p]) = v_med3_f32 (one op);
+    // the index follows with one compare (shared between neighbouring slots) and two selects.
     __device__ __forceinline__ void insert(float v, int idx) {
         if (v < d[K1 - 1]) {
+            bool lt_cur = true;                       // v < d[K1-1] holds inside the branch
 #pragma unroll
             for (int p = K1 - 1; p > 0; --p) {
                 const bool lt_prev = v < d[p - 1];
-                const bool lt_cur = v < d[p];
-                d[p] = lt_prev ? d[p - 1] : (lt_cur ? v : d[p]);
                 i[p] = lt_prev ? i[p - 1] : (lt_cur ? idx : i[p]);
+                d[p] = __builtin_amdgcn_fmed3f(d[p - 1], d[p], v);
+                lt_cur = lt_prev;
             }
-            const bool lt0 = v < d[0];
-            d[0] = lt0 ? v : d[0];
-            i[0] = lt0 ? idx : i[0];
+            i[0] = lt_cur ? idx : i[0];
+            d[0] = fminf(d[0], v);
         }
     }
     __device__ __forceinline__ void store(int2* dst) const {
@@ -87,14 +89,14 @@ __device__ __forceinline__ void merge_write(const int2* __restrict__ lists, int 
 // ------------------------------------------------------------------------------------------------
 // xyz path (C == 3): the cloud (x,y,z,|p|^2) sits in LDS; T lanes share one query, each scanning
 // every T-th candidate (one broadcast ds_read_b128 per candidate); lists are merged by tournament.
-// grid (ceil(N / (256/T)), B), block 256, dynamic LDS = chunk*16 + 256*K1*8
+// grid (ceil(N / (256/T)), B), block 256, dynamic LDS = max(chunk*16, 256*K1*8)
 // ------------------------------------------------------------------------------------------------
 template <int K1, int T>
 __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ x, int N, int k, int drop,
                                                    int32_t* __restrict__ idx, int chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* pts = reinterpret_cast<float4*>(smem);
-    int2* lists = reinterpret_cast<int2*>(smem + (size_t)chunk * sizeof(float4));
+    int2* lists = reinterpret_cast<int2*>(smem);          // aliases pts once the scan is over
     constexpr int Q = 256 / T;
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
@@ -127,7 +129,8 @@ __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ x, 
             }
         }
     }
-    top.store(lists + (size_t)tid * K1);   // each lane re-reads only its own list: no barrier needed
+    __syncthreads();                       // every lane is done with pts: reuse the LDS for the lists
+    top.store(lists + (size_t)tid * K1);   // each lane re-reads only its own list: no further barrier
     merge_write<K1, T>(lists, tid, t, k, drop, valid, idx + ((size_t)b * N + (valid ? q : 0)) * k);
 }
 
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) void quad_kernel(const float* __restrict__ x, 
 #define KF_CT_STRIDE 68   // candidate chunk row stride in floats (64 + 4: 16B aligned, odd # of 16B slots)
 
 template <int K1>
-__global__ __launch_bounds__(256) void knn_feat_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restrict__ x,
                                                        const float* __restrict__ quad, int N, int C, int k,
                                                        int drop, int32_t* __restrict__ idx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -281,20 +284,30 @@ __global__ __launch_bounds__(256) void knn_feat_kernel(const float* __restrict__
 
     const int ntiles = (N + 31) >> 5;
     const int nchunks = Cp >> 6;
-    // register prefetch of one candidate chunk: 32 rows x 32 float2 = 16 float2 per lane
+    // register prefetch of one candidate chunk: 32 rows x 32 float2 = 16 float2 per lane.
+    // BRANCH-FREE on purpose: a per-element "in range ? load : 0" makes hipcc branch around every load
+    // and wait vmcnt(0) before the next one (16 serialised L2 round trips per chunk, measured 6x
+    // slower).  Rows past N are clamped to row N-1 (their distances are discarded at insertion) and
+    // columns past C are clamped then zeroed by a select (zeros add exact 0 to the fma chain).
     float2 pre[16];
+    const bool evenC = (C & 1) == 0;
     auto prefetch = [&](int tile, int chunk) {
         const int c0 = tile * 32, kc = chunk * 64;
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int e = it * 64 + lane;
-            const int row = e >> 5, pair = e & 31;
+            const int row = min(c0 + (e >> 5), N - 1), pair = e & 31;
             const int kk = kc + pair * 2;
-            float2 v = make_float2(0.f, 0.f);
-            if (c0 + row < N) {
-                if (kk + 1 < C) v = *reinterpret_cast<const float2*>(xb + (size_t)(c0 + row) * C + kk);
-                else if (kk < C) v.x = xb[(size_t)(c0 + row) * C + kk];
+            const float* rp = xb + (size_t)row * C;
+            float2 v;
+            if (evenC) {                                   // wave-uniform: 8-byte aligned pair loads
+                v = *reinterpret_cast<const float2*>(rp + min(kk, C - 2));
+            } else {
+                v.x = rp[min(kk, C - 1)];
+                v.y = rp[min(kk + 1, C - 1)];
             }
+            v.x = kk < C ? v.x : 0.f;
+            v.y = kk + 1 < C ? v.y : 0.f;
             pre[it] = v;
         }
     };
@@ -302,8 +315,9 @@ __global__ __launch_bounds__(256) void knn_feat_kernel(const float* __restrict__
     int tile = wave, chunk = 0;
     if (tile < ntiles) prefetch(tile, 0);
     f32x16 acc;
+    float qc[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; qc[r] = 0.f; }
 
     while (tile < ntiles) {
         // registers -> wave-private LDS chunk (in-order LDS ops of one wave: no barrier required)
@@ -320,6 +334,15 @@ __global__ __launch_bounds__(256) void knn_feat_kernel(const float* __restrict__
         if (ntile < ntiles) prefetch(ntile, nchunk);
         __builtin_amdgcn_wave_barrier();
 
+        // |candidate|^2 of this lane's 16 rows: issued before the MFMAs of the tile's first chunk so the
+        // loads complete under them (index clamped instead of branching: no serialised load->use chains)
+        if (chunk == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cand = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                qc[r] = quadb[cand < N ? cand : N - 1];
+            }
+        }
         const float* arow = ctile + col * KF_CT_STRIDE + h * 32;
         const float* brow = qtile + col * QS + chunk * 64 + h * 32;
 #pragma unroll
@@ -339,10 +362,8 @@ __global__ __launch_bounds__(256) void knn_feat_kernel(const float* __restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cand = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (cand < N) {
-                    const float d = add_rn(add_rn(mul_rn(acc[r], -2.0f), quadb[cand]), qq);
-                    top.insert(d, cand);
-                }
+                const float d = add_rn(add_rn(mul_rn(acc[r], -2.0f), qc[r]), qq);
+                top.insert(cand < N ? d : INFINITY, cand);       // +inf never passes the strict '<'
                 acc[r] = 0.f;
             }
         }
@@ -410,7 +431,8 @@ static int pick_k1(int m) {
 template <int K1, int T>
 static int launch_knn3(const float* x, int B, int N, int k, int drop, int32_t* idx, hipStream_t st) {
     const int chunk = N < 4096 ? N : 4096;
-    const size_t lds = (size_t)chunk * 16 + (size_t)256 * K1 * 8;
+    size_t lds = (size_t)chunk * 16;
+    if (lds < (size_t)256 * K1 * 8) lds = (size_t)256 * K1 * 8;
     auto kern = knn3_kernel<K1, T>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
