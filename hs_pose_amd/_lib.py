@@ -30,6 +30,8 @@ SIGNATURES = {
     "hsp_gather_max_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "hsp_gather_rows_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "hsp_gather_rows_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "hsp_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
+    "hsp_wgrad_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     "hsp_chamfer_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "hsp_chamfer_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "hsp_fps_workspace_bytes": (_sz, [_i, _i]),

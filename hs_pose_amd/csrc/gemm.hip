@@ -1,0 +1,190 @@
+// gemm.hip -- split-K weight-gradient GEMM on the fp32 matrix cores of gfx950.
+//
+//   C[m][n] = sum_k A[k][m] * B[k][n]          A (K x M, row stride lda), B (K x N, row stride ldb)
+//   colsum[n] = sum_k B[k][n]                  (optional: the bias gradient, fused)
+//
+// This is the parameter-gradient shape of every dense op of the HS stack (reference: autograd of
+// `feature_map @ self.weights + self.bias`, network/fs_net_repo/gcn3d.py:171, and of the 1x1 Conv1d
+// layers :85,:149,:186): K = B*N point rows (16 448 at B=16, N=1028) against a small M x N weight
+// (128 x 1024 ...).  A library GEMM sees 32 output tiles and no parallelism over K (measured 36 TF/s);
+// here K is split over up to ~2000 independent waves.
+//
+// Each wave owns a 64x64 output tile for one K slice: 4 accumulators of v_mfma_f32_32x32x2_f32
+// (fp32 in, fp32 accumulate, an exact k-ordered fma chain).  Both operands are k-major rows, which
+// is exactly the MFMA operand layout (lane l supplies A[k = 2s + (l>>5)][m], B[k][n]): a lane reads one
+// float2 of A and one of B per k-pair straight from global memory -- the two components feed the
+// even-row / odd-row (even-col / odd-col) MFMA tiles, so every half-wave reads 256 contiguous bytes;
+// no LDS, no barriers, register double-buffered prefetch 4 k-pairs deep.  Partials go to a workspace
+// and are folded in a fixed order (deterministic) by wgrad_reduce_kernel, which writes C with an
+// arbitrary leading dimension (so a gradient can land in a column block of a larger tensor).
+#include "common.h"
+
+namespace hsp {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+#define WG_UNROLL 4   // k-pairs per prefetch group
+
+template <bool COLSUM>
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ A, int lda,
+                                                    const float* __restrict__ B, int ldb, int M, int N, int K,
+                                                    int SK, int kslice, float* __restrict__ part,
+                                                    float* __restrict__ cs_part) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tiles = (M >> 6) * (N >> 6);
+    if (w >= tiles * SK) return;
+    const int slice = w / tiles, t = w - slice * tiles;
+    const int tiles_m = M >> 6;
+    const int tn = t / tiles_m, tm = t - tn * tiles_m;   // tm fastest: the waves of a block share B rows (L1/L2 reuse)
+    const int m0 = tm << 6, n0 = tn << 6;
+    const int k0 = slice * kslice;
+    const int k1 = min(K, k0 + kslice);
+    const int h = lane >> 5, i = lane & 31;
+    const float* ap = A + m0 + 2 * i;
+    const float* bp = B + n0 + 2 * i;
+    f32x16 c00, c01, c10, c11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
+    float2 cs = make_float2(0.f, 0.f);
+
+    float2 a[WG_UNROLL], b[WG_UNROLL], an[WG_UNROLL], bn[WG_UNROLL];
+    auto load_group = [&](int kk, float2 (&aa)[WG_UNROLL], float2 (&bb)[WG_UNROLL]) {
+#pragma unroll
+        for (int u = 0; u < WG_UNROLL; ++u) {
+            const int k = kk + 2 * u + h;
+            const int kc = min(k, K - 1);                       // branch-free: clamp, then zero by select
+            float2 va = *reinterpret_cast<const float2*>(ap + (size_t)kc * lda);
+            float2 vb = *reinterpret_cast<const float2*>(bp + (size_t)kc * ldb);
+            const bool ok = k < k1;
+            aa[u] = make_float2(ok ? va.x : 0.f, ok ? va.y : 0.f);
+            bb[u] = make_float2(ok ? vb.x : 0.f, ok ? vb.y : 0.f);
+        }
+    };
+    if (k0 < k1) load_group(k0, a, b);
+    for (int kk = k0; kk < k1; kk += 2 * WG_UNROLL) {
+        if (kk + 2 * WG_UNROLL < k1) load_group(kk + 2 * WG_UNROLL, an, bn);
+#pragma unroll
+        for (int u = 0; u < WG_UNROLL; ++u) {
+            c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, c00, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].y, c01, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].x, c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, c11, 0, 0, 0);
+            if (COLSUM) { cs.x += b[u].x; cs.y += b[u].y; }
+        }
+#pragma unroll
+        for (int u = 0; u < WG_UNROLL; ++u) { a[u] = an[u]; b[u] = bn[u]; }
+    }
+    // accumulator r <-> tile row (r&3) + 8*(r>>2) + 4*h, tile col i; tile (ta,tb) holds C[m0+2*row+ta][n0+2*i+tb]
+    float* pc = part + (size_t)slice * M * N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        *reinterpret_cast<float2*>(pc + (size_t)(m0 + 2 * row) * N + n0 + 2 * i) = make_float2(c00[r], c01[r]);
+        *reinterpret_cast<float2*>(pc + (size_t)(m0 + 2 * row + 1) * N + n0 + 2 * i) = make_float2(c10[r], c11[r]);
+    }
+    if (COLSUM && tm == 0) {
+        cs.x += __shfl_xor(cs.x, 32);
+        cs.y += __shfl_xor(cs.y, 32);
+        if (h == 0) *reinterpret_cast<float2*>(cs_part + (size_t)slice * N + n0 + 2 * i) = cs;
+    }
+}
+
+// C[m][n] = sum_s part[s][m][n]; likewise colsum.  Workgroup = 64 float4 elements x 4 slice groups:
+// group g sums slices g, g+4, ... with loads in flight, the 4 groups are folded through LDS in a
+// fixed order (deterministic).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int SK, int M, int N,
+                                                           float* __restrict__ C, int ldc,
+                                                           const float* __restrict__ cs_part,
+                                                           float* __restrict__ colsum) {
+    __shared__ float4 red[4][64];
+    const int le = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int nq = N >> 2;
+    const long long total = (long long)M * nq;                 // float4 elements of C
+    const long long ncs = colsum ? (N >> 2) : 0;               // float4 elements of colsum
+    const long long e = (long long)blockIdx.x * 64 + le;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* src = nullptr;
+    size_t stride = 0;
+    if (e < total) { src = part + (size_t)e * 4; stride = (size_t)M * N; }
+    else if (e < total + ncs) { src = cs_part + (size_t)(e - total) * 4; stride = (size_t)N; }
+    if (src) {
+        float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        int sl = sg;
+        for (; sl + 4 < SK; sl += 8) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)sl * stride);
+            const float4 u = *reinterpret_cast<const float4*>(src + (size_t)(sl + 4) * stride);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            s2.x += u.x; s2.y += u.y; s2.z += u.z; s2.w += u.w;
+        }
+        if (sl < SK) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)sl * stride);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        s.x += s2.x; s.y += s2.y; s.z += s2.z; s.w += s2.w;
+    }
+    red[sg][le] = s;
+    __syncthreads();
+    if (sg == 0 && src) {
+        float4 r = red[0][le];
+#pragma unroll
+        for (int g = 1; g < 4; ++g) { const float4 v = red[g][le]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+        if (e < total) {
+            const int m = (int)(e / nq), q = (int)(e - (long long)m * nq);
+            float* c = C + (size_t)m * ldc + (q << 2);
+            c[0] = r.x; c[1] = r.y; c[2] = r.z; c[3] = r.w;    // ldc need not be a multiple of 4
+        } else {
+            *reinterpret_cast<float4*>(colsum + (size_t)(e - total) * 4) = r;
+        }
+    }
+}
+
+static int wgrad_pick_sk(int M, int N, int K, int* kslice) {
+    const int tiles = (M >> 6) * (N >> 6);
+    int sk = (2048 + tiles - 1) / tiles;                       // ~2 waves per SIMD
+    int max_sk = (K + 127) / 128;                              // at least 128 rows per slice
+    if (max_sk > 64) max_sk = 64;                              // bound the partial-sum traffic
+    if (sk > max_sk) sk = max_sk;
+    if (sk < 1) sk = 1;
+    int ks = (K + sk - 1) / sk;
+    ks = (ks + 2 * WG_UNROLL - 1) / (2 * WG_UNROLL) * (2 * WG_UNROLL);
+    sk = (K + ks - 1) / ks;
+    *kslice = ks;
+    return sk;
+}
+
+}  // namespace hsp
+
+using namespace hsp;
+
+extern "C" size_t hsp_wgrad_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    int ks;
+    const int sk = wgrad_pick_sk(M, N, K, &ks);
+    return (size_t)sk * ((size_t)M * N + N) * sizeof(float);
+}
+
+extern "C" int hsp_wgrad_f32(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc,
+                             float* colsum_B, void* ws, size_t ws_bytes, hspStream_t stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda < M || ldb < N || ldc < N) return HSP_ERR_BAD_ARG;
+    if ((M & 63) || (N & 63) || (lda & 1) || (ldb & 1)) return HSP_ERR_UNSUPPORTED;   // 64x64 wave tiles, float2 loads
+    if (!ws || ws_bytes < hsp_wgrad_workspace_bytes(M, N, K)) return HSP_ERR_WORKSPACE;
+    int ks;
+    const int sk = wgrad_pick_sk(M, N, K, &ks);
+    float* part = reinterpret_cast<float*>(ws);
+    float* cs_part = part + (size_t)sk * M * N;
+    const int waves = (M >> 6) * (N >> 6) * sk;
+    hipStream_t st = as_stream(stream);
+    if (colsum_B)
+        hipLaunchKernelGGL(wgrad_kernel<true>, dim3((waves + 3) / 4), dim3(256), 0, st, A, lda, B, ldb, M, N, K, sk, ks,
+                           part, cs_part);
+    else
+        hipLaunchKernelGGL(wgrad_kernel<false>, dim3((waves + 3) / 4), dim3(256), 0, st, A, lda, B, ldb, M, N, K, sk, ks,
+                           part, cs_part);
+    int rc = check_launch();
+    if (rc) return rc;
+    const long long total = (long long)M * (N >> 2) + (colsum_B ? (N >> 2) : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, part, sk, M, N, C,
+                       ldc, cs_part, colsum_B);
+    return check_launch();
+}

@@ -327,6 +327,30 @@ def orl_global(feat, idx, k):
 #             gX = g Wste + gfm W^T ; gWste = g^T X
 # ------------------------------------------------------------------------------------------------
 
+def wgrad(A2, B2, out=None, colsum=False):
+    """A2^T @ B2 for point-row matrices A2 (K,M), B2 (K,N) (rows may be strided views of wider tensors)
+    -> (M,N) [+ column sums of B2]: the parameter-gradient GEMM, split-K on the fp32 matrix cores.
+    ``out`` may be a column block of a larger tensor (last-dim stride 1).  Shapes the kernel does not
+    cover (M or N not a multiple of 64, e.g. the 3-wide xyz STE) go to hipBLASLt through torch."""
+    K, M = A2.shape
+    N = B2.shape[1]
+    ok = (M % 64 == 0 and N % 64 == 0 and A2.stride(1) == 1 and B2.stride(1) == 1
+          and A2.stride(0) % 2 == 0 and B2.stride(0) % 2 == 0 and A2.dtype == torch.float32 and A2.is_cuda)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A2.device)
+    if not ok or out.stride(1) != 1:
+        torch.mm(A2.t(), B2, out=out) if out.is_contiguous() else out.copy_(A2.t() @ B2)
+        return (out, B2.sum(dim=0)) if colsum else out
+    cs = torch.empty(N, dtype=torch.float32, device=A2.device) if colsum else None
+    L = lib()
+    wsb = L.hsp_wgrad_workspace_bytes(M, N, K)
+    ws = _ws(wsb, A2.device)
+    _run("hsp_wgrad_f32", (_p(A2), A2.stride(0), _p(B2), B2.stride(0), M, N, K, _p(out), out.stride(0), _p(cs),
+                           _p(ws), wsb, _stream()),
+         key=f"M{M}N{N}K{K}", abytes=4 * (K * (M + N) + M * N))
+    return (out, cs) if colsum else out
+
+
 def _orl_fwd_raw(F3, idx_x, k):
     B, N, C = F3.shape
     G = torch.empty(B, N, C, dtype=torch.float32, device=F3.device)
@@ -413,16 +437,15 @@ class _HSLayer(torch.autograd.Function):
         Wa, Wb = w_conv2[:, :C], w_conv2[:, C:]
         gt = g.sum(dim=1)                                                      # (B,C)
         g_conv2 = torch.empty_like(w_conv2)
-        torch.mm(g2.t(), F2, out=g_conv2[:, :C])                               # gWa (strided out)
-        torch.mm(gt.t(), fg, out=g_conv2[:, C:])                               # gWb
+        wgrad(g2, F2, out=g_conv2[:, :C])                                      # gWa, written in place (ldc = 2C)
+        g_conv2[:, C:] = gt.t() @ fg                                           # gWb (tiny)
         gF = torch.addmm(g2, g2, Wa)                                           # g + g Wa
         gF3 = gF.view(B, N, C)
         _orl_bwd_accumulate_raw((gt @ Wb) / N, idx_x, arg_o, k, gF3)
         gfm, gD = _rf_conv_bwd_raw(xyz, idx_f, directions, fm.view(B, N, -1), arg, gF3, S)
         gfm2 = gfm.view(B * N, -1)
-        gW = X2.t() @ gfm2
-        gb = gfm2.sum(dim=0)
-        g_ste = g2.t() @ X2
+        gW, gb = wgrad(X2, gfm2, colsum=True)                                  # X^T gfm and the bias gradient
+        g_ste = wgrad(g2, X2)
         gX3 = torch.empty(B, N, Cin, dtype=torch.float32, device=g.device)
         gXv = gX3.view(B * N, Cin)
         torch.mm(g2, w_ste, out=gXv)
@@ -469,8 +492,8 @@ class _SurfaceLayer(torch.autograd.Function):
         Wa, Wb = w_conv2[:, :C], w_conv2[:, C:]
         gt = g.sum(dim=1)
         g_conv2 = torch.empty_like(w_conv2)
-        torch.mm(g2.t(), F2, out=g_conv2[:, :C])
-        torch.mm(gt.t(), fg, out=g_conv2[:, C:])
+        wgrad(g2, F2, out=g_conv2[:, :C])
+        g_conv2[:, C:] = gt.t() @ fg
         gF = torch.addmm(g2, g2, Wa)
         gF3 = gF.view(B, N, C)
         _orl_bwd_accumulate_raw((gt @ Wb) / N, idx_x, arg_o, k, gF3)

@@ -146,6 +146,18 @@ int hsp_gather_rows_fwd(const float *feat, const int32_t *idx, int idx_shared, i
 int hsp_gather_rows_bwd(const float *grad_out, int grad_stride, const int32_t *idx, int idx_shared, int B,
                         int Nsrc, int Nq, int C, float *grad_feat, hspStream_t stream);
 
+/* ---- weight-gradient GEMM ---------------------------------------------------------------------
+ * replaces the parameter-gradient matmuls autograd runs for `feature_map @ self.weights + self.bias`
+ * (gcn3d.py:171) and the 1x1 Conv1d layers (gcn3d.py:85,149,186):
+ *   C[m][n] = sum_k A[k][m]*B[k][n],  A (K,M) row stride lda, B (K,N) row stride ldb, C row stride ldc;
+ *   colsum_B (N) = sum_k B[k][n] when non-NULL (the bias gradient).  K is the point-row count (deep),
+ * M and N multiples of 64; split-K over independent waves on v_mfma_f32_32x32x2_f32, partials folded in
+ * a fixed order (deterministic).  ws: hsp_wgrad_workspace_bytes(M,N,K).
+ */
+size_t hsp_wgrad_workspace_bytes(int M, int N, int K);
+int hsp_wgrad_f32(const float *A, int lda, const float *B, int ldb, int M, int N, int K, float *C, int ldc,
+                  float *colsum_B, void *ws, size_t ws_bytes, hspStream_t stream);
+
 /* ---- Chamfer distance -------------------------------------------------------------------------
  * replaces cd.forward_cuda / cd.backward_cuda    tools/pyTorchChamferDistance/chamfer_distance.cpp:27-56
  * xyz1 (B,n,3), xyz2 (B,m,3) -> dist1 (B,n), dist2 (B,m) squared NN distances, idx1/idx2 int32 arg-min

@@ -19,7 +19,7 @@ def _header_symbols():
 def test_library_exports_every_declared_symbol():
     from hs_pose_amd import _lib
     syms = _header_symbols()
-    assert len(syms) >= 23
+    assert len(syms) >= 25
     L = _lib.lib()
     for s in syms:
         assert hasattr(L, s), f"libhsp.so lacks {s}"
@@ -47,6 +47,9 @@ def test_argument_validation_without_gpu():
     assert L.hsp_gather_rows_fwd(one, one, 0, 1, 8, 8, 16, one, 8, null) == -1               # out_stride < C
     assert L.hsp_fps_f32(one, 1, 8, 9, one, one, 1024, null) == -1
     assert L.hsp_fps_workspace_bytes(2, 100) == 800
+    assert L.hsp_wgrad_f32(one, 128, one, 1024, 100, 1024, 4000, one, 1024, null, one, 1 << 30, null) == -2   # M % 64
+    assert L.hsp_wgrad_f32(one, 128, one, 1024, 128, 1024, 4000, one, 1024, null, null, 0, null) == -3
+    assert L.hsp_wgrad_workspace_bytes(128, 1024, 16448) > 0
     assert L.hsp_rf_bwd_workspace_bytes(896) > 0
 
 

@@ -270,3 +270,24 @@ def test_backward_is_bit_reproducible(dev, ref, monkeypatch):
         outs.append((f.grad.clone(), d.grad.clone(), ff.grad.clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("K,M,N,lda_pad,ldc_pad", [(16448, 128, 1024, 0, 0), (4112, 256, 2048, 0, 0), (1024, 512, 512, 0, 512),
+                                                   (1000, 64, 64, 64, 0), (4113, 128, 128, 0, 128), (37, 64, 128, 0, 0)])
+def test_wgrad_gemm(dev, ref, K, M, N, lda_pad, ldc_pad):
+    """split-K MFMA weight-gradient GEMM vs fp64: A^T B, fused column sum, strided operands / output."""
+    from hs_pose_amd import ops
+    Afull = ref.hash_tensor((K, M + lda_pad), 1, 1.0).to(dev)
+    B = ref.hash_tensor((K, N), 2, 1.0).to(dev)
+    A = Afull[:, :M]
+    outfull = torch.full((M, N + ldc_pad), 7.0, device=dev)
+    out, cs = ops.wgrad(A, B, out=outfull[:, ldc_pad:], colsum=True)
+    want = (A.double().t() @ B.double())
+    scale = want.abs().max().item()
+    assert (out.double() - want).abs().max().item() <= 2e-6 * scale * max(1.0, (K / 1000) ** 0.5)
+    assert (cs.double() - B.double().sum(0)).abs().max().item() <= 2e-6 * B.double().sum(0).abs().max().item() + 1e-4
+    if ldc_pad:
+        assert (outfull[:, :ldc_pad] == 7.0).all()          # the neighbouring column block is untouched
+    # bit-reproducible (fixed-order fold of the K slices)
+    out2 = ops.wgrad(A, B)
+    assert torch.equal(out2, out.contiguous())
