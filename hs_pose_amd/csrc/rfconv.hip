@@ -63,7 +63,7 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_kernel(const float* __restr
                                                             const float* __restrict__ dirs,
                                                             const float* __restrict__ fm, int B, int N, int k,
                                                             int S, int C, float* __restrict__ out,
-                                                            uint8_t* __restrict__ argmax) {
+                                                            uint16_t* __restrict__ argrow) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int SC = S * C;
     float* smax = reinterpret_cast<float*>(smem);             // SC
@@ -120,7 +120,9 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_kernel(const float* __restr
                         if (th.w > best.w) { best.w = th.w; a3 = n; }
                     }
                     *reinterpret_cast<float4*>(smax + j) = best;
-                    *reinterpret_cast<uchar4*>(argmax + pt * SC + j) = make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
+                    // the winning SOURCE ROW m* = idx[b,i,n*] (uint16): the backward needs neither idx nor n
+                    *reinterpret_cast<ushort4*>(argrow + pt * SC + j) =
+                        make_ushort4((unsigned short)sIdx[a0], (unsigned short)sIdx[a1], (unsigned short)sIdx[a2], (unsigned short)sIdx[a3]);
                 }
             }
             __syncthreads();
@@ -136,117 +138,10 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward (scatter form).  For every point i and column j: n = argmax, m = idx[i][n];
-//   grad_fm[b,m,C+j] += ga * theta        (atomic; support rows are shared between points)
-//   grad_fm[b,i,c]    = g[b,i,c]          (centre, plain store; the buffer was zeroed before)
-//   gD[d][j]         += ga * fm[b,m,C+j] * [z>0] * R[n][d]   (registers -> per-block partials in ws)
-// with ga = g[b,i,j%C] / S.  SURFACE: only gD, with fm := 1.
-// ws layout: [gridDim.x][3][SC] floats of partial direction gradients, reduced by rf_dirs_reduce_kernel.
-// dynamic LDS: (C + 4*k + k) floats
-// ------------------------------------------------------------------------------------------------
-template <bool SURFACE, int NCH>
-__global__ __launch_bounds__(RF_THREADS) void rf_bwd_kernel(const float* __restrict__ xyz,
-                                                            const int32_t* __restrict__ idx,
-                                                            const float* __restrict__ dirs,
-                                                            const float* __restrict__ fm,
-                                                            const uint8_t* __restrict__ argmax,
-                                                            const float* __restrict__ gout, int B, int N, int k,
-                                                            int S, int C, float* __restrict__ gfm,
-                                                            float* __restrict__ ws) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int SC = S * C;
-    float* sg = reinterpret_cast<float*>(smem);               // C : g / S
-    float4* sR = reinterpret_cast<float4*>(sg + C);           // k
-    int* sIdx = reinterpret_cast<int*>(sR + k);               // k
-    const int tid = threadIdx.x;
-    const int nq = SC >> 2;
-    const int fstride = (S + 1) * C;
-    const float Sdiv = (float)S;
-    // per-thread direction-gradient accumulators for its (up to NCH) float4 column groups
-    float4 gd0[NCH], gd1[NCH], gd2[NCH], dn0[NCH], dn1[NCH], dn2[NCH];
-#pragma unroll
-    for (int u = 0; u < NCH; ++u) {
-        gd0[u] = gd1[u] = gd2[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int cq = tid + u * RF_THREADS;
-        load_dirs_normed(dirs, SC, (cq < nq ? cq : 0) << 2, dn0[u], dn1[u], dn2[u]);
-    }
-    const PointIter it(B);
-    for (int b = it.b0; b < B; b += it.bstep) {
-        const float* xb = xyz + (size_t)b * N * 3;
-        for (int i = it.i0; i < N; i += it.istep) {
-            const size_t pt = (size_t)b * N + i;
-            __syncthreads();
-            if (tid < k) {
-                const int m = idx[pt * k + tid];
-                sIdx[tid] = m;
-                const float3 r = unit_dir(xb[i * 3], xb[i * 3 + 1], xb[i * 3 + 2], xb[m * 3], xb[m * 3 + 1], xb[m * 3 + 2]);
-                sR[tid] = make_float4(r.x, r.y, r.z, 0.f);
-            }
-            for (int c = tid; c < C; c += RF_THREADS) {
-                const float g = gout[pt * C + c];
-                sg[c] = __fdiv_rn(g, Sdiv);
-                if (!SURFACE) gfm[pt * fstride + c] = g;   // centre columns: dense, owned by this point
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < NCH; ++u) {
-                const int cq = tid + u * RF_THREADS;
-                if (cq < nq) {
-                    const int j = cq << 2;
-                    const uchar4 am = *reinterpret_cast<const uchar4*>(argmax + pt * SC + j);
-                    const int c = j % C;                     // C % 4 == 0: the 4 columns share s
-                    const float4 d0 = dn0[u], d1 = dn1[u], d2 = dn2[u];
-                    const float4 ga = *reinterpret_cast<const float4*>(sg + c);
-                    const unsigned char an[4] = {am.x, am.y, am.z, am.w};
-                    const float gav[4] = {ga.x, ga.y, ga.z, ga.w};
-                    const float d0v[4] = {d0.x, d0.y, d0.z, d0.w};
-                    const float d1v[4] = {d1.x, d1.y, d1.z, d1.w};
-                    const float d2v[4] = {d2.x, d2.y, d2.z, d2.w};
-                    float* a0p = reinterpret_cast<float*>(&gd0[u]);
-                    float* a1p = reinterpret_cast<float*>(&gd1[u]);
-                    float* a2p = reinterpret_cast<float*>(&gd2[u]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int n = an[e];
-                        const float4 r = sR[n];
-                        const float z = __fmaf_rn(r.z, d2v[e], __fmaf_rn(r.y, d1v[e], mul_rn(r.x, d0v[e])));
-                        float w = gav[e];
-                        if (!SURFACE) {
-                            const size_t off = ((size_t)b * N + sIdx[n]) * fstride + C + j + e;
-                            const float fv = fm[off];
-                            const float th = fmaxf(z, 0.f);
-                            if (th != 0.f && gav[e] != 0.f) atomicAdd(gfm + off, gav[e] * th);
-                            w = gav[e] * fv;
-                        }
-                        if (z > 0.f) {
-                            a0p[e] += w * r.x;
-                            a1p[e] += w * r.y;
-                            a2p[e] += w * r.z;
-                        }
-                    }
-                }
-            }
-        }
-    }
-    // per-block partials
-    float* wsb = ws + (size_t)blockIdx.x * 3 * SC;
-#pragma unroll
-    for (int u = 0; u < NCH; ++u) {
-        const int cq = tid + u * RF_THREADS;
-        if (cq < nq) {
-            const int j = cq << 2;
-            *reinterpret_cast<float4*>(wsb + j) = gd0[u];
-            *reinterpret_cast<float4*>(wsb + SC + j) = gd1[u];
-            *reinterpret_cast<float4*>(wsb + 2 * SC + j) = gd2[u];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // backward of HS_layer.graph_conv, GATHER form (no atomics, fixed summation order).
 // A workgroup owns one SOURCE row m at a time and walks the reverse-edge list of m (csr.hip):
 // for every edge e = i*k + n with idx[b,i,n] == m and every column j
-//     hit = (argmax[b,i,j] == n);  z = R(i->m) . dirs[:,j];  ga = g[b,i,j%C] / S
+//     hit = (argrow[b,i,j] == m);  z = R(i->m) . dirs[:,j];  ga = g[b,i,j%C] / S
 //     grad_fm[b,m,C+j] += hit ? ga * relu(z) : 0
 //     gD[d][j]         += hit && z>0 ? ga * fm[b,m,C+j] * R[d] : 0        (registers -> ws partials)
 // grad_fm[b,m,c] = g[b,m,c] (centre).  Edges are staged EB at a time in LDS (unit direction, slot n,
@@ -258,7 +153,7 @@ __global__ __launch_bounds__(RF_THREADS) void rf_bwd_kernel(const float* __restr
 template <int NCH>
 __global__ __launch_bounds__(RF_THREADS) void rf_conv_bwd_csr_kernel(
     const float* __restrict__ xyz, const float* __restrict__ dirs, const float* __restrict__ fm,
-    const uint8_t* __restrict__ argmax, const float* __restrict__ gout, const int32_t* __restrict__ rev_off,
+    const uint16_t* __restrict__ argrow, const float* __restrict__ gout, const int32_t* __restrict__ rev_off,
     const int32_t* __restrict__ rev_edge, int B, int N, int k, int S, int C, float* __restrict__ gfm,
     float* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -321,15 +216,15 @@ __global__ __launch_bounds__(RF_THREADS) void rf_conv_bwd_csr_kernel(
                     if (cq < nq) {
                         const int j = cq << 2;
                         const int c = j % C;
-                        uchar4 am[RF_EB];
+                        ushort4 am[RF_EB];
 #pragma unroll
-                        for (int t = 0; t < RF_EB; ++t)
-                            if (t < ne) am[t] = *reinterpret_cast<const uchar4*>(argmax + ((size_t)b * N + sI[t]) * SC + j);
+                        for (int t = 0; t < RF_EB; ++t)     // clamped slot instead of a branch around the load
+                            am[t] = *reinterpret_cast<const ushort4*>(argrow + ((size_t)b * N + sI[t < ne ? t : 0]) * SC + j);
 #pragma unroll
                         for (int t = 0; t < RF_EB; ++t) {
                             if (t < ne) {
                                 const float4 r = sR[t];
-                                const int n = __float_as_int(r.w);
+                                const int n = m;                    // a hit is "the winner of (i,j) is this row"
                                 const float4 ga = *reinterpret_cast<const float4*>(sg + t * C + c);
 #define RF_ONE(X)                                                                                         \
     if (am[t].X == n) {                                                                                   \
@@ -368,27 +263,32 @@ __global__ __launch_bounds__(RF_THREADS) void rf_conv_bwd_csr_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward of HS_layer.graph_conv, COLUMN-TILE LDS-SCATTER form (default).
-// One workgroup per (cloud b, tile of TC support columns).  The tile of grad_fm, acc[N][TC] fp32, lives
-// in LDS (66 KB at N=1028, TC=16); the workgroup sweeps the cloud's points i, and for each column j of
-// the tile routes  ga*relu(z)  to row m = idx[b,i,argmax[b,i,j]] with an LDS atomic add (ds_add_f32:
-// no L2 round trip, hub rows only serialise inside one wave), then writes every grad_fm row segment
-// once with 16-byte stores.  In-degree hubs of feature-space KNN graphs (hundreds of edges into one row)
-// cannot unbalance it, and no reverse index is needed.  The direction gradient is accumulated in
-// registers, folded across the workgroup's point lanes in LDS in a fixed order and written to
-// gd_part[b][3][SC] (exactly one writer per element); rf_dirs_reduce_kernel then sums the B clouds.
+// backward, COLUMN-TILE LDS-SCATTER form (default for HS_layer.graph_conv; SURFACE = the surface layer,
+// which has only the direction gradient).
+// One workgroup per (cloud b, tile of TC support columns).  The tile of grad_fm, acc[N][TC] fp32, and the
+// cloud's xyz live in LDS (66 KB + 12 KB at N=1028, TC=16); the workgroup sweeps the cloud's points i and,
+// for each column j of the tile, reads the winning source row m = argrow[b,i,j] (coalesced), rebuilds
+// R(i->m) from the LDS copy of xyz, and routes  ga*relu(z)  to acc[m] with an LDS atomic add
+// (ds_add_f32: no L2 round trip; hub rows of feature-space KNN graphs only serialise inside one wave);
+// every grad_fm row segment is then written once with 16-byte stores.  The only divergent global access
+// left is the one fm[b,m,C+j] value per element that the direction gradient needs.  That gradient is
+// accumulated in registers, folded across the workgroup's point lanes in LDS in a fixed order and written
+// to gd_part[b][3][SC] (one writer per element); rf_dirs_reduce_kernel sums the B clouds.
 // Only the LDS float adds are order-dependent; hsp_rf_conv_bwd (CSR form) is the bit-reproducible twin.
-// grid (SC/TC, B), block 256, dynamic LDS = max(N*TC, 256*12) floats
+// grid (SC/TC, B), block 512, dynamic LDS = max(N*TC (acc) + 3N (xyz), 512*12) floats
 // ------------------------------------------------------------------------------------------------
-template <int TC>
-__global__ __launch_bounds__(RF_THREADS) void rf_conv_bwd_tile_kernel(
-    const float* __restrict__ xyz, const int32_t* __restrict__ idx, const float* __restrict__ dirs,
-    const float* __restrict__ fm, const uint8_t* __restrict__ argmax, const float* __restrict__ gout, int B, int N,
-    int k, int S, int C, float* __restrict__ gfm, float* __restrict__ gd_part) {
+#define RF_TILE_THREADS 512   // 8 waves: with one 78 KB tile per workgroup this doubles the waves per CU
+
+template <int TC, bool SURFACE>
+__global__ __launch_bounds__(RF_TILE_THREADS) void rf_bwd_tile_kernel(
+    const float* __restrict__ xyz, const float* __restrict__ dirs, const float* __restrict__ fm,
+    const uint16_t* __restrict__ argrow, const float* __restrict__ gout, int B, int N, int S, int C,
+    float* __restrict__ gfm, float* __restrict__ gd_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* acc = reinterpret_cast<float*>(smem);
+    float* acc = reinterpret_cast<float*>(smem);                       // N*TC   (unused when SURFACE)
+    float* sx = acc + (SURFACE ? 0 : (size_t)N * TC);                  // 3*N
     constexpr int G = TC / 4;                 // float4 groups per tile
-    constexpr int PL = RF_THREADS / G;        // point lanes
+    constexpr int PL = RF_TILE_THREADS / G;        // point lanes
     const int SC = S * C;
     const int fstride = (S + 1) * C;
     const int tid = threadIdx.x;
@@ -398,28 +298,32 @@ __global__ __launch_bounds__(RF_THREADS) void rf_conv_bwd_tile_kernel(
     const int j = j0 + cg * 4;
     const int c = j % C;
     const float invS = 1.0f / (float)S;
-    for (int q = tid; q < N * G; q += RF_THREADS) *reinterpret_cast<float4*>(acc + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* xb = xyz + (size_t)b * N * 3;
+    if (!SURFACE)
+        for (int q = tid; q < N * G; q += RF_TILE_THREADS) *reinterpret_cast<float4*>(acc + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = tid; q < 3 * N; q += RF_TILE_THREADS) sx[q] = xb[q];
     float4 d0, d1, d2;
     load_dirs_normed(dirs, SC, j, d0, d1, d2);
     float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
-    const float* xb = xyz + (size_t)b * N * 3;
-    const float* fsup = fm + (size_t)b * N * fstride + C + j;
+    const float* fsup = SURFACE ? nullptr : fm + (size_t)b * N * fstride + C + j;
     __syncthreads();
     for (int p = pl; p < N; p += PL) {
         const size_t pt = (size_t)b * N + p;
-        const uchar4 am = *reinterpret_cast<const uchar4*>(argmax + pt * SC + j);
+        const ushort4 am = *reinterpret_cast<const ushort4*>(argrow + pt * SC + j);
         float4 ga = *reinterpret_cast<const float4*>(gout + pt * C + c);
         ga.x *= invS; ga.y *= invS; ga.z *= invS; ga.w *= invS;
-        const float px = xb[p * 3], py = xb[p * 3 + 1], pz = xb[p * 3 + 2];
-        const int32_t* nb = idx + pt * k;
+        const float px = sx[p * 3], py = sx[p * 3 + 1], pz = sx[p * 3 + 2];
 #define RF_T1(X, E)                                                                                  \
         {                                                                                            \
-            const int m = nb[am.X];                                                                  \
-            const float3 r = unit_dir(px, py, pz, xb[m * 3], xb[m * 3 + 1], xb[m * 3 + 2]);          \
+            const int m = am.X;                                                                      \
+            const float3 r = unit_dir(px, py, pz, sx[m * 3], sx[m * 3 + 1], sx[m * 3 + 2]);          \
             const float z = __fmaf_rn(r.z, d2.X, __fmaf_rn(r.y, d1.X, mul_rn(r.x, d0.X)));           \
             if (z > 0.f) {                                                                           \
-                atomicAdd(acc + m * TC + cg * 4 + E, ga.X * z);                                      \
-                const float w = ga.X * fsup[(size_t)m * fstride + E];                                \
+                float w = ga.X;                                                                      \
+                if (!SURFACE) {                                                                      \
+                    atomicAdd(acc + m * TC + cg * 4 + E, ga.X * z);                                  \
+                    w = ga.X * fsup[(size_t)m * fstride + E];                                        \
+                }                                                                                    \
                 g0.X += w * r.x; g1.X += w * r.y; g2.X += w * r.z;                                   \
             }                                                                                        \
         }
@@ -427,22 +331,24 @@ __global__ __launch_bounds__(RF_THREADS) void rf_conv_bwd_tile_kernel(
 #undef RF_T1
     }
     __syncthreads();
-    // flush the tile: one 16-byte store per (row, group)
-    for (int q = tid; q < N * G; q += RF_THREADS) {
-        const int m = q / G, g4 = q - m * G;
-        *reinterpret_cast<float4*>(gfm + ((size_t)b * N + m) * fstride + C + j0 + g4 * 4) =
-            *reinterpret_cast<const float4*>(acc + m * TC + g4 * 4);
-    }
-    if (j0 < C) {   // the first C/TC tiles also copy the centre columns grad_fm[b,m,c] = g[b,m,c]
-        for (int q = tid; q < N * G; q += RF_THREADS) {
+    if (!SURFACE) {
+        // flush the tile: one 16-byte store per (row, group)
+        for (int q = tid; q < N * G; q += RF_TILE_THREADS) {
             const int m = q / G, g4 = q - m * G;
-            *reinterpret_cast<float4*>(gfm + ((size_t)b * N + m) * fstride + j0 + g4 * 4) =
-                *reinterpret_cast<const float4*>(gout + ((size_t)b * N + m) * C + j0 + g4 * 4);
+            *reinterpret_cast<float4*>(gfm + ((size_t)b * N + m) * fstride + C + j0 + g4 * 4) =
+                *reinterpret_cast<const float4*>(acc + m * TC + g4 * 4);
         }
+        if (j0 < C) {   // the first C/TC tiles also copy the centre columns grad_fm[b,m,c] = g[b,m,c]
+            for (int q = tid; q < N * G; q += RF_TILE_THREADS) {
+                const int m = q / G, g4 = q - m * G;
+                *reinterpret_cast<float4*>(gfm + ((size_t)b * N + m) * fstride + j0 + g4 * 4) =
+                    *reinterpret_cast<const float4*>(gout + ((size_t)b * N + m) * C + j0 + g4 * 4);
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // fold the direction gradient across the PL point lanes (fixed order) -> gd_part[b][d][j]
-    float* red = acc;                                  // 256 x 12 floats
+    float* red = reinterpret_cast<float*>(smem);       // RF_TILE_THREADS x 12 floats
     float* mine = red + tid * 12;
     mine[0] = g0.x; mine[1] = g0.y; mine[2] = g0.z; mine[3] = g0.w;
     mine[4] = g1.x; mine[5] = g1.y; mine[6] = g1.z; mine[7] = g1.w;
@@ -523,16 +429,16 @@ using namespace hsp;
 
 static int rf_check(const void* a, const void* b, const void* c, int B, int N, int k, int S, int C) {
     if (!a || !b || !c || B <= 0 || N <= 0 || k <= 0 || S <= 0 || C <= 0) return HSP_ERR_BAD_ARG;
-    if (k > 255 || (C & 3)) return HSP_ERR_UNSUPPORTED;   // arg-max is a byte; float4 column groups
+    if (N > 65535 || (C & 3)) return HSP_ERR_UNSUPPORTED;   // winning rows are stored as uint16; float4 column groups
     return HSP_OK;
 }
 
 template <bool SURFACE>
 static int rf_fwd(const float* xyz, const int32_t* idx, const float* dirs, const float* fm, int B, int N, int k,
-                  int S, int C, float* out, uint8_t* argmax, hspStream_t stream) {
+                  int S, int C, float* out, uint16_t* argrow, hspStream_t stream) {
     int rc = rf_check(xyz, idx, dirs, B, N, k, S, C);
     if (rc) return rc;
-    if (!out || !argmax || (!SURFACE && !fm)) return HSP_ERR_BAD_ARG;
+    if (!out || !argrow || (!SURFACE && !fm)) return HSP_ERR_BAD_ARG;
     const size_t lds = (size_t)(S * C + 5 * k) * 4;
     if (lds > 64 * 1024) return HSP_ERR_UNSUPPORTED;
     const int grid = persistent_blocks((long long)B * N, 8);
@@ -540,7 +446,7 @@ static int rf_fwd(const float* xyz, const int32_t* idx, const float* dirs, const
     if (nch > 4) return HSP_ERR_UNSUPPORTED;              // S*C <= 4096
 #define RF_FWD_LAUNCH(NCH)                                                                                        \
     hipLaunchKernelGGL((rf_fwd_kernel<SURFACE, NCH>), dim3(grid), dim3(RF_THREADS), lds, as_stream(stream), xyz, idx, \
-                       dirs, fm, B, N, k, S, C, out, argmax)
+                       dirs, fm, B, N, k, S, C, out, argrow)
     switch (nch) {
         case 1: RF_FWD_LAUNCH(1); break;
         case 2: RF_FWD_LAUNCH(2); break;
@@ -552,13 +458,13 @@ static int rf_fwd(const float* xyz, const int32_t* idx, const float* dirs, const
 }
 
 extern "C" int hsp_rf_surface_fwd(const float* xyz, const int32_t* idx, const float* dirs_n, int B, int N, int k,
-                                  int S, int K, float* out, uint8_t* argmax, hspStream_t stream) {
-    return rf_fwd<true>(xyz, idx, dirs_n, nullptr, B, N, k, S, K, out, argmax, stream);
+                                  int S, int K, float* out, uint16_t* argrow, hspStream_t stream) {
+    return rf_fwd<true>(xyz, idx, dirs_n, nullptr, B, N, k, S, K, out, argrow, stream);
 }
 
 extern "C" int hsp_rf_conv_fwd(const float* xyz, const int32_t* idx, const float* dirs_n, const float* fm, int B,
-                               int N, int k, int S, int C, float* out, uint8_t* argmax, hspStream_t stream) {
-    return rf_fwd<false>(xyz, idx, dirs_n, fm, B, N, k, S, C, out, argmax, stream);
+                               int N, int k, int S, int C, float* out, uint16_t* argrow, hspStream_t stream) {
+    return rf_fwd<false>(xyz, idx, dirs_n, fm, B, N, k, S, C, out, argrow, stream);
 }
 
 extern "C" size_t hsp_rf_bwd_workspace_bytes(int SC) {
@@ -566,56 +472,13 @@ extern "C" size_t hsp_rf_bwd_workspace_bytes(int SC) {
     return (size_t)rf_bwd_grid_max(SC) * 3 * (size_t)SC * sizeof(float);
 }
 
-template <bool SURFACE>
-static int rf_bwd(const float* xyz, const int32_t* idx, const float* dirs, const float* fm, const uint8_t* argmax,
-                  const float* gout, int B, int N, int k, int S, int C, float* gfm, float* gdirs, void* ws,
-                  size_t ws_bytes, hspStream_t stream) {
-    int rc = rf_check(xyz, idx, dirs, B, N, k, S, C);
-    if (rc) return rc;
-    if (!argmax || !gout || !gdirs || (!SURFACE && (!fm || !gfm))) return HSP_ERR_BAD_ARG;
-    const int SC = S * C;
-    if (!ws || ws_bytes < hsp_rf_bwd_workspace_bytes(SC)) return HSP_ERR_WORKSPACE;
-    const int nq = SC >> 2;
-    const int nch = (nq + RF_THREADS - 1) / RF_THREADS;
-    if (nch > 4) return HSP_ERR_UNSUPPORTED;              // S*C <= 4096
-    hipStream_t st = as_stream(stream);
-    if (!SURFACE) {
-        hipError_t e = hipMemsetAsync(gfm, 0, (size_t)B * N * (S + 1) * C * sizeof(float), st);
-        if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
-    }
-    const int grid = rf_bwd_grid((long long)B * N, SC);
-    const size_t lds = (size_t)(C + 5 * k) * 4;
-    float* wsf = reinterpret_cast<float*>(ws);
-#define RF_BWD_LAUNCH(NCH)                                                                                     \
-    hipLaunchKernelGGL((rf_bwd_kernel<SURFACE, NCH>), dim3(grid), dim3(RF_THREADS), lds, st, xyz, idx, dirs, fm, \
-                       argmax, gout, B, N, k, S, C, gfm, wsf)
-    switch (nch) {
-        case 1: RF_BWD_LAUNCH(1); break;
-        case 2: RF_BWD_LAUNCH(2); break;
-        case 3: RF_BWD_LAUNCH(3); break;
-        default: RF_BWD_LAUNCH(4); break;
-    }
-#undef RF_BWD_LAUNCH
-    rc = check_launch();
-    if (rc) return rc;
-    hipLaunchKernelGGL(rf_dirs_reduce_kernel, dim3((SC + 63) / 64), dim3(1024), 0, st, wsf, grid, SC, dirs, gdirs);
-    return check_launch();
-}
-
-extern "C" int hsp_rf_surface_bwd(const float* xyz, const int32_t* idx, const float* dirs_n, const uint8_t* argmax,
-                                  const float* grad_out, int B, int N, int k, int S, int K, float* grad_dirs_n,
-                                  void* ws, size_t ws_bytes, hspStream_t stream) {
-    return rf_bwd<true>(xyz, idx, dirs_n, nullptr, argmax, grad_out, B, N, k, S, K, nullptr, grad_dirs_n, ws,
-                        ws_bytes, stream);   // no scatter in the surface layer: only the direction gradient
-}
-
-extern "C" int hsp_rf_conv_bwd(const float* xyz, const float* dirs_n, const float* fm, const uint8_t* argmax,
+extern "C" int hsp_rf_conv_bwd(const float* xyz, const float* dirs_n, const float* fm, const uint16_t* argrow,
                                const float* grad_out, const int32_t* rev_off, const int32_t* rev_edge, int B, int N,
                                int k, int S, int C, float* grad_fm, float* grad_dirs_n, void* ws, size_t ws_bytes,
                                hspStream_t stream) {
     int rc = rf_check(xyz, dirs_n, fm, B, N, k, S, C);
     if (rc) return rc;
-    if (!argmax || !grad_out || !rev_off || !rev_edge || !grad_fm || !grad_dirs_n) return HSP_ERR_BAD_ARG;
+    if (!argrow || !grad_out || !rev_off || !rev_edge || !grad_fm || !grad_dirs_n) return HSP_ERR_BAD_ARG;
     const int SC = S * C;
     if (!ws || ws_bytes < hsp_rf_bwd_workspace_bytes(SC)) return HSP_ERR_WORKSPACE;
     const int nq = SC >> 2;
@@ -627,7 +490,7 @@ extern "C" int hsp_rf_conv_bwd(const float* xyz, const float* dirs_n, const floa
     if (lds > 64 * 1024) return HSP_ERR_UNSUPPORTED;
     float* wsf = reinterpret_cast<float*>(ws);
 #define RF_CSR_LAUNCH(NCH)                                                                                        \
-    hipLaunchKernelGGL((rf_conv_bwd_csr_kernel<NCH>), dim3(grid), dim3(RF_THREADS), lds, st, xyz, dirs_n, fm, argmax, \
+    hipLaunchKernelGGL((rf_conv_bwd_csr_kernel<NCH>), dim3(grid), dim3(RF_THREADS), lds, st, xyz, dirs_n, fm, argrow, \
                        grad_out, rev_off, rev_edge, B, N, k, S, C, grad_fm, wsf)
     switch (nch) {
         case 1: RF_CSR_LAUNCH(1); break;
@@ -642,48 +505,64 @@ extern "C" int hsp_rf_conv_bwd(const float* xyz, const float* dirs_n, const floa
     return check_launch();
 }
 
-static int pick_tile_cols(int N, int C) {
-    for (int tc = 16; tc >= 4; tc >>= 1)
-        if (C % tc == 0 && (size_t)N * tc * 4 <= 144 * 1024) return tc;
+// column-tile scatter: the widest tile whose acc[N][TC] + xyz[N][3] fits two workgroups per CU, else one
+static int pick_tile_cols(int N, int C, bool surface) {
+    if (surface) return (C % 16 == 0) ? 16 : ((C % 8 == 0) ? 8 : 4);
+    for (int pass = 0; pass < 2; ++pass)
+        for (int tc = 16; tc >= 4; tc >>= 1)
+            if (C % tc == 0 && ((size_t)N * tc + 3 * (size_t)N) * 4 <= (pass == 0 ? 80u : 156u) * 1024) return tc;
     return 0;
 }
 
-extern "C" size_t hsp_rf_conv_bwd_scatter_workspace_bytes(int B, int SC) {
+extern "C" size_t hsp_rf_bwd_scatter_workspace_bytes(int B, int SC) {
     if (B <= 0 || SC <= 0) return 0;
     return (size_t)B * 3 * SC * sizeof(float);
 }
 
-extern "C" int hsp_rf_conv_bwd_scatter(const float* xyz, const int32_t* idx, const float* dirs_n, const float* fm,
-                                       const uint8_t* argmax, const float* grad_out, int B, int N, int k, int S, int C,
-                                       float* grad_fm, float* grad_dirs_n, void* ws, size_t ws_bytes,
-                                       hspStream_t stream) {
-    int rc = rf_check(xyz, idx, dirs_n, B, N, k, S, C);
+template <bool SURFACE>
+static int rf_bwd_scatter(const float* xyz, const float* dirs, const float* fm, const uint16_t* argrow,
+                          const float* gout, int B, int N, int S, int C, float* gfm, float* gdirs, void* ws,
+                          size_t ws_bytes, hspStream_t stream) {
+    int rc = rf_check(xyz, dirs, argrow, B, N, 1, S, C);
     if (rc) return rc;
-    if (!fm || !argmax || !grad_out || !grad_fm || !grad_dirs_n) return HSP_ERR_BAD_ARG;
+    if (!gout || !gdirs || (!SURFACE && (!fm || !gfm))) return HSP_ERR_BAD_ARG;
     const int SC = S * C;
-    if (!ws || ws_bytes < hsp_rf_conv_bwd_scatter_workspace_bytes(B, SC)) return HSP_ERR_WORKSPACE;
-    const int tc = pick_tile_cols(N, C);
+    if (!ws || ws_bytes < hsp_rf_bwd_scatter_workspace_bytes(B, SC)) return HSP_ERR_WORKSPACE;
+    const int tc = pick_tile_cols(N, C, SURFACE);
     if (!tc) return HSP_ERR_UNSUPPORTED;
-    size_t lds = (size_t)N * tc * 4;
-    if (lds < 256 * 12 * 4) lds = 256 * 12 * 4;
+    size_t lds = ((SURFACE ? 0 : (size_t)N * tc) + 3 * (size_t)N) * 4;
+    if (lds < RF_TILE_THREADS * 12 * 4) lds = RF_TILE_THREADS * 12 * 4;
     hipStream_t st = as_stream(stream);
     float* part = reinterpret_cast<float*>(ws);
     dim3 grid(SC / tc, B);
 #define RF_TILE_LAUNCH(TC)                                                                                          \
     {                                                                                                               \
-        auto kern = rf_conv_bwd_tile_kernel<TC>;                                                                    \
+        auto kern = rf_bwd_tile_kernel<TC, SURFACE>;                                                                \
         if (lds > 64 * 1024) {                                                                                      \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                 \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
             if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }                                  \
         }                                                                                                           \
-        hipLaunchKernelGGL(kern, grid, dim3(RF_THREADS), lds, st, xyz, idx, dirs_n, fm, argmax, grad_out, B, N, k, S, \
-                           C, grad_fm, part);                                                                       \
+        hipLaunchKernelGGL(kern, grid, dim3(RF_TILE_THREADS), lds, st, xyz, dirs, fm, argrow, gout, B, N, S, C, gfm, part); \
     }
     if (tc == 16) RF_TILE_LAUNCH(16) else if (tc == 8) RF_TILE_LAUNCH(8) else RF_TILE_LAUNCH(4)
 #undef RF_TILE_LAUNCH
     rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(rf_dirs_reduce_kernel, dim3((SC + 63) / 64), dim3(1024), 0, st, part, B, SC, dirs_n, grad_dirs_n);
+    hipLaunchKernelGGL(rf_dirs_reduce_kernel, dim3((SC + 63) / 64), dim3(1024), 0, st, part, B, SC, dirs, gdirs);
     return check_launch();
+}
+
+extern "C" int hsp_rf_surface_bwd(const float* xyz, const float* dirs_n, const uint16_t* argrow, const float* grad_out,
+                                  int B, int N, int S, int K, float* grad_dirs_n, void* ws, size_t ws_bytes,
+                                  hspStream_t stream) {
+    return rf_bwd_scatter<true>(xyz, dirs_n, nullptr, argrow, grad_out, B, N, S, K, nullptr, grad_dirs_n, ws, ws_bytes,
+                                stream);
+}
+
+extern "C" int hsp_rf_conv_bwd_scatter(const float* xyz, const float* dirs_n, const float* fm, const uint16_t* argrow,
+                                       const float* grad_out, int B, int N, int S, int C, float* grad_fm,
+                                       float* grad_dirs_n, void* ws, size_t ws_bytes, hspStream_t stream) {
+    return rf_bwd_scatter<false>(xyz, dirs_n, fm, argrow, grad_out, B, N, S, C, grad_fm, grad_dirs_n, ws, ws_bytes,
+                                 stream);
 }

@@ -158,7 +158,7 @@ class HSlayer_surface(nn.Module):
         if idx.shape[2] != neighbor_num:
             idx = idx[:, :, :neighbor_num].contiguous()
         return ops.surface_layer(vertices, idx, neighbor_num, self.support_num, self.directions,
-                                 self.STE_layer.weight.squeeze(-1), self.conv2.weight.squeeze(-1))
+                                 self.STE_layer.weight, self.conv2.weight)
 
     def graph_conv(self, neighbor_index, vertices, neighbor_num):
         """fused relu(R @ D^) -> max over neighbours -> mean over supports (reference :92-107).  Takes the
@@ -202,7 +202,7 @@ class HS_layer(nn.Module):
         neighbor_index = ops.knn(feature_map, neighbor_num)          # RF-F: neighbours in feature space
         return ops.hs_layer(vertices, feature_map, neighbor_index, _xyz_knn(vertices, neighbor_num), neighbor_num,
                             self.support_num, self.weights, self.bias, self.directions,
-                            self.STE_layer.weight.squeeze(-1), self.conv2.weight.squeeze(-1))
+                            self.STE_layer.weight, self.conv2.weight)
 
     def graph_conv(self, neighbor_index, feature_map, vertices, neighbor_num):
         """reference :158-181 with the gather, theta product, max and mean fused into one kernel."""

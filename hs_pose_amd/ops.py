@@ -152,9 +152,9 @@ class _RFSurface(torch.autograd.Function):
         SC = dirs_n.shape[1]
         K = SC // S
         out = torch.empty(B, N, K, dtype=torch.float32, device=xyz.device)
-        arg = torch.empty(B, N, SC, dtype=torch.uint8, device=xyz.device)
+        arg = torch.empty(B, N, SC, dtype=torch.uint16, device=xyz.device)
         _run("hsp_rf_surface_fwd", (_p(xyz), _p(idx), _p(dirs_n), B, N, k, S, K, _p(out), _p(arg), _stream()),
-             key=f"B{B}N{N}k{k}S{S}C{K}", abytes=B * N * (12 + 4 * k + 4 * K + SC) + 12 * SC)
+             key=f"B{B}N{N}k{k}S{S}C{K}", abytes=B * N * (12 + 4 * k + 4 * K + 2 * SC) + 12 * SC)
         ctx.save_for_backward(xyz, idx, dirs_n, arg)
         ctx.S = S
         return out
@@ -167,11 +167,11 @@ class _RFSurface(torch.autograd.Function):
         SC = dirs_n.shape[1]
         gd = torch.empty_like(dirs_n)
         L = lib()
-        wsb = L.hsp_rf_bwd_workspace_bytes(SC)
+        wsb = L.hsp_rf_bwd_scatter_workspace_bytes(B, SC)
         ws = _ws(wsb, g.device)
-        _run("hsp_rf_surface_bwd", (_p(xyz), _p(idx), _p(dirs_n), _p(arg), _p(g), B, N, k, ctx.S, SC // ctx.S,
-                                    _p(gd), _p(ws), wsb, _stream()),
-             key=f"B{B}N{N}k{k}S{ctx.S}C{SC // ctx.S}", abytes=B * N * (12 + 4 * k + 4 * (SC // ctx.S) + SC) + 24 * SC)
+        _run("hsp_rf_surface_bwd", (_p(xyz), _p(dirs_n), _p(arg), _p(g), B, N, ctx.S, SC // ctx.S, _p(gd), _p(ws), wsb,
+                                    _stream()),
+             key=f"B{B}N{N}S{ctx.S}C{SC // ctx.S}", abytes=B * N * (12 + 4 * (SC // ctx.S) + 2 * SC) + 24 * SC)
         return None, None, gd, None
 
 
@@ -188,9 +188,9 @@ class _RFConv(torch.autograd.Function):
         if fm.shape[-1] != (S + 1) * C:
             raise HspError("rf_conv: fm must have (S+1)*C columns")
         out = torch.empty(B, N, C, dtype=torch.float32, device=xyz.device)
-        arg = torch.empty(B, N, SC, dtype=torch.uint8, device=xyz.device)
+        arg = torch.empty(B, N, SC, dtype=torch.uint16, device=xyz.device)
         _run("hsp_rf_conv_fwd", (_p(xyz), _p(idx), _p(dirs_n), _p(fm), B, N, k, S, C, _p(out), _p(arg), _stream()),
-             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 4 * k + 4 * (S + 1) * C + 4 * C + SC) + 12 * SC)
+             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 4 * k + 4 * (S + 1) * C + 4 * C + 2 * SC) + 12 * SC)
         ctx.save_for_backward(xyz, idx, dirs_n, fm, arg)
         ctx.S = S
         return out
@@ -202,24 +202,7 @@ class _RFConv(torch.autograd.Function):
         B, N, k = idx.shape
         SC = dirs_n.shape[1]
         C = SC // ctx.S
-        gfm = torch.empty_like(fm)
-        gd = torch.empty_like(dirs_n)
-        L = lib()
-        if DETERMINISTIC:
-            wsb = L.hsp_rf_bwd_workspace_bytes(SC)
-            ws = _ws(wsb, g.device)
-            off, edge = rev_index(idx, k, N)
-            _run("hsp_rf_conv_bwd", (_p(xyz), _p(dirs_n), _p(fm), _p(arg), _p(g), _p(off), _p(edge), B, N, k, ctx.S, C,
-                                     _p(gfm), _p(gd), _p(ws), wsb, _stream()),
-                 key=f"B{B}N{N}k{k}S{ctx.S}C{C}",
-                 abytes=B * N * (12 + 8 * k + 4 * SC + SC + 4 * C + 4 * (ctx.S + 1) * C) + 24 * SC)
-        else:
-            wsb = L.hsp_rf_conv_bwd_scatter_workspace_bytes(B, SC)
-            ws = _ws(wsb, g.device)
-            _run("hsp_rf_conv_bwd_scatter", (_p(xyz), _p(idx), _p(dirs_n), _p(fm), _p(arg), _p(g), B, N, k, ctx.S, C,
-                                             _p(gfm), _p(gd), _p(ws), wsb, _stream()),
-                 key=f"B{B}N{N}k{k}S{ctx.S}C{C}",
-                 abytes=B * N * (12 + 4 * k + 4 * SC + SC + 4 * C + 4 * (ctx.S + 1) * C) + 24 * SC)
+        gfm, gd = _rf_conv_bwd_raw(xyz, idx, dirs_n, fm, arg, g, ctx.S)
         return None, None, gd, gfm, None
 
 
@@ -388,19 +371,22 @@ def _rf_conv_bwd_raw(xyz, idx, directions, fm, arg, gF3, S):
         off, edge = rev_index(idx, k, N)
         _run("hsp_rf_conv_bwd", (_p(xyz), _p(directions), _p(fm), _p(arg), _p(gF3), _p(off), _p(edge), B, N, k, S, C,
                                  _p(gfm), _p(gd), _p(ws), wsb, _stream()),
-             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 8 * k + 4 * SC + SC + 4 * C + 4 * (S + 1) * C) + 24 * SC)
+             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 8 * k + 4 * SC + 2 * SC + 4 * C + 4 * (S + 1) * C) + 24 * SC)
     else:
-        wsb = L.hsp_rf_conv_bwd_scatter_workspace_bytes(B, SC)
+        wsb = L.hsp_rf_bwd_scatter_workspace_bytes(B, SC)
         ws = _ws(wsb, gF3.device)
-        _run("hsp_rf_conv_bwd_scatter", (_p(xyz), _p(idx), _p(directions), _p(fm), _p(arg), _p(gF3), B, N, k, S, C,
-                                         _p(gfm), _p(gd), _p(ws), wsb, _stream()),
-             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 4 * k + 4 * SC + SC + 4 * C + 4 * (S + 1) * C) + 24 * SC)
+        _run("hsp_rf_conv_bwd_scatter", (_p(xyz), _p(directions), _p(fm), _p(arg), _p(gF3), B, N, S, C, _p(gfm), _p(gd),
+                                         _p(ws), wsb, _stream()),
+             key=f"B{B}N{N}S{S}C{C}", abytes=B * N * (12 + 4 * SC + 2 * SC + 4 * C + 4 * (S + 1) * C) + 24 * SC)
     return gfm, gd
 
 
 class _HSLayer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste, w_conv2):
+    def forward(ctx, xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste3, w_conv23):
+        # Conv1d weights arrive in their native (out, in, 1) shape and their gradients are returned in it:
+        # a squeezed view would make AccumulateGrad clone every gradient (one D2D copy per tensor and step)
+        w_ste, w_conv2 = w_ste3.squeeze(-1), w_conv23.squeeze(-1)
         xyz = _req(xyz, torch.float32, "hs_layer.xyz")
         X = _req(X, torch.float32, "hs_layer.X")
         idx_f = _req(idx_f, torch.int32, "hs_layer.idx_f")
@@ -412,9 +398,9 @@ class _HSLayer(torch.autograd.Function):
         X2 = X.view(B * N, Cin)
         fm = torch.addmm(bias, X2, weights)                                    # (BN, (S+1)C)
         F3 = torch.empty(B, N, C, dtype=torch.float32, device=X.device)
-        arg = torch.empty(B, N, SC, dtype=torch.uint8, device=X.device)
+        arg = torch.empty(B, N, SC, dtype=torch.uint16, device=X.device)
         _run("hsp_rf_conv_fwd", (_p(xyz), _p(idx_f), _p(directions), _p(fm), B, N, k, S, C, _p(F3), _p(arg), _stream()),
-             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 4 * k + 4 * (S + 1) * C + 4 * C + SC) + 12 * SC)
+             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 4 * k + 4 * (S + 1) * C + 4 * C + 2 * SC) + 12 * SC)
         fg, arg_o = _orl_fwd_raw(F3, idx_x, k)                                 # (B,C)
         F2 = F3.view(B * N, C)
         out3 = torch.empty(B, N, C, dtype=torch.float32, device=X.device)      # (returned as is: not a view)
@@ -422,13 +408,14 @@ class _HSLayer(torch.autograd.Function):
         torch.addmm(F2, F2, w_conv2[:, :C].t(), out=out)                       # F + F Wa^T
         out.addmm_(X2, w_ste.t())                                              # + X Wste^T
         out3 += (fg @ w_conv2[:, C:].t()).unsqueeze(1)                         # + t[b]
-        ctx.save_for_backward(xyz, X, idx_f, idx_x, fm, arg, F3, arg_o, fg, weights, directions, w_ste, w_conv2)
+        ctx.save_for_backward(xyz, X, idx_f, idx_x, fm, arg, F3, arg_o, fg, weights, directions, w_ste3, w_conv23)
         ctx.k, ctx.S = k, S
         return out3
 
     @staticmethod
     def backward(ctx, g):
-        xyz, X, idx_f, idx_x, fm, arg, F3, arg_o, fg, weights, directions, w_ste, w_conv2 = ctx.saved_tensors
+        xyz, X, idx_f, idx_x, fm, arg, F3, arg_o, fg, weights, directions, w_ste3, w_conv23 = ctx.saved_tensors
+        w_ste, w_conv2 = w_ste3.squeeze(-1), w_conv23.squeeze(-1)
         k, S = ctx.k, ctx.S
         g = _req(g, torch.float32, "hs_layer.grad")
         B, N, Cin = X.shape
@@ -450,14 +437,15 @@ class _HSLayer(torch.autograd.Function):
         gXv = gX3.view(B * N, Cin)
         torch.mm(g2, w_ste, out=gXv)
         gXv.addmm_(gfm2, weights.t())
-        return None, gX3, None, None, None, None, gW, gb, gD, g_ste, g_conv2
+        return None, gX3, None, None, None, None, gW, gb, gD, g_ste.unsqueeze_(-1), g_conv2.unsqueeze_(-1)
 
 
 class _SurfaceLayer(torch.autograd.Function):
     """HSlayer_surface.forward (gcn3d.py:79-90) as one node; xyz carries no gradient."""
 
     @staticmethod
-    def forward(ctx, xyz, idx_x, k, S, directions, w_ste, w_conv2):
+    def forward(ctx, xyz, idx_x, k, S, directions, w_ste3, w_conv23):
+        w_ste, w_conv2 = w_ste3.squeeze(-1), w_conv23.squeeze(-1)
         xyz = _req(xyz, torch.float32, "surface_layer.xyz")
         idx_x = _req(idx_x, torch.int32, "surface_layer.idx")
         directions = _req(directions, torch.float32, "surface_layer.directions")
@@ -467,9 +455,9 @@ class _SurfaceLayer(torch.autograd.Function):
         if idx_x.shape[2] != k:
             raise HspError("surface_layer: idx must have exactly k columns")
         F3 = torch.empty(B, N, C, dtype=torch.float32, device=xyz.device)
-        arg = torch.empty(B, N, SC, dtype=torch.uint8, device=xyz.device)
+        arg = torch.empty(B, N, SC, dtype=torch.uint16, device=xyz.device)
         _run("hsp_rf_surface_fwd", (_p(xyz), _p(idx_x), _p(directions), B, N, k, S, C, _p(F3), _p(arg), _stream()),
-             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 4 * k + 4 * C + SC) + 12 * SC)
+             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 4 * k + 4 * C + 2 * SC) + 12 * SC)
         fg, arg_o = _orl_fwd_raw(F3, idx_x, k)
         F2, x2 = F3.view(B * N, C), xyz.view(B * N, 3)
         out3 = torch.empty(B, N, C, dtype=torch.float32, device=xyz.device)
@@ -477,13 +465,14 @@ class _SurfaceLayer(torch.autograd.Function):
         torch.addmm(F2, F2, w_conv2[:, :C].t(), out=out)
         out.addmm_(x2, w_ste.t())
         out3 += (fg @ w_conv2[:, C:].t()).unsqueeze(1)
-        ctx.save_for_backward(xyz, idx_x, arg, F3, arg_o, fg, directions, w_conv2)
+        ctx.save_for_backward(xyz, idx_x, arg, F3, arg_o, fg, directions, w_conv23)
         ctx.k, ctx.S = k, S
         return out3
 
     @staticmethod
     def backward(ctx, g):
-        xyz, idx_x, arg, F3, arg_o, fg, directions, w_conv2 = ctx.saved_tensors
+        xyz, idx_x, arg, F3, arg_o, fg, directions, w_conv23 = ctx.saved_tensors
+        w_conv2 = w_conv23.squeeze(-1)
         k, S = ctx.k, ctx.S
         g = _req(g, torch.float32, "surface_layer.grad")
         B, N, C = F3.shape
@@ -499,18 +488,17 @@ class _SurfaceLayer(torch.autograd.Function):
         _orl_bwd_accumulate_raw((gt @ Wb) / N, idx_x, arg_o, k, gF3)
         gD = torch.empty_like(directions)
         L = lib()
-        wsb = L.hsp_rf_bwd_workspace_bytes(SC)
+        wsb = L.hsp_rf_bwd_scatter_workspace_bytes(B, SC)
         ws = _ws(wsb, g.device)
-        _run("hsp_rf_surface_bwd", (_p(xyz), _p(idx_x), _p(directions), _p(arg), _p(gF3), B, N, k, S, C, _p(gD), _p(ws),
-                                    wsb, _stream()),
-             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 4 * k + 4 * C + SC) + 24 * SC)
+        _run("hsp_rf_surface_bwd", (_p(xyz), _p(directions), _p(arg), _p(gF3), B, N, S, C, _p(gD), _p(ws), wsb, _stream()),
+             key=f"B{B}N{N}S{S}C{C}", abytes=B * N * (12 + 4 * C + 2 * SC) + 24 * SC)
         g_ste = g2.t() @ x2
-        return None, None, None, None, gD, g_ste, g_conv2
+        return None, None, None, None, gD, g_ste.unsqueeze_(-1), g_conv2.unsqueeze_(-1)
 
 
 def hs_layer(xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste, w_conv2):
     """HS_layer.forward (gcn3d.py:143-156) given the feature-space (idx_f, exactly k columns) and xyz-space
-    (idx_x, >= k columns) neighbour indices; w_ste (Cout,Cin), w_conv2 (Cout,2*Cout)."""
+    (idx_x, >= k columns) neighbour indices; w_ste (Cout,Cin,1), w_conv2 (Cout,2*Cout,1): the Conv1d weights."""
     return _HSLayer.apply(xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste, w_conv2)
 
 
@@ -542,9 +530,16 @@ class _GatherRows(torch.autograd.Function):
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
         B, Nsrc, Nq, C, shared = ctx.dims
-        g = _req(g, torch.float32, "gather_rows.grad")
+        if not (g.is_cuda and g.dtype == torch.float32):
+            raise HspError("gather_rows.grad: expected a float32 GPU tensor")
+        # a column slice of a wider row-major tensor (the grad of torch.cat) is consumed in place
+        if g.stride(2) == 1 and g.stride(0) == Nq * g.stride(1) and g.stride(1) >= C:
+            gstride = g.stride(1)
+        else:
+            g = g.contiguous()
+            gstride = C
         gfeat = torch.empty(B, Nsrc, C, dtype=torch.float32, device=g.device)
-        _run("hsp_gather_rows_bwd", (_p(g), C, _p(idx), shared, B, Nsrc, Nq, C, _p(gfeat), _stream()),
+        _run("hsp_gather_rows_bwd", (_p(g), gstride, _p(idx), shared, B, Nsrc, Nq, C, _p(gfeat), _stream()),
              key=f"B{B}Ns{Nsrc}Nq{Nq}C{C}", abytes=B * (4 * Nsrc * C + Nq * (4 + 4 * C)))
         return gfeat, None
 

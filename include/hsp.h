@@ -63,44 +63,47 @@ int hsp_nn1_f32(const float *tgt, int Nt, const float *src, int Ns, int B, int32
 
 /* ---- receptive-field graph convolution -------------------------------------------------------
  * replaces HSlayer_surface.graph_conv                 gcn3d.py:92-107   (+ directions of :49-59)
- * xyz (B,N,3), idx (B,N,k), dirs_n (3, S*K) = the RAW support-direction parameter; the kernels apply
+ * xyz (B,N,3), idx (B,N,k), dirs (3, S*K) = the RAW support-direction parameter; the kernels apply
  * F.normalize(dim=0) (gcn3d.py:100,166: D / max(||D||_col, 1e-12)) themselves, and the backward entry
  * points return the gradient w.r.t. the RAW parameter (normalisation Jacobian included).
- * out (B,N,K) = mean_s max_n relu(R[b,i,n,:] . D^[:, s*K+c]),  argmax (B,N,S*K) uint8 = winning n.
+ * out (B,N,K) = mean_s max_n relu(R[b,i,n,:] . D^[:, s*K+c]);
+ * argrow (B,N,S*K) uint16 = the SOURCE ROW idx[b,i,n*] of the winning neighbour (N <= 65535): all a
+ * backward needs -- neither idx nor the slot n is read again.
  * R = normalize(xyz[idx]-xyz) is recomputed in-kernel, never materialised.
  */
-int hsp_rf_surface_fwd(const float *xyz, const int32_t *idx, const float *dirs_n, int B, int N, int k,
-                       int S, int K, float *out, uint8_t *argmax, hspStream_t stream);
-/* grad_dirs_n (3,S*K) is OVERWRITTEN with d(loss)/d(raw directions).  ws: hsp_rf_bwd_workspace_bytes(S*K). */
-size_t hsp_rf_bwd_workspace_bytes(int SC);
-int hsp_rf_surface_bwd(const float *xyz, const int32_t *idx, const float *dirs_n, const uint8_t *argmax,
-                       const float *grad_out, int B, int N, int k, int S, int K, float *grad_dirs_n,
-                       void *ws, size_t ws_bytes, hspStream_t stream);
+int hsp_rf_surface_fwd(const float *xyz, const int32_t *idx, const float *dirs, int B, int N, int k,
+                       int S, int K, float *out, uint16_t *argrow, hspStream_t stream);
+/* grad_dirs (3,S*K) is OVERWRITTEN with d(loss)/d(raw directions).
+ * ws: hsp_rf_bwd_scatter_workspace_bytes(B, S*K). */
+size_t hsp_rf_bwd_scatter_workspace_bytes(int B, int SC);
+int hsp_rf_surface_bwd(const float *xyz, const float *dirs, const uint16_t *argrow, const float *grad_out,
+                       int B, int N, int S, int K, float *grad_dirs, void *ws, size_t ws_bytes,
+                       hspStream_t stream);
 
 /* replaces HS_layer.graph_conv after its fm GEMM      gcn3d.py:158-181  (gather of :39-47 fused)
  * fm (B,N,(S+1)*C) = feature_map @ weights + bias: columns [0,C) centre, [C+s*C+c] support s.
- * out (B,N,C) = fm[b,i,c] + mean_s max_n relu(R.dirs_n[:,sC+c]) * fm[b, idx[b,i,n], C+sC+c]
- * argmax (B,N,S*C) uint8.  The (B,N,k,S*C) tensors of the reference are never formed.
+ * out (B,N,C) = fm[b,i,c] + mean_s max_n relu(R.D^[:,sC+c]) * fm[b, idx[b,i,n], C+sC+c]
+ * argrow (B,N,S*C) uint16 as above.  The (B,N,k,S*C) tensors of the reference are never formed.
  */
-int hsp_rf_conv_fwd(const float *xyz, const int32_t *idx, const float *dirs_n, const float *fm, int B,
-                    int N, int k, int S, int C, float *out, uint8_t *argmax, hspStream_t stream);
-/* Backward, GATHER form: rev_off/rev_edge = hsp_rev_build(idx) of the SAME idx the forward used.
- * grad_fm (B,N,(S+1)*C) and grad_dirs_n (3,S*C) are OVERWRITTEN (every row written exactly once: no
- * atomics, no memset, fixed summation order). */
-int hsp_rf_conv_bwd(const float *xyz, const float *dirs_n, const float *fm, const uint8_t *argmax,
+int hsp_rf_conv_fwd(const float *xyz, const int32_t *idx, const float *dirs, const float *fm, int B,
+                    int N, int k, int S, int C, float *out, uint16_t *argrow, hspStream_t stream);
+/* Backward, COLUMN-TILE LDS-SCATTER form (the default of the Python mirror): a (cloud, 16-column) tile
+ * of grad_fm plus the cloud's xyz live in LDS; gradients are routed to row argrow[b,i,j] with ds_add_f32
+ * (immune to the in-degree hubs of feature-space graphs) and every row segment is written once.
+ * grad_fm (B,N,(S+1)*C) and grad_dirs (3,S*C) are OVERWRITTEN.  The LDS adds make grad_fm
+ * order-dependent in the last bits; hsp_rf_conv_bwd is the bit-reproducible twin.
+ * ws: hsp_rf_bwd_scatter_workspace_bytes(B, S*C). */
+int hsp_rf_conv_bwd_scatter(const float *xyz, const float *dirs, const float *fm, const uint16_t *argrow,
+                            const float *grad_out, int B, int N, int S, int C, float *grad_fm,
+                            float *grad_dirs, void *ws, size_t ws_bytes, hspStream_t stream);
+/* Backward, GATHER form over rev_off/rev_edge = hsp_rev_build(idx) of the SAME idx the forward used:
+ * every grad_fm row is summed in ascending edge order (no atomics, bit-reproducible).
+ * ws: hsp_rf_bwd_workspace_bytes(S*C). */
+size_t hsp_rf_bwd_workspace_bytes(int SC);
+int hsp_rf_conv_bwd(const float *xyz, const float *dirs, const float *fm, const uint16_t *argrow,
                     const float *grad_out, const int32_t *rev_off, const int32_t *rev_edge, int B, int N,
-                    int k, int S, int C, float *grad_fm, float *grad_dirs_n, void *ws, size_t ws_bytes,
+                    int k, int S, int C, float *grad_fm, float *grad_dirs, void *ws, size_t ws_bytes,
                     hspStream_t stream);
-
-/* Backward, COLUMN-TILE LDS-SCATTER form (the default of the Python mirror): same outputs as
- * hsp_rf_conv_bwd from idx itself, no reverse index; a (cloud, 16-column) tile of grad_fm is
- * accumulated in LDS with ds_add_f32 (immune to in-degree hubs of feature-space graphs) and written
- * once.  The LDS adds make grad_fm order-dependent in the last bits; use hsp_rf_conv_bwd when
- * bit-reproducible gradients are required.  ws: hsp_rf_conv_bwd_scatter_workspace_bytes(B, S*C). */
-size_t hsp_rf_conv_bwd_scatter_workspace_bytes(int B, int SC);
-int hsp_rf_conv_bwd_scatter(const float *xyz, const int32_t *idx, const float *dirs_n, const float *fm,
-                            const uint8_t *argmax, const float *grad_out, int B, int N, int k, int S, int C,
-                            float *grad_fm, float *grad_dirs_n, void *ws, size_t ws_bytes, hspStream_t stream);
 
 /* ---- reverse-edge (CSR) index of a neighbour graph --------------------------------------------
  * replaces the accumulate-scatter (_index_put_impl_) that autograd runs for the gather of

@@ -38,7 +38,7 @@ def test_argument_validation_without_gpu():
     assert L.hsp_knn_f32(one, 1, 100, 64, 4, 1, one, null, 0, null) == -3         # feature path needs workspace
     assert L.hsp_knn_workspace_bytes(2, 100, 3, 4) == 0
     assert L.hsp_knn_workspace_bytes(2, 100, 128, 4) == 2 * 100 * 4
-    assert L.hsp_rf_conv_fwd(one, one, one, one, 1, 8, 300, 7, 128, one, one, null) == -2   # k > 255
+    assert L.hsp_rf_conv_fwd(one, one, one, one, 1, 70000, 4, 7, 128, one, one, null) == -2  # N > 65535 (uint16 rows)
     assert L.hsp_rf_conv_fwd(one, one, one, one, 1, 8, 4, 7, 126, one, one, null) == -2     # C % 4
     assert L.hsp_rf_conv_bwd(one, one, one, one, one, one, one, 1, 8, 4, 7, 128, one, one, null, 0, null) == -3
     assert L.hsp_rev_build(one, 1, 8, 8, 4, 2, one, one, null) == -1                         # kstride < k
@@ -51,6 +51,8 @@ def test_argument_validation_without_gpu():
     assert L.hsp_wgrad_f32(one, 128, one, 1024, 128, 1024, 4000, one, 1024, null, null, 0, null) == -3
     assert L.hsp_wgrad_workspace_bytes(128, 1024, 16448) > 0
     assert L.hsp_rf_bwd_workspace_bytes(896) > 0
+    assert L.hsp_rf_bwd_scatter_workspace_bytes(16, 896) == 16 * 3 * 896 * 4
+    assert L.hsp_rf_conv_bwd_scatter(one, one, one, one, one, 1, 8, 7, 128, one, one, null, 0, null) == -3
 
 
 def test_state_dict_surface_matches_reference(flags, state_keys):
