@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4, help="clouds in the CPU-baseline sample")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-gemm-tuning", action="store_true", help="leave hipBLASLt/rocBLAS on their default heuristics")
     args = ap.parse_args()
 
     from hs_pose_amd import ops
@@ -90,6 +91,9 @@ def main():
 
     rank, world, device = init_distributed()
     assert device.type == "cuda", "bench.py measures the HIP path; it needs a GPU"
+    if not args.no_gemm_tuning:
+        from hs_pose_amd import gemm_tuning
+        gemm_tuning.enable()                            # library-GEMM solution selection (warm-up only)
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     B, N = args.batch, args.points
 

@@ -310,20 +310,21 @@ def orl_global(feat, idx, k):
 #             gX = g Wste + gfm W^T ; gWste = g^T X
 # ------------------------------------------------------------------------------------------------
 
-def wgrad(A2, B2, out=None, colsum=False):
-    """A2^T @ B2 for point-row matrices A2 (K,M), B2 (K,N) (rows may be strided views of wider tensors)
-    -> (M,N) [+ column sums of B2]: the parameter-gradient GEMM, split-K on the fp32 matrix cores.
-    ``out`` may be a column block of a larger tensor (last-dim stride 1).  Shapes the kernel does not
-    cover (M or N not a multiple of 64, e.g. the 3-wide xyz STE) go to hipBLASLt through torch."""
+_wgrad_choice = {}          # (M, N, K, colsum) -> "custom" | "library", measured at first use
+WGRAD_MODE = os.environ.get("HSP_WGRAD", "auto")     # auto | custom | library
+
+
+def _wgrad_library(A2, B2, out, colsum):
+    if out.is_contiguous():
+        torch.mm(A2.t(), B2, out=out)
+    else:
+        out.copy_(A2.t() @ B2)
+    return (out, B2.sum(dim=0)) if colsum else out
+
+
+def _wgrad_custom(A2, B2, out, colsum):
     K, M = A2.shape
     N = B2.shape[1]
-    ok = (M % 64 == 0 and N % 64 == 0 and A2.stride(1) == 1 and B2.stride(1) == 1
-          and A2.stride(0) % 2 == 0 and B2.stride(0) % 2 == 0 and A2.dtype == torch.float32 and A2.is_cuda)
-    if out is None:
-        out = torch.empty(M, N, dtype=torch.float32, device=A2.device)
-    if not ok or out.stride(1) != 1:
-        torch.mm(A2.t(), B2, out=out) if out.is_contiguous() else out.copy_(A2.t() @ B2)
-        return (out, B2.sum(dim=0)) if colsum else out
     cs = torch.empty(N, dtype=torch.float32, device=A2.device) if colsum else None
     L = lib()
     wsb = L.hsp_wgrad_workspace_bytes(M, N, K)
@@ -332,6 +333,47 @@ def wgrad(A2, B2, out=None, colsum=False):
                            _p(ws), wsb, _stream()),
          key=f"M{M}N{N}K{K}", abytes=4 * (K * (M + N) + M * N))
     return (out, cs) if colsum else out
+
+
+def _time_us(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / reps
+
+
+def wgrad(A2, B2, out=None, colsum=False):
+    """A2^T @ B2 for point-row matrices A2 (K,M), B2 (K,N) (rows may be strided views of wider tensors)
+    -> (M,N) [+ column sums of B2 = the bias gradient]: the parameter-gradient GEMM.  Two implementations:
+    the split-K fp32-MFMA kernel of csrc/gemm.hip (column sum fused, strided output, bit-reproducible) and
+    the BLAS library through torch.  ``HSP_WGRAD=auto`` (default) times both once per shape, outside any
+    graph capture, and keeps the faster; shapes the kernel does not cover (M or N not a multiple of 64,
+    e.g. the 3-wide xyz STE) always go to the library."""
+    K, M = A2.shape
+    N = B2.shape[1]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A2.device)
+    ok = (M % 64 == 0 and N % 64 == 0 and A2.stride(1) == 1 and B2.stride(1) == 1 and out.stride(1) == 1
+          and A2.stride(0) % 2 == 0 and B2.stride(0) % 2 == 0 and A2.dtype == torch.float32 and A2.is_cuda)
+    if not ok or WGRAD_MODE == "library":
+        return _wgrad_library(A2, B2, out, colsum)
+    if WGRAD_MODE == "custom":
+        return _wgrad_custom(A2, B2, out, colsum)
+    key = (M, N, K, bool(colsum))
+    choice = _wgrad_choice.get(key)
+    if choice is None:
+        if torch.cuda.is_current_stream_capturing() or _timer is not None:
+            choice = "custom"                       # cannot time here; decided on a later eager call
+        else:
+            t_c = _time_us(lambda: _wgrad_custom(A2, B2, out, colsum))
+            t_l = _time_us(lambda: _wgrad_library(A2, B2, out, colsum))
+            choice = _wgrad_choice[key] = "custom" if t_c <= t_l else "library"
+    return _wgrad_custom(A2, B2, out, colsum) if choice == "custom" else _wgrad_library(A2, B2, out, colsum)
 
 
 def _orl_fwd_raw(F3, idx_x, k):

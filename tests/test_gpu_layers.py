@@ -274,9 +274,10 @@ def test_backward_is_bit_reproducible(dev, ref, monkeypatch):
 
 @pytest.mark.parametrize("K,M,N,lda_pad,ldc_pad", [(16448, 128, 1024, 0, 0), (4112, 256, 2048, 0, 0), (1024, 512, 512, 0, 512),
                                                    (1000, 64, 64, 64, 0), (4113, 128, 128, 0, 128), (37, 64, 128, 0, 0)])
-def test_wgrad_gemm(dev, ref, K, M, N, lda_pad, ldc_pad):
+def test_wgrad_gemm(dev, ref, monkeypatch, K, M, N, lda_pad, ldc_pad):
     """split-K MFMA weight-gradient GEMM vs fp64: A^T B, fused column sum, strided operands / output."""
     from hs_pose_amd import ops
+    monkeypatch.setattr(ops, "WGRAD_MODE", "custom")
     Afull = ref.hash_tensor((K, M + lda_pad), 1, 1.0).to(dev)
     B = ref.hash_tensor((K, N), 2, 1.0).to(dev)
     A = Afull[:, :M]
