@@ -68,11 +68,11 @@ class FaceRecon(nn.Module):
         k = self.neighbor_num
         with gcn3d.knn_scope():
             fm_0 = F.relu(self.conv_0(vertices, k), inplace=True)
-            fm_1 = F.relu(_bn_rows(self.bn1, self.conv_1(vertices, fm_0, k)), inplace=True)
+            fm_1 = ops.bn_relu(self.conv_1(vertices, fm_0, k), self.bn1)
             v_pool_1, fm_pool_1 = self.pool_1(vertices, fm_1)
             k1 = min(k, v_pool_1.shape[1] // 8)
-            fm_2 = F.relu(_bn_rows(self.bn2, self.conv_2(v_pool_1, fm_pool_1, k1)), inplace=True)
-            fm_3 = F.relu(_bn_rows(self.bn3, self.conv_3(v_pool_1, fm_2, k1)), inplace=True)
+            fm_2 = ops.bn_relu(self.conv_2(v_pool_1, fm_pool_1, k1), self.bn2)
+            fm_3 = ops.bn_relu(self.conv_3(v_pool_1, fm_2, k1), self.bn3)
             v_pool_2, fm_pool_2 = self.pool_2(v_pool_1, fm_3)
             k2 = min(k, v_pool_2.shape[1] // 8)
             fm_4 = self.conv_4(v_pool_2, fm_pool_2, k2)

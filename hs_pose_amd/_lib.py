@@ -32,6 +32,10 @@ SIGNATURES = {
     "hsp_gather_rows_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "hsp_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
     "hsp_wgrad_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
+    "hsp_bn_workspace_bytes": (_sz, [_i, _i]),
+    "hsp_bn_relu_fwd": (_i, [_vp, _i, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "hsp_bn_relu_apply": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "hsp_bn_relu_bwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "hsp_chamfer_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "hsp_chamfer_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "hsp_fps_workspace_bytes": (_sz, [_i, _i]),

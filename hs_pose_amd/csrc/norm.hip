@@ -1,0 +1,257 @@
+// norm.hip -- fused train-mode BatchNorm1d + ReLU over point rows for gfx950.
+//
+// Replaces  F.relu(bn(x.transpose(1,2)).transpose(1,2))  of the HS stack (reference
+// network/fs_net_repo/FaceRecon.py:27-29, :90-95): BatchNorm1d over the channel dim of a (B,N,C)
+// tensor with batch statistics over the R = B*N rows, eps 1e-5, momentum 0.1, followed by ReLU.
+// The reference transposes to (B,C,N) and back; here rows stay point-major and one lane owns 4
+// channels, so every access is a 16-byte row segment.
+//
+//   forward   partial shifted sums per row chunk -> finalize (mean, invstd, running-stat update,
+//             num_batches_tracked) -> apply + ReLU                        (3 launches, x read twice)
+//   backward  dz = dy*[y>0]; partial (sum dz, sum dz*xhat) -> finalize (d gamma, d beta)
+//             -> dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat))   (3 launches)
+// Sums are "shifted" by the first row of the tensor (sum (x-s), sum (x-s)^2), which keeps fp32
+// cancellation harmless when |mean| >> std; partials are folded in a fixed order (deterministic).
+// HBM-bound: forward algorithmic bytes = 4*R*C in + 4*R*C out; backward 8*R*C in + 4*R*C out.
+#include "common.h"
+
+namespace hsp {
+
+#define BN_THREADS 256
+#define BN_ROWS_PER_BLOCK 64
+
+// partial[blk][0][c] = sum_r v1, partial[blk][1][c] = sum_r v2 over the rows of chunk blk, where
+//   MODE 0 (forward stats):  v1 = x - shift,  v2 = (x - shift)^2            shift = x[0][c]
+//   MODE 1 (backward):       v1 = dz,         v2 = dz * xhat                dz = relu ? dy*[a>0] : dy
+template <int MODE>
+__global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ dy, int R, int C,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, int relu,
+                                                                float* __restrict__ partial) {
+    __shared__ float4 red[2][BN_THREADS];
+    const int cq = C >> 2;                       // float4 groups per row
+    const int tid = threadIdx.x;
+    const int g = tid % cq, rl = tid / cq;       // BN_THREADS % cq == 0 is guaranteed by the launcher
+    const int RL = BN_THREADS / cq;
+    const int r0 = blockIdx.x * BN_ROWS_PER_BLOCK;
+    const int r1 = min(R, r0 + BN_ROWS_PER_BLOCK);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    float4 sh = make_float4(0.f, 0.f, 0.f, 0.f), mu = sh, is = sh, ga = sh, be = sh;
+    if (MODE == 0) {
+        sh = *reinterpret_cast<const float4*>(x + (g << 2));
+    } else {
+        mu = *reinterpret_cast<const float4*>(mean + (g << 2));
+        is = *reinterpret_cast<const float4*>(invstd + (g << 2));
+        ga = *reinterpret_cast<const float4*>(gamma + (g << 2));
+        be = *reinterpret_cast<const float4*>(beta + (g << 2));
+    }
+    for (int r = r0 + rl; r < r1; r += RL) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * C + (g << 2));
+        if (MODE == 0) {
+            const float a = v.x - sh.x, b = v.y - sh.y, c = v.z - sh.z, d = v.w - sh.w;
+            s1.x += a; s1.y += b; s1.z += c; s1.w += d;
+            s2.x += a * a; s2.y += b * b; s2.z += c * c; s2.w += d * d;
+        } else {
+            float4 dz = *reinterpret_cast<const float4*>(dy + (size_t)r * C + (g << 2));
+            const float4 xh = make_float4((v.x - mu.x) * is.x, (v.y - mu.y) * is.y, (v.z - mu.z) * is.z, (v.w - mu.w) * is.w);
+            if (relu) {
+                if (!(xh.x * ga.x + be.x > 0.f)) dz.x = 0.f;
+                if (!(xh.y * ga.y + be.y > 0.f)) dz.y = 0.f;
+                if (!(xh.z * ga.z + be.z > 0.f)) dz.z = 0.f;
+                if (!(xh.w * ga.w + be.w > 0.f)) dz.w = 0.f;
+            }
+            s1.x += dz.x; s1.y += dz.y; s1.z += dz.z; s1.w += dz.w;
+            s2.x += dz.x * xh.x; s2.y += dz.y * xh.y; s2.z += dz.z * xh.z; s2.w += dz.w * xh.w;
+        }
+    }
+    red[0][tid] = s1;
+    red[1][tid] = s2;
+    __syncthreads();
+    if (rl == 0) {
+        for (int l = 1; l < RL; ++l) {          // fixed order
+            const float4 a = red[0][l * cq + g], b = red[1][l * cq + g];
+            s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+            s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+        }
+        float* p = partial + (size_t)blockIdx.x * 2 * C;
+        *reinterpret_cast<float4*>(p + (g << 2)) = s1;
+        *reinterpret_cast<float4*>(p + C + (g << 2)) = s2;
+    }
+}
+
+// one thread per channel: fold the partials (ascending block order), then
+//   MODE 0: mean, biased var -> invstd; running stats (momentum, unbiased var); num_batches_tracked += 1
+//   MODE 1: dgamma = sum dz*xhat, dbeta = sum dz; also keep both means for the dx pass
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int R, int C,
+                                                          const float* __restrict__ x, float eps, float momentum,
+                                                          float* __restrict__ out_a, float* __restrict__ out_b,
+                                                          float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                          long long* __restrict__ num_batches) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f, t1 = 0.f, t2 = 0.f;
+    int b = 0;
+    for (; b + 1 < nblk; b += 2) {                // two independent chains keep loads in flight
+        s1 += partial[(size_t)b * 2 * C + c];
+        s2 += partial[(size_t)b * 2 * C + C + c];
+        t1 += partial[(size_t)(b + 1) * 2 * C + c];
+        t2 += partial[(size_t)(b + 1) * 2 * C + C + c];
+    }
+    if (b < nblk) { s1 += partial[(size_t)b * 2 * C + c]; s2 += partial[(size_t)b * 2 * C + C + c]; }
+    s1 += t1; s2 += t2;
+    if (MODE == 0) {
+        const float invR = 1.0f / (float)R;
+        const float ms = s1 * invR;                              // mean of (x - shift)
+        float var = s2 * invR - ms * ms;
+        if (var < 0.f) var = 0.f;
+        const float mean = x[c] + ms;
+        out_a[c] = mean;
+        out_b[c] = 1.0f / sqrtf(var + eps);
+        if (run_mean) {
+            run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mean;
+            const float unb = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
+            run_var[c] = (1.0f - momentum) * run_var[c] + momentum * unb;
+        }
+        if (num_batches && c == 0) *num_batches += 1;
+    } else {
+        out_a[c] = s2;      // d gamma
+        out_b[c] = s1;      // d beta
+    }
+}
+
+// y = relu?((x - mean) * invstd * gamma + beta)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, long long total4, int C,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int relu,
+                                                       float* __restrict__ y) {
+    const int cq = C >> 2;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
+        const int g = (int)(e % cq);
+        const float4 v = *reinterpret_cast<const float4*>(x + e * 4);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + (g << 2));
+        const float4 is = *reinterpret_cast<const float4*>(invstd + (g << 2));
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + (g << 2));
+        const float4 be = *reinterpret_cast<const float4*>(beta + (g << 2));
+        float4 o = make_float4((v.x - mu.x) * is.x * ga.x + be.x, (v.y - mu.y) * is.y * ga.y + be.y,
+                               (v.z - mu.z) * is.z * ga.z + be.z, (v.w - mu.w) * is.w * ga.w + be.w);
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        *reinterpret_cast<float4*>(y + e * 4) = o;
+    }
+}
+
+// dx = gamma*invstd*(dz - dbeta/R - xhat*dgamma/R)
+__global__ __launch_bounds__(256) void bn_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                    long long total4, int R, int C, const float* __restrict__ mean,
+                                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, const float* __restrict__ dgamma,
+                                                    const float* __restrict__ dbeta, int relu, float* __restrict__ dx) {
+    const int cq = C >> 2;
+    const float invR = 1.0f / (float)R;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
+        const int g = (int)(e % cq);
+        const float4 v = *reinterpret_cast<const float4*>(x + e * 4);
+        float4 dz = *reinterpret_cast<const float4*>(dy + e * 4);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + (g << 2));
+        const float4 is = *reinterpret_cast<const float4*>(invstd + (g << 2));
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + (g << 2));
+        const float4 be = *reinterpret_cast<const float4*>(beta + (g << 2));
+        const float4 dg = *reinterpret_cast<const float4*>(dgamma + (g << 2));
+        const float4 db = *reinterpret_cast<const float4*>(dbeta + (g << 2));
+        const float4 xh = make_float4((v.x - mu.x) * is.x, (v.y - mu.y) * is.y, (v.z - mu.z) * is.z, (v.w - mu.w) * is.w);
+        if (relu) {
+            if (!(xh.x * ga.x + be.x > 0.f)) dz.x = 0.f;
+            if (!(xh.y * ga.y + be.y > 0.f)) dz.y = 0.f;
+            if (!(xh.z * ga.z + be.z > 0.f)) dz.z = 0.f;
+            if (!(xh.w * ga.w + be.w > 0.f)) dz.w = 0.f;
+        }
+        float4 o;
+        o.x = ga.x * is.x * (dz.x - db.x * invR - xh.x * dg.x * invR);
+        o.y = ga.y * is.y * (dz.y - db.y * invR - xh.y * dg.y * invR);
+        o.z = ga.z * is.z * (dz.z - db.z * invR - xh.z * dg.z * invR);
+        o.w = ga.w * is.w * (dz.w - db.w * invR - xh.w * dg.w * invR);
+        *reinterpret_cast<float4*>(dx + e * 4) = o;
+    }
+}
+
+static int bn_blocks(int R) { return (R + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK; }
+
+static int bn_check(int R, int C) {
+    if (R <= 0 || C <= 0) return HSP_ERR_BAD_ARG;
+    if ((C & 3) || (BN_THREADS % (C >> 2)) != 0) return HSP_ERR_UNSUPPORTED;   // C in {4,8,...,1024} dividing 1024
+    return HSP_OK;
+}
+
+static int stream_grid4(long long total4) {
+    long long g = (total4 + 255) / 256;
+    const long long cap = (long long)HSP_NUM_CU * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace hsp
+
+using namespace hsp;
+
+extern "C" size_t hsp_bn_workspace_bytes(int R, int C) {
+    if (R <= 0 || C <= 0) return 0;
+    return (size_t)bn_blocks(R) * 2 * C * sizeof(float);
+}
+
+extern "C" int hsp_bn_relu_fwd(const float* x, int R, int C, const float* gamma, const float* beta, float eps,
+                               float momentum, int relu, float* y, float* save_mean, float* save_invstd,
+                               float* running_mean, float* running_var, long long* num_batches_tracked, void* ws,
+                               size_t ws_bytes, hspStream_t stream) {
+    if (!x || !gamma || !beta || !y || !save_mean || !save_invstd) return HSP_ERR_BAD_ARG;
+    int rc = bn_check(R, C);
+    if (rc) return rc;
+    if (!ws || ws_bytes < hsp_bn_workspace_bytes(R, C)) return HSP_ERR_WORKSPACE;
+    hipStream_t st = as_stream(stream);
+    float* part = reinterpret_cast<float*>(ws);
+    const int nblk = bn_blocks(R);
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nblk), dim3(BN_THREADS), 0, st, x, nullptr, R, C, nullptr, nullptr,
+                       nullptr, nullptr, 0, part);
+    hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 255) / 256), dim3(256), 0, st, part, nblk, R, C, x, eps, momentum,
+                       save_mean, save_invstd, running_mean, running_var, num_batches_tracked);
+    const long long total4 = (long long)R * (C >> 2);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid4(total4)), dim3(256), 0, st, x, total4, C, save_mean, save_invstd,
+                       gamma, beta, relu, y);
+    return check_launch();
+}
+
+extern "C" int hsp_bn_relu_apply(const float* x, int R, int C, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, int relu, float* y, hspStream_t stream) {
+    if (!x || !mean || !invstd || !gamma || !beta || !y) return HSP_ERR_BAD_ARG;
+    int rc = bn_check(R, C);
+    if (rc) return rc;
+    const long long total4 = (long long)R * (C >> 2);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid4(total4)), dim3(256), 0, as_stream(stream), x, total4, C, mean,
+                       invstd, gamma, beta, relu, y);
+    return check_launch();
+}
+
+extern "C" int hsp_bn_relu_bwd(const float* x, const float* dy, int R, int C, const float* gamma, const float* beta,
+                               const float* save_mean, const float* save_invstd, int relu, float* dx, float* dgamma,
+                               float* dbeta, void* ws, size_t ws_bytes, hspStream_t stream) {
+    if (!x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta) return HSP_ERR_BAD_ARG;
+    int rc = bn_check(R, C);
+    if (rc) return rc;
+    if (!ws || ws_bytes < hsp_bn_workspace_bytes(R, C)) return HSP_ERR_WORKSPACE;
+    hipStream_t st = as_stream(stream);
+    float* part = reinterpret_cast<float*>(ws);
+    const int nblk = bn_blocks(R);
+    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nblk), dim3(BN_THREADS), 0, st, x, dy, R, C, save_mean, save_invstd, gamma,
+                       beta, relu, part);
+    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 255) / 256), dim3(256), 0, st, part, nblk, R, C, x, 0.f, 0.f, dgamma,
+                       dbeta, nullptr, nullptr, nullptr);
+    const long long total4 = (long long)R * (C >> 2);
+    hipLaunchKernelGGL(bn_dx_kernel, dim3(stream_grid4(total4)), dim3(256), 0, st, x, dy, total4, R, C, save_mean,
+                       save_invstd, gamma, beta, dgamma, dbeta, relu, dx);
+    return check_launch();
+}

@@ -24,7 +24,8 @@ def enable(tune_missing=True, max_tuning_ms=30):
     if _enabled or not torch.cuda.is_available():
         return None
     tun = torch.cuda.tunable
-    work = os.path.join(tempfile.gettempdir(), f"hsp_tunableop_{os.getpid()}.csv")
+    # HSP_TUNABLEOP_OUT=<path>: keep the merged table there (used to regenerate the shipped one)
+    work = os.environ.get("HSP_TUNABLEOP_OUT") or os.path.join(tempfile.gettempdir(), f"hsp_tunableop_{os.getpid()}.csv")
     if os.path.exists(SHIPPED):
         shutil.copyfile(SHIPPED, work)          # never write into the source tree
     tun.enable(True)

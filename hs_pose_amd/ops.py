@@ -550,6 +550,63 @@ def surface_layer(xyz, idx_x, k, S, directions, w_ste, w_conv2):
 
 
 # ------------------------------------------------------------------------------------------------
+# fused train-mode BatchNorm1d + ReLU over point rows
+# ------------------------------------------------------------------------------------------------
+
+class _BNRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, num_batches, eps, momentum, relu):
+        x = _req(x, torch.float32, "bn_relu.x")
+        C = x.shape[-1]
+        R = x.numel() // C
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        L = lib()
+        wsb = L.hsp_bn_workspace_bytes(R, C)
+        ws = _ws(wsb, x.device)
+        _run("hsp_bn_relu_fwd", (_p(x), R, C, _p(weight), _p(bias), float(eps), float(momentum), 1 if relu else 0, _p(y),
+                                 _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(num_batches), _p(ws), wsb,
+                                 _stream()),
+             key=f"R{R}C{C}", abytes=8 * R * C)
+        ctx.save_for_backward(x, weight, bias, mean, invstd)
+        ctx.relu = relu
+        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, num_batches) if t is not None])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, mean, invstd = ctx.saved_tensors
+        dy = _req(dy, torch.float32, "bn_relu.grad")
+        C = x.shape[-1]
+        R = x.numel() // C
+        dx = torch.empty_like(x)
+        dg = torch.empty_like(weight)
+        db = torch.empty_like(bias)
+        L = lib()
+        wsb = L.hsp_bn_workspace_bytes(R, C)
+        ws = _ws(wsb, x.device)
+        _run("hsp_bn_relu_bwd", (_p(x), _p(dy), R, C, _p(weight), _p(bias), _p(mean), _p(invstd), 1 if ctx.relu else 0,
+                                 _p(dx), _p(dg), _p(db), _p(ws), wsb, _stream()),
+             key=f"R{R}C{C}", abytes=12 * R * C)
+        return dx, dg, db, None, None, None, None, None, None
+
+
+def bn_relu(x, bn, relu=True):
+    """relu(bn(x)) for point rows x (..., C) with an nn.BatchNorm1d module ``bn`` (its parameters, running
+    statistics and train/eval state are honoured exactly like calling the module on the (R,C) view, which
+    is what the reference's transpose->BatchNorm1d->transpose computes, FaceRecon.py:90-95)."""
+    C = x.shape[-1]
+    fused = (bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None and x.is_cuda
+             and x.dtype == torch.float32 and C % 4 == 0 and 256 % (C // 4) == 0)
+    if not fused:                                   # eval mode / exotic configurations: not on the training hot path
+        y = bn(x.reshape(-1, C)).view_as(x)
+        return torch.relu_(y) if relu else y
+    return _BNRelu.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
+                         bn.momentum, relu)
+
+
+# ------------------------------------------------------------------------------------------------
 # row gather
 # ------------------------------------------------------------------------------------------------
 

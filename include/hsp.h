@@ -161,6 +161,27 @@ size_t hsp_wgrad_workspace_bytes(int M, int N, int K);
 int hsp_wgrad_f32(const float *A, int lda, const float *B, int ldb, int M, int N, int K, float *C, int ldc,
                   float *colsum_B, void *ws, size_t ws_bytes, hspStream_t stream);
 
+/* ---- BatchNorm1d (train mode) + ReLU over point rows -------------------------------------------
+ * replaces F.relu(bn(x.transpose(1,2)).transpose(1,2))          FaceRecon.py:27-29, :90-95
+ * x (R,C) point rows (R = B*N), batch statistics over R (biased variance for the normalisation, eps),
+ * running_mean/var updated in place with `momentum` (unbiased variance) and *num_batches_tracked += 1
+ * when the pointers are non-NULL -- nn.BatchNorm1d semantics.  y = relu ? max(0, bn(x)) : bn(x).
+ * save_mean / save_invstd (C) feed the backward.  ws: hsp_bn_workspace_bytes(R, C).
+ */
+size_t hsp_bn_workspace_bytes(int R, int C);
+int hsp_bn_relu_fwd(const float *x, int R, int C, const float *gamma, const float *beta, float eps,
+                    float momentum, int relu, float *y, float *save_mean, float *save_invstd,
+                    float *running_mean, float *running_var, long long *num_batches_tracked, void *ws,
+                    size_t ws_bytes, hspStream_t stream);
+/* the affine + ReLU part alone with given statistics (eval mode: mean = running_mean,
+ * invstd = 1/sqrt(running_var + eps)) */
+int hsp_bn_relu_apply(const float *x, int R, int C, const float *mean, const float *invstd,
+                      const float *gamma, const float *beta, int relu, float *y, hspStream_t stream);
+/* dx (R,C), dgamma (C), dbeta (C) OVERWRITTEN; x is the forward INPUT (the ReLU mask is recomputed). */
+int hsp_bn_relu_bwd(const float *x, const float *dy, int R, int C, const float *gamma, const float *beta,
+                    const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma,
+                    float *dbeta, void *ws, size_t ws_bytes, hspStream_t stream);
+
 /* ---- Chamfer distance -------------------------------------------------------------------------
  * replaces cd.forward_cuda / cd.backward_cuda    tools/pyTorchChamferDistance/chamfer_distance.cpp:27-56
  * xyz1 (B,n,3), xyz2 (B,m,3) -> dist1 (B,n), dist2 (B,m) squared NN distances, idx1/idx2 int32 arg-min

@@ -19,7 +19,7 @@ def _header_symbols():
 def test_library_exports_every_declared_symbol():
     from hs_pose_amd import _lib
     syms = _header_symbols()
-    assert len(syms) >= 25
+    assert len(syms) >= 29
     L = _lib.lib()
     for s in syms:
         assert hasattr(L, s), f"libhsp.so lacks {s}"
@@ -50,6 +50,9 @@ def test_argument_validation_without_gpu():
     assert L.hsp_wgrad_f32(one, 128, one, 1024, 100, 1024, 4000, one, 1024, null, one, 1 << 30, null) == -2   # M % 64
     assert L.hsp_wgrad_f32(one, 128, one, 1024, 128, 1024, 4000, one, 1024, null, null, 0, null) == -3
     assert L.hsp_wgrad_workspace_bytes(128, 1024, 16448) > 0
+    assert L.hsp_bn_relu_fwd(one, 100, 12, one, one, 1e-5, 0.1, 1, one, one, one, null, null, null, one, 1 << 20, null) == -2   # 256 % (C/4)
+    assert L.hsp_bn_relu_fwd(one, 100, 128, one, one, 1e-5, 0.1, 1, one, one, one, null, null, null, null, 0, null) == -3
+    assert L.hsp_bn_workspace_bytes(16448, 128) == 257 * 2 * 128 * 4
     assert L.hsp_rf_bwd_workspace_bytes(896) > 0
     assert L.hsp_rf_bwd_scatter_workspace_bytes(16, 896) == 16 * 3 * 896 * 4
     assert L.hsp_rf_conv_bwd_scatter(one, one, one, one, one, 1, 8, 7, 128, one, one, null, 0, null) == -3

@@ -292,3 +292,37 @@ def test_wgrad_gemm(dev, ref, monkeypatch, K, M, N, lda_pad, ldc_pad):
     # bit-reproducible (fixed-order fold of the K slices)
     out2 = ops.wgrad(A, B)
     assert torch.equal(out2, out.contiguous())
+
+
+@pytest.mark.parametrize("B,N,C,relu", [(16, 1028, 128, True), (2, 257, 256, True), (3, 100, 64, False)])
+def test_bn_relu_fused(dev, ref, B, N, C, relu):
+    """fused train-mode BatchNorm1d+ReLU vs torch's module on the same rows: output, input / affine
+    gradients, running statistics and num_batches_tracked."""
+    from hs_pose_amd import ops
+    x = (ref.hash_tensor((B, N, C), 5, 1.0) * 0.3 + ref.hash_tensor((1, 1, C), 6, 2.0)).to(dev)   # |mean| >> std
+    up = ref.hash_tensor((B, N, C), 7, 1.0).to(dev)
+    mods = []
+    for _ in range(2):
+        bn = torch.nn.BatchNorm1d(C).to(dev)
+        with torch.no_grad():
+            bn.weight.copy_(ref.hash_tensor((C,), 8, 0.3).to(dev) + 1.0)
+            bn.bias.copy_(ref.hash_tensor((C,), 9, 0.2).to(dev))
+        mods.append(bn)
+    a = x.clone().requires_grad_(True)
+    b = x.clone().requires_grad_(True)
+    got = ops.bn_relu(a, mods[0], relu=relu)
+    want = mods[1](b.reshape(B * N, C)).view(B, N, C)
+    if relu:
+        want = torch.relu(want)
+    close(got, want, tol=2e-5, what="bn_relu out")
+    (got * up).sum().backward()
+    (want * up).sum().backward()
+    gclose(a.grad, b.grad, "bn_relu dx")
+    gclose(mods[0].weight.grad, mods[1].weight.grad, "bn_relu dgamma")
+    gclose(mods[0].bias.grad, mods[1].bias.grad, "bn_relu dbeta")
+    close(mods[0].running_mean, mods[1].running_mean, tol=1e-5, what="running_mean")
+    close(mods[0].running_var, mods[1].running_var, tol=1e-5, what="running_var")
+    assert int(mods[0].num_batches_tracked) == 1
+    # eval mode goes through the module itself
+    mods[0].eval(); mods[1].eval()
+    close(ops.bn_relu(x, mods[0], relu=relu), torch.relu(mods[1](x.reshape(-1, C))).view_as(x) if relu else mods[1](x.reshape(-1, C)).view_as(x), tol=2e-5)
