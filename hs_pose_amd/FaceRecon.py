@@ -80,10 +80,9 @@ class FaceRecon(nn.Module):
 
         nearest_pool_1 = ops.nn1(vertices, v_pool_1)
         nearest_pool_2 = ops.nn1(vertices, v_pool_2)
-        up_2 = ops.gather_rows(fm_2, nearest_pool_1)
-        up_3 = ops.gather_rows(fm_3, nearest_pool_1)
-        up_4 = ops.gather_rows(fm_4, nearest_pool_2)
-        feat = torch.cat([fm_0, fm_1, up_2, up_3, up_4, one_hot.unsqueeze(1).expand(-1, vertice_num, -1)], dim=2)
+        # nearest up-sampling of the coarse levels, the one-hot category columns and the concat in one kernel
+        feat = ops.assemble_feat([(fm_0, None, 0), (fm_1, None, 0), (fm_2, nearest_pool_1, 1), (fm_3, nearest_pool_1, 1),
+                                  (fm_4, nearest_pool_2, 1), (one_hot, None, 2)])
 
         if FLAGS.train:
             rows = feat.reshape(bs * vertice_num, -1)

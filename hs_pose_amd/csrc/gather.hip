@@ -44,6 +44,113 @@ __global__ __launch_bounds__(256) void gather_max_fwd_kernel(const float* __rest
     }
 }
 
+// ORL global feature in one pass (reference get_ORL_global, gcn3d.py:211-218, before the repeat):
+//   fg[b,c] = (1/N) sum_i max_{n<k} feat[b, idx[b,i,n], c],   argmax (B,N,C) uint8 = winning slot
+// One workgroup per (cloud, chunk of ORL_ROWS points): a lane owns 4 channels of a point, takes the max
+// over the k gathered rows, the chunk's column sums are folded through LDS in a fixed order and written
+// to part[b][chunk][C]; orl_finalize_kernel folds the chunks (deterministic).  The (B,N,C) max tensor of
+// the reference is never written.
+#define ORL_ROWS 64          // upper bound of points per chunk (workspace sizing)
+__global__ __launch_bounds__(256) void orl_partial_kernel(const float* __restrict__ feat,
+                                                          const int32_t* __restrict__ idx, int N, int k,
+                                                          int kstride, int C, uint8_t* __restrict__ argmax,
+                                                          float* __restrict__ part, int nchunk, int rows) {
+    __shared__ float4 red[256];
+    const int cq = C >> 2;
+    const int tid = threadIdx.x;
+    const int g = tid % cq, rl = tid / cq, RL = 256 / cq;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int r0 = chunk * rows, r1 = min(N, r0 + rows);
+    const float* fb = feat + (size_t)b * N * C + (g << 2);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = r0 + rl; i < r1; i += RL) {
+        const int32_t* nb = idx + ((size_t)b * N + i) * kstride;
+        float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll 4
+        for (int n = 0; n < k; ++n) {
+            const float4 f = *reinterpret_cast<const float4*>(fb + (size_t)nb[n] * C);
+            if (f.x > best.x) { best.x = f.x; a0 = n; }
+            if (f.y > best.y) { best.y = f.y; a1 = n; }
+            if (f.z > best.z) { best.z = f.z; a2 = n; }
+            if (f.w > best.w) { best.w = f.w; a3 = n; }
+        }
+        *reinterpret_cast<uchar4*>(argmax + ((size_t)b * N + i) * C + (g << 2)) =
+            make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
+        s.x += best.x; s.y += best.y; s.z += best.z; s.w += best.w;
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (rl == 0) {
+        for (int l = 1; l < RL; ++l) { const float4 v = red[l * cq + g]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        *reinterpret_cast<float4*>(part + ((size_t)b * nchunk + chunk) * C + (g << 2)) = s;
+    }
+}
+
+// out[b][c] = scale * sum_chunk part[b][chunk][c]   (also the generic "column sum per cloud" second stage)
+__global__ __launch_bounds__(256) void chunk_fold_kernel(const float* __restrict__ part, int B, int nchunk, int C,
+                                                         float scale, float* __restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= B * C) return;
+    const int b = e / C, c = e - b * C;
+    const float* p = part + (size_t)b * nchunk * C + c;
+    float s0 = 0.f, s1 = 0.f;
+    int ch = 0;
+    for (; ch + 1 < nchunk; ch += 2) { s0 += p[(size_t)ch * C]; s1 += p[(size_t)(ch + 1) * C]; }
+    if (ch < nchunk) s0 += p[(size_t)ch * C];
+    out[e] = (s0 + s1) * scale;
+}
+
+// part[b][chunk][c] = sum of x[b][i][c] over the chunk's rows (first stage of a per-cloud column sum)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int N, int C,
+                                                             float* __restrict__ part, int nchunk, int rows) {
+    __shared__ float4 red[256];
+    const int cq = C >> 2;
+    const int tid = threadIdx.x;
+    const int g = tid % cq, rl = tid / cq, RL = 256 / cq;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int r0 = chunk * rows, r1 = min(N, r0 + rows);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = r0 + rl; i < r1; i += RL) {
+        const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)b * N + i) * C + (g << 2));
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (rl == 0) {
+        for (int l = 1; l < RL; ++l) { const float4 v = red[l * cq + g]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        *reinterpret_cast<float4*>(part + ((size_t)b * nchunk + chunk) * C + (g << 2)) = s;
+    }
+}
+
+// feat rows assembled from column segments (reference FaceRecon.py:100-107: nearest up-sampling gathers,
+// one-hot category columns and torch.cat) in ONE pass: segment s of row (b,i) comes from
+//   kind 0: src[(b*N + i)*w + c]      kind 1: src[(b*Ns + idx[b*N+i])*w + c]      kind 2: src[b*w + c]
+struct ConcatSeg { const float* src; const int32_t* idx; int width; int kind; int nsrc; int col0; };
+struct ConcatDesc { ConcatSeg seg[8]; int nseg; int even; };
+
+__global__ __launch_bounds__(256) void concat_rows_kernel(ConcatDesc d, int B, int N, int W, float* __restrict__ out) {
+    const long long rows = (long long)B * N;
+    for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int b = (int)(row / N);
+        float* o = out + (size_t)row * W;
+        for (int s = 0; s < d.nseg; ++s) {
+            const ConcatSeg sg = d.seg[s];
+            const float* src;
+            if (sg.kind == 0) src = sg.src + (size_t)row * sg.width;
+            else if (sg.kind == 1) src = sg.src + ((size_t)b * sg.nsrc + sg.idx[row]) * sg.width;
+            else src = sg.src + (size_t)b * sg.width;
+            if (d.even) {       // every width / column offset / row stride even: 8-byte accesses
+                const float2* s2 = reinterpret_cast<const float2*>(src);
+                float2* o2 = reinterpret_cast<float2*>(o + sg.col0);
+                for (int c = threadIdx.x; c < (sg.width >> 1); c += 256) o2[c] = s2[c];
+            } else {
+                for (int c = threadIdx.x; c < sg.width; c += 256) o[sg.col0 + c] = src[c];
+            }
+        }
+    }
+}
+
 // scatter-add of the pooled gradient to the winning source rows (grad_feat pre-zeroed)
 __global__ __launch_bounds__(256) void gather_max_bwd_kernel(const float* __restrict__ gout, int gbcast,
                                                              const int32_t* __restrict__ idx,
@@ -99,7 +206,10 @@ __global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const float* __re
         const size_t row = (size_t)b * Nq + q;
         if (MODE == 1) {
             const int m = idx_shared ? idx[q] : idx[row];
-            const float4 gv = *reinterpret_cast<const float4*>(gout + row * gstride + j);
+            // rows of a column block of a wider tensor are only 8-byte aligned (stride 1286): two float2 loads
+            const float2 g01 = *reinterpret_cast<const float2*>(gout + row * gstride + j);
+            const float2 g23 = *reinterpret_cast<const float2*>(gout + row * gstride + j + 2);
+            const float4 gv = make_float4(g01.x, g01.y, g23.x, g23.y);
             float* a = acc + m * TC + cg * 4;
             if (gv.x != 0.f) atomicAdd(a + 0, gv.x);
             if (gv.y != 0.f) atomicAdd(a + 1, gv.y);
@@ -268,6 +378,16 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float* __res
     }
 }
 
+// points per chunk for the two-stage per-cloud reductions: enough chunks to fill the chip, at least one
+// row per row-lane, at most ORL_ROWS (the workspace is sized for the smallest chunk count = ORL_ROWS rows)
+static int chunk_rows(int B, int N, int C) {
+    const int RL = 256 / (C >> 2);
+    long long r = ((long long)B * N + 1023) / 1024;
+    if (r < RL) r = RL;
+    if (r > ORL_ROWS) r = ORL_ROWS;
+    return (int)r;
+}
+
 static int stream_grid(long long threads) {
     long long g = (threads + 255) / 256;
     const long long cap = (long long)HSP_NUM_CU * 8;
@@ -335,7 +455,7 @@ extern "C" int hsp_gather_rows_bwd(const float* grad_out, int grad_stride, const
     if (!grad_out || !idx || !grad_feat || B <= 0 || Nsrc <= 0 || Nq <= 0 || C <= 0 || grad_stride < C)
         return HSP_ERR_BAD_ARG;
     hipStream_t st = as_stream(stream);
-    if ((C & 3) == 0 && (grad_stride & 3) == 0)
+    if ((C & 3) == 0 && (grad_stride & 1) == 0 && (reinterpret_cast<uintptr_t>(grad_out) & 7) == 0)
         if (const int tc = pick_scatter_cols(Nsrc, C))
             return launch_scatter_tile<1>(tc, grad_out, grad_stride, 0, idx, idx_shared, nullptr, nullptr, B, Nsrc, Nq,
                                           Nq, 1, C, grad_feat, 0, st);
@@ -356,5 +476,65 @@ extern "C" int hsp_gather_max_bwd_csr(const float* grad_out, int grad_bcast, con
     const long long total = (long long)B * Nsrc * (C >> 2);
     hipLaunchKernelGGL(gather_max_bwd_csr_kernel, dim3(stream_grid(total)), dim3(256), 0, as_stream(stream), grad_out,
                        grad_bcast, argmax, rev_off, rev_edge, B, Nsrc, Nq, k, C, grad_feat);
+    return check_launch();
+}
+
+extern "C" size_t hsp_orl_workspace_bytes(int B, int N, int C) {
+    if (B <= 0 || N <= 0 || C <= 0 || (C & 3) || (256 % (C >> 2))) return 0;
+    const int rows = chunk_rows(B, N, C);
+    return (size_t)B * ((N + rows - 1) / rows) * C * sizeof(float);
+}
+
+extern "C" int hsp_orl_global_fwd(const float* feat, const int32_t* idx, int B, int N, int k, int kstride, int C,
+                                  float* fg, uint8_t* argmax, void* ws, size_t ws_bytes, hspStream_t stream) {
+    if (!feat || !idx || !fg || !argmax || B <= 0 || N <= 0 || k <= 0 || kstride < k || C <= 0) return HSP_ERR_BAD_ARG;
+    if ((C & 3) || (256 % (C >> 2)) || k > 255) return HSP_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < hsp_orl_workspace_bytes(B, N, C)) return HSP_ERR_WORKSPACE;
+    hipStream_t st = as_stream(stream);
+    const int rows = chunk_rows(B, N, C);
+    const int nchunk = (N + rows - 1) / rows;
+    float* part = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL(orl_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, feat, idx, N, k, kstride, C, argmax, part, nchunk, rows);
+    hipLaunchKernelGGL(chunk_fold_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, B, nchunk, C, 1.0f / (float)N, fg);
+    return check_launch();
+}
+
+extern "C" int hsp_colsum_rows(const float* x, int B, int N, int C, float* out, void* ws, size_t ws_bytes,
+                               hspStream_t stream) {
+    if (!x || !out || B <= 0 || N <= 0 || C <= 0) return HSP_ERR_BAD_ARG;
+    if ((C & 3) || (256 % (C >> 2))) return HSP_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < hsp_orl_workspace_bytes(B, N, C)) return HSP_ERR_WORKSPACE;
+    hipStream_t st = as_stream(stream);
+    const int rows = chunk_rows(B, N, C);
+    const int nchunk = (N + rows - 1) / rows;
+    float* part = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, x, N, C, part, nchunk, rows);
+    hipLaunchKernelGGL(chunk_fold_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, B, nchunk, C, 1.0f, out);
+    return check_launch();
+}
+
+extern "C" int hsp_concat_rows(int nseg, const float* const* src, const int32_t* const* idx, const int* width,
+                               const int* kind, const int* nsrc, int B, int N, float* out, hspStream_t stream) {
+    if (nseg <= 0 || nseg > 8 || !src || !width || !kind || !out || B <= 0 || N <= 0) return HSP_ERR_BAD_ARG;
+    ConcatDesc d;
+    d.nseg = nseg;
+    int col = 0;
+    for (int s = 0; s < nseg; ++s) {
+        if (!src[s] || width[s] <= 0 || kind[s] < 0 || kind[s] > 2 || (kind[s] == 1 && (!idx || !idx[s]))) return HSP_ERR_BAD_ARG;
+        d.seg[s].src = src[s];
+        d.seg[s].idx = idx ? idx[s] : nullptr;
+        d.seg[s].width = width[s];
+        d.seg[s].kind = kind[s];
+        d.seg[s].nsrc = nsrc ? nsrc[s] : 0;
+        d.seg[s].col0 = col;
+        col += width[s];
+    }
+    d.even = 1;
+    for (int s = 0; s < nseg; ++s)
+        if ((width[s] & 1) || (reinterpret_cast<uintptr_t>(src[s]) & 7)) d.even = 0;
+    if (reinterpret_cast<uintptr_t>(out) & 7) d.even = 0;
+    const long long rows = (long long)B * N;
+    const int grid = (int)(rows < 8192 ? rows : 8192);
+    hipLaunchKernelGGL(concat_rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), d, B, N, col, out);
     return check_launch();
 }

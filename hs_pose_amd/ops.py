@@ -261,14 +261,11 @@ class _OrlGlobal(torch.autograd.Function):
         idx = _req(idx, torch.int32, "orl.idx")
         B, N, C = feat.shape
         kstride = idx.shape[2]
-        G = torch.empty(B, N, C, dtype=torch.float32, device=feat.device)
-        arg = torch.empty(B, N, C, dtype=torch.uint8, device=feat.device)
-        _run("hsp_gather_max_fwd", (_p(feat), _p(idx), _vp(0), B, N, N, N, k, kstride, C, _p(G), _p(arg), _stream()),
-             key=f"B{B}Ns{N}Nq{N}k{k}C{C}", abytes=B * N * (4 * C + 4 * k + 5 * C))
+        fg, arg = _orl_fwd_raw(feat, idx, k)
         ctx.save_for_backward(idx, arg)
         ctx.dims = (B, N, kstride, C)
         ctx.k = k
-        return G.mean(dim=1)
+        return fg
 
     @staticmethod
     def backward(ctx, gfg):
@@ -377,12 +374,29 @@ def wgrad(A2, B2, out=None, colsum=False):
 
 
 def _orl_fwd_raw(F3, idx_x, k):
+    """(fg (B,C), argmax (B,N,C) uint8): mean over points of the neighbourhood max, one pass, no (B,N,C) max tensor"""
     B, N, C = F3.shape
-    G = torch.empty(B, N, C, dtype=torch.float32, device=F3.device)
+    fg = torch.empty(B, C, dtype=torch.float32, device=F3.device)
     arg = torch.empty(B, N, C, dtype=torch.uint8, device=F3.device)
-    _run("hsp_gather_max_fwd", (_p(F3), _p(idx_x), _vp(0), B, N, N, N, k, idx_x.shape[2], C, _p(G), _p(arg), _stream()),
-         key=f"B{B}Ns{N}Nq{N}k{k}C{C}", abytes=B * N * (4 * C + 4 * k + 5 * C))
-    return G.mean(dim=1), arg
+    L = lib()
+    wsb = L.hsp_orl_workspace_bytes(B, N, C)
+    ws = _ws(wsb, F3.device)
+    _run("hsp_orl_global_fwd", (_p(F3), _p(idx_x), B, N, k, idx_x.shape[2], C, _p(fg), _p(arg), _p(ws), wsb, _stream()),
+         key=f"B{B}N{N}k{k}C{C}", abytes=B * N * (4 * C + 4 * k + C))
+    return fg, arg
+
+
+def colsum_rows(x3):
+    """(B,C) = x3.sum(dim=1) for a contiguous (B,N,C) fp32 tensor: deterministic two-stage column sum"""
+    B, N, C = x3.shape
+    if C % 4 or 256 % (C // 4) or not x3.is_contiguous():
+        return x3.sum(dim=1)
+    out = torch.empty(B, C, dtype=torch.float32, device=x3.device)
+    L = lib()
+    wsb = L.hsp_orl_workspace_bytes(B, N, C)
+    ws = _ws(wsb, x3.device)
+    _run("hsp_colsum_rows", (_p(x3), B, N, C, _p(out), _p(ws), wsb, _stream()), key=f"B{B}N{N}C{C}", abytes=4 * B * N * C)
+    return out
 
 
 def _orl_bwd_accumulate_raw(gfg_over_n, idx_x, arg, k, gF3):
@@ -464,7 +478,7 @@ class _HSLayer(torch.autograd.Function):
         C = F3.shape[2]
         g2, X2, F2 = g.view(B * N, C), X.view(B * N, Cin), F3.view(B * N, C)
         Wa, Wb = w_conv2[:, :C], w_conv2[:, C:]
-        gt = g.sum(dim=1)                                                      # (B,C)
+        gt = colsum_rows(g)                                                    # (B,C) = sum_i g
         g_conv2 = torch.empty_like(w_conv2)
         wgrad(g2, F2, out=g_conv2[:, :C])                                      # gWa, written in place (ldc = 2C)
         g_conv2[:, C:] = gt.t() @ fg                                           # gWb (tiny)
@@ -521,7 +535,7 @@ class _SurfaceLayer(torch.autograd.Function):
         SC = directions.shape[1]
         g2, F2, x2 = g.view(B * N, C), F3.view(B * N, C), xyz.view(B * N, 3)
         Wa, Wb = w_conv2[:, :C], w_conv2[:, C:]
-        gt = g.sum(dim=1)
+        gt = colsum_rows(g)
         g_conv2 = torch.empty_like(w_conv2)
         wgrad(g2, F2, out=g_conv2[:, :C])
         g_conv2[:, C:] = gt.t() @ fg
@@ -646,6 +660,77 @@ class _GatherRows(torch.autograd.Function):
 def gather_rows(feat, idx):
     """feat (B,Nsrc,C), idx int32 (B,Nq) or shared (Nq,) -> (B,Nq,C)."""
     return _GatherRows.apply(feat, idx)
+
+
+# ------------------------------------------------------------------------------------------------
+# feat assembly: nearest up-sampling + one-hot + concat in one kernel (FaceRecon.py:100-107)
+# ------------------------------------------------------------------------------------------------
+
+class _AssembleFeat(torch.autograd.Function):
+    """feat (B,N,W) = cat[ direct..., gathered(src, nearest idx)..., per-cloud... ] along channels.
+    segs: list of (tensor, idx or None, kind) with kind 0 direct (B,N,w), 1 gathered rows of (B,Ns,w) by an
+    int32 (B,N) index, 2 per-cloud (B,w) broadcast over the points."""
+
+    @staticmethod
+    def forward(ctx, kinds, idxs, *tensors):
+        B, N = None, None
+        for t, kd in zip(tensors, kinds):
+            if kd == 0:
+                B, N = t.shape[0], t.shape[1]
+        tensors = [_req(t, torch.float32, "assemble_feat.src") for t in tensors]
+        idxs = [(_req(i, torch.int32, "assemble_feat.idx") if i is not None else None) for i in idxs]
+        n = len(tensors)
+        widths = [t.shape[-1] for t in tensors]
+        W = sum(widths)
+        out = torch.empty(B, N, W, dtype=torch.float32, device=tensors[0].device)
+        src = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tensors])
+        ix = (ctypes.c_void_p * n)(*[(i.data_ptr() if i is not None else 0) for i in idxs])
+        wd = (ctypes.c_int * n)(*widths)
+        kd = (ctypes.c_int * n)(*kinds)
+        ns = (ctypes.c_int * n)(*[(t.shape[1] if k_ == 1 else 0) for t, k_ in zip(tensors, kinds)])
+        _run("hsp_concat_rows", (n, ctypes.cast(src, _vp), ctypes.cast(ix, _vp), ctypes.cast(wd, _vp), ctypes.cast(kd, _vp),
+                                 ctypes.cast(ns, _vp), B, N, _p(out), _stream()),
+             key=f"B{B}N{N}W{W}", abytes=8 * B * N * W)
+        ctx.kinds, ctx.widths = kinds, widths
+        ctx.nsrc = [t.shape[1] for t in tensors]
+        ctx.save_for_backward(*[i for i in idxs if i is not None])
+        ctx.has_idx = [i is not None for i in idxs]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if not g.is_contiguous():
+            g = g.contiguous()
+        B, N, W = g.shape
+        saved = list(ctx.saved_tensors)
+        grads, col = [], 0
+        for s_, (kd, w) in enumerate(zip(ctx.kinds, ctx.widths)):
+            gs = g[:, :, col:col + w]
+            if not ctx.needs_input_grad[2 + s_]:
+                grads.append(None)
+                if ctx.has_idx[s_]:
+                    saved.pop(0)
+            elif kd == 0:
+                grads.append(gs)                                   # strided view: consumers take it as is / copy
+            elif kd == 1:
+                idx = saved.pop(0)
+                Ns = ctx.nsrc[s_]
+                gfeat = torch.empty(B, Ns, w, dtype=torch.float32, device=g.device)
+                _run("hsp_gather_rows_bwd", (_p(gs), W, _p(idx), 0, B, Ns, N, w, _p(gfeat), _stream()),
+                     key=f"B{B}Ns{Ns}Nq{N}C{w}", abytes=B * (4 * Ns * w + N * (4 + 4 * w)))
+                grads.append(gfeat)
+            else:
+                grads.append(gs.sum(dim=1))
+            col += w
+        return (None, None, *grads)
+
+
+def assemble_feat(segments):
+    """segments: list of (tensor, idx_or_None, kind) -> (B,N,sum widths); see _AssembleFeat."""
+    tensors = [s_[0] for s_ in segments]
+    idxs = [s_[1] for s_ in segments]
+    kinds = [s_[2] for s_ in segments]
+    return _AssembleFeat.apply(kinds, idxs, *tensors)
 
 
 # ------------------------------------------------------------------------------------------------

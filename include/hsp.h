@@ -137,6 +137,27 @@ int hsp_gather_max_bwd_csr(const float *grad_out, int grad_bcast, const uint8_t 
                            const int32_t *rev_edge, int B, int Nsrc, int Nq, int k, int C, float *grad_feat,
                            hspStream_t stream);
 
+/* ORL global feature in one pass (get_ORL_global, gcn3d.py:211-218, before the repeat):
+ * fg (B,C) = mean_i max_{n<k} feat[b, idx[b,i,n], :], argmax (B,N,C) uint8; the (B,N,C) max tensor is never
+ * written.  idx (B,N,kstride).  ws: hsp_orl_workspace_bytes(B,N,C).  Backward: hsp_gather_max_bwd(grad_bcast=1). */
+size_t hsp_orl_workspace_bytes(int B, int N, int C);
+int hsp_orl_global_fwd(const float *feat, const int32_t *idx, int B, int N, int k, int kstride, int C,
+                       float *fg, uint8_t *argmax, void *ws, size_t ws_bytes, hspStream_t stream);
+/* out (B,C) = sum_i x[b,i,:]  (the per-cloud column sum autograd takes of a gradient that was
+ * broadcast over the points, e.g. d/d(fg Wb^T)); deterministic two-stage.  ws as above. */
+int hsp_colsum_rows(const float *x, int B, int N, int C, float *out, void *ws, size_t ws_bytes,
+                    hspStream_t stream);
+
+/* ---- feature assembly ---------------------------------------------------------------------------
+ * replaces the nearest-up-sampling gathers + one-hot repeat + torch.cat     FaceRecon.py:100-107
+ * out (B,N,sum width): column segment s of row (b,i) is
+ *   kind 0: src[s][(b*N+i)*w .. ]   kind 1: src[s][(b*nsrc[s] + idx[s][b*N+i])*w ..]   kind 2: src[s][b*w ..]
+ * (host arrays of nseg <= 8 entries; device pointers inside).  The backward of kind-1 segments is
+ * hsp_gather_rows_bwd with grad_stride = total width.
+ */
+int hsp_concat_rows(int nseg, const float *const *src, const int32_t *const *idx, const int *width,
+                    const int *kind, const int *nsrc, int B, int N, float *out, hspStream_t stream);
+
 /* ---- row gather (nearest up-sample, vertex select) -------------------------------------------
  * replaces indexing_neighbor_new(t, nearest).squeeze(2)    FaceRecon.py:102-104 ; vertices[:, sample_idx]
  * feat (B,Nsrc,C); idx (B,Nq) or, when idx_shared != 0, (Nq) shared by the batch.
