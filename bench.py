@@ -101,7 +101,7 @@ def main():
     torch.manual_seed(0)
     net = FaceRecon().to(device).train()
     params = [p for p in net.parameters()]
-    reducer = GradReducer(params) if world > 1 else None
+    reducer = None                                     # eager fallback only (hooks must not exist during capture)
     centred, obj, dfeat = make_inputs(B, N, device, seed=rank)
     torch.manual_seed(1 + rank)                         # Pool_layer randperm stream (per rank)
 
@@ -114,19 +114,30 @@ def main():
             reducer.finish()
 
     graphed = None
-    if not args.no_graph and world == 1:
+    use_dist = dist.is_initialized()
+    if not args.no_graph:
         # hipGraph replay of zero_grad+fwd+bwd (hs_pose_amd/graph.py); the Pool_layer randperm draws stay on
-        # the host, before each replay.  (N>1: eager, so the bucketed RCCL all-reduce overlaps backward.)
+        # the host, before each replay.  Data parallel: the captured step also packs all gradients into one
+        # flat buffer, which is mean-all-reduced with a single RCCL collective after every replay.
         from hs_pose_amd.graph import GraphedStep
         try:
-            graphed = GraphedStep(net, centred, obj, dfeat)
+            graphed = GraphedStep(net, centred, obj, dfeat, flat_grads=use_dist)
         except Exception as exc:                           # capture unsupported -> measure eagerly, say so
             print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
             graphed = None
-    step = graphed.run if graphed is not None else eager_step
+    if graphed is None and use_dist and world > 1:
+        reducer = GradReducer(params)                      # bucketed all-reduce launched from autograd hooks
+
+    def graphed_step():
+        graphed.run()
+        if use_dist:
+            dist.all_reduce(graphed.flat_grad, op=dist.ReduceOp.SUM)
+            graphed.flat_grad.mul_(1.0 / world)
+
+    step = graphed_step if graphed is not None else eager_step
 
     def fence():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -153,7 +164,7 @@ def main():
         ops.set_timer(None)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
 
@@ -194,7 +205,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_sample)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

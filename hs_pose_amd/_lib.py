@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhsp.so")
+# HSP_LIB=<path> loads another build of the same ABI (profiling variants); default: the in-tree library
+LIB_PATH = os.environ.get("HSP_LIB") or os.path.join(_HERE, "libhsp.so")
 _lib = None
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t

@@ -331,7 +331,9 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
         // next (tile, chunk) of this wave
         int ntile = tile, nchunk = chunk + 1;
         if (nchunk == nchunks) { nchunk = 0; ntile = tile + 4; }
+#ifndef HSP_ABLATE_PREFETCH
         if (ntile < ntiles) prefetch(ntile, nchunk);
+#endif
         __builtin_amdgcn_wave_barrier();
 
         // |candidate|^2 of this lane's 16 rows: issued before the MFMAs of the tile's first chunk so the
@@ -345,6 +347,7 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
         }
         const float* arow = ctile + col * KF_CT_STRIDE + h * 32;
         const float* brow = qtile + col * QS + chunk * 64 + h * 32;
+#ifndef HSP_ABLATE_MFMA
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             const float4 a4 = *reinterpret_cast<const float4*>(arow + 4 * g);
@@ -354,6 +357,7 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
         }
+#endif
         __builtin_amdgcn_wave_barrier();
 
         if (chunk == nchunks - 1) {
@@ -363,7 +367,11 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
             for (int r = 0; r < 16; ++r) {
                 const int cand = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const float d = add_rn(add_rn(mul_rn(acc[r], -2.0f), qc[r]), qq);
+#ifndef HSP_ABLATE_INSERT
                 top.insert(cand < N ? d : INFINITY, cand);       // +inf never passes the strict '<'
+#else
+                if (d == 12345.678f) top.insert(d, cand);        // profiling variant: keep d live, never insert
+#endif
                 acc[r] = 0.f;
             }
         }

@@ -307,27 +307,41 @@ __global__ __launch_bounds__(RF_TILE_THREADS) void rf_bwd_tile_kernel(
     float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
     const float* fsup = SURFACE ? nullptr : fm + (size_t)b * N * fstride + C + j;
     __syncthreads();
+    // software pipeline: the next point's winning rows / gradient are in flight while this one is processed,
+    // and the four fm values (the only divergent global reads) are requested before any dependent math
+    ushort4 am_n = make_ushort4(0, 0, 0, 0);
+    float4 ga_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pl < N) {
+        am_n = *reinterpret_cast<const ushort4*>(argrow + ((size_t)b * N + pl) * SC + j);
+        ga_n = *reinterpret_cast<const float4*>(gout + ((size_t)b * N + pl) * C + c);
+    }
     for (int p = pl; p < N; p += PL) {
-        const size_t pt = (size_t)b * N + p;
-        const ushort4 am = *reinterpret_cast<const ushort4*>(argrow + pt * SC + j);
-        float4 ga = *reinterpret_cast<const float4*>(gout + pt * C + c);
+        const ushort4 am = am_n;
+        float4 ga = ga_n;
+        const int pn = p + PL < N ? p + PL : p;                      // clamped: no branch around the loads
+        am_n = *reinterpret_cast<const ushort4*>(argrow + ((size_t)b * N + pn) * SC + j);
+        ga_n = *reinterpret_cast<const float4*>(gout + ((size_t)b * N + pn) * C + c);
+        float f0 = 1.f, f1 = 1.f, f2 = 1.f, f3 = 1.f;
+        if (!SURFACE) {
+            f0 = fsup[(size_t)am.x * fstride + 0];
+            f1 = fsup[(size_t)am.y * fstride + 1];
+            f2 = fsup[(size_t)am.z * fstride + 2];
+            f3 = fsup[(size_t)am.w * fstride + 3];
+        }
         ga.x *= invS; ga.y *= invS; ga.z *= invS; ga.w *= invS;
         const float px = sx[p * 3], py = sx[p * 3 + 1], pz = sx[p * 3 + 2];
-#define RF_T1(X, E)                                                                                  \
+#define RF_T1(X, E, FV)                                                                              \
         {                                                                                            \
             const int m = am.X;                                                                      \
             const float3 r = unit_dir(px, py, pz, sx[m * 3], sx[m * 3 + 1], sx[m * 3 + 2]);          \
             const float z = __fmaf_rn(r.z, d2.X, __fmaf_rn(r.y, d1.X, mul_rn(r.x, d0.X)));           \
             if (z > 0.f) {                                                                           \
-                float w = ga.X;                                                                      \
-                if (!SURFACE) {                                                                      \
-                    atomicAdd(acc + m * TC + cg * 4 + E, ga.X * z);                                  \
-                    w = ga.X * fsup[(size_t)m * fstride + E];                                        \
-                }                                                                                    \
+                if (!SURFACE) atomicAdd(acc + m * TC + cg * 4 + E, ga.X * z);                        \
+                const float w = ga.X * FV;                                                           \
                 g0.X += w * r.x; g1.X += w * r.y; g2.X += w * r.z;                                   \
             }                                                                                        \
         }
-        RF_T1(x, 0) RF_T1(y, 1) RF_T1(z, 2) RF_T1(w, 3)
+        RF_T1(x, 0, f0) RF_T1(y, 1, f1) RF_T1(z, 2, f2) RF_T1(w, 3, f3)
 #undef RF_T1
     }
     __syncthreads();

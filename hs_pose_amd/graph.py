@@ -29,7 +29,10 @@ class GraphedStep:
     (``load_inputs`` copies new data in); parameter ``.grad`` tensors live in the graph's memory pool
     and are overwritten by every replay; ``feat`` is the static output."""
 
-    def __init__(self, face_recon, centred, obj, dfeat, warmup=3):
+    def __init__(self, face_recon, centred, obj, dfeat, warmup=3, flat_grads=False):
+        """flat_grads=True additionally packs every parameter gradient into ONE contiguous buffer
+        (``self.flat_grad``, one captured multi-tensor copy per step) so a data-parallel caller can
+        all-reduce the step's gradients with a single RCCL collective right after the replay."""
         self.net = face_recon
         self.centred, self.obj, self.dfeat = centred, obj, dfeat
         B, N, _ = centred.shape
@@ -39,6 +42,9 @@ class GraphedStep:
                          torch.empty(int(int(N / 4) / 4), dtype=torch.int32, device=dev)]
         self.params = [p for p in face_recon.parameters() if p.requires_grad]
         self.feat = None
+        self.flat_grad = None
+        if flat_grads:
+            self.flat_grad = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
         self._upload_pool_indices()
         prev_timer = ops.set_timer(None)               # HIP events cannot be recorded inside a capture
         try:
@@ -62,6 +68,9 @@ class GraphedStep:
             _, _, feat = self.net(self.centred, self.obj)
         feat.backward(self.dfeat)
         self.feat = feat
+        if self.flat_grad is not None:
+            torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params],
+                      out=self.flat_grad)
 
     def _upload_pool_indices(self):
         for buf, idx in zip(self.pool_idx, draw_pool_indices(self.n_points)):
@@ -77,3 +86,11 @@ class GraphedStep:
         self._upload_pool_indices()
         self.graph.replay()
         return self.feat
+
+    def grad_views(self):
+        """per-parameter views into flat_grad (after an all-reduce these ARE the averaged gradients)"""
+        out, off = [], 0
+        for p in self.params:
+            out.append(self.flat_grad[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        return out

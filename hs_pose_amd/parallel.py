@@ -22,13 +22,14 @@ import torch.distributed as dist
 def init_distributed():
     """(rank, world_size, device) from the torchrun environment; RCCL ('nccl') on GPU, gloo on CPU."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    force = os.environ.get("HSP_FORCE_DIST", "0") == "1"      # test hook: 1-rank process group
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available()
     device = torch.device(f"cuda:{local}") if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
