@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void gather_max_fwd_kernel(const float* __rest
 // over the k gathered rows, the chunk's column sums are folded through LDS in a fixed order and written
 // to part[b][chunk][C]; orl_finalize_kernel folds the chunks (deterministic).  The (B,N,C) max tensor of
 // the reference is never written.
-#define ORL_ROWS 64          // upper bound of points per chunk (workspace sizing)
+#define ORL_ROWS 128         // upper bound of points per chunk
 __global__ __launch_bounds__(256) void orl_partial_kernel(const float* __restrict__ feat,
                                                           const int32_t* __restrict__ idx, int N, int k,
                                                           int kstride, int C, uint8_t* __restrict__ argmax,
@@ -190,7 +190,8 @@ __global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const float* __re
                                                                int idx_shared, const int32_t* __restrict__ qsel,
                                                                const uint8_t* __restrict__ argmax, int Nsrc,
                                                                int Nidx, int Nq, int kstride, int C,
-                                                               float* __restrict__ gfeat, int accumulate) {
+                                                               float* __restrict__ gfeat, int accumulate,
+                                                               const float* __restrict__ extra) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* acc = reinterpret_cast<float*>(smem);
     int* cnt = reinterpret_cast<int*>(smem);
@@ -248,6 +249,10 @@ __global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const float* __re
         }
         float4* dst = reinterpret_cast<float4*>(gfeat + ((size_t)b * Nsrc + m) * C + j0 + g4 * 4);
         if (accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        if (extra) {
+            const float4 o = *reinterpret_cast<const float4*>(extra + ((size_t)b * Nsrc + m) * C + j0 + g4 * 4);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
         *dst = v;
     }
 }
@@ -261,7 +266,7 @@ static int pick_scatter_cols(int Nsrc, int C) {
 template <int MODE>
 static int launch_scatter_tile(int tc, const float* gout, int gstride, int gbcast, const int32_t* idx, int idx_shared,
                                const int32_t* qsel, const uint8_t* argmax, int B, int Nsrc, int Nidx, int Nq,
-                               int kstride, int C, float* gfeat, int accumulate, hipStream_t st) {
+                               int kstride, int C, float* gfeat, int accumulate, const float* extra, hipStream_t st) {
     const size_t lds = (size_t)Nsrc * tc * 4;
     dim3 grid(C / tc, B);
 #define SC_LAUNCH(TC)                                                                                              \
@@ -273,7 +278,7 @@ static int launch_scatter_tile(int tc, const float* gout, int gstride, int gbcas
             if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }                                 \
         }                                                                                                          \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, gout, gstride, gbcast, idx, idx_shared, qsel, argmax, Nsrc, \
-                           Nidx, Nq, kstride, C, gfeat, accumulate);                                               \
+                           Nidx, Nq, kstride, C, gfeat, accumulate, extra);                                        \
     }
     if (tc == 16) SC_LAUNCH(16) else if (tc == 8) SC_LAUNCH(8) else SC_LAUNCH(4)
 #undef SC_LAUNCH
@@ -382,7 +387,8 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float* __res
 // row per row-lane, at most ORL_ROWS (the workspace is sized for the smallest chunk count = ORL_ROWS rows)
 static int chunk_rows(int B, int N, int C) {
     const int RL = 256 / (C >> 2);
-    long long r = ((long long)B * N + 1023) / 1024;
+    long long r = ((long long)B * N + 511) / 512;           // ~512 workgroups ...
+    if (r < (N + 31) / 32) r = (N + 31) / 32;               // ... but at most 32 chunks per cloud for the serial fold
     if (r < RL) r = RL;
     if (r > ORL_ROWS) r = ORL_ROWS;
     return (int)r;
@@ -415,7 +421,7 @@ extern "C" int hsp_gather_max_fwd(const float* feat, const int32_t* idx, const i
 
 extern "C" int hsp_gather_max_bwd(const float* grad_out, int grad_bcast, const int32_t* idx, const int32_t* qsel,
                                   const uint8_t* argmax, int B, int Nsrc, int Nidx, int Nq, int kstride, int C,
-                                  float* grad_feat, int accumulate, hspStream_t stream) {
+                                  float* grad_feat, int accumulate, const float* extra, hspStream_t stream) {
     if (!grad_out || !idx || !argmax || !grad_feat || B <= 0 || Nsrc <= 0 || Nidx <= 0 || Nq <= 0 || kstride <= 0 || C <= 0)
         return HSP_ERR_BAD_ARG;
     if (!qsel && Nq != Nidx) return HSP_ERR_BAD_ARG;
@@ -423,7 +429,8 @@ extern "C" int hsp_gather_max_bwd(const float* grad_out, int grad_bcast, const i
     hipStream_t st = as_stream(stream);
     if (const int tc = pick_scatter_cols(Nsrc, C))
         return launch_scatter_tile<0>(tc, grad_out, C, grad_bcast, idx, 0, qsel, argmax, B, Nsrc, Nidx, Nq, kstride, C,
-                                      grad_feat, accumulate, st);
+                                      grad_feat, accumulate, extra, st);
+    if (extra) return HSP_ERR_UNSUPPORTED;                 // the global-atomic fallback has no fused add
     if (!accumulate) {
         hipError_t e = hipMemsetAsync(grad_feat, 0, (size_t)B * Nsrc * C * sizeof(float), st);
         if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
@@ -458,7 +465,7 @@ extern "C" int hsp_gather_rows_bwd(const float* grad_out, int grad_stride, const
     if ((C & 3) == 0 && (grad_stride & 1) == 0 && (reinterpret_cast<uintptr_t>(grad_out) & 7) == 0)
         if (const int tc = pick_scatter_cols(Nsrc, C))
             return launch_scatter_tile<1>(tc, grad_out, grad_stride, 0, idx, idx_shared, nullptr, nullptr, B, Nsrc, Nq,
-                                          Nq, 1, C, grad_feat, 0, st);
+                                          Nq, 1, C, grad_feat, 0, nullptr, st);
     hipError_t e = hipMemsetAsync(grad_feat, 0, (size_t)B * Nsrc * C * sizeof(float), st);
     if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
     const long long total = (long long)B * Nq * C;

@@ -18,7 +18,7 @@
 namespace hsp {
 
 #define BN_THREADS 256
-#define BN_ROWS_PER_BLOCK 64
+#define BN_MAX_PARTIALS 64        // the finalize kernel folds this many partials per channel serially
 
 // partial[blk][0][c] = sum_r v1, partial[blk][1][c] = sum_r v2 over the rows of chunk blk, where
 //   MODE 0 (forward stats):  v1 = x - shift,  v2 = (x - shift)^2            shift = x[0][c]
@@ -30,14 +30,14 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float* __r
                                                                 const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, int relu,
-                                                                float* __restrict__ partial) {
+                                                                float* __restrict__ partial, int rows_per_block) {
     __shared__ float4 red[2][BN_THREADS];
     const int cq = C >> 2;                       // float4 groups per row
     const int tid = threadIdx.x;
     const int g = tid % cq, rl = tid / cq;       // BN_THREADS % cq == 0 is guaranteed by the launcher
     const int RL = BN_THREADS / cq;
-    const int r0 = blockIdx.x * BN_ROWS_PER_BLOCK;
-    const int r1 = min(R, r0 + BN_ROWS_PER_BLOCK);
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(R, r0 + rows_per_block);
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     float4 sh = make_float4(0.f, 0.f, 0.f, 0.f), mu = sh, is = sh, ga = sh, be = sh;
     if (MODE == 0) {
@@ -179,7 +179,12 @@ __global__ __launch_bounds__(256) void bn_dx_kernel(const float* __restrict__ x,
     }
 }
 
-static int bn_blocks(int R) { return (R + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK; }
+static int bn_rows_per_block(int R) {
+    int r = (R + BN_MAX_PARTIALS - 1) / BN_MAX_PARTIALS;
+    if (r < 64) r = 64;
+    return r;
+}
+static int bn_blocks(int R) { const int r = bn_rows_per_block(R); return (R + r - 1) / r; }
 
 static int bn_check(int R, int C) {
     if (R <= 0 || C <= 0) return HSP_ERR_BAD_ARG;
@@ -216,7 +221,7 @@ extern "C" int hsp_bn_relu_fwd(const float* x, int R, int C, const float* gamma,
     float* part = reinterpret_cast<float*>(ws);
     const int nblk = bn_blocks(R);
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nblk), dim3(BN_THREADS), 0, st, x, nullptr, R, C, nullptr, nullptr,
-                       nullptr, nullptr, 0, part);
+                       nullptr, nullptr, 0, part, bn_rows_per_block(R));
     hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 255) / 256), dim3(256), 0, st, part, nblk, R, C, x, eps, momentum,
                        save_mean, save_invstd, running_mean, running_var, num_batches_tracked);
     const long long total4 = (long long)R * (C >> 2);
@@ -247,7 +252,7 @@ extern "C" int hsp_bn_relu_bwd(const float* x, const float* dy, int R, int C, co
     float* part = reinterpret_cast<float*>(ws);
     const int nblk = bn_blocks(R);
     hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nblk), dim3(BN_THREADS), 0, st, x, dy, R, C, save_mean, save_invstd, gamma,
-                       beta, relu, part);
+                       beta, relu, part, bn_rows_per_block(R));
     hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 255) / 256), dim3(256), 0, st, part, nblk, R, C, x, 0.f, 0.f, dgamma,
                        dbeta, nullptr, nullptr, nullptr);
     const long long total4 = (long long)R * (C >> 2);

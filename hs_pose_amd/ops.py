@@ -247,7 +247,7 @@ class _GatherMax(torch.autograd.Function):
         g = _req(g, torch.float32, "gather_max.grad")
         gfeat = torch.empty(B, Nsrc, C, dtype=torch.float32, device=g.device)
         _run("hsp_gather_max_bwd", (_p(g), 0, _p(idx), _p(qsel), _p(arg), B, Nsrc, Nidx, Nq, kstride, C, _p(gfeat), 0,
-                                    _stream()),
+                                    _vp(0), _stream()),
              key=f"B{B}Ns{Nsrc}Nq{Nq}C{C}", abytes=B * (4 * Nsrc * C + Nq * (4 * kstride + 5 * C)))
         return gfeat, None, None, None
 
@@ -278,7 +278,8 @@ class _OrlGlobal(torch.autograd.Function):
             _run("hsp_gather_max_bwd_csr", (_p(g), 1, _p(arg), _p(off), _p(edge), B, N, N, ctx.k, C, _p(gfeat), _stream()),
                  key=f"B{B}Ns{N}Nq{N}k{ctx.k}C{C}bc", abytes=B * N * (4 * C + 8 * ctx.k + C))
         else:                  # LDS tile kernel; broadcast gradient => integer counts => reproducible as well
-            _run("hsp_gather_max_bwd", (_p(g), 1, _p(idx), _vp(0), _p(arg), B, N, N, N, kstride, C, _p(gfeat), 0, _stream()),
+            _run("hsp_gather_max_bwd", (_p(g), 1, _p(idx), _vp(0), _p(arg), B, N, N, N, kstride, C, _p(gfeat), 0, _vp(0),
+                                        _stream()),
                  key=f"B{B}Ns{N}Nq{N}C{C}bc", abytes=B * N * (4 * C + 4 * kstride + C))
         return gfeat, None, None
 
@@ -399,8 +400,8 @@ def colsum_rows(x3):
     return out
 
 
-def _orl_bwd_accumulate_raw(gfg_over_n, idx_x, arg, k, gF3):
-    """gF3[b, idx_x[b,i,arg[b,i,c]], c] += gfg_over_n[b,c]   (in place)"""
+def _orl_bwd_accumulate_raw(gfg_over_n, idx_x, arg, k, gF3, extra=None):
+    """gF3[b,m,c] += extra[b,m,c] + gfg_over_n[b,c] * #{i : idx_x[b,i,arg[b,i,c]] == m}     (in place, one pass)"""
     B, N, C = gF3.shape
     if DETERMINISTIC:
         tmp = torch.empty_like(gF3)
@@ -408,10 +409,12 @@ def _orl_bwd_accumulate_raw(gfg_over_n, idx_x, arg, k, gF3):
         _run("hsp_gather_max_bwd_csr", (_p(gfg_over_n), 1, _p(arg), _p(off), _p(edge), B, N, N, k, C, _p(tmp), _stream()),
              key=f"B{B}Ns{N}Nq{N}k{k}C{C}bc", abytes=B * N * (4 * C + 8 * k + C))
         gF3.add_(tmp)
+        if extra is not None:
+            gF3.add_(extra)
     else:
         _run("hsp_gather_max_bwd", (_p(gfg_over_n), 1, _p(idx_x), _vp(0), _p(arg), B, N, N, N, idx_x.shape[2], C,
-                                    _p(gF3), 1, _stream()),
-             key=f"B{B}Ns{N}Nq{N}C{C}bc+", abytes=B * N * (8 * C + 4 * idx_x.shape[2] + C))
+                                    _p(gF3), 1, _p(extra), _stream()),
+             key=f"B{B}Ns{N}Nq{N}C{C}bc+", abytes=B * N * (12 * C + 4 * idx_x.shape[2] + C))
 
 
 def _rf_conv_bwd_raw(xyz, idx, directions, fm, arg, gF3, S):
@@ -482,9 +485,9 @@ class _HSLayer(torch.autograd.Function):
         g_conv2 = torch.empty_like(w_conv2)
         wgrad(g2, F2, out=g_conv2[:, :C])                                      # gWa, written in place (ldc = 2C)
         g_conv2[:, C:] = gt.t() @ fg                                           # gWb (tiny)
-        gF = torch.addmm(g2, g2, Wa)                                           # g + g Wa
-        gF3 = gF.view(B, N, C)
-        _orl_bwd_accumulate_raw((gt @ Wb) / N, idx_x, arg_o, k, gF3)
+        gF3 = torch.empty(B, N, C, dtype=torch.float32, device=g.device)
+        torch.mm(g2, Wa, out=gF3.view(B * N, C))                               # g Wa ...
+        _orl_bwd_accumulate_raw((gt @ Wb) / N, idx_x, arg_o, k, gF3, extra=g)  # ... + g + ORL scatter, one pass
         gfm, gD = _rf_conv_bwd_raw(xyz, idx_f, directions, fm.view(B, N, -1), arg, gF3, S)
         gfm2 = gfm.view(B * N, -1)
         gW, gb = wgrad(X2, gfm2, colsum=True)                                  # X^T gfm and the bias gradient
@@ -539,9 +542,9 @@ class _SurfaceLayer(torch.autograd.Function):
         g_conv2 = torch.empty_like(w_conv2)
         wgrad(g2, F2, out=g_conv2[:, :C])
         g_conv2[:, C:] = gt.t() @ fg
-        gF = torch.addmm(g2, g2, Wa)
-        gF3 = gF.view(B, N, C)
-        _orl_bwd_accumulate_raw((gt @ Wb) / N, idx_x, arg_o, k, gF3)
+        gF3 = torch.empty(B, N, C, dtype=torch.float32, device=g.device)
+        torch.mm(g2, Wa, out=gF3.view(B * N, C))
+        _orl_bwd_accumulate_raw((gt @ Wb) / N, idx_x, arg_o, k, gF3, extra=g)
         gD = torch.empty_like(directions)
         L = lib()
         wsb = L.hsp_rf_bwd_scatter_workspace_bytes(B, SC)

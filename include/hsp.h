@@ -130,6 +130,7 @@ int hsp_gather_max_fwd(const float *feat, const int32_t *idx, const int32_t *qse
 int hsp_gather_max_bwd(const float *grad_out, int grad_bcast, const int32_t *idx, const int32_t *qsel,
                        const uint8_t *argmax, int B, int Nsrc, int Nidx, int Nq, int kstride, int C,
                        float *grad_feat, int accumulate /* !=0: add into grad_feat instead of overwriting */,
+                       const float *extra /* optional (B,Nsrc,C) tensor added in the same pass, or NULL */,
                        hspStream_t stream);
 /* the same result in GATHER form over hsp_rev_build(idx, k) (qsel == NULL case, Nq rows of idx):
  * each grad_feat row written once, no atomics. */
