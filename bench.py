@@ -58,7 +58,9 @@ def cpu_baseline(n_points, sample_clouds):
         if p[k].is_floating_point() and "running" not in k:
             p[k].requires_grad_(True)
     centred, obj, dfeat = make_inputs(sample_clouds, n_points, torch.device("cpu"))
-    cores = os.cpu_count() or 1
+    # MKL/oneDNN on these small per-cloud matrices stops scaling (and then degrades) beyond a few dozen
+    # threads; use at most 32 and report the number actually used
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     torch.manual_seed(1)
     t0 = time.perf_counter()
@@ -78,7 +80,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="clouds per GPU")
     ap.add_argument("--points", type=int, default=1028)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=4, help="clouds in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=2, help="clouds in the CPU-baseline sample")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="leave hipBLASLt/rocBLAS on their default heuristics")

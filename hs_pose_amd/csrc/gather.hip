@@ -257,6 +257,24 @@ __global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const float* __re
     }
 }
 
+// out[b,i,:] += f[b,i,:] + t[b,:]   -- the residual + per-cloud ORL bias of an HS layer in one pass
+// (reference: "conv2(cat[feature, f_global]) + feature", gcn3d.py:112,186, with the f_global half of conv2
+// reduced to the per-cloud row t = f_global Wb^T)
+__global__ __launch_bounds__(256) void residual_bias_kernel(float* __restrict__ out, const float* __restrict__ f,
+                                                            const float* __restrict__ t, long long total4, int N,
+                                                            int C) {
+    const int cq = C >> 2;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
+        const int g = (int)(e % cq);
+        const int b = (int)((e / cq) / N);
+        float4 o = *reinterpret_cast<const float4*>(out + e * 4);
+        const float4 a = *reinterpret_cast<const float4*>(f + e * 4);
+        const float4 tb = *reinterpret_cast<const float4*>(t + (size_t)b * C + (g << 2));
+        o.x += a.x + tb.x; o.y += a.y + tb.y; o.z += a.z + tb.z; o.w += a.w + tb.w;
+        *reinterpret_cast<float4*>(out + e * 4) = o;
+    }
+}
+
 static int pick_scatter_cols(int Nsrc, int C) {
     for (int tc = 16; tc >= 4; tc >>= 1)
         if (C % tc == 0 && (size_t)Nsrc * tc * 4 <= 144 * 1024) return tc;
@@ -543,5 +561,14 @@ extern "C" int hsp_concat_rows(int nseg, const float* const* src, const int32_t*
     const long long rows = (long long)B * N;
     const int grid = (int)(rows < 8192 ? rows : 8192);
     hipLaunchKernelGGL(concat_rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), d, B, N, col, out);
+    return check_launch();
+}
+
+extern "C" int hsp_residual_bias(float* out, const float* f, const float* t, int B, int N, int C, hspStream_t stream) {
+    if (!out || !f || !t || B <= 0 || N <= 0 || C <= 0) return HSP_ERR_BAD_ARG;
+    if (C & 3) return HSP_ERR_UNSUPPORTED;
+    const long long total4 = (long long)B * N * (C >> 2);
+    hipLaunchKernelGGL(residual_bias_kernel, dim3(stream_grid(total4)), dim3(256), 0, as_stream(stream), out, f, t, total4,
+                       N, C);
     return check_launch();
 }

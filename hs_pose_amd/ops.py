@@ -387,6 +387,13 @@ def _orl_fwd_raw(F3, idx_x, k):
     return fg, arg
 
 
+def _residual_bias(out3, f3, t2):
+    """out3 (B,N,C) += f3 + t2[:, None, :]  in place"""
+    B, N, C = out3.shape
+    _run("hsp_residual_bias", (_p(out3), _p(f3), _p(t2.contiguous()), B, N, C, _stream()), key=f"B{B}N{N}C{C}",
+         abytes=12 * B * N * C)
+
+
 def colsum_rows(x3):
     """(B,C) = x3.sum(dim=1) for a contiguous (B,N,C) fp32 tensor: deterministic two-stage column sum"""
     B, N, C = x3.shape
@@ -464,9 +471,9 @@ class _HSLayer(torch.autograd.Function):
         F2 = F3.view(B * N, C)
         out3 = torch.empty(B, N, C, dtype=torch.float32, device=X.device)      # (returned as is: not a view)
         out = out3.view(B * N, C)
-        torch.addmm(F2, F2, w_conv2[:, :C].t(), out=out)                       # F + F Wa^T
-        out.addmm_(X2, w_ste.t())                                              # + X Wste^T
-        out3 += (fg @ w_conv2[:, C:].t()).unsqueeze(1)                         # + t[b]
+        torch.mm(X2, w_ste.t(), out=out)                                       # X Wste^T
+        out.addmm_(F2, w_conv2[:, :C].t())                                     # + F Wa^T
+        _residual_bias(out3, F3, fg @ w_conv2[:, C:].t())                      # + F + t[b]   (one pass)
         ctx.save_for_backward(xyz, X, idx_f, idx_x, fm, arg, F3, arg_o, fg, weights, directions, w_ste3, w_conv23)
         ctx.k, ctx.S = k, S
         return out3
@@ -521,9 +528,9 @@ class _SurfaceLayer(torch.autograd.Function):
         F2, x2 = F3.view(B * N, C), xyz.view(B * N, 3)
         out3 = torch.empty(B, N, C, dtype=torch.float32, device=xyz.device)
         out = out3.view(B * N, C)
-        torch.addmm(F2, F2, w_conv2[:, :C].t(), out=out)
-        out.addmm_(x2, w_ste.t())
-        out3 += (fg @ w_conv2[:, C:].t()).unsqueeze(1)
+        torch.mm(x2, w_ste.t(), out=out)
+        out.addmm_(F2, w_conv2[:, :C].t())
+        _residual_bias(out3, F3, fg @ w_conv2[:, C:].t())
         ctx.save_for_backward(xyz, idx_x, arg, F3, arg_o, fg, directions, w_conv23)
         ctx.k, ctx.S = k, S
         return out3

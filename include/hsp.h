@@ -149,6 +149,10 @@ int hsp_orl_global_fwd(const float *feat, const int32_t *idx, int B, int N, int 
 int hsp_colsum_rows(const float *x, int B, int N, int C, float *out, void *ws, size_t ws_bytes,
                     hspStream_t stream);
 
+/* out (B,N,C) += f (B,N,C) + t (B,C) broadcast over the points: the "+ feature" residual and the per-cloud
+ * half of conv2 of an HS layer (gcn3d.py:112,186) in one pass. */
+int hsp_residual_bias(float *out, const float *f, const float *t, int B, int N, int C, hspStream_t stream);
+
 /* ---- feature assembly ---------------------------------------------------------------------------
  * replaces the nearest-up-sampling gathers + one-hot repeat + torch.cat     FaceRecon.py:100-107
  * out (B,N,sum width): column segment s of row (b,i) is
