@@ -64,6 +64,8 @@ def test_knn_ties_value_equal(dev, ref, oc):
     (1, 4100, 3, 20, 1),      # more points than one LDS chunk
     (2, 40, 8, 4, 1), (2, 70, 100, 8, 1), (1, 33, 64, 2, 1), (2, 130, 192, 20, 0), (1, 500, 128, 32, 1),
     (1, 31, 6, 3, 1),
+    (16, 1028, 128, 20, 1),   # the bench shape: 32 MFMA tiles + the 4-query remainder kernel per cloud
+    (32, 260, 64, 8, 1),      # remainder kernel with K1 = 9
 ])
 def test_knn_vs_c_oracle(dev, ref, oc, B, N, C, k, drop):
     from hs_pose_amd import ops
