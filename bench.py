@@ -30,6 +30,8 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+MFMA_F32_PEAK_TFLOPS = 157.3   # same guide: v_mfma_f32_32x32x2_f32 dense peak (= the fp32 vector rate)
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01", "traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 
 
 def make_inputs(B, N, device, seed=0):
@@ -80,7 +82,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="clouds per GPU")
     ap.add_argument("--points", type=int, default=1028)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2, help="clouds in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=16, help="clouds in the CPU-baseline sample (one per-GPU batch)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="leave hipBLASLt/rocBLAS on their default heuristics")
@@ -174,8 +176,24 @@ def main():
         summ = timer.summary()
         # dominant kernel = the C-ABI call with the largest total time in the timed region
         (kname, kkey), kd = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
-        achieved = kd["abytes"] / (kd["avg_us"] * 1e-6) / 1e9
         hsp_ms = sum(d["total_ms"] for d in summ.values()) / args.steps
+        if kd.get("aflops", 0) > 0:       # GEMM-shaped kernel (feature-space distance tiles / weight gradient): MFMA roofline
+            achieved = kd["aflops"] / (kd["avg_us"] * 1e-6) / 1e12
+            roof = {"bound": "mfma", "kernel": f"{kname}[{kkey}]", "achieved": round(achieved, 3),
+                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 5),
+                    "avg_us": round(kd["avg_us"], 2), "algorithmic_flops_per_launch": kd["aflops"],
+                    "algorithmic_bytes_per_launch": kd["abytes"], "traffic": None}
+        else:
+            achieved = kd["abytes"] / (kd["avg_us"] * 1e-6) / 1e9
+            roof = {"bound": "hbm", "kernel": f"{kname}[{kkey}]", "achieved": round(achieved, 2),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "avg_us": round(kd["avg_us"], 2), "algorithmic_bytes_per_launch": kd["abytes"], "traffic": None}
+        try:                               # HBM bytes per launch measured with rocprofv3 PMC passes (committed with the profile)
+            with open(TRAFFIC_JSON) as f:
+                tj = json.load(f)
+            roof["traffic"] = tj.get(f"{kname}[{kkey}]", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
         if args.breakdown:
             for (n_, k_), d in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
                 print(f"{n_:22s} {k_:28s} calls/step {d['calls'] / args.steps:4.1f}  avg {d['avg_us']:9.1f} us  "
@@ -199,10 +217,7 @@ def main():
                                    f"train-mode BN, random-init weights (BASELINE configs[1] shape)",
                        "global_batch": world * B, "points": N, "parallelism": f"dp{world}", "hipgraph": graphed is not None,
                        "libhsp_ms_per_step": round(hsp_ms, 4)},
-            "roofline": {"bound": "hbm", "kernel": f"{kname}[{kkey}]", "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "avg_us": round(kd["avg_us"], 2), "algorithmic_bytes_per_launch": kd["abytes"],
-                         "traffic": None},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_sample)

@@ -236,6 +236,72 @@ __global__ __launch_bounds__(256) void quad_kernel(const float* __restrict__ x, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// remainder queries of the feature path.  N = 1028 = 32*32 + 4 leaves 4 queries per cloud that would
+// cost a whole MFMA workgroup (33 instead of 32 tiles: 528 workgroups on 256 CUs, a 3:2 imbalance).
+// They are handled here: one workgroup per query; thread t owns candidates t, t+256, ... and runs four
+// of their k-ordered fma chains at a time (same chain as the MFMA path: bit-identical distances); the
+// 256 per-thread lists are merged by a wave tournament (64 -> 1 per wave) and a 4-way one.
+// Runs as extra workgroups of knn_feat_kernel's grid (blockIdx.x >= full_tiles), concurrently with the MFMA tiles.
+// LDS = max(C*4, 256*K1*8) + 4*K1*8
+// ------------------------------------------------------------------------------------------------
+template <int K1>
+__device__ __forceinline__ void knn_feat_tail_body(char* smem, const float* __restrict__ x,
+                                                   const float* __restrict__ quad, int N, int C, int k, int drop,
+                                                   int q, int32_t* __restrict__ idx) {
+    float* sq = reinterpret_cast<float*>(smem);               // the query row
+    int2* lists = reinterpret_cast<int2*>(smem);              // 256 lists, aliased after the scan
+    int2* wl = lists + 256 * K1;                              // 4 per-wave merged lists
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.y;                                 // q < N by construction
+    const float* xb = x + (size_t)b * N * C;
+    const float* quadb = quad + (size_t)b * N;
+    for (int e = tid; e < C; e += 256) sq[e] = xb[(size_t)q * C + e];
+    __syncthreads();
+    TopList<K1> top;
+    top.init();
+    const float qn = quadb[q];
+    for (int j0 = tid; j0 < N; j0 += 4 * 256) {
+        // four candidates per pass (clamped rows: a clamped duplicate is discarded below), independent chains
+        const int j1 = j0 + 256, j2 = j0 + 512, j3 = j0 + 768;
+        const float* r0 = xb + (size_t)j0 * C;
+        const float* r1 = xb + (size_t)min(j1, N - 1) * C;
+        const float* r2 = xb + (size_t)min(j2, N - 1) * C;
+        const float* r3 = xb + (size_t)min(j3, N - 1) * C;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int c = 0;
+        for (; c + 3 < C; c += 4) {                         // 16-byte row segments (C % 4 == 0 keeps them aligned)
+            const float4 qv = *reinterpret_cast<const float4*>(sq + c);
+            const float4 v0 = *reinterpret_cast<const float4*>(r0 + c);
+            const float4 v1 = *reinterpret_cast<const float4*>(r1 + c);
+            const float4 v2 = *reinterpret_cast<const float4*>(r2 + c);
+            const float4 v3 = *reinterpret_cast<const float4*>(r3 + c);
+            a0 = __fmaf_rn(qv.w, v0.w, __fmaf_rn(qv.z, v0.z, __fmaf_rn(qv.y, v0.y, __fmaf_rn(qv.x, v0.x, a0))));
+            a1 = __fmaf_rn(qv.w, v1.w, __fmaf_rn(qv.z, v1.z, __fmaf_rn(qv.y, v1.y, __fmaf_rn(qv.x, v1.x, a1))));
+            a2 = __fmaf_rn(qv.w, v2.w, __fmaf_rn(qv.z, v2.z, __fmaf_rn(qv.y, v2.y, __fmaf_rn(qv.x, v2.x, a2))));
+            a3 = __fmaf_rn(qv.w, v3.w, __fmaf_rn(qv.z, v3.z, __fmaf_rn(qv.y, v3.y, __fmaf_rn(qv.x, v3.x, a3))));
+        }
+        for (; c < C; ++c) {
+            const float qc = sq[c];
+            a0 = __fmaf_rn(qc, r0[c], a0);
+            a1 = __fmaf_rn(qc, r1[c], a1);
+            a2 = __fmaf_rn(qc, r2[c], a2);
+            a3 = __fmaf_rn(qc, r3[c], a3);
+        }
+        top.insert(add_rn(add_rn(mul_rn(a0, -2.0f), quadb[j0]), qn), j0);
+        if (j1 < N) top.insert(add_rn(add_rn(mul_rn(a1, -2.0f), quadb[j1]), qn), j1);
+        if (j2 < N) top.insert(add_rn(add_rn(mul_rn(a2, -2.0f), quadb[j2]), qn), j2);
+        if (j3 < N) top.insert(add_rn(add_rn(mul_rn(a3, -2.0f), quadb[j3]), qn), j3);
+    }
+    __syncthreads();
+    top.store(lists + (size_t)tid * K1);
+    // 64 lists of a wave -> one sorted list of k+drop pairs (padded with +inf)
+    for (int p = lane; p < K1; p += 64) wl[w * K1 + p] = make_int2(__float_as_int(INFINITY), INT_MAX);
+    merge_write<K1, 64, true>(lists, tid, lane, k, drop, true, nullptr, wl + w * K1);
+    __syncthreads();
+    if (w == 0) merge_write<K1, 4>(wl, lane & 3, lane & 3, k, drop, lane < 4, idx + ((size_t)b * N + q) * k);
+}
+
+// ------------------------------------------------------------------------------------------------
 // feature path (any C that is a multiple of 64, or any even C via zero padding of the last chunk):
 // one block = 32 queries of one cloud, 4 waves; wave w takes candidate tiles w, w+4, ... (32 rows
 // each).  Distances of a 32x32 (candidate x query) tile come from v_mfma_f32_32x32x2_f32 over
@@ -252,8 +318,15 @@ __global__ __launch_bounds__(256) void quad_kernel(const float* __restrict__ x, 
 template <int K1>
 __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restrict__ x,
                                                        const float* __restrict__ quad, int N, int C, int k,
-                                                       int drop, int32_t* __restrict__ idx) {
+                                                       int drop, int32_t* __restrict__ idx, int full_tiles,
+                                                       int ntail) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // remainder queries: one workgroup each.  They take the LOWEST block ids so that they are dispatched
+    // first and run alongside the MFMA tiles instead of after them.
+    if ((int)blockIdx.x < ntail) {
+        knn_feat_tail_body<K1>(smem, x, quad, N, C, k, drop, full_tiles * 32 + (int)blockIdx.x, idx);
+        return;
+    }
     const int Cp = (C + 63) & ~63;          // K padded to a multiple of 64 with zeros (adds exact 0s)
     const int QS = Cp + 4;                  // query row stride (floats)
     float* qtile = reinterpret_cast<float*>(smem);
@@ -262,7 +335,7 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
     const int col = lane & 31, h = lane >> 5;
     float* ctile = qtile + 32 * QS + wave * 32 * KF_CT_STRIDE;
     const int b = blockIdx.y;
-    const int q0 = blockIdx.x * 32;
+    const int q0 = ((int)blockIdx.x - ntail) * 32;
     const float* xb = x + (size_t)b * N * C;
     const float* quadb = quad + (size_t)b * N;
 
@@ -398,73 +471,6 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// remainder queries of the feature path.  N = 1028 = 32*32 + 4 leaves 4 queries per cloud that would
-// cost a whole MFMA workgroup (33 instead of 32 tiles: 528 workgroups on 256 CUs, a 3:2 imbalance).
-// They are handled here: one workgroup per query; thread t owns candidates t, t+256, ... and runs four
-// of their k-ordered fma chains at a time (same chain as the MFMA path: bit-identical distances); the
-// 256 per-thread lists are merged by a wave tournament (64 -> 1 per wave) and a 4-way one.
-// grid (rem, B), block 256, dynamic LDS = max(C*4, 256*K1*8) + 4*K1*8
-// ------------------------------------------------------------------------------------------------
-template <int K1>
-__global__ __launch_bounds__(256) void knn_feat_tail_kernel(const float* __restrict__ x,
-                                                            const float* __restrict__ quad, int N, int C, int k,
-                                                            int drop, int q_begin, int32_t* __restrict__ idx) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sq = reinterpret_cast<float*>(smem);               // the query row
-    int2* lists = reinterpret_cast<int2*>(smem);              // 256 lists, aliased after the scan
-    int2* wl = lists + 256 * K1;                              // 4 per-wave merged lists
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int b = blockIdx.y;
-    const int q = q_begin + blockIdx.x;                       // < N by construction
-    const float* xb = x + (size_t)b * N * C;
-    const float* quadb = quad + (size_t)b * N;
-    for (int e = tid; e < C; e += 256) sq[e] = xb[(size_t)q * C + e];
-    __syncthreads();
-    TopList<K1> top;
-    top.init();
-    const float qn = quadb[q];
-    for (int j0 = tid; j0 < N; j0 += 4 * 256) {
-        // four candidates per pass (clamped rows: a clamped duplicate is discarded below), independent chains
-        const int j1 = j0 + 256, j2 = j0 + 512, j3 = j0 + 768;
-        const float* r0 = xb + (size_t)j0 * C;
-        const float* r1 = xb + (size_t)min(j1, N - 1) * C;
-        const float* r2 = xb + (size_t)min(j2, N - 1) * C;
-        const float* r3 = xb + (size_t)min(j3, N - 1) * C;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int c = 0;
-        for (; c + 3 < C; c += 4) {                         // 16-byte row segments (C % 4 == 0 keeps them aligned)
-            const float4 qv = *reinterpret_cast<const float4*>(sq + c);
-            const float4 v0 = *reinterpret_cast<const float4*>(r0 + c);
-            const float4 v1 = *reinterpret_cast<const float4*>(r1 + c);
-            const float4 v2 = *reinterpret_cast<const float4*>(r2 + c);
-            const float4 v3 = *reinterpret_cast<const float4*>(r3 + c);
-            a0 = __fmaf_rn(qv.w, v0.w, __fmaf_rn(qv.z, v0.z, __fmaf_rn(qv.y, v0.y, __fmaf_rn(qv.x, v0.x, a0))));
-            a1 = __fmaf_rn(qv.w, v1.w, __fmaf_rn(qv.z, v1.z, __fmaf_rn(qv.y, v1.y, __fmaf_rn(qv.x, v1.x, a1))));
-            a2 = __fmaf_rn(qv.w, v2.w, __fmaf_rn(qv.z, v2.z, __fmaf_rn(qv.y, v2.y, __fmaf_rn(qv.x, v2.x, a2))));
-            a3 = __fmaf_rn(qv.w, v3.w, __fmaf_rn(qv.z, v3.z, __fmaf_rn(qv.y, v3.y, __fmaf_rn(qv.x, v3.x, a3))));
-        }
-        for (; c < C; ++c) {
-            const float qc = sq[c];
-            a0 = __fmaf_rn(qc, r0[c], a0);
-            a1 = __fmaf_rn(qc, r1[c], a1);
-            a2 = __fmaf_rn(qc, r2[c], a2);
-            a3 = __fmaf_rn(qc, r3[c], a3);
-        }
-        top.insert(add_rn(add_rn(mul_rn(a0, -2.0f), quadb[j0]), qn), j0);
-        if (j1 < N) top.insert(add_rn(add_rn(mul_rn(a1, -2.0f), quadb[j1]), qn), j1);
-        if (j2 < N) top.insert(add_rn(add_rn(mul_rn(a2, -2.0f), quadb[j2]), qn), j2);
-        if (j3 < N) top.insert(add_rn(add_rn(mul_rn(a3, -2.0f), quadb[j3]), qn), j3);
-    }
-    __syncthreads();
-    top.store(lists + (size_t)tid * K1);
-    // 64 lists of a wave -> one sorted list of k+drop pairs (padded with +inf)
-    for (int p = lane; p < K1; p += 64) wl[w * K1 + p] = make_int2(__float_as_int(INFINITY), INT_MAX);
-    merge_write<K1, 64, true>(lists, tid, lane, k, drop, true, nullptr, wl + w * K1);
-    __syncthreads();
-    if (w == 0) merge_write<K1, 4>(wl, lane & 3, lane & 3, k, drop, lane < 4, idx + ((size_t)b * N + q) * k);
-}
-
-// ------------------------------------------------------------------------------------------------
 // top-1 nearest source row per target row (C == 3); d = (s2[j] + t2[i]) - 2*inner   (gcn3d.py:34)
 // grid (ceil(Nt/256), B), block 256, dynamic LDS = Ns*16
 // ------------------------------------------------------------------------------------------------
@@ -541,12 +547,7 @@ static int launch_knn_feat(const float* x, const float* quad, int B, int N, int 
     const size_t lds_lists = (size_t)256 * K1 * 8;
     if (lds_lists > lds) lds = lds_lists;
     auto kern = knn_feat_kernel<K1>;
-    if (lds > 64 * 1024) {
-        if (lds > 160 * 1024) return HSP_ERR_UNSUPPORTED;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
-    }
-    // a remainder of <= 8 queries per cloud goes to the tail kernel instead of a nearly empty MFMA tile
+    // a remainder of <= 8 queries per cloud goes to remainder workgroups instead of a nearly empty MFMA tile
     int full_tiles = (N + 31) / 32;
     const int rem = N & 31;
     // ... when that removes a partial round of workgroups (2 resident per CU at 3 waves/SIMD... measured)
@@ -554,19 +555,19 @@ static int launch_knn_feat(const float* x, const float* quad, int B, int N, int 
     const bool fewer_rounds = (with_rem + 511) / 512 > (without + 511) / 512;
     const bool tail = rem > 0 && rem <= 8 && N >= 64 && (C & 3) == 0 && fewer_rounds;
     if (tail) full_tiles -= 1;
-    dim3 grid(full_tiles, B);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, quad, N, C, k, drop, idx);
-    int rc = check_launch();
-    if (rc || !tail) return rc;
-    size_t lds_t = (size_t)C * 4;
-    if (lds_lists > lds_t) lds_t = lds_lists;
-    lds_t += (size_t)4 * K1 * 8;
-    auto tk = knn_feat_tail_kernel<K1>;
-    if (lds_t > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
+    if (tail) {
+        size_t lds_t = (size_t)C * 4;
+        if (lds_lists > lds_t) lds_t = lds_lists;
+        lds_t += (size_t)4 * K1 * 8;
+        if (lds_t > lds) lds = lds_t;
+    }
+    if (lds > 64 * 1024) {
+        if (lds > 160 * 1024) return HSP_ERR_UNSUPPORTED;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
     }
-    hipLaunchKernelGGL(tk, dim3(rem, B), dim3(256), lds_t, st, x, quad, N, C, k, drop, full_tiles * 32, idx);
+    dim3 grid(full_tiles + (tail ? rem : 0), B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, quad, N, C, k, drop, idx, full_tiles, tail ? rem : 0);
     return check_launch();
 }
 

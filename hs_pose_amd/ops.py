@@ -48,13 +48,13 @@ class KernelTimer:
 
     def __init__(self, only=None):
         self.only = set(only) if only else None
-        self.records = []          # (name, key, abytes, ev0, ev1)
+        self.records = []          # (name, key, abytes, aflops, ev0, ev1)
 
     def summary(self):
         """{(name, key): dict(calls, total_ms, avg_us, abytes)} -- call after torch.cuda.synchronize()."""
         out = {}
-        for name, key, ab, e0, e1 in self.records:
-            d = out.setdefault((name, key), dict(calls=0, total_ms=0.0, abytes=ab))
+        for name, key, ab, fl, e0, e1 in self.records:
+            d = out.setdefault((name, key), dict(calls=0, total_ms=0.0, abytes=ab, aflops=fl))
             d["calls"] += 1
             d["total_ms"] += e0.elapsed_time(e1)
         for d in out.values():
@@ -72,8 +72,9 @@ def set_timer(t):
     return prev
 
 
-def _run(name, args, key="", abytes=0):
-    """call libhsp entry point ``name``; raise on a non-zero return code."""
+def _run(name, args, key="", abytes=0, aflops=0):
+    """call libhsp entry point ``name``; raise on a non-zero return code.  abytes / aflops: the call's
+    algorithmic bytes and (for GEMM-shaped, MFMA-bound kernels) flops, for bench.py's roofline line."""
     fn = getattr(lib(), name)
     t = _timer
     if t is not None and (t.only is None or name in t.only):
@@ -82,7 +83,7 @@ def _run(name, args, key="", abytes=0):
         e0.record()
         rc = fn(*args)
         e1.record()
-        t.records.append((name, key, abytes, e0, e1))
+        t.records.append((name, key, abytes, aflops, e0, e1))
     else:
         rc = fn(*args)
     check(rc, name)
@@ -101,7 +102,8 @@ def knn(x, k, drop_first=True):
     wsb = L.hsp_knn_workspace_bytes(B, N, C, k)
     ws = _ws(wsb, x.device)
     _run("hsp_knn_f32", (_p(x), B, N, C, k, 1 if drop_first else 0, _p(idx), _p(ws), wsb, _stream()),
-         key=f"B{B}N{N}C{C}k{k}", abytes=B * N * (4 * C + 4 * k + (8 if C != 3 else 0)))
+         key=f"B{B}N{N}C{C}k{k}", abytes=B * N * (4 * C + 4 * k + (8 if C != 3 else 0)),
+         aflops=(2 * B * N * N * C if C != 3 else 0))       # feature path: the distance GEMM on the fp32 matrix cores
     return idx
 
 
@@ -329,7 +331,7 @@ def _wgrad_custom(A2, B2, out, colsum):
     ws = _ws(wsb, A2.device)
     _run("hsp_wgrad_f32", (_p(A2), A2.stride(0), _p(B2), B2.stride(0), M, N, K, _p(out), out.stride(0), _p(cs),
                            _p(ws), wsb, _stream()),
-         key=f"M{M}N{N}K{K}", abytes=4 * (K * (M + N) + M * N))
+         key=f"M{M}N{N}K{K}", abytes=4 * (K * (M + N) + M * N), aflops=2 * M * N * K)
     return (out, cs) if colsum else out
 
 

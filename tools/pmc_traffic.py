@@ -1,0 +1,50 @@
+"""Turn the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only, as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes) into profiles/<round>/traffic.json, keyed by the
+bench.py roofline kernel key.
+
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch/f_counter_collection.csv \
+                                gpurun_out/pmc_write/w_counter_collection.csv profiles/r01/traffic.json
+
+Units / corrections (guide, section HBM): the counters are in KiB; on gfx950 FETCH_SIZE reports half
+of the bytes of wide coalesced reads, so reads are doubled:  hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024.
+"""
+import collections
+import csv
+import json
+import sys
+
+# rocprof kernel name fragment + flattened grid size  ->  bench.py key   (B=16, N=1028 workload)
+MAP = {
+    ("knn_feat_kernel<21>", "131072"): "hsp_knn_f32[B16N1028C128k20]",
+    ("rf_fwd_kernel<false, 1>", "524288"): "hsp_rf_conv_fwd[B16N1028k20S7C128]",
+    ("rf_fwd_kernel<true, 1>", "524288"): "hsp_rf_surface_fwd[B16N1028k20S7C128]",
+    ("rf_bwd_tile_kernel<16, false>", "458752"): "hsp_rf_conv_bwd_scatter[B16N1028S7C128]",
+    ("rf_bwd_tile_kernel<16, true>", "458752"): "hsp_rf_surface_bwd[B16N1028S7C128]",
+    ("knn3_kernel<21, 16>", "266240"): "hsp_knn_f32[B16N1028C3k20]",
+}
+
+
+def agg(path, counter):
+    a = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            a[(r["Kernel_Name"], r["Grid_Size"])].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in a.items()}
+
+
+def main(fetch_csv, write_csv, out_json):
+    f, w = agg(fetch_csv, "FETCH_SIZE"), agg(write_csv, "WRITE_SIZE")
+    out = {}
+    for (name, grid), fv in f.items():
+        for (frag, g), key in MAP.items():
+            if frag in name and g == grid:
+                wv = w.get((name, grid), 0.0)
+                out[key] = {"FETCH_SIZE_KiB": round(fv, 1), "WRITE_SIZE_KiB": round(wv, 1),
+                            "hbm_bytes_per_launch": int((2 * fv + wv) * 1024),
+                            "correction": "reads doubled (gfx950 FETCH_SIZE counts 64 B per 128 B request)"}
+    json.dump(out, open(out_json, "w"), indent=1, sort_keys=True)
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
