@@ -19,8 +19,11 @@ class _Flags:
         gcn_sup_num=7,        # config.py:39  support directions S
         gcn_n_num=20,         # config.py:40  neighbours k
         random_points=1028,   # config.py:43
+        sample_method='basic',  # config.py:44
         train=1,              # config.py:48
         batch_size=16,        # config.py:55
+        lr=1e-4,              # config.py:96
+        lr_pose=1.0,          # config.py:98
     )
 
     def __init__(self):

@@ -796,3 +796,75 @@ def fps(xyz, n_samples):
     _run("hsp_fps_f32", (_p(xyz), B, N, n_samples, _p(sel), _p(ws), wsb, _stream()),
          key=f"B{B}N{N}n{n_samples}", abytes=B * (12 * N + 4 * n_samples))
     return sel
+
+
+# ------------------------------------------------------------------------------------------------
+# inference front / back end: depth -> cloud, axes -> pose matrix (no gradient)
+# ------------------------------------------------------------------------------------------------
+
+def pc_compact(mask, depth):
+    """mask, depth (B,HW) fp32 -> (pix (B,HW) int32, count (B) int32): ids of the pixels with
+    mask * (depth > 0) > 0, row-major (pc_sample.py:38-39, :52-54); entries past count[b] are undefined."""
+    mask = _req(mask.detach(), torch.float32, "pc_compact.mask")
+    depth = _req(depth.detach(), torch.float32, "pc_compact.depth")
+    if mask.dim() != 2 or mask.shape != depth.shape:
+        raise HspError("pc_compact: expects mask and depth of the same (B,HW) shape")
+    B, HW = mask.shape
+    pix = torch.empty(B, HW, dtype=torch.int32, device=mask.device)
+    count = torch.empty(B, dtype=torch.int32, device=mask.device)
+    _run("hsp_pc_compact", (_p(mask), _p(depth), B, HW, _p(pix), _p(count), _stream()),
+         key=f"B{B}HW{HW}", abytes=B * HW * 12)
+    return pix, count
+
+
+def pc_gather(depth, coor2d, camK, pix, choose):
+    """back-project the chosen valid pixels: (B,S,3) metres (pc_sample.py:41-50, :66, :77)."""
+    depth = _req(depth.detach(), torch.float32, "pc_gather.depth")
+    coor2d = _req(coor2d.detach(), torch.float32, "pc_gather.coor2d")
+    camK = _req(camK.detach(), torch.float32, "pc_gather.camK")
+    pix = _req(pix, torch.int32, "pc_gather.pix")
+    choose = _req(choose, torch.int32, "pc_gather.choose")
+    B, HW = depth.shape
+    if coor2d.shape != (B, 2, HW) or camK.shape != (B, 3, 3) or pix.shape != (B, HW) or choose.shape[0] != B:
+        raise HspError("pc_gather: expects depth (B,HW), coor2d (B,2,HW), camK (B,3,3), pix (B,HW), choose (B,S)")
+    S = choose.shape[1]
+    pc = torch.empty(B, S, 3, dtype=torch.float32, device=depth.device)
+    _run("hsp_pc_gather", (_p(depth), _p(coor2d), _p(camK), _p(pix), _p(choose), B, HW, S, _p(pc), _stream()),
+         key=f"B{B}S{S}", abytes=B * S * 32)
+    return pc
+
+
+def generate_rt(p_green, p_red, f_green, f_red, T, sym):
+    """(B,4,4) pose matrices; semantics of geom_utils.generate_RT(mode='vec')."""
+    pg = _req(p_green.detach(), torch.float32, "generate_rt.p_green")
+    pr = _req(p_red.detach(), torch.float32, "generate_rt.p_red")
+    fg = _req(f_green.detach(), torch.float32, "generate_rt.f_green")
+    fr = _req(f_red.detach(), torch.float32, "generate_rt.f_red")
+    T = _req(T.detach(), torch.float32, "generate_rt.T")
+    sym = _req(sym.detach().float(), torch.float32, "generate_rt.sym")
+    B = pg.shape[0]
+    if pg.shape != (B, 3) or pr.shape != (B, 3) or T.shape != (B, 3) or fg.numel() != B or fr.numel() != B \
+            or sym.dim() != 2 or sym.shape[0] != B:
+        raise HspError("generate_rt: expects p_green/p_red/T (B,3), f_green/f_red (B), sym (B,>=1)")
+    out = torch.empty(B, 4, 4, dtype=torch.float32, device=pg.device)
+    _run("hsp_generate_rt", (_p(pg), _p(pr), _p(fg), _p(fr), _p(T), _p(sym), sym.shape[1], B, _p(out), _stream()),
+         key=f"B{B}", abytes=B * (11 * 4 + 64))
+    return out
+
+
+def depth_to_pcl(depth, xymap, camK64, pix, choose):
+    """dataset-side back-projection (load_data.py:322-333 then / 1000.0): float64 arithmetic with a float64
+    K (B,3,3), fp32 (B,S,3) result."""
+    depth = _req(depth.detach(), torch.float32, "depth_to_pcl.depth")
+    xymap = _req(xymap.detach(), torch.float32, "depth_to_pcl.xymap")
+    camK64 = _req(camK64.detach(), torch.float64, "depth_to_pcl.camK")
+    pix = _req(pix, torch.int32, "depth_to_pcl.pix")
+    choose = _req(choose, torch.int32, "depth_to_pcl.choose")
+    B, HW = depth.shape
+    if xymap.shape != (B, 2, HW) or camK64.numel() != B * 9 or pix.shape != (B, HW) or choose.shape[0] != B:
+        raise HspError("depth_to_pcl: expects depth (B,HW), xymap (B,2,HW), camK (B,3,3) f64, pix (B,HW), choose (B,S)")
+    S = choose.shape[1]
+    pc = torch.empty(B, S, 3, dtype=torch.float32, device=depth.device)
+    _run("hsp_depth_to_pcl", (_p(depth), _p(xymap), _p(camK64), _p(pix), _p(choose), B, HW, S, _p(pc), _stream()),
+         key=f"B{B}S{S}", abytes=B * S * 32)
+    return pc

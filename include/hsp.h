@@ -208,6 +208,35 @@ int hsp_bn_relu_bwd(const float *x, const float *dy, int R, int C, const float *
                     const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma,
                     float *dbeta, void *ws, size_t ws_bytes, hspStream_t stream);
 
+/* ---- depth -> point cloud front end -------------------------------------------------------------
+ * replaces the device work of PC_sample(obj_mask, Depth, camK, coor2d)    network/point_sample/pc_sample.py:8-77
+ * mask (B,HW) fp32 (object mask, already arg-maxed if it was a 2-channel prediction), depth (B,HW).
+ * hsp_pc_compact: pix (B,HW) int32 = ids of the pixels with mask*(depth>0) > 0 in row-major order (the order
+ * of torch boolean indexing), count (B) int32.  The HOST then draws np.random.choice(count[b], S, replace =
+ * count[b] < S) per image exactly like the reference (pc_sample.py:57-66) and
+ * hsp_pc_gather back-projects the chosen pixels: pc (B,S,3) = ((u-cx)*d/fx, (v-cy)*d/fy, d) / 1000,
+ * coor2d (B,2,HW), camK (B,3,3), choose (B,S) int32.
+ */
+int hsp_pc_compact(const float *mask, const float *depth, int B, int HW, int32_t *pix, int32_t *count,
+                   hspStream_t stream);
+int hsp_pc_gather(const float *depth, const float *coor2d, const float *camK, const int32_t *pix,
+                  const int32_t *choose, int B, int HW, int S, float *pc, hspStream_t stream);
+
+/* dataset-side variant: replaces PoseDataset._depth_to_pcl(depth, K, xymap, mask) / 1000.0
+ * datasets/load_data.py:322-333, :275 (numpy float64 arithmetic, fp32 result).  camK (B,9) DOUBLE, as the
+ * loader holds it; mask/compaction via hsp_pc_compact; choose = the loader's _sample_points ids (:308-320). */
+int hsp_depth_to_pcl(const float *depth, const float *xymap, const double *camK, const int32_t *pix,
+                     const int32_t *choose, int B, int HW, int S, float *pc, hspStream_t stream);
+
+/* ---- pose matrix assembly -----------------------------------------------------------------------
+ * replaces generate_RT([p_green,p_red],[f_green,f_red], T, 'vec', sym)     tools/geom_utils.py:232-244
+ * (with to_R_matrices / get_vertical_rot_vec_in_batch / get_rot_mat_y_first, tools/rot_utils.py:39-100)
+ * p_green, p_red (B,3) unit axes, f_green, f_red (B) confidences, T (B,3), sym (B, sym_stride) (column 0 == 1
+ * zeroes the red confidence) -> out (B,4,4).
+ */
+int hsp_generate_rt(const float *p_green, const float *p_red, const float *f_green, const float *f_red,
+                    const float *T, const float *sym, int sym_stride, int B, float *out, hspStream_t stream);
+
 /* ---- Chamfer distance -------------------------------------------------------------------------
  * replaces cd.forward_cuda / cd.backward_cuda    tools/pyTorchChamferDistance/chamfer_distance.cpp:27-56
  * xyz1 (B,n,3), xyz2 (B,m,3) -> dist1 (B,n), dist2 (B,m) squared NN distances, idx1/idx2 int32 arg-min

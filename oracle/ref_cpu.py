@@ -287,6 +287,101 @@ def chamfer(x1: Tensor, x2: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
 
 
 # ---------------------------------------------------------------------------------------------
+# inference front / back end                         pc_sample.py:8-77, load_data.py:308-333,
+#                                                    geom_utils.py:232-244, rot_utils.py:39-100
+# ---------------------------------------------------------------------------------------------
+
+def valid_pixels(mask_hw: Tensor, depth_hw: Tensor) -> Tensor:
+    """row-major ids of the pixels with mask * (depth > 0) > 0 (pc_sample.py:38-39, :52; the order of
+    boolean-mask indexing)."""
+    fuse = mask_hw.reshape(-1).float() * (depth_hw.reshape(-1) > 0.0).float()
+    return torch.nonzero(fuse > 0).reshape(-1)
+
+
+def pc_sample(obj_mask: Tensor, depth: Tensor, camK: Tensor, coor2d: Tensor, samplenum: int, rng) -> Optional[Tensor]:
+    """PC_sample with an explicit numpy RandomState-like ``rng`` (the reference uses the global one):
+    per image one ``rng.choice(l_all, samplenum, replace=l_all < samplenum)`` (pc_sample.py:57-66);
+    None stands for the reference's (None, None) return (:59-60)."""
+    if obj_mask.shape[1] == 2:
+        obj_mask = torch.max(F.softmax(obj_mask, dim=1), dim=1)[1]
+    bs = depth.shape[0]
+    out = torch.zeros(bs, samplenum, 3)
+    for i in range(bs):
+        d = depth[i].reshape(-1)
+        u, v = coor2d[i, 0].reshape(-1), coor2d[i, 1].reshape(-1)
+        fx, fy, ux, uy = camK[i, 0, 0], camK[i, 1, 1], camK[i, 0, 2], camK[i, 1, 2]
+        x = (u - ux) * d / fx
+        y = (v - uy) * d / fy
+        ids = valid_pixels(obj_mask[i], depth[i])
+        l_all = ids.numel()
+        if l_all <= 1.0:
+            return None
+        choose = torch.as_tensor(rng.choice(l_all, samplenum, replace=l_all < samplenum))
+        sel = ids[choose]
+        out[i] = torch.stack([x[sel], y[sel], d[sel]], dim=1)
+    return out / 1000.0
+
+
+def depth_to_pcl(depth, K, xymap, mask):
+    """PoseDataset._depth_to_pcl (load_data.py:322-333) in numpy float64, all valid pixels, fp32 result
+    (NOT yet divided by 1000)."""
+    import numpy as np
+    K = np.asarray(K, dtype=np.float64).reshape(-1)
+    cx, cy, fx, fy = K[2], K[5], K[0], K[4]
+    d = np.asarray(depth).reshape(-1).astype(np.float64)
+    valid = ((d > 0) * np.asarray(mask).reshape(-1)) > 0
+    d = d[valid]
+    xm = np.asarray(xymap[0]).reshape(-1)[valid].astype(np.float64)
+    ym = np.asarray(xymap[1]).reshape(-1)[valid].astype(np.float64)
+    return np.stack(((xm - cx) * d / fx, (ym - cy) * d / fy, d), axis=-1).astype(np.float32)
+
+
+def sample_points(pcl, n_pts: int, rng):
+    """PoseDataset._sample_points (load_data.py:308-320) with an explicit ``rng``."""
+    import numpy as np
+    total = pcl.shape[0]
+    if total < n_pts:
+        return np.concatenate([np.tile(pcl, (n_pts // total, 1)), pcl[:n_pts % total]], axis=0)
+    if total > n_pts:
+        return pcl[rng.permutation(total)[:n_pts]]
+    return pcl
+
+
+def _rodrigues(rx: Tensor, s: Tensor, c: Tensor) -> Tensor:
+    """to_rot_matrix_in_batch (rot_utils.py:67-75): rotation about unit axis rx, (B,3,3)."""
+    x, y, z = rx[:, 0:1], rx[:, 1:2], rx[:, 2:3]
+    t = 1 - c
+    r1 = torch.cat([x * x * t + c, x * y * t - z * s, x * z * t + y * s], dim=-1)
+    r2 = torch.cat([y * x * t + z * s, y * y * t + c, y * z * t - x * s], dim=-1)
+    r3 = torch.cat([x * z * t - y * s, z * y * t + x * s, z * z * t + c], dim=-1)
+    return torch.stack([r1, r2, r3], dim=-2)
+
+
+def generate_rt(p_green: Tensor, p_red: Tensor, f_green: Tensor, f_red: Tensor, T: Tensor, sym: Tensor) -> Tensor:
+    """generate_RT(mode='vec') (geom_utils.py:232-244): the red confidence is zeroed for symmetric objects,
+    both axes are rotated about their common normal by confidence-weighted shares of (angle - pi/2)
+    (rot_utils.py:39-65), then orthonormalised y-first (rot_utils.py:77-86)."""
+    c1 = f_green.reshape(-1, 1)
+    c2 = torch.where(sym[:, 0] == 1, torch.zeros_like(f_red.reshape(-1)), f_red.reshape(-1)).reshape(-1, 1)
+    y, z = p_green, p_red
+    rx = torch.cross(y, z, dim=-1)
+    rx = rx / (torch.norm(rx, dim=-1, keepdim=True) + 1e-8)
+    cos = torch.clamp(torch.sum(y * z, dim=-1, keepdim=True), -1 + 1e-6, 1 - 1e-6)
+    theta = torch.acos(cos)
+    th2 = c1 / (c1 + c2) * (theta - math.pi / 2)
+    th1 = c2 / (c1 + c2) * (theta - math.pi / 2)
+    ny = torch.matmul(_rodrigues(rx, torch.sin(th1), torch.cos(th1)), y.unsqueeze(-1)).squeeze(-1)
+    nz = torch.matmul(_rodrigues(rx, torch.sin(-th2), torch.cos(-th2)), z.unsqueeze(-1)).squeeze(-1)
+    yy = F.normalize(ny, p=2, dim=-1)
+    zz = F.normalize(torch.cross(nz, yy, dim=-1), p=2, dim=-1)
+    xx = torch.cross(yy, zz, dim=-1)
+    res = torch.eye(4, dtype=T.dtype).unsqueeze(0).repeat(T.shape[0], 1, 1)
+    res[:, :3, :3] = torch.stack((xx, yy, zz), dim=-1)
+    res[:, :3, 3] = T
+    return res
+
+
+# ---------------------------------------------------------------------------------------------
 # deterministic closed-form parameter fill shared by the golden generator and the tests
 # ---------------------------------------------------------------------------------------------
 
@@ -352,3 +447,39 @@ def _is_seq_bn(key: str, state: Dict[str, Tensor]) -> bool:
     running_mean entry."""
     stem = key.rsplit(".", 1)[0]
     return (stem + ".running_mean") in state
+
+
+def frontend_inputs(B, H, W, seed, radii):
+    """closed-form depth crops: a disc-shaped object mask of the given radius per image, depth in mm with
+    ~8 % invalid (zero) pixels, a crop-window pixel grid and per-image intrinsics."""
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    depth = torch.empty(B, 1, H, W)
+    mask = torch.empty(B, 1, H, W)
+    coor = torch.empty(B, 2, H, W)
+    camK = torch.zeros(B, 3, 3)
+    for b in range(B):
+        u = hash_tensor((H, W), seed + 10 * b, 0.5, 0.5)            # [0,1)
+        d = 600.0 + 400.0 * hash_tensor((H, W), seed + 10 * b + 1, 0.5, 0.5)
+        depth[b, 0] = torch.where(u < 0.08, torch.zeros_like(d), d)
+        r2 = (yy - H / 2.0 + b) ** 2 + (xx - W / 2.0 - b) ** 2
+        mask[b, 0] = (r2 < radii[b] ** 2).float()
+        coor[b, 0] = xx * 1.75 + 100.0 + 3 * b                          # crop-resized pixel grid
+        coor[b, 1] = yy * 1.75 + 60.0 + 2 * b
+        camK[b] = torch.tensor([[577.5 + b, 0.0, 319.5], [0.0, 577.5 - b, 239.5], [0.0, 0.0, 1.0]])
+    return mask, depth, camK, coor
+
+
+def generate_rt_inputs():
+    """closed-form (p_green, p_red, f_green, f_red, T, sym) for the generate_RT fixture: unit axes incl. a nearly
+    parallel and an exactly perpendicular pair, confidences in (0,1), every third object symmetric."""
+    Bn = 16
+    pg = F.normalize(hash_tensor((Bn, 3), 1000, 1.0), dim=1)
+    pr = F.normalize(hash_tensor((Bn, 3), 1001, 1.0), dim=1)
+    pr[3] = F.normalize(pg[3] + 0.05 * pr[3], dim=0)      # nearly parallel axes
+    pr[4] = F.normalize(torch.cross(pg[4], pr[4], dim=0), dim=0)   # exactly perpendicular
+    fg = torch.sigmoid(hash_tensor((Bn,), 1002, 3.0))
+    fr = torch.sigmoid(hash_tensor((Bn,), 1003, 3.0))
+    T = hash_tensor((Bn, 3), 1004, 0.3) + torch.tensor([0.0, 0.0, 0.8])
+    sym = torch.zeros(Bn, 4)
+    sym[::3, 0] = 1.0                                                         # bottle / bowl / can style symmetry
+    return pg, pr, fg, fr, T, sym
