@@ -315,7 +315,11 @@ __device__ __forceinline__ void knn_feat_tail_body(char* smem, const float* __re
 // ------------------------------------------------------------------------------------------------
 #define KF_CT_STRIDE 68   // candidate chunk row stride in floats (64 + 4: 16B aligned, odd # of 16B slots)
 
-template <int K1>
+// FULLK: C is a multiple of 64 (every shape of the HS stack).  Candidate chunks are then fetched with raw
+// buffer loads: one descriptor per cloud, a loop-invariant per-lane voffset and a scalar soffset per
+// element, so the 16 loads of a chunk cost no vector address arithmetic, and rows past N read as 0
+// (their |c|^2 is staged as +inf, which makes the distance +inf without a per-candidate select).
+template <int K1, bool FULLK>
 __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restrict__ x,
                                                        const float* __restrict__ quad, int N, int C, int k,
                                                        int drop, int32_t* __restrict__ idx, int full_tiles,
@@ -331,9 +335,10 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
     const int QS = Cp + 4;                  // query row stride (floats)
     float* qtile = reinterpret_cast<float*>(smem);
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int col = lane & 31, h = lane >> 5;
     float* ctile = qtile + 32 * QS + wave * 32 * KF_CT_STRIDE;
+    float* qsm = qtile + 32 * QS + 4 * 32 * KF_CT_STRIDE + wave * 32;   // |c|^2 of the current candidate tile
     const int b = blockIdx.y;
     const int q0 = ((int)blockIdx.x - ntail) * 32;
     const float* xb = x + (size_t)b * N * C;
@@ -363,40 +368,55 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
 
     const int ntiles = (N + 31) >> 5;
     const int nchunks = Cp >> 6;
-    // register prefetch of one candidate chunk: 32 rows x 32 float2 = 16 float2 per lane.
-    // BRANCH-FREE on purpose: a per-element "in range ? load : 0" makes hipcc branch around every load
-    // and wait vmcnt(0) before the next one (16 serialised L2 round trips per chunk, measured 6x
-    // slower).  Rows past N are clamped to row N-1 (their distances are discarded at insertion) and
-    // columns past C are clamped then zeroed by a select (zeros add exact 0 to the fma chain).
+    // register prefetch of one candidate chunk: 32 rows x 32 float2 = 16 float2 per lane; lane (h, pair)
+    // takes rows h, h+2, ... of the tile, so every half-wave reads 256 contiguous bytes of one row.
     float2 pre[16];
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)((size_t)N * C * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t qrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(quadb), 0, N * 4, 0x00020000);
+    const int lane_off = (h * C + 2 * col) * 4;              // loop-invariant voffset (bytes)
+    const int row2 = 2 * C * 4;                              // two rows down (bytes)
     const bool evenC = (C & 1) == 0;
     auto prefetch = [&](int tile, int chunk) {
-        const int c0 = tile * 32, kc = chunk * 64;
+        if (FULLK) {
+            const int s0 = (tile * 32 * C + chunk * 64) * 4;
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int e = it * 64 + lane;
-            const int row = min(c0 + (e >> 5), N - 1), pair = e & 31;
-            const int kk = kc + pair * 2;
-            const float* rp = xb + (size_t)row * C;
-            float2 v;
-            if (evenC) {                                   // wave-uniform: 8-byte aligned pair loads
-                v = *reinterpret_cast<const float2*>(rp + min(kk, C - 2));
-            } else {
-                v.x = rp[min(kk, C - 1)];
-                v.y = rp[min(kk + 1, C - 1)];
+            for (int it = 0; it < 16; ++it) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b64(xrs, lane_off, s0 + it * row2, 0);
+                pre[it] = make_float2(__int_as_float(v[0]), __int_as_float(v[1]));
             }
-            v.x = kk < C ? v.x : 0.f;
-            v.y = kk + 1 < C ? v.y : 0.f;
-            pre[it] = v;
+        } else {
+            // generic C, BRANCH-FREE on purpose: a per-element "in range ? load : 0" makes hipcc branch
+            // around every load and wait vmcnt(0) before the next one.  Rows past N are clamped (their
+            // |c|^2 is +inf), columns past C are clamped then zeroed by a select (exact 0s in the chain).
+            const int c0 = tile * 32, kc = chunk * 64;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int e = it * 64 + lane;
+                const int row = min(c0 + (e >> 5), N - 1), pair = e & 31;
+                const int kk = kc + pair * 2;
+                const float* rp = xb + (size_t)row * C;
+                float2 v;
+                if (evenC) {                                   // wave-uniform: 8-byte aligned pair loads
+                    v = *reinterpret_cast<const float2*>(rp + min(kk, C - 2));
+                } else {
+                    v.x = rp[min(kk, C - 1)];
+                    v.y = rp[min(kk + 1, C - 1)];
+                }
+                v.x = kk < C ? v.x : 0.f;
+                v.y = kk + 1 < C ? v.y : 0.f;
+                pre[it] = v;
+            }
         }
     };
 
     int tile = wave, chunk = 0;
     if (tile < ntiles) prefetch(tile, 0);
     f32x16 acc;
-    float qc[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; qc[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    unsigned qraw = 0;                                      // |c|^2 bits of candidate tile*32 + col
 
     while (tile < ntiles) {
         // registers -> wave-private LDS chunk (in-order LDS ops of one wave: no barrier required)
@@ -407,26 +427,18 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
             ctile[row * KF_CT_STRIDE + pair] = pre[it].x;
             ctile[row * KF_CT_STRIDE + 32 + pair] = pre[it].y;
         }
+        // |candidate|^2 of the tile's 32 rows (one per lane pair), +inf past N: in flight under the MFMAs
+        if (chunk == 0) {
+            qraw = __builtin_amdgcn_raw_buffer_load_b32(qrs, (tile * 32 + col) * 4, 0, 0);   // reads 0 past N
+        }
         // next (tile, chunk) of this wave
         int ntile = tile, nchunk = chunk + 1;
         if (nchunk == nchunks) { nchunk = 0; ntile = tile + 4; }
-#ifndef HSP_ABLATE_PREFETCH
         if (ntile < ntiles) prefetch(ntile, nchunk);
-#endif
         __builtin_amdgcn_wave_barrier();
 
-        // |candidate|^2 of this lane's 16 rows: issued before the MFMAs of the tile's first chunk so the
-        // loads complete under them (index clamped instead of branching: no serialised load->use chains)
-        if (chunk == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cand = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                qc[r] = quadb[cand < N ? cand : N - 1];
-            }
-        }
         const float* arow = ctile + col * KF_CT_STRIDE + h * 32;
         const float* brow = qtile + col * QS + chunk * 64 + h * 32;
-#ifndef HSP_ABLATE_MFMA
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             const float4 a4 = *reinterpret_cast<const float4*>(arow + 4 * g);
@@ -436,22 +448,24 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
         }
-#endif
         __builtin_amdgcn_wave_barrier();
 
         if (chunk == nchunks - 1) {
             // tile finished: fold the 16 distances of this lane into its list (rows ascend with r)
-            const int c0 = tile * 32;
+            qsm[col] = tile * 32 + col < N ? __uint_as_float(qraw) : INFINITY;   // both halves: same value
+            __builtin_amdgcn_wave_barrier();
+            const int c0 = tile * 32 + 4 * h;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cand = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float d = add_rn(add_rn(mul_rn(acc[r], -2.0f), qc[r]), qq);
-#ifndef HSP_ABLATE_INSERT
-                top.insert(cand < N ? d : INFINITY, cand);       // +inf never passes the strict '<'
-#else
-                if (d == 12345.678f) top.insert(d, cand);        // profiling variant: keep d live, never insert
-#endif
-                acc[r] = 0.f;
+            for (int g = 0; g < 4; ++g) {
+                const float4 qc = *reinterpret_cast<const float4*>(qsm + 8 * g + 4 * h);
+                const float qcv[4] = {qc.x, qc.y, qc.z, qc.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = 4 * g + u;
+                    const float d = add_rn(add_rn(mul_rn(acc[r], -2.0f), qcv[u]), qq);   // +inf past N
+                    top.insert(d, c0 + 8 * g + u);           // +inf never passes the strict '<'
+                    acc[r] = 0.f;
+                }
             }
         }
         tile = ntile;
@@ -543,10 +557,11 @@ template <int K1>
 static int launch_knn_feat(const float* x, const float* quad, int B, int N, int C, int k, int drop,
                            int32_t* idx, hipStream_t st) {
     const int Cp = (C + 63) & ~63;
-    size_t lds = (size_t)(32 * (Cp + 4) + 4 * 32 * KF_CT_STRIDE) * 4;
+    size_t lds = (size_t)(32 * (Cp + 4) + 4 * 32 * KF_CT_STRIDE + 4 * 32) * 4;
     const size_t lds_lists = (size_t)256 * K1 * 8;
     if (lds_lists > lds) lds = lds_lists;
-    auto kern = knn_feat_kernel<K1>;
+    const bool fullk = (C & 63) == 0 && (size_t)N * C * 4 < ((size_t)1 << 31);
+    auto kern = fullk ? knn_feat_kernel<K1, true> : knn_feat_kernel<K1, false>;
     // a remainder of <= 8 queries per cloud goes to remainder workgroups instead of a nearly empty MFMA tile
     int full_tiles = (N + 31) / 32;
     const int rem = N & 31;
