@@ -43,6 +43,20 @@ struct TopList {
             d[0] = fminf(d[0], v);
         }
     }
+    // same update without the guard: a no-op for v = +inf (med3 keeps d[p], no compare passes), so a
+    // wave can run it unconditionally with +inf in the lanes that have nothing to insert (no divergence).
+    __device__ __forceinline__ void insert_always(float v, int idx) {
+        bool lt_cur = v < d[K1 - 1];
+#pragma unroll
+        for (int p = K1 - 1; p > 0; --p) {
+            const bool lt_prev = v < d[p - 1];
+            i[p] = lt_prev ? i[p - 1] : (lt_cur ? idx : i[p]);
+            d[p] = __builtin_amdgcn_fmed3f(d[p - 1], d[p], v);
+            lt_cur = lt_prev;
+        }
+        i[0] = lt_cur ? idx : i[0];
+        d[0] = fminf(d[0], v);
+    }
     __device__ __forceinline__ void store(int2* dst) const {
 #pragma unroll
         for (int p = 0; p < K1; ++p) dst[p] = make_int2(__float_as_int(d[p]), i[p]);
@@ -236,29 +250,81 @@ __global__ __launch_bounds__(256) void quad_kernel(const float* __restrict__ x, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// exact selection of the m = k + drop nearest out of N distances held in LDS, by ONE wave:
+//   1. tau = the m-th smallest of the 64 lane-local minima (radix select over ballots): m distinct
+//      candidates are <= tau, so everything above it is out;
+//   2. the survivors (about m + 3) are compacted in index order and ranked by (distance, index) against
+//      each other; ranks [drop, m) are the answer, already in order.
+// dl: N floats (N >= 64), sv: N int2 of scratch, both LDS
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned sortable_key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+
+__device__ __forceinline__ void knn_select_wave(const float* dl, int2* sv, int N, int k, int drop,
+                                                int32_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int m = k + drop;
+    float lmin = INFINITY;
+    for (int j = lane; j < N; j += 64) lmin = fminf(lmin, dl[j]);
+    // radix select, most significant bit first: the m-th smallest of the 64 keys
+    const unsigned key = sortable_key(lmin);
+    unsigned prefix = 0;
+    int need = m;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned hi = bit == 31 ? 0u : (0xffffffffu << (bit + 1));
+        const bool zero = ((key ^ prefix) & hi) == 0 && ((key >> bit) & 1u) == 0;
+        const int c0 = __popcll(__ballot(zero));
+        if (need > c0) { need -= c0; prefix |= 1u << bit; }
+    }
+    const float tau = __uint_as_float(prefix ^ ((prefix >> 31) ? 0x80000000u : 0xffffffffu));   // key -> float
+    int n = 0;
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        const int j = j0 + lane;
+        const float d = j < N ? dl[j] : INFINITY;
+        const bool keep = j < N && d <= tau;
+        const unsigned long long bal = __ballot(keep);
+        if (keep) sv[n + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(__float_as_int(d), j);
+        n += __popcll(bal);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < n; e += 64) {
+        const int2 me = sv[e];
+        const float de = __int_as_float(me.x);
+        int rank = 0;
+        for (int f = 0; f < n; ++f) {
+            const int2 o = sv[f];
+            const float df = __int_as_float(o.x);
+            rank += (df < de || (df == de && o.y < me.y)) ? 1 : 0;
+        }
+        if (rank >= drop && rank < m) out[rank - drop] = me.y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // remainder queries of the feature path.  N = 1028 = 32*32 + 4 leaves 4 queries per cloud that would
 // cost a whole MFMA workgroup (33 instead of 32 tiles: 528 workgroups on 256 CUs, a 3:2 imbalance).
 // They are handled here: one workgroup per query; thread t owns candidates t, t+256, ... and runs four
-// of their k-ordered fma chains at a time (same chain as the MFMA path: bit-identical distances); the
-// 256 per-thread lists are merged by a wave tournament (64 -> 1 per wave) and a 4-way one.
-// Runs as extra workgroups of knn_feat_kernel's grid (blockIdx.x >= full_tiles), concurrently with the MFMA tiles.
-// LDS = max(C*4, 256*K1*8) + 4*K1*8
+// of their k-ordered fma chains at a time (same chain as the MFMA path: bit-identical distances) into
+// an LDS array; wave 0 then selects (knn_select_wave).
+// Runs as extra workgroups of knn_feat_kernel's grid (the lowest block ids), concurrently with the MFMA tiles.
+// LDS = C*4 + 12*(N+3)
 // ------------------------------------------------------------------------------------------------
 template <int K1>
 __device__ __forceinline__ void knn_feat_tail_body(char* smem, const float* __restrict__ x,
                                                    const float* __restrict__ quad, int N, int C, int k, int drop,
                                                    int q, int32_t* __restrict__ idx) {
-    float* sq = reinterpret_cast<float*>(smem);               // the query row
-    int2* lists = reinterpret_cast<int2*>(smem);              // 256 lists, aliased after the scan
-    int2* wl = lists + 256 * K1;                              // 4 per-wave merged lists
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int Np = (N + 3) & ~3;                              // keeps sv / sq 16-byte aligned
+    float* dl = reinterpret_cast<float*>(smem);               // N distances
+    int2* sv = reinterpret_cast<int2*>(dl + Np);              // selection scratch
+    float* sq = reinterpret_cast<float*>(sv + Np);            // the query row
+    const int tid = threadIdx.x;
     const int b = blockIdx.y;                                 // q < N by construction
     const float* xb = x + (size_t)b * N * C;
     const float* quadb = quad + (size_t)b * N;
     for (int e = tid; e < C; e += 256) sq[e] = xb[(size_t)q * C + e];
     __syncthreads();
-    TopList<K1> top;
-    top.init();
     const float qn = quadb[q];
     for (int j0 = tid; j0 < N; j0 += 4 * 256) {
         // four candidates per pass (clamped rows: a clamped duplicate is discarded below), independent chains
@@ -287,18 +353,66 @@ __device__ __forceinline__ void knn_feat_tail_body(char* smem, const float* __re
             a2 = __fmaf_rn(qc, r2[c], a2);
             a3 = __fmaf_rn(qc, r3[c], a3);
         }
-        top.insert(add_rn(add_rn(mul_rn(a0, -2.0f), quadb[j0]), qn), j0);
-        if (j1 < N) top.insert(add_rn(add_rn(mul_rn(a1, -2.0f), quadb[j1]), qn), j1);
-        if (j2 < N) top.insert(add_rn(add_rn(mul_rn(a2, -2.0f), quadb[j2]), qn), j2);
-        if (j3 < N) top.insert(add_rn(add_rn(mul_rn(a3, -2.0f), quadb[j3]), qn), j3);
+        dl[j0] = add_rn(add_rn(mul_rn(a0, -2.0f), quadb[j0]), qn);
+        if (j1 < N) dl[j1] = add_rn(add_rn(mul_rn(a1, -2.0f), quadb[j1]), qn);
+        if (j2 < N) dl[j2] = add_rn(add_rn(mul_rn(a2, -2.0f), quadb[j2]), qn);
+        if (j3 < N) dl[j3] = add_rn(add_rn(mul_rn(a3, -2.0f), quadb[j3]), qn);
     }
     __syncthreads();
-    top.store(lists + (size_t)tid * K1);
-    // 64 lists of a wave -> one sorted list of k+drop pairs (padded with +inf)
-    for (int p = lane; p < K1; p += 64) wl[w * K1 + p] = make_int2(__float_as_int(INFINITY), INT_MAX);
-    merge_write<K1, 64, true>(lists, tid, lane, k, drop, true, nullptr, wl + w * K1);
-    __syncthreads();
-    if (w == 0) merge_write<K1, 4>(wl, lane & 3, lane & 3, k, drop, lane < 4, idx + ((size_t)b * N + q) * k);
+    if (tid < 64) knn_select_wave(dl, sv, N, k, drop, idx + ((size_t)b * N + q) * k);
+}
+
+// ------------------------------------------------------------------------------------------------
+// remainder queries when the MFMA grid already fills the chip (B * tiles >= 2 workgroups per CU): extra
+// workgroups in that launch would only slow their CUs down.  The inner products are symmetric -- the fma
+// chain of (t, j) and of (j, t) multiplies the same pairs in the same order -- so the MFMA workgroups,
+// which meet the remainder rows t as CANDIDATES of their 32 queries j, also write
+// d(t, j) = ((inner * -2) + |x_j|^2) + |x_t|^2 to dtail[b][t][j]; this kernel adds the rem x rem
+// remainder-remainder pairs (rows staged through LDS with coalesced loads, same k-ordered chain) and
+// selects, one wave per remainder query.
+// grid (ceil(rem/4), B), block 256, LDS = 4 * (12*(N+3) + (1+rem)*C*4)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void knn_feat_sym_tail_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ quad,
+                                                                const float* __restrict__ dtail, int N, int C,
+                                                                int k, int drop, int nfull,
+                                                                int32_t* __restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rem = N - nfull, b = blockIdx.y;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= rem) return;
+    const int Np = (N + 3) & ~3;
+    const size_t per_wave = (size_t)3 * Np + (size_t)(1 + rem) * C;
+    float* dl = reinterpret_cast<float*>(smem) + wave * per_wave;
+    int2* sv = reinterpret_cast<int2*>(dl + Np);
+    float* rows = reinterpret_cast<float*>(sv + Np);          // [query row | rem candidate rows]
+    const int q = nfull + t;
+    const float* xb = x + (size_t)b * N * C;
+    const float* quadb = quad + (size_t)b * N;
+    const float* drow = dtail + ((size_t)b * rem + t) * nfull;
+    // all global loads first: the distances written by the MFMA workgroups and the 1 + rem rows
+    for (int j0 = lane; j0 < nfull; j0 += 8 * 64) {
+        float tv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tv[u] = drow[min(j0 + u * 64, nfull - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (j0 + u * 64 < nfull) dl[j0 + u * 64] = tv[u];
+    }
+    for (int e = lane; e < (1 + rem) * C; e += 64) {
+        const int r = e / C, c = e - r * C;
+        rows[e] = xb[(size_t)(r == 0 ? q : nfull + r - 1) * C + c];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < rem) {
+        const float* rc = rows + (size_t)(1 + lane) * C;
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) a = __fmaf_rn(rows[c], rc[c], a);
+        dl[nfull + lane] = add_rn(add_rn(mul_rn(a, -2.0f), quadb[nfull + lane]), quadb[q]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    knn_select_wave(dl, sv, N, k, drop, idx + ((size_t)b * N + q) * k);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -323,7 +437,7 @@ template <int K1, bool FULLK>
 __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restrict__ x,
                                                        const float* __restrict__ quad, int N, int C, int k,
                                                        int drop, int32_t* __restrict__ idx, int full_tiles,
-                                                       int ntail) {
+                                                       int ntail, float* __restrict__ dtail) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // remainder queries: one workgroup each.  They take the LOWEST block ids so that they are dispatched
     // first and run alongside the MFMA tiles instead of after them.
@@ -339,6 +453,15 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
     const int col = lane & 31, h = lane >> 5;
     float* ctile = qtile + 32 * QS + wave * 32 * KF_CT_STRIDE;
     float* qsm = qtile + 32 * QS + 4 * 32 * KF_CT_STRIDE + wave * 32;   // |c|^2 of the current candidate tile
+    // shared pruning bound.  List l = (wave, half) of query q publishes its a_l-th smallest distance so far,
+    // sum_l a_l = K1 >= k + drop: the K1 candidates behind those entries are all <= tau_q = max_l pub[q][l], so
+    // a candidate with d > tau_q has k + drop strictly closer ones and can never be selected.  Entries only
+    // decrease, so a stale read is still a valid bound: no barrier, plain 32-bit LDS stores / loads.
+    float* pub = qtile + 32 * QS + 4 * 32 * KF_CT_STRIDE + 4 * 32;     // [32 queries][8 lists]
+    constexpr bool SHARE_OK = K1 >= 8;
+    constexpr int A_HI = SHARE_OK ? K1 / 8 : 0, A_LO = SHARE_OK ? K1 / 8 - 1 : 0;   // a_l - 1 for l < K1 % 8, else
+    const bool SHARE = SHARE_OK && ((N + 31) >> 5) >= 4;    // all four waves own a tile
+    pub[tid] = INFINITY;
     const int b = blockIdx.y;
     const int q0 = ((int)blockIdx.x - ntail) * 32;
     const float* xb = x + (size_t)b * N * C;
@@ -451,10 +574,36 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
         __builtin_amdgcn_wave_barrier();
 
         if (chunk == nchunks - 1) {
-            // tile finished: fold the 16 distances of this lane into its list (rows ascend with r)
+            // tile finished: fold the 16 distances of this lane into its list (rows ascend with r).
+            // A candidate can only matter if d <= tau_q, the shared bound below, and d < this list's worst;
+            // the survivors (few once the lists have warmed up) are inserted by a drain loop that runs
+            // max-over-lanes(#survivors) times instead of once per candidate.
             qsm[col] = tile * 32 + col < N ? __uint_as_float(qraw) : INFINITY;   // both halves: same value
             __builtin_amdgcn_wave_barrier();
-            const int c0 = tile * 32 + 4 * h;
+            if (dtail && tile == ntiles - 1) {
+                // symmetric remainder path (knn_feat_sym_tail_kernel): the rows of this partial tile are the
+                // remainder QUERIES t; their distance to this lane's query j, in the association of query t
+                const int nfull = full_tiles * 32, rem = N - nfull;
+                if (h * 4 < rem) {
+                    const float4 qc = *reinterpret_cast<const float4*>(qsm + 4 * h);
+                    const float qcv[4] = {qc.x, qc.y, qc.z, qc.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (h * 4 + u < rem)
+                            dtail[((size_t)b * rem + h * 4 + u) * nfull + q] =
+                                add_rn(add_rn(mul_rn(acc[u], -2.0f), qq), qcv[u]);
+                }
+            }
+            float thr = top.d[K1 - 1];
+            if (SHARE) {
+                const float4 t0 = *reinterpret_cast<const float4*>(pub + col * 8);
+                const float4 t1 = *reinterpret_cast<const float4*>(pub + col * 8 + 4);
+                const float tau = fmaxf(fmaxf(fmaxf(t0.x, t0.y), fmaxf(t0.z, t0.w)),
+                                        fmaxf(fmaxf(t1.x, t1.y), fmaxf(t1.z, t1.w)));
+                thr = fminf(thr, tau);
+            }
+            float* stash = ctile;                           // the chunk is consumed: 16 x 64 floats fit
+            unsigned m = 0;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 qc = *reinterpret_cast<const float4*>(qsm + 8 * g + 4 * h);
@@ -463,10 +612,30 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
                 for (int u = 0; u < 4; ++u) {
                     const int r = 4 * g + u;
                     const float d = add_rn(add_rn(mul_rn(acc[r], -2.0f), qcv[u]), qq);   // +inf past N
-                    top.insert(d, c0 + 8 * g + u);           // +inf never passes the strict '<'
+                    stash[r * 64 + lane] = d;
+                    m |= d <= thr ? (1u << r) : 0u;          // conservative: insert() re-checks d < worst
                     acc[r] = 0.f;
                 }
             }
+            __builtin_amdgcn_wave_barrier();
+            const int c0 = tile * 32 + 4 * h;
+            // software-pipelined: the next survivor is fetched from the stash while the current one is inserted
+            bool has = m != 0;
+            int r = has ? __builtin_ctz(m) : 0;              // ascending r == ascending candidate index
+            m &= m - 1;                                      // 0 stays 0
+            float v = stash[r * 64 + lane];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {                // wave-uniform early-out, straight-line bodies
+                if (!__any(has)) break;
+                const bool has_n = m != 0;
+                const int r_n = has_n ? __builtin_ctz(m) : 0;
+                m &= m - 1;
+                const float v_n = stash[r_n * 64 + lane];
+                top.insert_always(has ? v : INFINITY, c0 + (r & 3) + 8 * (r >> 2));
+                has = has_n; r = r_n; v = v_n;
+            }
+            if (SHARE) pub[col * 8 + wave * 2 + h] = (wave * 2 + h < (K1 & 7)) ? top.d[A_HI] : top.d[A_LO];
+            __builtin_amdgcn_wave_barrier();
         }
         tile = ntile;
         chunk = nchunk;
@@ -553,36 +722,57 @@ static int launch_knn3_t(const float* x, int B, int N, int k, int drop, int32_t*
     return launch_knn3<K1, 16>(x, B, N, k, drop, idx, st);
 }
 
-template <int K1>
-static int launch_knn_feat(const float* x, const float* quad, int B, int N, int C, int k, int drop,
-                           int32_t* idx, hipStream_t st) {
+// how the N % 32 remainder queries of the feature path are handled
+enum { KF_REM_TILE = 0,    // as a 33rd, nearly empty MFMA query tile
+       KF_REM_WG = 1,      // one extra workgroup per query in the same launch (grid below 2 workgroups / CU: they run on idle CUs)
+       KF_REM_SYM = 2 };   // symmetric path + knn_feat_sym_tail_kernel (grid already fills the chip)
+
+static size_t knn_feat_lds(int C, int K1) {
     const int Cp = (C + 63) & ~63;
-    size_t lds = (size_t)(32 * (Cp + 4) + 4 * 32 * KF_CT_STRIDE + 4 * 32) * 4;
+    const size_t lds = (size_t)(32 * (Cp + 4) + 4 * 32 * KF_CT_STRIDE + 4 * 32 + 32 * 8) * 4;
     const size_t lds_lists = (size_t)256 * K1 * 8;
-    if (lds_lists > lds) lds = lds_lists;
+    return lds_lists > lds ? lds_lists : lds;
+}
+
+static int knn_feat_rem_mode(int B, int N, int C) {
+    const int rem = N & 31;
+    if (rem == 0 || rem > 8 || N < 64) return KF_REM_TILE;
+    const long long full = (long long)(N / 32) * B;
+    if (full >= 512) {
+        const size_t lds_s = (size_t)4 * (12 * ((size_t)N + 3) + (size_t)(1 + rem) * C * 4);
+        return lds_s <= 160 * 1024 ? KF_REM_SYM : KF_REM_TILE;
+    }
+    const size_t lds_t = (size_t)C * 4 + (size_t)12 * (N + 3);
+    return ((C & 3) == 0 && lds_t <= knn_feat_lds(C, 3)) ? KF_REM_WG : KF_REM_TILE;
+}
+
+template <int K1>
+static int launch_knn_feat(const float* x, const float* quad, float* dtail, int B, int N, int C, int k, int drop,
+                           int32_t* idx, hipStream_t st) {
+    const size_t lds = knn_feat_lds(C, K1);
     const bool fullk = (C & 63) == 0 && (size_t)N * C * 4 < ((size_t)1 << 31);
     auto kern = fullk ? knn_feat_kernel<K1, true> : knn_feat_kernel<K1, false>;
-    // a remainder of <= 8 queries per cloud goes to remainder workgroups instead of a nearly empty MFMA tile
-    int full_tiles = (N + 31) / 32;
-    const int rem = N & 31;
-    // ... when that removes a partial round of workgroups (2 resident per CU at 3 waves/SIMD... measured)
-    const long long with_rem = (long long)full_tiles * B, without = (long long)(full_tiles - 1) * B;
-    const bool fewer_rounds = (with_rem + 511) / 512 > (without + 511) / 512;
-    const bool tail = rem > 0 && rem <= 8 && N >= 64 && (C & 3) == 0 && fewer_rounds;
-    if (tail) full_tiles -= 1;
-    if (tail) {
-        size_t lds_t = (size_t)C * 4;
-        if (lds_lists > lds_t) lds_t = lds_lists;
-        lds_t += (size_t)4 * K1 * 8;
-        if (lds_t > lds) lds = lds_t;
-    }
+    const int mode = knn_feat_rem_mode(B, N, C);
+    const int rem = mode == KF_REM_TILE ? 0 : (N & 31);
+    const int full_tiles = (N - rem + 31) / 32;
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) return HSP_ERR_UNSUPPORTED;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
     }
-    dim3 grid(full_tiles + (tail ? rem : 0), B);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, quad, N, C, k, drop, idx, full_tiles, tail ? rem : 0);
+    const int ntail = mode == KF_REM_WG ? rem : 0;
+    hipLaunchKernelGGL(kern, dim3(full_tiles + ntail, B), dim3(256), lds, st, x, quad, N, C, k, drop, idx, full_tiles,
+                       ntail, mode == KF_REM_SYM ? dtail : nullptr);
+    int rc = check_launch();
+    if (rc || mode != KF_REM_SYM) return rc;
+    const size_t lds_s = (size_t)4 * (12 * ((size_t)N + 3) + (size_t)(1 + rem) * C * 4);
+    if (lds_s > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_feat_sym_tail_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+        if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
+    }
+    hipLaunchKernelGGL(knn_feat_sym_tail_kernel, dim3((rem + 3) / 4, B), dim3(256), lds_s, st, x, quad, dtail, N, C, k,
+                       drop, N - rem, idx);
     return check_launch();
 }
 
@@ -592,8 +782,10 @@ using namespace hsp;
 
 extern "C" size_t hsp_knn_workspace_bytes(int B, int N, int C, int k) {
     (void)k;
-    if (C == 3) return 0;
-    return (size_t)B * N * sizeof(float);   // quad
+    if (C == 3 || B <= 0 || N <= 0) return 0;
+    // |x|^2 per row; in the symmetric remainder mode also the remainder-query distances d(t, j)
+    const int rows_extra = knn_feat_rem_mode(B, N, C) == KF_REM_SYM ? (N & 31) : 0;
+    return (size_t)B * N * sizeof(float) * (size_t)(1 + rows_extra);
 }
 
 extern "C" int hsp_knn_f32(const float* x, int B, int N, int C, int k, int drop_first, int32_t* idx, void* ws,
@@ -625,7 +817,7 @@ extern "C" int hsp_knn_f32(const float* x, int B, int N, int C, int k, int drop_
     hipLaunchKernelGGL(quad_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, x, rows, C, quad);
     int rc = check_launch();
     if (rc) return rc;
-#define CALLF(K) launch_knn_feat<K>(x, quad, B, N, C, k, drop, idx, st)
+#define CALLF(K) launch_knn_feat<K>(x, quad, quad + rows, B, N, C, k, drop, idx, st)
     HSP_K1_SWITCH(CALLF)
 #undef CALLF
 #undef HSP_K1_SWITCH

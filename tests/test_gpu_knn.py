@@ -64,8 +64,13 @@ def test_knn_ties_value_equal(dev, ref, oc):
     (1, 4100, 3, 20, 1),      # more points than one LDS chunk
     (2, 40, 8, 4, 1), (2, 70, 100, 8, 1), (1, 33, 64, 2, 1), (2, 130, 192, 20, 0), (1, 500, 128, 32, 1),
     (1, 31, 6, 3, 1),
-    (16, 1028, 128, 20, 1),   # the bench shape: 32 MFMA tiles + the 4-query remainder kernel per cloud
-    (32, 260, 64, 8, 1),      # remainder kernel with K1 = 9
+    (16, 1028, 128, 20, 1),   # the bench shape: 32 MFMA tiles + the 4 remainder queries through the symmetric path
+    (32, 260, 64, 8, 1),      # remainder queries with K1 = 9
+    (3, 1032, 128, 20, 1),    # 8 remainder queries as extra workgroups
+    (17, 1032, 64, 20, 1),    # 8 remainder queries, symmetric path (>= 512 tiles): both halves of the partial tile
+    (64, 260, 7, 5, 1),       # symmetric path with odd C (generic load path), K1 = 9
+    (2, 69, 7, 5, 1),         # 5 remainder queries, odd C (generic load path)
+    (2, 72, 64, 20, 1),       # only two query tiles: waves 2, 3 idle, no shared bound
 ])
 def test_knn_vs_c_oracle(dev, ref, oc, B, N, C, k, drop):
     from hs_pose_amd import ops
@@ -87,6 +92,12 @@ def test_knn_duplicate_points(dev, ref, oc):
     xf = torch.cat([xf, xf[:, :56]], dim=1).contiguous()
     idx = ops.knn(xf.to(dev), 8).cpu().numpy()
     assert np.array_equal(idx, oc.knn(xf.numpy(), 8))
+    # duplicates across the remainder rows (N = 260: rows 256..259 repeat rows 0..3) and a shared bound full of ties
+    xg = torch.relu(ref.hash_tensor((2, 256, 64), 79, 1.0))
+    xg = torch.cat([xg, xg[:, :4]], dim=1).contiguous()
+    xg[:, 100:140] = xg[:, 60:61]                                  # 41 identical rows: ties at distance 0
+    idx = ops.knn(xg.to(dev), 20).cpu().numpy()
+    assert np.array_equal(idx, oc.knn(xg.numpy(), 20))
 
 
 @pytest.mark.parametrize("name", ["nn1_1028_257", "nn1_1028_64"])

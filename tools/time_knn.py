@@ -6,7 +6,7 @@ import torch
 from hs_pose_amd import ops
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-shapes = [(16, 1028, 128, 20), (16, 257, 128, 20), (16, 257, 256, 20), (16, 64, 256, 8), (16, 1028, 3, 20), (16, 257, 3, 20)]
+shapes = [(16, 1024, 128, 20), (16, 1028, 128, 20), (16, 257, 128, 20), (16, 257, 256, 20), (16, 64, 256, 8), (16, 1028, 3, 20), (16, 257, 3, 20)]
 for B, N, C, k in shapes:
     x = torch.relu(torch.randn(B, N, C, device=dev)) if C != 3 else torch.randn(B, N, C, device=dev)
     for _ in range(5):
