@@ -21,10 +21,11 @@ SIGNATURES = {
     "hsp_rf_surface_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "hsp_rf_bwd_workspace_bytes": (_sz, [_i]),
     "hsp_rf_surface_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
-    "hsp_rf_conv_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "hsp_rf_conv_wants_fwin": (_i, [_i, _i, _i]),
+    "hsp_rf_conv_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "hsp_rf_conv_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "hsp_rf_bwd_scatter_workspace_bytes": (_sz, [_i, _i]),
-    "hsp_rf_conv_bwd_scatter": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "hsp_rf_conv_bwd_scatter": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "hsp_rev_build": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "hsp_gather_max_bwd_csr": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "hsp_gather_max_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

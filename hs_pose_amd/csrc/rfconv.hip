@@ -57,13 +57,15 @@ struct PointIter {
 // forward.  SURFACE=true: out = mean_s max_n relu(z);  false: out = fm_c + mean_s max_n relu(z)*fm_support
 // dynamic LDS: (S*C + 4*k + k) floats
 // ------------------------------------------------------------------------------------------------
-template <bool SURFACE, int NCH>
+// WF: also record the winners' support values (fwin)
+template <bool SURFACE, int NCH, bool WF>
 __global__ __launch_bounds__(RF_THREADS) void rf_fwd_kernel(const float* __restrict__ xyz,
                                                             const int32_t* __restrict__ idx,
                                                             const float* __restrict__ dirs,
                                                             const float* __restrict__ fm, int B, int N, int k,
                                                             int S, int C, float* __restrict__ out,
-                                                            uint16_t* __restrict__ argrow) {
+                                                            uint16_t* __restrict__ argrow,
+                                                            float* __restrict__ fwin) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int SC = S * C;
     float* smax = reinterpret_cast<float*>(smem);             // SC
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_kernel(const float* __restr
                     const int j = cq << 2;
                     float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
                     int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                    float4 wf = make_float4(1.f, 1.f, 1.f, 1.f);          // the support value behind each winner
                     const float* fsup = SURFACE ? nullptr : fm + (size_t)b * N * fstride + C + j;
 #pragma unroll 4
                     for (int n = 0; n < k; ++n) {
@@ -113,12 +116,21 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_kernel(const float* __restr
                             const float4 f = *reinterpret_cast<const float4*>(fsup + (size_t)sIdx[n] * fstride);
                             th.x = mul_rn(th.x, f.x); th.y = mul_rn(th.y, f.y);
                             th.z = mul_rn(th.z, f.z); th.w = mul_rn(th.w, f.w);
+                            if (WF) {
+                                if (th.x > best.x) wf.x = f.x;
+                                if (th.y > best.y) wf.y = f.y;
+                                if (th.z > best.z) wf.z = f.z;
+                                if (th.w > best.w) wf.w = f.w;
+                            }
                         }
                         if (th.x > best.x) { best.x = th.x; a0 = n; }
                         if (th.y > best.y) { best.y = th.y; a1 = n; }
                         if (th.z > best.z) { best.z = th.z; a2 = n; }
                         if (th.w > best.w) { best.w = th.w; a3 = n; }
                     }
+                    // ... and that winner's support value fm[b,m*,C+j]: the backward's direction gradient reads it
+                    // as a stream instead of gathering 4-byte values from N rows (4x the HBM traffic, measured)
+                    if (WF) *reinterpret_cast<float4*>(fwin + pt * SC + j) = wf;
                     *reinterpret_cast<float4*>(smax + j) = best;
                     // the winning SOURCE ROW m* = idx[b,i,n*] (uint16): the backward needs neither idx nor n
                     *reinterpret_cast<ushort4*>(argrow + pt * SC + j) =
@@ -270,8 +282,9 @@ __global__ __launch_bounds__(RF_THREADS) void rf_conv_bwd_csr_kernel(
 // for each column j of the tile, reads the winning source row m = argrow[b,i,j] (coalesced), rebuilds
 // R(i->m) from the LDS copy of xyz, and routes  ga*relu(z)  to acc[m] with an LDS atomic add
 // (ds_add_f32: no L2 round trip; hub rows of feature-space KNN graphs only serialise inside one wave);
-// every grad_fm row segment is then written once with 16-byte stores.  The only divergent global access
-// left is the one fm[b,m,C+j] value per element that the direction gradient needs.  That gradient is
+// every grad_fm row segment is then written once with 16-byte stores.  The fm[b,m,C+j] value per element
+// that the direction gradient needs comes from fwin[b,i,j], stored by the forward next to argrow (a stream,
+// where gathering it from fm fetched a 64-byte sector per 4-byte value).  That gradient is
 // accumulated in registers, folded across the workgroup's point lanes in LDS in a fixed order and written
 // to gd_part[b][3][SC] (one writer per element); rf_dirs_reduce_kernel sums the B clouds.
 // Only the LDS float adds are order-dependent; hsp_rf_conv_bwd (CSR form) is the bit-reproducible twin.
@@ -279,9 +292,11 @@ __global__ __launch_bounds__(RF_THREADS) void rf_conv_bwd_csr_kernel(
 // ------------------------------------------------------------------------------------------------
 #define RF_TILE_THREADS 512   // 8 waves: with one 78 KB tile per workgroup this doubles the waves per CU
 
-template <int TC, bool SURFACE>
+// FWIN: the support values come from the forward's fwin stream; else they are gathered from fm (fine while a
+// cloud's fm stays L2-resident: small N)
+template <int TC, bool SURFACE, bool FWIN>
 __global__ __launch_bounds__(RF_TILE_THREADS) void rf_bwd_tile_kernel(
-    const float* __restrict__ xyz, const float* __restrict__ dirs, const float* __restrict__ fm,
+    const float* __restrict__ xyz, const float* __restrict__ dirs, const float* __restrict__ fwin,
     const uint16_t* __restrict__ argrow, const float* __restrict__ gout, int B, int N, int S, int C,
     float* __restrict__ gfm, float* __restrict__ gd_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -305,24 +320,27 @@ __global__ __launch_bounds__(RF_TILE_THREADS) void rf_bwd_tile_kernel(
     float4 d0, d1, d2;
     load_dirs_normed(dirs, SC, j, d0, d1, d2);
     float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
-    const float* fsup = SURFACE ? nullptr : fm + (size_t)b * N * fstride + C + j;
+    const float* fsup = (SURFACE || FWIN) ? nullptr : fwin + (size_t)b * N * fstride + C + j;   // (fwin is fm then)
     __syncthreads();
-    // software pipeline: the next point's winning rows / gradient are in flight while this one is processed,
-    // and the four fm values (the only divergent global reads) are requested before any dependent math
+    // software pipeline: the next point's winning rows / their support values / gradient are in flight while
+    // this one is processed; with FWIN every global read of the loop is a coalesced stream
     ushort4 am_n = make_ushort4(0, 0, 0, 0);
-    float4 ga_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ga_n = make_float4(0.f, 0.f, 0.f, 0.f), fw_n = make_float4(1.f, 1.f, 1.f, 1.f);
     if (pl < N) {
         am_n = *reinterpret_cast<const ushort4*>(argrow + ((size_t)b * N + pl) * SC + j);
         ga_n = *reinterpret_cast<const float4*>(gout + ((size_t)b * N + pl) * C + c);
+        if (!SURFACE && FWIN) fw_n = *reinterpret_cast<const float4*>(fwin + ((size_t)b * N + pl) * SC + j);
     }
     for (int p = pl; p < N; p += PL) {
         const ushort4 am = am_n;
         float4 ga = ga_n;
+        const float4 fw = fw_n;
         const int pn = p + PL < N ? p + PL : p;                      // clamped: no branch around the loads
         am_n = *reinterpret_cast<const ushort4*>(argrow + ((size_t)b * N + pn) * SC + j);
         ga_n = *reinterpret_cast<const float4*>(gout + ((size_t)b * N + pn) * C + c);
-        float f0 = 1.f, f1 = 1.f, f2 = 1.f, f3 = 1.f;
-        if (!SURFACE) {
+        if (!SURFACE && FWIN) fw_n = *reinterpret_cast<const float4*>(fwin + ((size_t)b * N + pn) * SC + j);
+        float f0 = fw.x, f1 = fw.y, f2 = fw.z, f3 = fw.w;
+        if (!SURFACE && !FWIN) {
             f0 = fsup[(size_t)am.x * fstride + 0];
             f1 = fsup[(size_t)am.y * fstride + 1];
             f2 = fsup[(size_t)am.z * fstride + 2];
@@ -449,7 +467,7 @@ static int rf_check(const void* a, const void* b, const void* c, int B, int N, i
 
 template <bool SURFACE>
 static int rf_fwd(const float* xyz, const int32_t* idx, const float* dirs, const float* fm, int B, int N, int k,
-                  int S, int C, float* out, uint16_t* argrow, hspStream_t stream) {
+                  int S, int C, float* out, uint16_t* argrow, float* fwin, hspStream_t stream) {
     int rc = rf_check(xyz, idx, dirs, B, N, k, S, C);
     if (rc) return rc;
     if (!out || !argrow || (!SURFACE && !fm)) return HSP_ERR_BAD_ARG;
@@ -459,8 +477,12 @@ static int rf_fwd(const float* xyz, const int32_t* idx, const float* dirs, const
     const int nch = ((S * C >> 2) + RF_THREADS - 1) / RF_THREADS;
     if (nch > 4) return HSP_ERR_UNSUPPORTED;              // S*C <= 4096
 #define RF_FWD_LAUNCH(NCH)                                                                                        \
-    hipLaunchKernelGGL((rf_fwd_kernel<SURFACE, NCH>), dim3(grid), dim3(RF_THREADS), lds, as_stream(stream), xyz, idx, \
-                       dirs, fm, B, N, k, S, C, out, argrow)
+    if (!SURFACE && fwin)                                                                                          \
+        hipLaunchKernelGGL((rf_fwd_kernel<SURFACE, NCH, !SURFACE>), dim3(grid), dim3(RF_THREADS), lds, as_stream(stream), \
+                           xyz, idx, dirs, fm, B, N, k, S, C, out, argrow, fwin);                                 \
+    else                                                                                                           \
+        hipLaunchKernelGGL((rf_fwd_kernel<SURFACE, NCH, false>), dim3(grid), dim3(RF_THREADS), lds, as_stream(stream), \
+                           xyz, idx, dirs, fm, B, N, k, S, C, out, argrow, fwin)
     switch (nch) {
         case 1: RF_FWD_LAUNCH(1); break;
         case 2: RF_FWD_LAUNCH(2); break;
@@ -473,12 +495,18 @@ static int rf_fwd(const float* xyz, const int32_t* idx, const float* dirs, const
 
 extern "C" int hsp_rf_surface_fwd(const float* xyz, const int32_t* idx, const float* dirs_n, int B, int N, int k,
                                   int S, int K, float* out, uint16_t* argrow, hspStream_t stream) {
-    return rf_fwd<true>(xyz, idx, dirs_n, nullptr, B, N, k, S, K, out, argrow, stream);
+    return rf_fwd<true>(xyz, idx, dirs_n, nullptr, B, N, k, S, K, out, argrow, nullptr, stream);
+}
+
+// the forward's fwin stream pays off once a cloud's fm no longer stays in its XCD's L2 next to the other streams
+extern "C" int hsp_rf_conv_wants_fwin(int N, int S, int C) {
+    return (size_t)N * (S + 1) * C * sizeof(float) >= ((size_t)3 << 20) ? 1 : 0;
 }
 
 extern "C" int hsp_rf_conv_fwd(const float* xyz, const int32_t* idx, const float* dirs_n, const float* fm, int B,
-                               int N, int k, int S, int C, float* out, uint16_t* argrow, hspStream_t stream) {
-    return rf_fwd<false>(xyz, idx, dirs_n, fm, B, N, k, S, C, out, argrow, stream);
+                               int N, int k, int S, int C, float* out, uint16_t* argrow, float* fwin,
+                               hspStream_t stream) {
+    return rf_fwd<false>(xyz, idx, dirs_n, fm, B, N, k, S, C, out, argrow, fwin, stream);
 }
 
 extern "C" size_t hsp_rf_bwd_workspace_bytes(int SC) {
@@ -533,7 +561,7 @@ extern "C" size_t hsp_rf_bwd_scatter_workspace_bytes(int B, int SC) {
     return (size_t)B * 3 * SC * sizeof(float);
 }
 
-template <bool SURFACE>
+template <bool SURFACE, bool FWIN>
 static int rf_bwd_scatter(const float* xyz, const float* dirs, const float* fm, const uint16_t* argrow,
                           const float* gout, int B, int N, int S, int C, float* gfm, float* gdirs, void* ws,
                           size_t ws_bytes, hspStream_t stream) {
@@ -551,7 +579,7 @@ static int rf_bwd_scatter(const float* xyz, const float* dirs, const float* fm, 
     dim3 grid(SC / tc, B);
 #define RF_TILE_LAUNCH(TC)                                                                                          \
     {                                                                                                               \
-        auto kern = rf_bwd_tile_kernel<TC, SURFACE>;                                                                \
+        auto kern = rf_bwd_tile_kernel<TC, SURFACE, FWIN>;                                                                \
         if (lds > 64 * 1024) {                                                                                      \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                 \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
@@ -570,13 +598,17 @@ static int rf_bwd_scatter(const float* xyz, const float* dirs, const float* fm, 
 extern "C" int hsp_rf_surface_bwd(const float* xyz, const float* dirs_n, const uint16_t* argrow, const float* grad_out,
                                   int B, int N, int S, int K, float* grad_dirs_n, void* ws, size_t ws_bytes,
                                   hspStream_t stream) {
-    return rf_bwd_scatter<true>(xyz, dirs_n, nullptr, argrow, grad_out, B, N, S, K, nullptr, grad_dirs_n, ws, ws_bytes,
+    return rf_bwd_scatter<true, false>(xyz, dirs_n, nullptr, argrow, grad_out, B, N, S, K, nullptr, grad_dirs_n, ws, ws_bytes,
                                 stream);
 }
 
-extern "C" int hsp_rf_conv_bwd_scatter(const float* xyz, const float* dirs_n, const float* fm, const uint16_t* argrow,
-                                       const float* grad_out, int B, int N, int S, int C, float* grad_fm,
-                                       float* grad_dirs_n, void* ws, size_t ws_bytes, hspStream_t stream) {
-    return rf_bwd_scatter<false>(xyz, dirs_n, fm, argrow, grad_out, B, N, S, C, grad_fm, grad_dirs_n, ws, ws_bytes,
-                                 stream);
+extern "C" int hsp_rf_conv_bwd_scatter(const float* xyz, const float* dirs_n, const float* fm, const float* fwin,
+                                       const uint16_t* argrow, const float* grad_out, int B, int N, int S, int C,
+                                       float* grad_fm, float* grad_dirs_n, void* ws, size_t ws_bytes,
+                                       hspStream_t stream) {
+    if (fwin)
+        return rf_bwd_scatter<false, true>(xyz, dirs_n, fwin, argrow, grad_out, B, N, S, C, grad_fm, grad_dirs_n, ws,
+                                           ws_bytes, stream);
+    return rf_bwd_scatter<false, false>(xyz, dirs_n, fm, argrow, grad_out, B, N, S, C, grad_fm, grad_dirs_n, ws, ws_bytes,
+                                        stream);
 }

@@ -190,16 +190,15 @@ class _RFConv(torch.autograd.Function):
         if fm.shape[-1] != (S + 1) * C:
             raise HspError("rf_conv: fm must have (S+1)*C columns")
         out = torch.empty(B, N, C, dtype=torch.float32, device=xyz.device)
-        arg = torch.empty(B, N, SC, dtype=torch.uint16, device=xyz.device)
-        _run("hsp_rf_conv_fwd", (_p(xyz), _p(idx), _p(dirs_n), _p(fm), B, N, k, S, C, _p(out), _p(arg), _stream()),
-             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 4 * k + 4 * (S + 1) * C + 4 * C + 2 * SC) + 12 * SC)
-        ctx.save_for_backward(xyz, idx, dirs_n, fm, arg)
+        out, arg, fwin = _rf_conv_fwd_raw(xyz, idx, dirs_n, fm, S, any(ctx.needs_input_grad))
+        ctx.save_for_backward(xyz, idx, dirs_n, fwin if fwin is not None else fm, arg)
         ctx.S = S
         return out
 
     @staticmethod
     def backward(ctx, g):
-        xyz, idx, dirs_n, fm, arg = ctx.saved_tensors
+        xyz, idx, dirs_n, fm, arg = ctx.saved_tensors          # fm: the winners' support values (or fm itself
+                                                                 # in DETERMINISTIC mode)
         g = _req(g, torch.float32, "rf_conv.grad")
         B, N, k = idx.shape
         SC = dirs_n.shape[1]
@@ -426,11 +425,30 @@ def _orl_bwd_accumulate_raw(gfg_over_n, idx_x, arg, k, gF3, extra=None):
              key=f"B{B}Ns{N}Nq{N}C{C}bc+", abytes=B * N * (12 * C + 4 * idx_x.shape[2] + C))
 
 
-def _rf_conv_bwd_raw(xyz, idx, directions, fm, arg, gF3, S):
+def _rf_conv_fwd_raw(xyz, idx, directions, fm, S, need_bwd=True):
+    """(out (B,N,C), argrow (B,N,SC) uint16, fwin (B,N,SC) | None).  fwin = the winners' support values, all the
+    column-tile backward needs of fm once a cloud's fm outgrows L2 (hsp_rf_conv_wants_fwin); smaller layers and
+    the gather-form backward (DETERMINISTIC) read fm itself."""
     B, N, k = idx.shape
     SC = directions.shape[1]
     C = SC // S
-    gfm = torch.empty_like(fm)
+    out = torch.empty(B, N, C, dtype=torch.float32, device=xyz.device)
+    arg = torch.empty(B, N, SC, dtype=torch.uint16, device=xyz.device)
+    want = need_bwd and not DETERMINISTIC and lib().hsp_rf_conv_wants_fwin(N, S, C)
+    fwin = torch.empty(B, N, SC, dtype=torch.float32, device=xyz.device) if want else None
+    _run("hsp_rf_conv_fwd", (_p(xyz), _p(idx), _p(directions), _p(fm), B, N, k, S, C, _p(out), _p(arg), _p(fwin),
+                             _stream()),
+         key=f"B{B}N{N}k{k}S{S}C{C}",
+         abytes=B * N * (12 + 4 * k + 4 * (S + 1) * C + 4 * C + 2 * SC + (4 * SC if fwin is not None else 0)) + 12 * SC)
+    return out, arg, fwin
+
+
+def _rf_conv_bwd_raw(xyz, idx, directions, fm, arg, gF3, S):
+    """fm: either fm (B,N,(S+1)C) or the forward's fwin (B,N,SC) (told apart by the width)."""
+    B, N, k = idx.shape
+    SC = directions.shape[1]
+    C = SC // S
+    gfm = torch.empty(B, N, (S + 1) * C, dtype=torch.float32, device=gF3.device)
     gd = torch.empty_like(directions)
     L = lib()
     if DETERMINISTIC:
@@ -443,8 +461,9 @@ def _rf_conv_bwd_raw(xyz, idx, directions, fm, arg, gF3, S):
     else:
         wsb = L.hsp_rf_bwd_scatter_workspace_bytes(B, SC)
         ws = _ws(wsb, gF3.device)
-        _run("hsp_rf_conv_bwd_scatter", (_p(xyz), _p(directions), _p(fm), _p(arg), _p(gF3), B, N, S, C, _p(gfm), _p(gd),
-                                         _p(ws), wsb, _stream()),
+        is_fwin = fm.shape[-1] == SC
+        _run("hsp_rf_conv_bwd_scatter", (_p(xyz), _p(directions), _p(None if is_fwin else fm), _p(fm if is_fwin else None),
+                                         _p(arg), _p(gF3), B, N, S, C, _p(gfm), _p(gd), _p(ws), wsb, _stream()),
              key=f"B{B}N{N}S{S}C{C}", abytes=B * N * (12 + 4 * SC + 2 * SC + 4 * C + 4 * (S + 1) * C) + 24 * SC)
     return gfm, gd
 
@@ -465,10 +484,11 @@ class _HSLayer(torch.autograd.Function):
         C = SC // S
         X2 = X.view(B * N, Cin)
         fm = torch.addmm(bias, X2, weights)                                    # (BN, (S+1)C)
-        F3 = torch.empty(B, N, C, dtype=torch.float32, device=X.device)
-        arg = torch.empty(B, N, SC, dtype=torch.uint16, device=X.device)
-        _run("hsp_rf_conv_fwd", (_p(xyz), _p(idx_f), _p(directions), _p(fm), B, N, k, S, C, _p(F3), _p(arg), _stream()),
-             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 4 * k + 4 * (S + 1) * C + 4 * C + 2 * SC) + 12 * SC)
+        need_bwd = any(ctx.needs_input_grad)
+        F3, arg, fwin = _rf_conv_fwd_raw(xyz, idx_f, directions, fm.view(B, N, -1), S, need_bwd)
+        if fwin is not None:
+            fm = fwin                                                          # fm itself is no longer needed
+        fm = fm.view(B, N, -1)
         fg, arg_o = _orl_fwd_raw(F3, idx_x, k)                                 # (B,C)
         F2 = F3.view(B * N, C)
         out3 = torch.empty(B, N, C, dtype=torch.float32, device=X.device)      # (returned as is: not a view)

@@ -84,16 +84,24 @@ int hsp_rf_surface_bwd(const float *xyz, const float *dirs, const uint16_t *argr
  * fm (B,N,(S+1)*C) = feature_map @ weights + bias: columns [0,C) centre, [C+s*C+c] support s.
  * out (B,N,C) = fm[b,i,c] + mean_s max_n relu(R.D^[:,sC+c]) * fm[b, idx[b,i,n], C+sC+c]
  * argrow (B,N,S*C) uint16 as above.  The (B,N,k,S*C) tensors of the reference are never formed.
+ * fwin (B,N,S*C) fp32 or NULL: the winner's support value fm[b, argrow[b,i,j], C+j], which
+ * hsp_rf_conv_bwd_scatter reads as a stream (inference passes NULL).
  */
+int hsp_rf_conv_wants_fwin(int N, int S, int C);
 int hsp_rf_conv_fwd(const float *xyz, const int32_t *idx, const float *dirs, const float *fm, int B,
-                    int N, int k, int S, int C, float *out, uint16_t *argrow, hspStream_t stream);
+                    int N, int k, int S, int C, float *out, uint16_t *argrow, float *fwin,
+                    hspStream_t stream);
 /* Backward, COLUMN-TILE LDS-SCATTER form (the default of the Python mirror): a (cloud, 16-column) tile
  * of grad_fm plus the cloud's xyz live in LDS; gradients are routed to row argrow[b,i,j] with ds_add_f32
  * (immune to the in-degree hubs of feature-space graphs) and every row segment is written once.
  * grad_fm (B,N,(S+1)*C) and grad_dirs (3,S*C) are OVERWRITTEN.  The LDS adds make grad_fm
  * order-dependent in the last bits; hsp_rf_conv_bwd is the bit-reproducible twin.
+ * fwin: the forward's (B,N,S*C) winner support values (then fm may be NULL), or NULL: the values are
+ * gathered from fm (B,N,(S+1)*C).  hsp_rf_conv_wants_fwin(N,S,C) says which is faster (fwin once a cloud's
+ * fm outgrows the L2 share it gets).
  * ws: hsp_rf_bwd_scatter_workspace_bytes(B, S*C). */
-int hsp_rf_conv_bwd_scatter(const float *xyz, const float *dirs, const float *fm, const uint16_t *argrow,
+int hsp_rf_conv_bwd_scatter(const float *xyz, const float *dirs, const float *fm, const float *fwin,
+                            const uint16_t *argrow,
                             const float *grad_out, int B, int N, int S, int C, float *grad_fm,
                             float *grad_dirs, void *ws, size_t ws_bytes, hspStream_t stream);
 /* Backward, GATHER form over rev_off/rev_edge = hsp_rev_build(idx) of the SAME idx the forward used:

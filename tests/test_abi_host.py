@@ -19,7 +19,7 @@ def _header_symbols():
 def test_library_exports_every_declared_symbol():
     from hs_pose_amd import _lib
     syms = _header_symbols()
-    assert len(syms) >= 38
+    assert len(syms) >= 39
     L = _lib.lib()
     for s in syms:
         assert hasattr(L, s), f"libhsp.so lacks {s}"
@@ -38,8 +38,8 @@ def test_argument_validation_without_gpu():
     assert L.hsp_knn_f32(one, 1, 100, 64, 4, 1, one, null, 0, null) == -3         # feature path needs workspace
     assert L.hsp_knn_workspace_bytes(2, 100, 3, 4) == 0
     assert L.hsp_knn_workspace_bytes(2, 100, 128, 4) == 2 * 100 * 4
-    assert L.hsp_rf_conv_fwd(one, one, one, one, 1, 70000, 4, 7, 128, one, one, null) == -2  # N > 65535 (uint16 rows)
-    assert L.hsp_rf_conv_fwd(one, one, one, one, 1, 8, 4, 7, 126, one, one, null) == -2     # C % 4
+    assert L.hsp_rf_conv_fwd(one, one, one, one, 1, 70000, 4, 7, 128, one, one, null, null) == -2  # N > 65535 (uint16 rows)
+    assert L.hsp_rf_conv_fwd(one, one, one, one, 1, 8, 4, 7, 126, one, one, null, null) == -2     # C % 4
     assert L.hsp_rf_conv_bwd(one, one, one, one, one, one, one, 1, 8, 4, 7, 128, one, one, null, 0, null) == -3
     assert L.hsp_rev_build(one, 1, 8, 8, 4, 2, one, one, null) == -1                         # kstride < k
     assert L.hsp_gather_max_bwd_csr(one, 0, one, one, one, 1, 8, 8, 4, 126, one, null) == -2  # C % 4
@@ -55,7 +55,7 @@ def test_argument_validation_without_gpu():
     assert L.hsp_bn_workspace_bytes(16448, 128) == 64 * 2 * 128 * 4          # 64 row chunks of 257 rows
     assert L.hsp_rf_bwd_workspace_bytes(896) > 0
     assert L.hsp_rf_bwd_scatter_workspace_bytes(16, 896) == 16 * 3 * 896 * 4
-    assert L.hsp_rf_conv_bwd_scatter(one, one, one, one, one, 1, 8, 7, 128, one, one, null, 0, null) == -3
+    assert L.hsp_rf_conv_bwd_scatter(one, one, one, null, one, one, 1, 8, 7, 128, one, one, null, 0, null) == -3
 
 
 def test_state_dict_surface_matches_reference(flags, state_keys):

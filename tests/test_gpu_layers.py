@@ -326,3 +326,36 @@ def test_bn_relu_fused(dev, ref, B, N, C, relu):
     # eval mode goes through the module itself
     mods[0].eval(); mods[1].eval()
     close(ops.bn_relu(x, mods[0], relu=relu), torch.relu(mods[1](x.reshape(-1, C))).view_as(x) if relu else mods[1](x.reshape(-1, C)).view_as(x), tol=2e-5)
+
+
+def test_rf_conv_backward_fwin_stream_equals_fm_gather(dev, ref):
+    """the column-tile backward takes the winners' support values either from the forward's fwin stream (large
+    layers) or by gathering fm (small ones): same numbers, so the same gradients up to LDS-add order."""
+    from hs_pose_amd import ops
+    from hs_pose_amd.ops import _p, _run, _stream, _ws
+    from hs_pose_amd._lib import lib
+    B, N, k, S, C = 2, 300, 8, 7, 64
+    SC = S * C
+    xyz = ref.hash_tensor((B, N, 3), 501, 0.5).to(dev)
+    fm = ref.hash_tensor((B, N, (S + 1) * C), 502, 1.0).to(dev)
+    dirs = ref.hash_tensor((3, SC), 503, 1.0).to(dev)
+    g = ref.hash_tensor((B, N, C), 504, 1.0).to(dev)
+    idx = ops.knn(xyz, k)
+    out = torch.empty(B, N, C, device=dev)
+    arg = torch.empty(B, N, SC, dtype=torch.uint16, device=dev)
+    fwin = torch.empty(B, N, SC, device=dev)
+    _run("hsp_rf_conv_fwd", (_p(xyz), _p(idx), _p(dirs), _p(fm), B, N, k, S, C, _p(out), _p(arg), _p(fwin), _stream()))
+    want = torch.gather(fm[:, :, C:], 1, arg.to(torch.int64))                 # fm[b, argrow[b,i,j], C+j]
+    assert torch.equal(fwin, want)
+    wsb = lib().hsp_rf_bwd_scatter_workspace_bytes(B, SC)
+    res = []
+    for a_fm, a_fw in ((fm, None), (None, fwin)):
+        gfm = torch.empty(B, N, (S + 1) * C, device=dev)
+        gd = torch.empty(3, SC, device=dev)
+        ws = _ws(wsb, dev)
+        _run("hsp_rf_conv_bwd_scatter", (_p(xyz), _p(dirs), _p(a_fm), _p(a_fw), _p(arg), _p(g), B, N, S, C, _p(gfm), _p(gd),
+                                         _p(ws), wsb, _stream()))
+        res.append((gfm, gd))
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-5)
+    assert lib().hsp_rf_conv_wants_fwin(1028, 7, 128) == 1 and lib().hsp_rf_conv_wants_fwin(64, 7, 512) == 0
