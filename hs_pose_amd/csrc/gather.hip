@@ -94,11 +94,15 @@ __global__ __launch_bounds__(256) void chunk_fold_kernel(const float* __restrict
     if (e >= B * C) return;
     const int b = e / C, c = e - b * C;
     const float* p = part + (size_t)b * nchunk * C + c;
-    float s0 = 0.f, s1 = 0.f;
+    // 8 independent partial sums: 8 loads in flight per round trip (the fold is a latency chain, not bandwidth)
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int ch = 0;
-    for (; ch + 1 < nchunk; ch += 2) { s0 += p[(size_t)ch * C]; s1 += p[(size_t)(ch + 1) * C]; }
-    if (ch < nchunk) s0 += p[(size_t)ch * C];
-    out[e] = (s0 + s1) * scale;
+    for (; ch + 7 < nchunk; ch += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += p[(size_t)(ch + u) * C];
+    }
+    for (; ch < nchunk; ++ch) s[ch & 7] += p[(size_t)ch * C];
+    out[e] = (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) * scale;
 }
 
 // part[b][chunk][c] = sum of x[b][i][c] over the chunk's rows (first stage of a per-cloud column sum)

@@ -86,23 +86,30 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float* __r
 //   MODE 0: mean, biased var -> invstd; running stats (momentum, unbiased var); num_batches_tracked += 1
 //   MODE 1: dgamma = sum dz*xhat, dbeta = sum dz; also keep both means for the dx pass
 template <int MODE>
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int R, int C,
-                                                          const float* __restrict__ x, float eps, float momentum,
-                                                          float* __restrict__ out_a, float* __restrict__ out_b,
-                                                          float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                          long long* __restrict__ num_batches) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float s1 = 0.f, s2 = 0.f, t1 = 0.f, t2 = 0.f;
-    int b = 0;
-    for (; b + 1 < nblk; b += 2) {                // two independent chains keep loads in flight
-        s1 += partial[(size_t)b * 2 * C + c];
-        s2 += partial[(size_t)b * 2 * C + C + c];
-        t1 += partial[(size_t)(b + 1) * 2 * C + c];
-        t2 += partial[(size_t)(b + 1) * 2 * C + C + c];
-    }
-    if (b < nblk) { s1 += partial[(size_t)b * 2 * C + c]; s2 += partial[(size_t)b * 2 * C + C + c]; }
-    s1 += t1; s2 += t2;
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int R, int C,
+                                                           const float* __restrict__ x, float eps, float momentum,
+                                                           float* __restrict__ out_a, float* __restrict__ out_b,
+                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                           long long* __restrict__ num_batches) {
+    // workgroup = 64 channels x 16 slices of the partials: every thread sums its <= BN_MAX_PARTIALS/16 partials with
+    // all loads in flight (a single thread walking 64 partials is a 10 us chain of L2 round trips), then the 16
+    // slices are folded through LDS in a fixed order (deterministic)
+    __shared__ float red[16][2][64];
+    const int lc = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lc;
+    float a1 = 0.f, a2 = 0.f;
+    if (c < C)
+        for (int b = sl; b < nblk; b += 16) {
+            a1 += partial[(size_t)b * 2 * C + c];
+            a2 += partial[(size_t)b * 2 * C + C + c];
+        }
+    red[sl][0][lc] = a1;
+    red[sl][1][lc] = a2;
+    __syncthreads();
+    if (sl != 0 || c >= C) return;
+    float s1 = red[0][0][lc], s2 = red[0][1][lc];
+#pragma unroll
+    for (int t = 1; t < 16; ++t) { s1 += red[t][0][lc]; s2 += red[t][1][lc]; }
     if (MODE == 0) {
         const float invR = 1.0f / (float)R;
         const float ms = s1 * invR;                              // mean of (x - shift)
@@ -222,7 +229,7 @@ extern "C" int hsp_bn_relu_fwd(const float* x, int R, int C, const float* gamma,
     const int nblk = bn_blocks(R);
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nblk), dim3(BN_THREADS), 0, st, x, nullptr, R, C, nullptr, nullptr,
                        nullptr, nullptr, 0, part, bn_rows_per_block(R));
-    hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 255) / 256), dim3(256), 0, st, part, nblk, R, C, x, eps, momentum,
+    hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 63) / 64), dim3(1024), 0, st, part, nblk, R, C, x, eps, momentum,
                        save_mean, save_invstd, running_mean, running_var, num_batches_tracked);
     const long long total4 = (long long)R * (C >> 2);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid4(total4)), dim3(256), 0, st, x, total4, C, save_mean, save_invstd,
@@ -253,7 +260,7 @@ extern "C" int hsp_bn_relu_bwd(const float* x, const float* dy, int R, int C, co
     const int nblk = bn_blocks(R);
     hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nblk), dim3(BN_THREADS), 0, st, x, dy, R, C, save_mean, save_invstd, gamma,
                        beta, relu, part, bn_rows_per_block(R));
-    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 255) / 256), dim3(256), 0, st, part, nblk, R, C, x, 0.f, 0.f, dgamma,
+    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 63) / 64), dim3(1024), 0, st, part, nblk, R, C, x, 0.f, 0.f, dgamma,
                        dbeta, nullptr, nullptr, nullptr);
     const long long total4 = (long long)R * (C >> 2);
     hipLaunchKernelGGL(bn_dx_kernel, dim3(stream_grid4(total4)), dim3(256), 0, st, x, dy, total4, R, C, save_mean,
