@@ -154,6 +154,123 @@ __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ x, 
     merge_write<K1, T>(lists, tid, t, k, drop, valid, idx + ((size_t)b * N + (valid ? q : 0)) * k);
 }
 
+__device__ __forceinline__ unsigned sortable_key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// xyz path, one WAVE per query (64 <= N <= 64*S): lane l owns candidates l, l+64, ... and keeps their S
+// distances in registers; the k + drop nearest are then selected exactly as in knn_select_wave (a bound
+// from the 64 lane minima by radix select over ballots, compaction of the ~k+4 survivors, ranking by
+// (distance, index)) -- about 600 wave instructions per query, where 16 lanes x 64 sorted-list inserts
+// cost ~2000.  Each wave takes QW consecutive queries.
+// grid (ceil(N / (4*QW)), B), block 256, LDS = N*16 (cloud) + 4 * KNN3W_CAP*8 (survivor scratch per wave)
+// ------------------------------------------------------------------------------------------------
+#define KNN3W_QW 4
+#define KNN3W_CAP 128   // survivor scratch entries per wave (typically ~k + 4 are used)
+
+template <int S>
+__global__ __launch_bounds__(256) void knn3_wave_kernel(const float* __restrict__ x, int N, int k, int drop,
+                                                        int32_t* __restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* pts = reinterpret_cast<float4*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int2* sv = reinterpret_cast<int2*>(pts + N) + (size_t)wave * KNN3W_CAP;
+    const int b = blockIdx.y;
+    const float* xb = x + (size_t)b * N * 3;
+    for (int j = tid; j < N; j += 256) {
+        const float px = xb[j * 3 + 0], py = xb[j * 3 + 1], pz = xb[j * 3 + 2];
+        pts[j] = make_float4(px, py, pz, quad3(px, py, pz));
+    }
+    __syncthreads();
+    const int m = k + drop;
+    for (int qi = 0; qi < KNN3W_QW; ++qi) {
+        const int q = (blockIdx.x * 4 + wave) * KNN3W_QW + qi;       // wave-uniform
+        if (q >= N) break;
+        const float4 qp = pts[q];
+        float d[S];
+        float lmin = INFINITY;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int j = lane + 64 * s;
+            const float4 c = pts[j < N ? j : N - 1];
+            const float inner = dot3_chain(qp.x, qp.y, qp.z, c.x, c.y, c.z);
+            const float dv = add_rn(add_rn(mul_rn(inner, -2.0f), c.w), qp.w);
+            d[s] = j < N ? dv : INFINITY;
+            lmin = fminf(lmin, d[s]);
+        }
+        // the m-th smallest of the 64 lane minima: m distinct candidates are <= tau
+        const unsigned key = sortable_key(lmin);
+        unsigned prefix = 0;
+        int need = m;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned hi = bit == 31 ? 0u : (0xffffffffu << (bit + 1));
+            const bool zero = ((key ^ prefix) & hi) == 0 && ((key >> bit) & 1u) == 0;
+            const int c0 = __popcll(__ballot(zero));
+            if (need > c0) { need -= c0; prefix |= 1u << bit; }
+        }
+        const float tau = __uint_as_float(prefix ^ ((prefix >> 31) ? 0x80000000u : 0xffffffffu));
+        int n = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const bool keep = d[s] <= tau;                    // +inf padding never passes a finite tau
+            const unsigned long long bal = __ballot(keep);
+            const int pos = n + __popcll(bal & ((1ull << lane) - 1ull));
+            if (keep && pos < KNN3W_CAP) sv[pos] = make_int2(__float_as_int(d[s]), lane + 64 * s);
+            n += __popcll(bal);
+        }
+        __builtin_amdgcn_wave_barrier();
+        int32_t* out = idx + ((size_t)b * N + q) * k;
+        if (n <= KNN3W_CAP) {
+            for (int e = lane; e < n; e += 64) {
+                const int2 me = sv[e];
+                const float de = __int_as_float(me.x);
+                int rank = 0;
+                for (int f = 0; f < n; ++f) {
+                    const int2 o = sv[f];
+                    const float df = __int_as_float(o.x);
+                    rank += (df < de || (df == de && o.y < me.y)) ? 1 : 0;
+                }
+                if (rank >= drop && rank < m) out[rank - drop] = me.y;
+            }
+        } else {
+            // more survivors than scratch (heavily duplicated points): extract the m smallest (distance, index)
+            // pairs one at a time -- lane-local minimum above the previous pick, then a bitwise descent over
+            // ballots for the wave minimum.  Slow (~150 ballots per pick) but exact and scratch-free.
+            unsigned pk = 0;                                  // previous pick: sortable distance key, index
+            int pj = -1;
+            for (int r = 0; r < m; ++r) {
+                unsigned bk = 0xffffffffu;
+                int bj = 0x7fffffff;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const unsigned ks = sortable_key(d[s]);
+                    const int j = lane + 64 * s;
+                    const bool after = r == 0 || ks > pk || (ks == pk && j > pj);
+                    const bool better = ks < bk || (ks == bk && j < bj);
+                    if (j < N && after && better) { bk = ks; bj = j; }
+                }
+                unsigned long long live = __ballot(bj != 0x7fffffff);
+                unsigned wk = 0;
+                for (int bit = 31; bit >= 0; --bit) {         // smallest key among the live lanes
+                    const unsigned long long z = __ballot(((bk >> bit) & 1u) == 0) & live;
+                    if (z) live = z; else wk |= 1u << bit;
+                }
+                int wj = 0;
+                for (int bit = 15; bit >= 0; --bit) {         // smallest index among the lanes holding that key
+                    const unsigned long long z = __ballot(((bj >> bit) & 1) == 0) & live;
+                    if (z) live = z; else wj |= 1 << bit;
+                }
+                if (lane == 0 && r >= drop) out[r - drop] = wj;
+                pk = wk; pj = wj;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                      // sv is reused by the next query
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // quad[r] = sum_c x[r][c]^2 in ATen's CPU order (oracle/hsp_oracle.c aten_row_sum): 8-lane vector
 // partials with 4-way ILP, then a sequential horizontal sum.  One thread per row.
@@ -257,10 +374,6 @@ __global__ __launch_bounds__(256) void quad_kernel(const float* __restrict__ x, 
 //      each other; ranks [drop, m) are the answer, already in order.
 // dl: N floats (N >= 64), sv: N int2 of scratch, both LDS
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned sortable_key(float f) {
-    const unsigned u = __float_as_uint(f);
-    return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
-}
 
 __device__ __forceinline__ void knn_select_wave(const float* dl, int2* sv, int N, int k, int drop,
                                                 int32_t* __restrict__ out) {
@@ -714,9 +827,27 @@ static int launch_knn3(const float* x, int B, int N, int k, int drop, int32_t* i
     return check_launch();
 }
 
+template <int S>
+static int launch_knn3_wave(const float* x, int B, int N, int k, int drop, int32_t* idx, hipStream_t st) {
+    const size_t lds = (size_t)N * 16 + (size_t)4 * KNN3W_CAP * 8;
+    auto kern = knn3_wave_kernel<S>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
+    }
+    hipLaunchKernelGGL(kern, dim3((N + 4 * KNN3W_QW - 1) / (4 * KNN3W_QW), B), dim3(256), lds, st, x, N, k, drop, idx);
+    return check_launch();
+}
+
 template <int K1>
 static int launch_knn3_t(const float* x, int B, int N, int k, int drop, int32_t* idx, hipStream_t st) {
     const long long nq = (long long)B * N;
+    // one wave per query while the per-lane distances fit in registers and the grid is not already huge
+    if (N >= 64 && nq < 131072) {
+        if (N <= 64 * 5) return launch_knn3_wave<5>(x, B, N, k, drop, idx, st);
+        if (N <= 64 * 9) return launch_knn3_wave<9>(x, B, N, k, drop, idx, st);
+        if (N <= 64 * 17) return launch_knn3_wave<17>(x, B, N, k, drop, idx, st);
+    }
     if (nq >= 131072) return launch_knn3<K1, 1>(x, B, N, k, drop, idx, st);
     if (nq >= 32768) return launch_knn3<K1, 4>(x, B, N, k, drop, idx, st);
     return launch_knn3<K1, 16>(x, B, N, k, drop, idx, st);

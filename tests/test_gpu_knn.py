@@ -88,6 +88,14 @@ def test_knn_duplicate_points(dev, ref, oc):
     x = torch.cat([base, base[:, :212]], dim=1).contiguous()      # 512 points, 212 duplicated
     idx = ops.knn(x.to(dev), 20).cpu().numpy()
     assert np.array_equal(idx, oc.knn(x.numpy(), 20))
+    # more coincident points than the wave kernel's survivor scratch: its extraction fallback
+    heavy = ref.hash_tensor((2, 400, 3), 80, 0.1)
+    heavy[:, 50:250] = heavy[:, 10:11]                            # 201 identical points (all mutual distances tie)
+    heavy[:, 300:340] = heavy[:, 20:21]
+    idx = ops.knn(heavy.to(dev), 20).cpu().numpy()
+    assert np.array_equal(idx, oc.knn(heavy.numpy(), 20))
+    idx = ops.knn(heavy.to(dev), 4, drop_first=False).cpu().numpy()
+    assert np.array_equal(idx, oc.knn(heavy.numpy(), 4, 0))
     xf = torch.relu(ref.hash_tensor((1, 200, 32), 78, 1.0))
     xf = torch.cat([xf, xf[:, :56]], dim=1).contiguous()
     idx = ops.knn(xf.to(dev), 8).cpu().numpy()
