@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ A,
                                                     int SK, int kslice, float* __restrict__ part,
                                                     float* __restrict__ cs_part) {
     const int lane = threadIdx.x & 63;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int w = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, and provably so
     const int tiles = (M >> 6) * (N >> 6);
     if (w >= tiles * SK) return;
     const int slice = w / tiles, t = w - slice * tiles;
@@ -41,39 +41,57 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ A,
     const int k0 = slice * kslice;
     const int k1 = min(K, k0 + kslice);
     const int h = lane >> 5, i = lane & 31;
-    const float* ap = A + m0 + 2 * i;
-    const float* bp = B + n0 + 2 * i;
+    // operands by raw buffer loads: descriptor over the whole matrix, per-lane byte offset fixed for the kernel
+    // (row parity h, columns 2i, 2i+1 of the tile), row pair selected by a scalar offset -> no vector address
+    // arithmetic in the loop, and rows >= K (ragged end of the last slice; slices are multiples of 8 rows) read 0
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(A), 0, (int)((((size_t)K - 1) * lda + M) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(B), 0, (int)((((size_t)K - 1) * ldb + N) * 4), 0x00020000);
+    const int va = (h * lda + m0 + 2 * i) * 4, vb = (h * ldb + n0 + 2 * i) * 4;
     f32x16 c00, c01, c10, c11;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
     float2 cs = make_float2(0.f, 0.f);
 
-    float2 a[WG_UNROLL], b[WG_UNROLL], an[WG_UNROLL], bn[WG_UNROLL];
+    // two register buffers, used alternately (no copies): the loads of group g+1 are in flight under the 16 MFMAs
+    // of group g and are first touched when group g+1 starts
+    float2 a0[WG_UNROLL], b0[WG_UNROLL], a1[WG_UNROLL], b1[WG_UNROLL];
     auto load_group = [&](int kk, float2 (&aa)[WG_UNROLL], float2 (&bb)[WG_UNROLL]) {
 #pragma unroll
         for (int u = 0; u < WG_UNROLL; ++u) {
-            const int k = kk + 2 * u + h;
-            const int kc = min(k, K - 1);                       // branch-free: clamp, then zero by select
-            float2 va = *reinterpret_cast<const float2*>(ap + (size_t)kc * lda);
-            float2 vb = *reinterpret_cast<const float2*>(bp + (size_t)kc * ldb);
-            const bool ok = k < k1;
-            aa[u] = make_float2(ok ? va.x : 0.f, ok ? va.y : 0.f);
-            bb[u] = make_float2(ok ? vb.x : 0.f, ok ? vb.y : 0.f);
+            const auto x = __builtin_amdgcn_raw_buffer_load_b64(ra, va, (kk + 2 * u) * lda * 4, 0);
+            const auto y = __builtin_amdgcn_raw_buffer_load_b64(rb, vb, (kk + 2 * u) * ldb * 4, 0);
+            aa[u] = make_float2(__int_as_float(x[0]), __int_as_float(x[1]));
+            bb[u] = make_float2(__int_as_float(y[0]), __int_as_float(y[1]));
         }
     };
-    if (k0 < k1) load_group(k0, a, b);
-    for (int kk = k0; kk < k1; kk += 2 * WG_UNROLL) {
-        if (kk + 2 * WG_UNROLL < k1) load_group(kk + 2 * WG_UNROLL, an, bn);
+    auto mma_group = [&](const float2 (&aa)[WG_UNROLL], const float2 (&bb)[WG_UNROLL]) {
 #pragma unroll
         for (int u = 0; u < WG_UNROLL; ++u) {
-            c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, c00, 0, 0, 0);
-            c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].y, c01, 0, 0, 0);
-            c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].x, c10, 0, 0, 0);
-            c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, c11, 0, 0, 0);
-            if (COLSUM) { cs.x += b[u].x; cs.y += b[u].y; }
+            c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[u].x, bb[u].x, c00, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[u].x, bb[u].y, c01, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[u].y, bb[u].x, c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[u].y, bb[u].y, c11, 0, 0, 0);
+            if (COLSUM) { cs.x += bb[u].x; cs.y += bb[u].y; }
         }
-#pragma unroll
-        for (int u = 0; u < WG_UNROLL; ++u) { a[u] = an[u]; b[u] = bn[u]; }
+    };
+    constexpr int GR = 2 * WG_UNROLL;                       // k rows per group
+    // the next group is requested unconditionally (past the slice it is simply not used; past K it reads 0):
+    // a branch around the loads would make the compiler wait for them at the join
+    // Branch-free body (slices are multiples of 2 groups; the ragged end of the last slice multiplies zeros): with
+    // an early exit between a load group and its MFMAs hipcc sinks the loads behind the branch, next to their
+    // use, and nothing is prefetched.  sched_barrier keeps the machine scheduler from interleaving them back.
+    load_group(k0, a0, b0);
+    for (int kk = k0; kk < k1; kk += 2 * GR) {
+        load_group(kk + GR, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_group(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_group(kk + 2 * GR, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_group(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
     }
     // accumulator r <-> tile row (r&3) + 8*(r>>2) + 4*h, tile col i; tile (ta,tb) holds C[m0+2*row+ta][n0+2*i+tb]
     float* pc = part + (size_t)slice * M * N;
@@ -147,7 +165,7 @@ static int wgrad_pick_sk(int M, int N, int K, int* kslice) {
     if (sk > max_sk) sk = max_sk;
     if (sk < 1) sk = 1;
     int ks = (K + sk - 1) / sk;
-    ks = (ks + 2 * WG_UNROLL - 1) / (2 * WG_UNROLL) * (2 * WG_UNROLL);
+    ks = (ks + 4 * WG_UNROLL - 1) / (4 * WG_UNROLL) * (4 * WG_UNROLL);     // whole pairs of prefetch groups
     sk = (K + ks - 1) / ks;
     *kslice = ks;
     return sk;

@@ -1,0 +1,13 @@
+"""per-(kernel, grid) duration table from a rocprofv3 kernel trace CSV: python tools/trace_by_shape.py trace.csv steps [filter]"""
+import csv, collections, sys
+f, steps = sys.argv[1], float(sys.argv[2])
+flt = sys.argv[3].split(",") if len(sys.argv) > 3 else None
+acc = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    n = r["Kernel_Name"]
+    if flt and not any(x in n for x in flt):
+        continue
+    key = (n[:60], f'{r["Grid_Size_X"]}x{r["Grid_Size_Y"]}', r["Workgroup_Size_X"])
+    acc[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+    print(f"{k[0]:60s} grid {k[1]:>12s} wg {k[2]:>5s} calls/step {len(v)/steps:4.1f} avg {sum(v)/len(v):7.1f} us  per-step {sum(v)/steps:7.1f}")
