@@ -47,6 +47,10 @@ SIGNATURES = {
     "hsp_pc_gather": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "hsp_depth_to_pcl": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "hsp_generate_rt": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "hsp_sumsq_workspace_bytes": (_sz, [ctypes.c_longlong]),
+    "hsp_sumsq_f32": (_i, [_vp, ctypes.c_longlong, _vp, _vp, _sz, _vp]),
+    "hsp_ranger_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                             ctypes.c_float, ctypes.c_float, _i, _i, ctypes.c_float, _i, _vp, ctypes.c_float, _vp]),
     "hsp_chamfer_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "hsp_chamfer_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "hsp_fps_workspace_bytes": (_sz, [_i, _i]),

@@ -245,6 +245,25 @@ int hsp_depth_to_pcl(const float *depth, const float *xymap, const double *camK,
 int hsp_generate_rt(const float *p_green, const float *p_red, const float *f_green, const float *f_red,
                     const float *T, const float *sym, int sym_stride, int B, float *out, hspStream_t stream);
 
+/* ---- optimizer step (training driver) ---------------------------------------------------------------
+ * All parameters / gradients / optimizer state of a parameter group live in flat fp32 buffers; `rows` (device)
+ * lists the dim-0 slices of every >= 2-D tensor (gc = 1: gradient centralisation applies) and chunks of the
+ * 1-D tensors (gc = 0).
+ * hsp_sumsq_f32: out[0] = sum x^2 (the squared total norm of torch.nn.utils.clip_grad_norm_, engine/train.py:99).
+ * hsp_ranger_step replaces Ranger.step() tools/torch_utils/solver/ranger2020.py:135-246 for the whole group:
+ *   clip (coef = min(1, max_norm / (sqrt(*gnorm_sq) + 1e-6)); gnorm_sq NULL = no clipping), gradient
+ *   centralisation (before the moments, or with gc_after on the generalised gradient), RAdam moments,
+ *   adaptive (N_sma > threshold, decided by the host from the step count) or plain momentum step with
+ *   step_lr = step_size * lr, weight decay, and on lookahead steps slow += la_alpha * (p - slow); p = slow.
+ */
+typedef struct HspRowDesc { long long offset; int len; int gc; } HspRowDesc;
+size_t hsp_sumsq_workspace_bytes(long long n);
+int hsp_sumsq_f32(const float *x, long long n, float *out, void *ws, size_t ws_bytes, hspStream_t stream);
+int hsp_ranger_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, float *slow,
+                    const HspRowDesc *rows, int nrows, float beta1, float beta2, float eps, float weight_decay,
+                    float step_lr, int adaptive, int lookahead, float la_alpha, int gc_after,
+                    const float *gnorm_sq, float max_norm, hspStream_t stream);
+
 /* ---- Chamfer distance -------------------------------------------------------------------------
  * replaces cd.forward_cuda / cd.backward_cuda    tools/pyTorchChamferDistance/chamfer_distance.cpp:27-56
  * xyz1 (B,n,3), xyz2 (B,m,3) -> dist1 (B,n), dist2 (B,m) squared NN distances, idx1/idx2 int32 arg-min

@@ -382,6 +382,80 @@ def generate_rt(p_green: Tensor, p_red: Tensor, f_green: Tensor, f_red: Tensor, 
 
 
 # ---------------------------------------------------------------------------------------------
+# training driver: gradient clipping, Ranger step, learning-rate schedule
+#     engine/train.py:96-110, tools/torch_utils/solver/ranger2020.py:135-246, lr_scheduler.py:177-263
+# ---------------------------------------------------------------------------------------------
+
+def clip_grads_(grads: Sequence[Tensor], max_norm: float) -> Tensor:
+    """torch.nn.utils.clip_grad_norm_ (L2): total = ||(||g_i||)_i||, g_i *= min(1, max_norm / (total + 1e-6))."""
+    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g, 2.0) for g in grads]), 2.0)
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in grads:
+        g.mul_(coef)
+    return total
+
+
+def ranger_step_(params: Sequence[Tensor], grads: Sequence[Tensor], state: List[Dict[str, Tensor]], step: int, *, lr: float,
+                 alpha: float = 0.5, k: int = 6, n_sma_threshold: float = 5, betas=(0.95, 0.999), eps: float = 1e-5,
+                 weight_decay: float = 0.0, use_gc: bool = True, gc_conv_only: bool = False, gc_loc: bool = True) -> None:
+    """one Ranger.step() for `step` (1-based) on every tensor: gradient centralisation over all dims but the
+    first (ranger2020.py:31-41), RAdam moments and rectified step size (:186-212), adaptive or plain update
+    (:215-229), Lookahead interpolation every k steps (:232-238).  state[i]: exp_avg, exp_avg_sq, slow_buffer."""
+    beta1, beta2 = betas
+    beta2_t = beta2 ** step
+    n_max = 2 / (1 - beta2) - 1
+    n_sma = n_max - 2 * step * beta2_t / (1 - beta2_t)
+    if n_sma > n_sma_threshold:
+        step_size = math.sqrt((1 - beta2_t) * (n_sma - 4) / (n_max - 4) * (n_sma - 2) / n_sma * n_max / (n_max - 2)) / (1 - beta1 ** step)
+    else:
+        step_size = 1.0 / (1 - beta1 ** step)
+
+    def central(x):
+        if use_gc and x.dim() > (3 if gc_conv_only else 1):
+            return x - x.mean(dim=tuple(range(1, x.dim())), keepdim=True)
+        return x
+
+    for p, g, st in zip(params, grads, state):
+        g = central(g) if gc_loc else g
+        st["exp_avg_sq"].mul_(beta2).addcmul_(g, g, value=1 - beta2)
+        st["exp_avg"].mul_(beta1).add_(g, alpha=1 - beta1)
+        if n_sma > n_sma_threshold:
+            G = st["exp_avg"] / (st["exp_avg_sq"].sqrt() + eps)
+        else:
+            G = st["exp_avg"]              # an ALIAS in the reference (:219): the in-place ops below then also
+                                           # rewrite exp_avg during the first, non-adaptive steps -- kept as is
+        if weight_decay != 0:
+            G.add_(p, alpha=weight_decay)
+        if not gc_loc:
+            G.copy_(central(G))
+        p.add_(G, alpha=-step_size * lr)
+        if step % k == 0:
+            st["slow_buffer"].add_(p - st["slow_buffer"], alpha=alpha)
+            p.copy_(st["slow_buffer"])
+
+
+def flat_and_anneal_factor(x: int, total_iters: int, warmup_iters: int = 1000, warmup_factor: float = 0.001,
+                           anneal_point: float = 0.72, target_lr_factor: float = 0.0) -> float:
+    """the reference's default schedule (linear warm-up, flat, cosine anneal): lr_scheduler.py:219-261."""
+    anneal_start = anneal_point * total_iters
+    if x < warmup_iters:
+        a = float(x) / warmup_iters
+        return warmup_factor * (1 - a) + a
+    if x >= anneal_start:
+        return target_lr_factor + 0.5 * (1 - target_lr_factor) * (
+            1 + math.cos(math.pi * ((float(x) - anneal_start) / (total_iters - anneal_start))))
+    return 1
+
+
+OPT_SHAPES = [(4, 6), (5, 3, 1), (7,), (3, 2, 2, 2), (9, 70), (4200,)]
+
+
+def opt_case_tensors(step: int):
+    """closed-form gradients of optimizer-fixture step `step` (1-based); step 0: the initial parameters."""
+    return [hash_tensor(sh, 3000 + 37 * step + i, 1.0 if step else 0.5) for i, sh in enumerate(OPT_SHAPES)]
+
+
+# ---------------------------------------------------------------------------------------------
 # deterministic closed-form parameter fill shared by the golden generator and the tests
 # ---------------------------------------------------------------------------------------------
 

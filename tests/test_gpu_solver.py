@@ -1,0 +1,117 @@
+"""GPU parity (through the C-ABI): the fused Ranger step + device-side gradient clipping against the
+fixtures written by the reference optimizer, and its checkpoint compatibility."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from test_solver_oracle import CASES
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(ref, dev):
+    return [torch.nn.Parameter(t.clone().to(dev)) for t in ref.opt_case_tensors(0)]
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_fused_ranger_matches_reference(dev, ref, name):
+    from hs_pose_amd.solver import Ranger, clip_grad_norm_
+    g, c = golden(name), CASES[name]
+    params = _params(ref, dev)
+    opt = Ranger(params, lr=c["lr"], **c["kw"])
+    for step in range(1, c["nsteps"] + 1):
+        for p, gr in zip(params, ref.opt_case_tensors(step)):
+            p.grad.copy_(gr.to(dev))                       # .grad is a view of the flat gradient buffer
+        norm = clip_grad_norm_(opt, c["max_norm"])
+        opt.step()
+        if f"s{step}.norm" in g.files:
+            assert abs(float(norm) - float(g[f"s{step}.norm"][0])) <= 1e-5 * float(norm)
+            for i, p in enumerate(params):
+                err = np.abs(p.detach().cpu().numpy() - g[f"s{step}.p{i}"]).max()
+                assert err <= 2e-6, (name, step, i, err)      # fp32, fused multiply-adds and a different sum order
+    for i, p in enumerate(params):
+        st = opt.state[p]
+        assert st["step"] == c["nsteps"]
+        assert np.abs(st["exp_avg"].cpu().numpy() - g[f"final.m{i}"]).max() <= 2e-6
+        assert np.abs(st["exp_avg_sq"].cpu().numpy() - g[f"final.v{i}"]).max() <= 2e-6
+        assert np.abs(st["slow_buffer"].cpu().numpy() - g[f"final.slow{i}"]).max() <= 2e-6
+
+
+def test_gradients_replaced_by_autograd_are_picked_up(dev, ref):
+    """a first backward after ``p.grad = None`` makes a fresh .grad tensor: step() copies it back into the flat buffer."""
+    from hs_pose_amd.solver import Ranger
+    a = _params(ref, dev)
+    b = _params(ref, dev)
+    oa, ob = Ranger(a, lr=1e-2), Ranger(b, lr=1e-2)
+    grads = [t.to(dev) for t in ref.opt_case_tensors(1)]
+    for p, gr in zip(a, grads):
+        p.grad.copy_(gr)
+    for p, gr in zip(b, grads):
+        p.grad = None
+        (p * gr).sum().backward()
+    oa.step(); ob.step()
+    for p, q in zip(a, b):
+        assert torch.equal(p, q)
+    ob.zero_grad()
+    assert all(float(p.grad.abs().max()) == 0.0 for p in b)
+
+
+def test_state_dict_round_trip_with_reference_layout(dev, ref):
+    """per-parameter step / exp_avg / exp_avg_sq / slow_buffer entries, as the reference Ranger saves them."""
+    from hs_pose_amd.solver import Ranger
+    c = CASES["solver_ranger_default"]
+    g = golden("solver_ranger_default")
+    pa = _params(ref, dev)
+    oa = Ranger(pa, lr=c["lr"])
+    for step in range(1, 7):
+        for p, gr in zip(pa, ref.opt_case_tensors(step)):
+            p.grad.copy_(gr.to(dev))
+        oa.clip_grad_norm_(c["max_norm"]); oa.step()
+    sd = oa.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq", "slow_buffer"}
+    assert sd["param_groups"][0]["betas"] == (0.95, 0.999) and sd["param_groups"][0]["k"] == 6
+    # a fresh optimizer on the same weights resumes from the checkpoint and lands on the reference's step 13
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    ob = Ranger(pb, lr=c["lr"])
+    ob.load_state_dict({"state": {k: {n: (v.cpu() if torch.is_tensor(v) else v) for n, v in s.items()} for k, s in sd["state"].items()},
+                        "param_groups": sd["param_groups"]})
+    for step in range(7, 14):
+        for p, gr in zip(pb, ref.opt_case_tensors(step)):
+            p.grad.copy_(gr.to(dev))
+        ob.clip_grad_norm_(c["max_norm"]); ob.step()
+    for i, p in enumerate(pb):
+        assert np.abs(p.detach().cpu().numpy() - g[f"s13.p{i}"]).max() <= 2e-6
+
+
+def test_sumsq_and_clip_coefficient(dev, ref):
+    from hs_pose_amd import ops
+    from hs_pose_amd._lib import lib
+    for n in (1, 3, 4, 1000, 262147):
+        x = ref.hash_tensor((n + 4,), 77 + n, 2.0).to(dev)[:n]          # 16-byte aligned start
+        out = torch.empty(1, device=dev)
+        wsb = lib().hsp_sumsq_workspace_bytes(n)
+        ws = ops._ws(wsb, dev)
+        ops._run("hsp_sumsq_f32", (ops._p(x), n, ops._p(out), ops._p(ws), wsb, ops._stream()))
+        want = float((x.double() ** 2).sum())
+        assert abs(float(out) - want) <= 1e-5 * want
+
+
+def test_optimizer_on_the_network(dev, flags):
+    """build_params -> build_optimizer -> build_lr_rate as engine/train.py:44-58 does; one clipped step moves every weight."""
+    from hs_pose_amd.HSPose import HSPose
+    from hs_pose_amd.solver import build_lr_rate, build_optimizer, clip_grad_norm_
+    flags.train = 1
+    net = HSPose("PoseNet_only").to(dev)
+    opt = build_optimizer(net.build_params(training_stage_freeze=[]))
+    sch = build_lr_rate(opt, total_iters=150 * 1500)
+    assert abs(opt.param_groups[0]["lr"] - 1e-4 * 0.001) < 1e-12          # warm-up start
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    for p in net.parameters():
+        p.grad.copy_(1e3 * torch.randn_like(p))            # (warm-up lr is 1e-7: keep the update above fp32 resolution)
+    norm = clip_grad_norm_(opt, 1e9)
+    opt.step(); sch.step()
+    assert 1e6 < float(norm) < 1e7                          # ~ 1e3 * sqrt(9.7e6)
+    moved = [k for k, v in net.named_parameters() if not torch.equal(v, before[k])]
+    assert len(moved) == len(before)
+    assert opt.param_groups[0]["lr"] > 1e-4 * 0.001
