@@ -1,0 +1,69 @@
+"""Train-step driver semantics of the reference's ``engine/train.py:72-130``, around the fused
+optimizer of ``hs_pose_amd.solver``:
+
+  total_loss NaN -> the iteration is skipped (counters advance, nothing else happens)       train.py:91-95
+  backward; clip_grad_norm_(network.parameters(), 5) after EVERY backward                    train.py:98-99,103-104
+  optimizer.step(); scheduler.step(); optimizer.zero_grad() when global_step % accumulate == 0   train.py:97-102
+  checkpoint = {'seed','epoch','posenet_state_dict','scheduler','optimizer'}                 train.py:115-123
+
+``TrainDriver.step(total_loss)`` is the body of that loop for one batch.  With ``check_nan=False`` the NaN test
+(the loop's only host synchronisation besides logging) is skipped.
+"""
+import math
+
+import torch
+
+from .config import FLAGS
+from .solver import build_lr_rate, build_optimizer
+
+
+class TrainDriver:
+    def __init__(self, network, optimizer=None, scheduler=None, total_iters=None, accumulate=None, max_norm=5,
+                 check_nan=True, global_step=0):
+        self.network = network
+        self.optimizer = optimizer if optimizer is not None else build_optimizer(network.build_params(training_stage_freeze=[]))
+        if scheduler is None:
+            if total_iters is None:
+                total_iters = int(getattr(FLAGS, "train_steps", 1500)) * int(getattr(FLAGS, "total_epoch", 150))
+            scheduler = build_lr_rate(self.optimizer, total_iters=total_iters)
+        self.scheduler = scheduler
+        self.accumulate = int(accumulate if accumulate is not None else getattr(FLAGS, "accumulate", 1))
+        self.max_norm = max_norm
+        self.check_nan = check_nan
+        self.global_step = int(global_step)
+        self.skipped = 0
+
+    def step(self, total_loss):
+        """one batch of engine/train.py's loop; returns False when the batch was skipped for a NaN loss."""
+        if self.check_nan and math.isnan(float(total_loss.detach())):
+            print('Found nan in total loss')
+            self.global_step += 1
+            self.skipped += 1
+            return False
+        total_loss.backward()
+        self.optimizer.clip_grad_norm_(self.max_norm)
+        if self.global_step % self.accumulate == 0:
+            self.optimizer.step()
+            self.scheduler.step()
+            self.optimizer.zero_grad()
+        self.global_step += 1
+        return True
+
+    def checkpoint(self, seed, epoch):
+        """the dict engine/train.py:115-123 passes to torch.save (same keys, same sub-layouts)."""
+        return {
+            'seed': seed,
+            'epoch': epoch,
+            'posenet_state_dict': self.network.state_dict(),
+            'scheduler': self.scheduler.state_dict(),
+            'optimizer': self.optimizer.state_dict(),
+        }
+
+    def load_checkpoint(self, ckpt):
+        """resume (engine/train.py:46-57 loads model weights; optimizer / scheduler state restored when present)."""
+        self.network.load_state_dict(ckpt['posenet_state_dict'])
+        if 'optimizer' in ckpt:
+            self.optimizer.load_state_dict(ckpt['optimizer'])
+        if 'scheduler' in ckpt:
+            self.scheduler.load_state_dict(ckpt['scheduler'])
+        return ckpt.get('epoch', 0)

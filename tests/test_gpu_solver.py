@@ -115,3 +115,37 @@ def test_optimizer_on_the_network(dev, flags):
     moved = [k for k, v in net.named_parameters() if not torch.equal(v, before[k])]
     assert len(moved) == len(before)
     assert opt.param_groups[0]["lr"] > 1e-4 * 0.001
+
+
+def test_train_driver_loop_semantics(dev, flags, tmp_path):
+    """engine/train.py:72-123: NaN skip, clip after every backward, step / schedule / zero_grad every `accumulate`
+    batches, checkpoint keys."""
+    from hs_pose_amd.HSPose import HSPose
+    from hs_pose_amd.train import TrainDriver
+    flags.train = 0                                           # the small eval-mode module set is enough here
+    net = HSPose("PoseNet_only").to(dev)
+    drv = TrainDriver(net, total_iters=100, accumulate=2, check_nan=True)
+    w = net.posenet.ts.conv1.weight
+    w0 = w.detach().clone()
+
+    def loss_of(scale):
+        return scale * sum((p * p).sum() for p in net.parameters())
+
+    assert drv.step(loss_of(float("nan"))) is False            # skipped: counters advance, nothing else
+    assert drv.global_step == 1 and drv.skipped == 1 and torch.equal(w, w0) and float(w.grad.abs().max()) == 0.0
+    assert drv.step(loss_of(1.0)) is True                      # global_step 1: accumulate only
+    assert drv.global_step == 2 and torch.equal(w, w0) and float(w.grad.abs().max()) > 0.0
+    lr_before = drv.optimizer.param_groups[0]["lr"]
+    assert drv.step(loss_of(1.0)) is True                      # global_step 2: optimizer + scheduler + zero_grad
+    assert not torch.equal(w, w0) and float(w.grad.abs().max()) == 0.0
+    assert drv.optimizer.param_groups[0]["lr"] != lr_before
+    ck = drv.checkpoint(seed=3, epoch=7)
+    assert list(ck) == ['seed', 'epoch', 'posenet_state_dict', 'scheduler', 'optimizer']
+    path = tmp_path / "model_07.pth"
+    torch.save(ck, path)
+    net2 = HSPose("PoseNet_only").to(dev)
+    drv2 = TrainDriver(net2, total_iters=100, accumulate=2)
+    assert drv2.load_checkpoint(torch.load(path, weights_only=False)) == 7
+    assert torch.equal(net2.posenet.ts.conv1.weight, w)
+    assert drv2.optimizer.state[net2.posenet.ts.conv1.weight]["step"] == 1
+    assert drv2.scheduler.last_epoch == drv.scheduler.last_epoch
