@@ -207,57 +207,95 @@ __global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const float* __re
     const int j = j0 + cg * 4;
     for (int q = tid; q < Nsrc * G; q += 256) *reinterpret_cast<float4*>(acc + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
-    for (int q = pl; q < Nq; q += PL) {
-        const size_t row = (size_t)b * Nq + q;
+    // FL points per pass: their arg-max bytes / gradients first, then the dependent neighbour-index gathers, then the
+    // LDS adds -- two global round trips per pass instead of two per point
+    constexpr int FL = 4;
+    for (int q0 = pl; q0 < Nq; q0 += PL * FL) {
         if (MODE == 1) {
-            const int m = idx_shared ? idx[q] : idx[row];
-            // rows of a column block of a wider tensor are only 8-byte aligned (stride 1286): two float2 loads
-            const float2 g01 = *reinterpret_cast<const float2*>(gout + row * gstride + j);
-            const float2 g23 = *reinterpret_cast<const float2*>(gout + row * gstride + j + 2);
-            const float4 gv = make_float4(g01.x, g01.y, g23.x, g23.y);
-            float* a = acc + m * TC + cg * 4;
-            if (gv.x != 0.f) atomicAdd(a + 0, gv.x);
-            if (gv.y != 0.f) atomicAdd(a + 1, gv.y);
-            if (gv.z != 0.f) atomicAdd(a + 2, gv.z);
-            if (gv.w != 0.f) atomicAdd(a + 3, gv.w);
+#pragma unroll
+            for (int u = 0; u < FL; ++u) {
+                const int q = q0 + u * PL;
+                if (q < Nq) {
+                    const size_t row = (size_t)b * Nq + q;
+                    const int m = idx_shared ? idx[q] : idx[row];
+                    // rows of a column block of a wider tensor are only 8-byte aligned (stride 1286): two float2 loads
+                    const float2 g01 = *reinterpret_cast<const float2*>(gout + row * gstride + j);
+                    const float2 g23 = *reinterpret_cast<const float2*>(gout + row * gstride + j + 2);
+                    float* a = acc + m * TC + cg * 4;
+                    if (g01.x != 0.f) atomicAdd(a + 0, g01.x);
+                    if (g01.y != 0.f) atomicAdd(a + 1, g01.y);
+                    if (g23.x != 0.f) atomicAdd(a + 2, g23.x);
+                    if (g23.y != 0.f) atomicAdd(a + 3, g23.y);
+                }
+            }
         } else {
-            const int qi = qsel ? qsel[q] : q;
-            const int32_t* nb = idx + ((size_t)b * Nidx + qi) * kstride;
-            const uchar4 am = *reinterpret_cast<const uchar4*>(argmax + row * C + j);
-            const int m0 = nb[am.x], m1 = nb[am.y], m2 = nb[am.z], m3 = nb[am.w];
-            if (gbcast) {
-                atomicAdd(cnt + m0 * TC + cg * 4 + 0, 1);
-                atomicAdd(cnt + m1 * TC + cg * 4 + 1, 1);
-                atomicAdd(cnt + m2 * TC + cg * 4 + 2, 1);
-                atomicAdd(cnt + m3 * TC + cg * 4 + 3, 1);
-            } else {
-                const float4 gv = *reinterpret_cast<const float4*>(gout + row * gstride + j);
-                if (gv.x != 0.f) atomicAdd(acc + m0 * TC + cg * 4 + 0, gv.x);
-                if (gv.y != 0.f) atomicAdd(acc + m1 * TC + cg * 4 + 1, gv.y);
-                if (gv.z != 0.f) atomicAdd(acc + m2 * TC + cg * 4 + 2, gv.z);
-                if (gv.w != 0.f) atomicAdd(acc + m3 * TC + cg * 4 + 3, gv.w);
+            uchar4 am[FL];
+            float4 gv[FL];
+            const int32_t* nb[FL];
+#pragma unroll
+            for (int u = 0; u < FL; ++u) {
+                const int q = min(q0 + u * PL, Nq - 1);
+                const size_t row = (size_t)b * Nq + q;
+                const int qi = qsel ? qsel[q] : q;
+                nb[u] = idx + ((size_t)b * Nidx + qi) * kstride;
+                am[u] = *reinterpret_cast<const uchar4*>(argmax + row * C + j);
+                gv[u] = gbcast ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(gout + row * gstride + j);
+            }
+            int m0[FL], m1[FL], m2[FL], m3[FL];
+#pragma unroll
+            for (int u = 0; u < FL; ++u) { m0[u] = nb[u][am[u].x]; m1[u] = nb[u][am[u].y]; m2[u] = nb[u][am[u].z]; m3[u] = nb[u][am[u].w]; }
+#pragma unroll
+            for (int u = 0; u < FL; ++u) {
+                if (q0 + u * PL < Nq) {
+                    if (gbcast) {
+                        atomicAdd(cnt + m0[u] * TC + cg * 4 + 0, 1);
+                        atomicAdd(cnt + m1[u] * TC + cg * 4 + 1, 1);
+                        atomicAdd(cnt + m2[u] * TC + cg * 4 + 2, 1);
+                        atomicAdd(cnt + m3[u] * TC + cg * 4 + 3, 1);
+                    } else {
+                        if (gv[u].x != 0.f) atomicAdd(acc + m0[u] * TC + cg * 4 + 0, gv[u].x);
+                        if (gv[u].y != 0.f) atomicAdd(acc + m1[u] * TC + cg * 4 + 1, gv[u].y);
+                        if (gv[u].z != 0.f) atomicAdd(acc + m2[u] * TC + cg * 4 + 2, gv[u].z);
+                        if (gv[u].w != 0.f) atomicAdd(acc + m3[u] * TC + cg * 4 + 3, gv[u].w);
+                    }
+                }
             }
         }
     }
     __syncthreads();
+    // flush: every thread handles FL (row, group) elements at a time with all their global loads issued before the
+    // first dependent add (one element per iteration left the 2-3 loads of each store as a serial latency chain:
+    // 23 of the kernel's 31 us at B=16 N=1028 C=128)
     float4 gb = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int q = tid; q < Nsrc * G; q += 256) {
-        const int m = q / G, g4 = q - m * G;
-        float4 v;
-        if (MODE == 0 && gbcast) {
-            gb = *reinterpret_cast<const float4*>(gout + (size_t)b * C + j0 + g4 * 4);
-            const int4 cv = *reinterpret_cast<const int4*>(cnt + m * TC + g4 * 4);
-            v = make_float4(gb.x * cv.x, gb.y * cv.y, gb.z * cv.z, gb.w * cv.w);
-        } else {
-            v = *reinterpret_cast<const float4*>(acc + m * TC + g4 * 4);
+    if (MODE == 0 && gbcast) gb = *reinterpret_cast<const float4*>(gout + (size_t)b * C + j);   // (q % G == cg for all of a thread's q)
+    const int total = Nsrc * G;
+    for (int q0 = tid; q0 < total; q0 += 256 * FL) {
+        float4 o[FL], x[FL];
+#pragma unroll
+        for (int u = 0; u < FL; ++u) {
+            const int q = min(q0 + u * 256, total - 1);
+            const int m = q / G, g4 = q - m * G;
+            const size_t off = ((size_t)b * Nsrc + m) * C + j0 + g4 * 4;
+            o[u] = accumulate ? *reinterpret_cast<const float4*>(gfeat + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            x[u] = extra ? *reinterpret_cast<const float4*>(extra + off) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        float4* dst = reinterpret_cast<float4*>(gfeat + ((size_t)b * Nsrc + m) * C + j0 + g4 * 4);
-        if (accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-        if (extra) {
-            const float4 o = *reinterpret_cast<const float4*>(extra + ((size_t)b * Nsrc + m) * C + j0 + g4 * 4);
-            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+#pragma unroll
+        for (int u = 0; u < FL; ++u) {
+            const int q = q0 + u * 256;
+            if (q < total) {
+                const int m = q / G, g4 = q - m * G;
+                float4 v;
+                if (MODE == 0 && gbcast) {
+                    const int4 cv = *reinterpret_cast<const int4*>(cnt + m * TC + g4 * 4);
+                    v = make_float4(gb.x * cv.x, gb.y * cv.y, gb.z * cv.z, gb.w * cv.w);
+                } else {
+                    v = *reinterpret_cast<const float4*>(acc + m * TC + g4 * 4);
+                }
+                if (accumulate) { v.x += o[u].x; v.y += o[u].y; v.z += o[u].z; v.w += o[u].w; }
+                if (extra) { v.x += x[u].x; v.y += x[u].y; v.z += x[u].z; v.w += x[u].w; }
+                *reinterpret_cast<float4*>(gfeat + ((size_t)b * Nsrc + m) * C + j0 + g4 * 4) = v;
+            }
         }
-        *dst = v;
     }
 }
 
