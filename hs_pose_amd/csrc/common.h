@@ -57,4 +57,12 @@ __device__ __forceinline__ float3 unit_dir(float px, float py, float pz, float q
     return make_float3(__fdiv_rn(dx, nrm), __fdiv_rn(dy, nrm), __fdiv_rn(dz, nrm));
 }
 
+// the same direction for gradient work: one v_rsq_f32 and three multiplies instead of a correctly rounded sqrt and
+// three divisions (~45 instructions); agrees with unit_dir to ~1 ulp, which only ever scales a gradient term
+__device__ __forceinline__ float3 unit_dir_fast(float px, float py, float pz, float qx, float qy, float qz) {
+    const float dx = qx - px, dy = qy - py, dz = qz - pz;
+    const float inv = fminf(__builtin_amdgcn_rsqf(dx * dx + dy * dy + dz * dz), 1e12f);   // 1 / max(|v|, 1e-12)
+    return make_float3(dx * inv, dy * inv, dz * inv);
+}
+
 }  // namespace hsp

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(RF_TILE_THREADS) void rf_bwd_tile_kernel(
 #define RF_T1(X, E, FV)                                                                              \
         {                                                                                            \
             const int m = am.X;                                                                      \
-            const float3 r = unit_dir(px, py, pz, sx[m * 3], sx[m * 3 + 1], sx[m * 3 + 2]);          \
+            const float3 r = unit_dir_fast(px, py, pz, sx[m * 3], sx[m * 3 + 1], sx[m * 3 + 2]);     \
             const float z = __fmaf_rn(r.z, d2.X, __fmaf_rn(r.y, d1.X, mul_rn(r.x, d0.X)));           \
             if (z > 0.f) {                                                                           \
                 if (!SURFACE) atomicAdd(acc + m * TC + cg * 4 + E, ga.X * z);                        \
