@@ -18,7 +18,7 @@
 namespace hsp {
 
 #define BN_THREADS 256
-#define BN_MAX_PARTIALS 64        // the finalize kernel folds this many partials per channel serially
+#define BN_MAX_PARTIALS 512       // row chunks (workgroups of the partial kernels); folded 16-way parallel by finalize
 
 // partial[blk][0][c] = sum_r v1, partial[blk][1][c] = sum_r v2 over the rows of chunk blk, where
 //   MODE 0 (forward stats):  v1 = x - shift,  v2 = (x - shift)^2            shift = x[0][c]
@@ -98,11 +98,23 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     const int lc = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lc;
     float a1 = 0.f, a2 = 0.f;
-    if (c < C)
-        for (int b = sl; b < nblk; b += 16) {
-            a1 += partial[(size_t)b * 2 * C + c];
-            a2 += partial[(size_t)b * 2 * C + C + c];
+    if (c < C) {
+        float u1[4] = {0.f, 0.f, 0.f, 0.f}, u2[4] = {0.f, 0.f, 0.f, 0.f};
+        int b = sl;
+        for (; b + 48 < nblk; b += 64) {                    // 8 loads in flight
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                u1[u] += partial[(size_t)(b + 16 * u) * 2 * C + c];
+                u2[u] += partial[(size_t)(b + 16 * u) * 2 * C + C + c];
+            }
         }
+        for (; b < nblk; b += 16) {
+            u1[0] += partial[(size_t)b * 2 * C + c];
+            u2[0] += partial[(size_t)b * 2 * C + C + c];
+        }
+        a1 = (u1[0] + u1[1]) + (u1[2] + u1[3]);
+        a2 = (u2[0] + u2[1]) + (u2[2] + u2[3]);
+    }
     red[sl][0][lc] = a1;
     red[sl][1][lc] = a2;
     __syncthreads();
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(256) void bn_dx_kernel(const float* __restrict__ x,
 
 static int bn_rows_per_block(int R) {
     int r = (R + BN_MAX_PARTIALS - 1) / BN_MAX_PARTIALS;
-    if (r < 64) r = 64;
+    if (r < 32) r = 32;
     return r;
 }
 static int bn_blocks(int R) { const int r = bn_rows_per_block(R); return (R + r - 1) / r; }

@@ -52,7 +52,7 @@ def test_argument_validation_without_gpu():
     assert L.hsp_wgrad_workspace_bytes(128, 1024, 16448) > 0
     assert L.hsp_bn_relu_fwd(one, 100, 12, one, one, 1e-5, 0.1, 1, one, one, one, null, null, null, one, 1 << 20, null) == -2   # 256 % (C/4)
     assert L.hsp_bn_relu_fwd(one, 100, 128, one, one, 1e-5, 0.1, 1, one, one, one, null, null, null, null, 0, null) == -3
-    assert L.hsp_bn_workspace_bytes(16448, 128) == 64 * 2 * 128 * 4          # 64 row chunks of 257 rows
+    assert L.hsp_bn_workspace_bytes(16448, 128) == 499 * 2 * 128 * 4         # 499 row chunks of 33 rows
     assert L.hsp_rf_bwd_workspace_bytes(896) > 0
     assert L.hsp_rf_bwd_scatter_workspace_bytes(16, 896) == 16 * 3 * 896 * 4
     assert L.hsp_rf_conv_bwd_scatter(one, one, one, null, one, one, 1, 8, 7, 128, one, one, null, 0, null) == -3

@@ -15,12 +15,15 @@ import sys
 
 # rocprof kernel name fragment + flattened grid size  ->  bench.py key   (B=16, N=1028 workload)
 MAP = {
-    ("knn_feat_kernel<21>", "131072"): "hsp_knn_f32[B16N1028C128k20]",
-    ("rf_fwd_kernel<false, 1>", "524288"): "hsp_rf_conv_fwd[B16N1028k20S7C128]",
-    ("rf_fwd_kernel<true, 1>", "524288"): "hsp_rf_surface_fwd[B16N1028k20S7C128]",
-    ("rf_bwd_tile_kernel<16, false>", "458752"): "hsp_rf_conv_bwd_scatter[B16N1028S7C128]",
-    ("rf_bwd_tile_kernel<16, true>", "458752"): "hsp_rf_surface_bwd[B16N1028S7C128]",
-    ("knn3_kernel<21, 16>", "266240"): "hsp_knn_f32[B16N1028C3k20]",
+    ("knn_feat_kernel<21, true>", "131072"): "hsp_knn_f32[B16N1028C128k20]",
+    ("rf_fwd_kernel<false, 1, true>", "524288"): "hsp_rf_conv_fwd[B16N1028k20S7C128]",
+    ("rf_fwd_kernel<true, 1, false>", "524288"): "hsp_rf_surface_fwd[B16N1028k20S7C128]",
+    ("rf_bwd_tile_kernel<16, false, true>", "458752"): "hsp_rf_conv_bwd_scatter[B16N1028S7C128]",
+    ("rf_bwd_tile_kernel<16, false, false>", "917504"): "hsp_rf_conv_bwd_scatter[B16N257S7C256]",
+    ("rf_fwd_kernel<false, 2, false>", "524288"): "hsp_rf_conv_fwd[B16N257k20S7C256]",
+    ("rf_bwd_tile_kernel<16, true, false>", "458752"): "hsp_rf_surface_bwd[B16N1028S7C128]",
+    ("knn3_wave_kernel<17>", "266240"): "hsp_knn_f32[B16N1028C3k20]",
+    ("wgrad_kernel<true>", "129024"): "hsp_wgrad_f32[M128N1024K16448]",
 }
 
 
