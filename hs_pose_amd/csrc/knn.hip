@@ -334,6 +334,32 @@ __device__ __forceinline__ void multi_row_sum(const float* __restrict__ row, lon
         for (int l = 0; l < W; ++l) out[k][l] = acc[0][k][l];
 }
 
+// the same sum for 8 <= C < 512, C % 8 == 0 (every feature width of the stack), with 32 lanes per row: lane
+// 8k + l IS ATen's partial accumulator (ILP slot k, vector lane l) -- it adds elements 32 i + 8k + l in ascending i,
+// so a row is read with fully coalesced 128-byte requests instead of one strided row per thread -- then the same
+// fixed-order combination: leftover 8-wide chunks into slot 0, slots 1..3 into slot 0, vector lanes 0..7 in order.
+__global__ __launch_bounds__(256) void quad32_kernel(const float* __restrict__ x, long long rows, int C,
+                                                     float* __restrict__ quad) {
+    const int lane = threadIdx.x & 63, sub = lane & 31, base = lane & 32;
+    const long long r = ((long long)blockIdx.x * 256 + threadIdx.x) >> 5;
+    const bool live = r < rows;
+    const float* row = x + (live ? r : 0) * C;
+    const int vec_size = C >> 3, size_ilp = vec_size >> 2;
+    float a = 0.f;
+    for (int i = 0; i < size_ilp; ++i) { const float v = row[i * 32 + sub]; a = add_rn(a, mul_rn(v, v)); }
+    if (sub < 8)
+        for (int m = size_ilp * 4; m < vec_size; ++m) { const float v = row[m * 8 + sub]; a = add_rn(a, mul_rn(v, v)); }
+    // slots k = 1, 2, 3 into slot 0 (lanes 0..7 of the half-wave)
+    float t = a;
+    t = add_rn(t, __shfl(a, base | ((sub + 8) & 31)));
+    t = add_rn(t, __shfl(a, base | ((sub + 16) & 31)));
+    t = add_rn(t, __shfl(a, base | ((sub + 24) & 31)));
+    float fin = 0.f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) fin = add_rn(fin, __shfl(t, base | l));
+    if (live && sub == 0) quad[r] = fin;
+}
+
 __global__ __launch_bounds__(256) void quad_kernel(const float* __restrict__ x, long long rows, int C,
                                                    float* __restrict__ quad) {
     const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -945,7 +971,10 @@ extern "C" int hsp_knn_f32(const float* x, int B, int N, int C, int k, int drop_
     if (hsp_knn_workspace_bytes(B, N, C, k) > ws_bytes || !ws) return HSP_ERR_WORKSPACE;
     float* quad = reinterpret_cast<float*>(ws);
     const long long rows = (long long)B * N;
-    hipLaunchKernelGGL(quad_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, x, rows, C, quad);
+    if (C >= 8 && C < 512 && (C & 7) == 0)
+        hipLaunchKernelGGL(quad32_kernel, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, st, x, rows, C, quad);
+    else
+        hipLaunchKernelGGL(quad_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, x, rows, C, quad);
     int rc = check_launch();
     if (rc) return rc;
 #define CALLF(K) launch_knn_feat<K>(x, quad, quad + rows, B, N, C, k, drop, idx, st)
