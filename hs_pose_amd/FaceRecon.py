@@ -76,7 +76,6 @@ class FaceRecon(nn.Module):
             v_pool_2, fm_pool_2 = self.pool_2(v_pool_1, fm_3)
             k2 = min(k, v_pool_2.shape[1] // 8)
             fm_4 = self.conv_4(v_pool_2, fm_pool_2, k2)
-        f_global = fm_4.max(1)[0]
 
         nearest_pool_1 = ops.nn1(vertices, v_pool_1)
         nearest_pool_2 = ops.nn1(vertices, v_pool_2)
@@ -85,6 +84,7 @@ class FaceRecon(nn.Module):
                                   (fm_4, nearest_pool_2, 1), (one_hot, None, 2)])
 
         if FLAGS.train:
+            f_global = fm_4.max(1)[0]          # (FaceRecon.py:98 computes it unconditionally; only this branch reads it)
             rows = feat.reshape(bs * vertice_num, -1)
             h = _conv_bn_relu_rows(self.conv1d_block, rows, 3)                       # (B*N, 256)
             r = _conv_bn_relu_rows(self.recon_head, h, 1)
