@@ -19,16 +19,21 @@ namespace hsp {
 
 #define REV_THREADS 1024
 
+// EDGES_IN_LDS: the edge array is assembled and sorted in LDS and written out once, coalesced (the per-row
+// insertion sort is a chain of dependent accesses: ~100 cycles a step in LDS, 1-2 us a step in global memory)
+template <bool EDGES_IN_LDS>
 __global__ __launch_bounds__(REV_THREADS) void rev_build_kernel(const int32_t* __restrict__ idx, int Nq, int Nsrc,
                                                                 int k, int kstride, int32_t* __restrict__ rev_off,
                                                                 int32_t* __restrict__ rev_edge) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* cnt = reinterpret_cast<int*>(smem);            // Nsrc + 1 (histogram, then cursor)
-    __shared__ int part[REV_THREADS];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    int* led = cnt + Nsrc + 1;                          // E edges (EDGES_IN_LDS)
+    __shared__ int wsum[REV_THREADS / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int32_t* ib = idx + (size_t)b * Nq * kstride;
     int32_t* off = rev_off + (size_t)b * (Nsrc + 1);
     int32_t* edge = rev_edge + (size_t)b * Nq * k;
+    int* ed = EDGES_IN_LDS ? led : edge;
     const int E = Nq * k;
 
     for (int m = tid; m <= Nsrc; m += REV_THREADS) cnt[m] = 0;
@@ -38,20 +43,30 @@ __global__ __launch_bounds__(REV_THREADS) void rev_build_kernel(const int32_t* _
         atomicAdd(&cnt[ib[(size_t)i * kstride + n]], 1);
     }
     __syncthreads();
-    // exclusive scan of cnt[0..Nsrc): thread t owns a contiguous slice
+    // exclusive scan of cnt[0..Nsrc): thread t owns a contiguous slice; wave scan by shuffles, 16 wave totals by wave 0
     const int per = (Nsrc + REV_THREADS - 1) / REV_THREADS;
     const int lo = min(tid * per, Nsrc), hi = min(lo + per, Nsrc);
     int s = 0;
     for (int m = lo; m < hi; ++m) s += cnt[m];
-    part[tid] = s;
-    __syncthreads();
-    for (int d = 1; d < REV_THREADS; d <<= 1) {          // Hillis-Steele inclusive scan of the partials
-        const int v = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    int inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(inc, d);
+        if (lane >= d) inc += v;
     }
-    int run = tid ? part[tid - 1] : 0;
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    if (wv == 0) {
+        int t = lane < REV_THREADS / 64 ? wsum[lane] : 0;
+#pragma unroll
+        for (int d = 1; d < REV_THREADS / 64; d <<= 1) {
+            const int v = __shfl_up(t, d);
+            if (lane >= d) t += v;
+        }
+        if (lane < REV_THREADS / 64) wsum[lane] = t;    // inclusive wave totals
+    }
+    __syncthreads();
+    int run = inc - s + (wv ? wsum[wv - 1] : 0);
     for (int m = lo; m < hi; ++m) {
         const int c = cnt[m];
         cnt[m] = run;                                    // becomes the fill cursor
@@ -66,21 +81,25 @@ __global__ __launch_bounds__(REV_THREADS) void rev_build_kernel(const int32_t* _
         if (e < E) {
             const int i = e / k, n = e - i * k;
             const int pos = atomicAdd(&cnt[ib[(size_t)i * kstride + n]], 1);
-            edge[pos] = e;
+            ed[pos] = e;
         }
         __syncthreads();
     }
-    __threadfence_block();
+    if (!EDGES_IN_LDS) __threadfence_block();
     __syncthreads();
-    // nearly sorted lists -> insertion sort per row (global memory, L2 resident)
+    // nearly sorted lists -> insertion sort per row; after the fill cnt[m] is the END of row m, its start the end of m-1
     for (int m = tid; m < Nsrc; m += REV_THREADS) {
-        const int a = off[m], z = (m + 1 < Nsrc) ? off[m + 1] : E;
+        const int a = m ? cnt[m - 1] : 0, z = cnt[m];
         for (int p = a + 1; p < z; ++p) {
-            const int v = edge[p];
+            const int v = ed[p];
             int q = p - 1;
-            while (q >= a && edge[q] > v) { edge[q + 1] = edge[q]; --q; }
-            edge[q + 1] = v;
+            while (q >= a && ed[q] > v) { ed[q + 1] = ed[q]; --q; }
+            ed[q + 1] = v;
         }
+    }
+    if (EDGES_IN_LDS) {
+        __syncthreads();
+        for (int e = tid; e < E; e += REV_THREADS) edge[e] = led[e];
     }
 }
 
@@ -91,13 +110,17 @@ using namespace hsp;
 extern "C" int hsp_rev_build(const int32_t* idx, int B, int Nq, int Nsrc, int k, int kstride, int32_t* rev_off,
                              int32_t* rev_edge, hspStream_t stream) {
     if (!idx || !rev_off || !rev_edge || B <= 0 || Nq <= 0 || Nsrc <= 0 || k <= 0 || kstride < k) return HSP_ERR_BAD_ARG;
-    const size_t lds = (size_t)(Nsrc + 1) * sizeof(int);
-    if (lds > 140 * 1024) return HSP_ERR_UNSUPPORTED;
+    const size_t lds0 = (size_t)(Nsrc + 1) * sizeof(int);
+    if (lds0 > 140 * 1024) return HSP_ERR_UNSUPPORTED;
+    const size_t lds1 = lds0 + (size_t)Nq * k * sizeof(int);
+    const bool in_lds = lds1 <= 140 * 1024;
+    const size_t lds = in_lds ? lds1 : lds0;
+    auto kern = in_lds ? rev_build_kernel<true> : rev_build_kernel<false>;
     if (lds > 60 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rev_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
     }
-    hipLaunchKernelGGL(rev_build_kernel, dim3(B), dim3(REV_THREADS), lds, as_stream(stream), idx, Nq, Nsrc, k, kstride,
-                       rev_off, rev_edge);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(REV_THREADS), lds, as_stream(stream), idx, Nq, Nsrc, k, kstride, rev_off,
+                       rev_edge);
     return check_launch();
 }

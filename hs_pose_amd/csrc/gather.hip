@@ -551,6 +551,58 @@ extern "C" int hsp_gather_rows_bwd(const float* grad_out, int grad_stride, const
     return check_launch();
 }
 
+// gather form of hsp_gather_rows_bwd over the reverse index of the (B,Nq) row map: a workgroup row-lane owns one
+// SOURCE row m and sums the gradient rows of the queries that selected it, in ascending query order (no atomics,
+// bit-reproducible), reading every gradient row segment whole.  The column-tile scatter form reads a 64-byte
+// slice of every 5 KB gradient row per tile: 30-45 us where this takes under 10.
+__global__ __launch_bounds__(256) void gather_rows_bwd_csr_kernel(const float* __restrict__ gout, int gstride,
+                                                                  const int32_t* __restrict__ rev_off,
+                                                                  const int32_t* __restrict__ rev_edge, int B,
+                                                                  int Nsrc, int Nq, int C,
+                                                                  float* __restrict__ gfeat) {
+    const int pairs = C >> 1;                               // float2 columns (gradient rows are 8-byte aligned)
+    const int tpr = pairs < 256 ? pairs : 256;              // threads per row
+    const int RB = 256 / tpr;
+    const int rl = threadIdx.x / tpr, t = threadIdx.x - rl * tpr;
+    const long long row = (long long)blockIdx.x * RB + rl;  // b*Nsrc + m
+    if (rl >= RB || row >= (long long)B * Nsrc) return;
+    const int m = (int)(row % Nsrc), b = (int)(row / Nsrc);
+    const int32_t* off = rev_off + (size_t)b * (Nsrc + 1);
+    const int32_t* edge = rev_edge + (size_t)b * Nq;
+    const int o0 = off[m], o1 = off[m + 1];
+    const float* gb = gout + (size_t)b * Nq * gstride;
+    for (int p = t; p < pairs; p += tpr) {
+        float2 acc = make_float2(0.f, 0.f);
+        for (int e = o0; e < o1; e += 4) {                  // 4 rows in flight, added in edge order
+            float2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = edge[min(e + u, o1 - 1)];
+                v[u] = *reinterpret_cast<const float2*>(gb + (size_t)q * gstride + 2 * p);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e + u < o1) { acc.x += v[u].x; acc.y += v[u].y; }
+        }
+        *reinterpret_cast<float2*>(gfeat + (size_t)row * C + 2 * p) = acc;
+    }
+}
+
+extern "C" int hsp_gather_rows_bwd_csr(const float* grad_out, int grad_stride, const int32_t* rev_off,
+                                       const int32_t* rev_edge, int B, int Nsrc, int Nq, int C, float* grad_feat,
+                                       hspStream_t stream) {
+    if (!grad_out || !rev_off || !rev_edge || !grad_feat || B <= 0 || Nsrc <= 0 || Nq <= 0 || C <= 0 || grad_stride < C)
+        return HSP_ERR_BAD_ARG;
+    if ((C & 1) || (grad_stride & 1) || (reinterpret_cast<uintptr_t>(grad_out) & 7) || (256 % ((C >> 1) < 256 ? (C >> 1) : 256)))
+        return HSP_ERR_UNSUPPORTED;                         // float2 columns, whole rows per workgroup
+    const int tpr = (C >> 1) < 256 ? (C >> 1) : 256;
+    const int RB = 256 / tpr;
+    const long long rows = (long long)B * Nsrc;
+    hipLaunchKernelGGL(gather_rows_bwd_csr_kernel, dim3((unsigned)((rows + RB - 1) / RB)), dim3(256), 0, as_stream(stream),
+                       grad_out, grad_stride, rev_off, rev_edge, B, Nsrc, Nq, C, grad_feat);
+    return check_launch();
+}
+
 extern "C" int hsp_gather_max_bwd_csr(const float* grad_out, int grad_bcast, const uint8_t* argmax,
                                       const int32_t* rev_off, const int32_t* rev_edge, int B, int Nsrc, int Nq, int k,
                                       int C, float* grad_feat, hspStream_t stream) {

@@ -131,7 +131,10 @@ def rev_index(idx, k, n_src):
     hit = cache.get((k, n_src))
     if hit is not None:
         return hit
-    B, Nq, kstride = idx.shape
+    if idx.dim() == 2:                                        # a row map (B,Nq): one edge per query
+        (B, Nq), kstride = idx.shape, 1
+    else:
+        B, Nq, kstride = idx.shape
     off = torch.empty(B, n_src + 1, dtype=torch.int32, device=idx.device)
     edge = torch.empty(B, Nq * k, dtype=torch.int32, device=idx.device)
     _run("hsp_rev_build", (_p(idx), B, Nq, n_src, k, kstride, _p(off), _p(edge), _stream()),
@@ -748,8 +751,14 @@ class _AssembleFeat(torch.autograd.Function):
                 idx = saved.pop(0)
                 Ns = ctx.nsrc[s_]
                 gfeat = torch.empty(B, Ns, w, dtype=torch.float32, device=g.device)
-                _run("hsp_gather_rows_bwd", (_p(gs), W, _p(idx), 0, B, Ns, N, w, _p(gfeat), _stream()),
-                     key=f"B{B}Ns{Ns}Nq{N}C{w}", abytes=B * (4 * Ns * w + N * (4 + 4 * w)))
+                if w % 2 == 0 and W % 2 == 0 and (w // 2 >= 256 or 256 % (w // 2) == 0) and gs.data_ptr() % 8 == 0:
+                    # gather form over the reverse map (memoised on idx: fm_2 and fm_3 share one); deterministic
+                    off, edge = rev_index(idx, 1, Ns)
+                    _run("hsp_gather_rows_bwd_csr", (_p(gs), W, _p(off), _p(edge), B, Ns, N, w, _p(gfeat), _stream()),
+                         key=f"B{B}Ns{Ns}Nq{N}C{w}", abytes=B * (4 * Ns * w + N * (4 + 4 * w)))
+                else:
+                    _run("hsp_gather_rows_bwd", (_p(gs), W, _p(idx), 0, B, Ns, N, w, _p(gfeat), _stream()),
+                         key=f"B{B}Ns{Ns}Nq{N}C{w}", abytes=B * (4 * Ns * w + N * (4 + 4 * w)))
                 grads.append(gfeat)
             else:
                 grads.append(gs.sum(dim=1))

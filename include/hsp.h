@@ -182,6 +182,11 @@ int hsp_gather_rows_fwd(const float *feat, const int32_t *idx, int idx_shared, i
 /* grad_feat (B,Nsrc,C) OVERWRITTEN; grad_out rows at grad_out + (b*Nq+q)*grad_stride. */
 int hsp_gather_rows_bwd(const float *grad_out, int grad_stride, const int32_t *idx, int idx_shared, int B,
                         int Nsrc, int Nq, int C, float *grad_feat, hspStream_t stream);
+/* the same backward in gather form over (rev_off, rev_edge) = hsp_rev_build(idx as (B,Nq,1), k = 1): every source row
+ * sums its queries' gradient rows in ascending query order (no atomics, bit-reproducible), whole row segments at
+ * a time -- the faster form when grad_out is a column block of a much wider tensor (the 1286-wide feature). */
+int hsp_gather_rows_bwd_csr(const float *grad_out, int grad_stride, const int32_t *rev_off, const int32_t *rev_edge,
+                            int B, int Nsrc, int Nq, int C, float *grad_feat, hspStream_t stream);
 
 /* ---- weight-gradient GEMM ---------------------------------------------------------------------
  * replaces the parameter-gradient matmuls autograd runs for `feature_map @ self.weights + self.bias`

@@ -359,3 +359,26 @@ def test_rf_conv_backward_fwin_stream_equals_fm_gather(dev, ref):
     assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=1e-6)
     assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-5)
     assert lib().hsp_rf_conv_wants_fwin(1028, 7, 128) == 1 and lib().hsp_rf_conv_wants_fwin(64, 7, 512) == 0
+
+
+@pytest.mark.parametrize("B,Ns,Nq,C,W", [(3, 37, 150, 64, 200), (2, 64, 1028, 512, 1286), (2, 257, 1028, 256, 1286)])
+def test_gather_rows_bwd_csr_matches_scatter(dev, ref, B, Ns, Nq, C, W):
+    """nearest-up-sampling backward, gather form over the reverse map == the column-tile scatter form == index_add."""
+    from hs_pose_amd import ops
+    from hs_pose_amd.ops import _p, _run, _stream
+    g_full = ref.hash_tensor((B, Nq, W), 610 + C, 1.0).to(dev)
+    gs = g_full[:, :, 6:6 + C]                                   # a column block of a wider gradient (8-byte aligned)
+    idx = torch.from_numpy((ref.hash_unit(B * Nq, 611) * Ns).astype(np.int32)).view(B, Nq).to(dev)
+    idx[:, :5] = 0                                               # a small hub
+    off, edge = ops.rev_index(idx, 1, Ns)
+    a = torch.empty(B, Ns, C, device=dev)
+    b_ = torch.empty(B, Ns, C, device=dev)
+    _run("hsp_gather_rows_bwd_csr", (_p(gs), W, _p(off), _p(edge), B, Ns, Nq, C, _p(a), _stream()))
+    _run("hsp_gather_rows_bwd", (_p(gs), W, _p(idx), 0, B, Ns, Nq, C, _p(b_), _stream()))
+    want = torch.zeros(B, Ns, C, device=dev)
+    for bb in range(B):
+        want[bb].index_add_(0, idx[bb].long(), gs[bb])
+    assert torch.allclose(a, want, rtol=1e-5, atol=1e-5) and torch.allclose(b_, want, rtol=1e-5, atol=1e-5)
+    a2 = torch.empty_like(a)
+    _run("hsp_gather_rows_bwd_csr", (_p(gs), W, _p(off), _p(edge), B, Ns, Nq, C, _p(a2), _stream()))
+    assert torch.equal(a, a2)                                    # fixed summation order
