@@ -25,16 +25,29 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 #define WG_UNROLL 4   // k-pairs per prefetch group
 
-template <bool COLSUM>
+// KB = 1: the 4 waves of a workgroup take 4 neighbouring tiles of one K slice (they share B rows in L1).
+// KB = 4: they take 4 consecutive K slices of ONE tile and fold their accumulators through LDS (fixed order), so
+//         a small output with a long K (128x128 <- 16448 rows) can be cut into hundreds of slices -- enough waves to
+//         fill the chip -- without multiplying the partial sums the reduce kernel has to read.
+template <bool COLSUM, int KB>
 __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ A, int lda,
                                                     const float* __restrict__ B, int ldb, int M, int N, int K,
                                                     int SK, int kslice, float* __restrict__ part,
                                                     float* __restrict__ cs_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
-    const int w = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, and provably so
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, and provably so
     const int tiles = (M >> 6) * (N >> 6);
-    if (w >= tiles * SK) return;
-    const int slice = w / tiles, t = w - slice * tiles;
+    int slice, t;
+    if (KB == 1) {
+        const int w = blockIdx.x * 4 + wv;
+        if (w >= tiles * SK) return;
+        slice = w / tiles; t = w - slice * tiles;
+    } else {
+        const int grp = blockIdx.x / tiles;
+        t = blockIdx.x - grp * tiles;
+        slice = grp * 4 + wv;                               // slices past K read zeros
+    }
     const int tiles_m = M >> 6;
     const int tn = t / tiles_m, tm = t - tn * tiles_m;   // tm fastest: the waves of a block share B rows (L1/L2 reuse)
     const int m0 = tm << 6, n0 = tn << 6;
@@ -94,17 +107,53 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ A,
         __builtin_amdgcn_sched_barrier(0);
     }
     // accumulator r <-> tile row (r&3) + 8*(r>>2) + 4*h, tile col i; tile (ta,tb) holds C[m0+2*row+ta][n0+2*i+tb]
-    float* pc = part + (size_t)slice * M * N;
+    if (KB == 1) {
+        float* pc = part + (size_t)slice * M * N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            *reinterpret_cast<float2*>(pc + (size_t)(m0 + 2 * row) * N + n0 + 2 * i) = make_float2(c00[r], c01[r]);
+            *reinterpret_cast<float2*>(pc + (size_t)(m0 + 2 * row + 1) * N + n0 + 2 * i) = make_float2(c10[r], c11[r]);
+        }
+        if (COLSUM && tm == 0) {
+            cs.x += __shfl_xor(cs.x, 32);
+            cs.y += __shfl_xor(cs.y, 32);
+            if (h == 0) *reinterpret_cast<float2*>(cs_part + (size_t)slice * N + n0 + 2 * i) = cs;
+        }
+        return;
+    }
+    // KB == 4: buf[wave][acc][r][lane]; wave a then folds accumulator a of the four waves (order 0..3) and stores its
+    // interleaved quarter of the tile; the column sums go through csb[wave][lane]
+    float* buf = reinterpret_cast<float*>(smem);
+    float2* csb = reinterpret_cast<float2*>(buf + 4 * 4 * 16 * 64);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        *reinterpret_cast<float2*>(pc + (size_t)(m0 + 2 * row) * N + n0 + 2 * i) = make_float2(c00[r], c01[r]);
-        *reinterpret_cast<float2*>(pc + (size_t)(m0 + 2 * row + 1) * N + n0 + 2 * i) = make_float2(c10[r], c11[r]);
+        buf[((wv * 4 + 0) * 16 + r) * 64 + lane] = c00[r];
+        buf[((wv * 4 + 1) * 16 + r) * 64 + lane] = c01[r];
+        buf[((wv * 4 + 2) * 16 + r) * 64 + lane] = c10[r];
+        buf[((wv * 4 + 3) * 16 + r) * 64 + lane] = c11[r];
     }
-    if (COLSUM && tm == 0) {
-        cs.x += __shfl_xor(cs.x, 32);
-        cs.y += __shfl_xor(cs.y, 32);
-        if (h == 0) *reinterpret_cast<float2*>(cs_part + (size_t)slice * N + n0 + 2 * i) = cs;
+    if (COLSUM) csb[wv * 64 + lane] = cs;
+    __syncthreads();
+    const int grp = blockIdx.x / tiles;
+    float* pc = part + (size_t)grp * M * N;
+    const int ta = wv >> 1, tb = wv & 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = buf[((0 * 4 + wv) * 16 + r) * 64 + lane];
+        v += buf[((1 * 4 + wv) * 16 + r) * 64 + lane];
+        v += buf[((2 * 4 + wv) * 16 + r) * 64 + lane];
+        v += buf[((3 * 4 + wv) * 16 + r) * 64 + lane];
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        pc[(size_t)(m0 + 2 * row + ta) * N + n0 + 2 * i + tb] = v;
+    }
+    if (COLSUM && tm == 0 && wv == 0) {
+        float2 c = csb[lane];
+#pragma unroll
+        for (int w2 = 1; w2 < 4; ++w2) { c.x += csb[w2 * 64 + lane].x; c.y += csb[w2 * 64 + lane].y; }
+        c.x += __shfl_xor(c.x, 32);
+        c.y += __shfl_xor(c.y, 32);
+        if (h == 0) *reinterpret_cast<float2*>(cs_part + (size_t)grp * N + n0 + 2 * i) = c;
     }
 }
 
@@ -157,17 +206,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-static int wgrad_pick_sk(int M, int N, int K, int* kslice) {
+// (slices, rows per slice, waves of a workgroup along K)
+static int wgrad_pick_sk(int M, int N, int K, int* kslice, int* kblock) {
     const int tiles = (M >> 6) * (N >> 6);
+    constexpr int G = 4 * WG_UNROLL;                           // whole pairs of prefetch groups
+    if (tiles <= 64) {
+        // few tiles: 4 K slices per workgroup, folded in LDS; >= 32 rows per slice, <= 64 partial sums
+        int sk = 2048 / tiles;
+        if (sk > K / 32) sk = K / 32;
+        if (sk > 256) sk = 256;
+        if (sk >= 8) {
+            int ks = (K + sk - 1) / sk;
+            ks = (ks + G - 1) / G * G;
+            sk = (K + ks - 1) / ks;
+            sk = (sk + 3) & ~3;
+            *kslice = ks;
+            *kblock = 4;
+            return sk;
+        }
+    }
     int sk = (2048 + tiles - 1) / tiles;                       // ~2 waves per SIMD
     int max_sk = (K + 127) / 128;                              // at least 128 rows per slice
     if (max_sk > 64) max_sk = 64;                              // bound the partial-sum traffic
     if (sk > max_sk) sk = max_sk;
     if (sk < 1) sk = 1;
     int ks = (K + sk - 1) / sk;
-    ks = (ks + 4 * WG_UNROLL - 1) / (4 * WG_UNROLL) * (4 * WG_UNROLL);     // whole pairs of prefetch groups
+    ks = (ks + G - 1) / G * G;
     sk = (K + ks - 1) / ks;
     *kslice = ks;
+    *kblock = 1;
     return sk;
 }
 
@@ -177,9 +244,26 @@ using namespace hsp;
 
 extern "C" size_t hsp_wgrad_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    int ks;
-    const int sk = wgrad_pick_sk(M, N, K, &ks);
-    return (size_t)sk * ((size_t)M * N + N) * sizeof(float);
+    int ks, kb;
+    const int sk = wgrad_pick_sk(M, N, K, &ks, &kb);
+    return (size_t)(sk / kb) * ((size_t)M * N + N) * sizeof(float);
+}
+
+template <bool COLSUM>
+static int wgrad_launch(const float* A, int lda, const float* B, int ldb, int M, int N, int K, int sk, int ks, int kb,
+                        float* part, float* cs_part, hipStream_t st) {
+    const int tiles = (M >> 6) * (N >> 6);
+    if (kb == 1) {
+        hipLaunchKernelGGL((wgrad_kernel<COLSUM, 1>), dim3((tiles * sk + 3) / 4), dim3(256), 0, st, A, lda, B, ldb, M, N, K,
+                           sk, ks, part, cs_part);
+        return check_launch();
+    }
+    const size_t lds = (size_t)4 * 4 * 16 * 64 * sizeof(float) + (size_t)4 * 64 * sizeof(float2);
+    auto kern = wgrad_kernel<COLSUM, 4>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
+    hipLaunchKernelGGL(kern, dim3(tiles * (sk / 4)), dim3(256), lds, st, A, lda, B, ldb, M, N, K, sk, ks, part, cs_part);
+    return check_launch();
 }
 
 extern "C" int hsp_wgrad_f32(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc,
@@ -187,22 +271,17 @@ extern "C" int hsp_wgrad_f32(const float* A, int lda, const float* B, int ldb, i
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda < M || ldb < N || ldc < N) return HSP_ERR_BAD_ARG;
     if ((M & 63) || (N & 63) || (lda & 1) || (ldb & 1)) return HSP_ERR_UNSUPPORTED;   // 64x64 wave tiles, float2 loads
     if (!ws || ws_bytes < hsp_wgrad_workspace_bytes(M, N, K)) return HSP_ERR_WORKSPACE;
-    int ks;
-    const int sk = wgrad_pick_sk(M, N, K, &ks);
+    int ks, kb;
+    const int sk = wgrad_pick_sk(M, N, K, &ks, &kb);
+    const int nparts = sk / kb;
     float* part = reinterpret_cast<float*>(ws);
-    float* cs_part = part + (size_t)sk * M * N;
-    const int waves = (M >> 6) * (N >> 6) * sk;
+    float* cs_part = part + (size_t)nparts * M * N;
     hipStream_t st = as_stream(stream);
-    if (colsum_B)
-        hipLaunchKernelGGL(wgrad_kernel<true>, dim3((waves + 3) / 4), dim3(256), 0, st, A, lda, B, ldb, M, N, K, sk, ks,
-                           part, cs_part);
-    else
-        hipLaunchKernelGGL(wgrad_kernel<false>, dim3((waves + 3) / 4), dim3(256), 0, st, A, lda, B, ldb, M, N, K, sk, ks,
-                           part, cs_part);
-    int rc = check_launch();
+    int rc = colsum_B ? wgrad_launch<true>(A, lda, B, ldb, M, N, K, sk, ks, kb, part, cs_part, st)
+                      : wgrad_launch<false>(A, lda, B, ldb, M, N, K, sk, ks, kb, part, cs_part, st);
     if (rc) return rc;
     const long long total = (long long)M * (N >> 2) + (colsum_B ? (N >> 2) : 0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, part, sk, M, N, C,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, part, nparts, M, N, C,
                        ldc, cs_part, colsum_B);
     return check_launch();
 }
