@@ -550,8 +550,10 @@ extern "C" int hsp_rf_conv_bwd(const float* xyz, const float* dirs_n, const floa
 // column-tile scatter: the widest tile whose acc[N][TC] + xyz[N][3] fits two workgroups per CU, else one
 static int pick_tile_cols(int N, int C, bool surface) {
     if (surface) return (C % 16 == 0) ? 16 : ((C % 8 == 0) ? 8 : 4);
+    // small clouds take wider tiles (up to 64 columns): the per-workgroup set-up (direction normalisation, tile
+    // zeroing / flush, gradient fold) is then amortised over 4x the elements and the row segments read are longer
     for (int pass = 0; pass < 2; ++pass)
-        for (int tc = 16; tc >= 4; tc >>= 1)
+        for (int tc = 64; tc >= 4; tc >>= 1)
             if (C % tc == 0 && ((size_t)N * tc + 3 * (size_t)N) * 4 <= (pass == 0 ? 80u : 156u) * 1024) return tc;
     return 0;
 }
@@ -587,7 +589,8 @@ static int rf_bwd_scatter(const float* xyz, const float* dirs, const float* fm, 
         }                                                                                                           \
         hipLaunchKernelGGL(kern, grid, dim3(RF_TILE_THREADS), lds, st, xyz, dirs, fm, argrow, gout, B, N, S, C, gfm, part); \
     }
-    if (tc == 16) RF_TILE_LAUNCH(16) else if (tc == 8) RF_TILE_LAUNCH(8) else RF_TILE_LAUNCH(4)
+    if (tc == 64) RF_TILE_LAUNCH(64) else if (tc == 32) RF_TILE_LAUNCH(32) else if (tc == 16) RF_TILE_LAUNCH(16)
+    else if (tc == 8) RF_TILE_LAUNCH(8) else RF_TILE_LAUNCH(4)
 #undef RF_TILE_LAUNCH
     rc = check_launch();
     if (rc) return rc;
