@@ -548,13 +548,15 @@ extern "C" int hsp_rf_conv_bwd(const float* xyz, const float* dirs_n, const floa
 }
 
 // column-tile scatter: the widest tile whose acc[N][TC] + xyz[N][3] fits two workgroups per CU, else one
-static int pick_tile_cols(int N, int C, bool surface) {
+static int pick_tile_cols(int N, int C, bool surface, int B = 0, int SC = 0) {
     if (surface) return (C % 16 == 0) ? 16 : ((C % 8 == 0) ? 8 : 4);
     // small clouds take wider tiles (up to 64 columns): the per-workgroup set-up (direction normalisation, tile
     // zeroing / flush, gradient fold) is then amortised over 4x the elements and the row segments read are longer
     for (int pass = 0; pass < 2; ++pass)
-        for (int tc = 64; tc >= 4; tc >>= 1)
+        for (int tc = 64; tc >= 4; tc >>= 1) {
+            if (tc > 16 && (long long)(SC / tc) * B < 2 * HSP_NUM_CU) continue;   // ... while the grid still fills the chip
             if (C % tc == 0 && ((size_t)N * tc + 3 * (size_t)N) * 4 <= (pass == 0 ? 80u : 156u) * 1024) return tc;
+        }
     return 0;
 }
 
@@ -572,7 +574,7 @@ static int rf_bwd_scatter(const float* xyz, const float* dirs, const float* fm, 
     if (!gout || !gdirs || (!SURFACE && (!fm || !gfm))) return HSP_ERR_BAD_ARG;
     const int SC = S * C;
     if (!ws || ws_bytes < hsp_rf_bwd_scatter_workspace_bytes(B, SC)) return HSP_ERR_WORKSPACE;
-    const int tc = pick_tile_cols(N, C, SURFACE);
+    const int tc = pick_tile_cols(N, C, SURFACE, B, S * C);
     if (!tc) return HSP_ERR_UNSUPPORTED;
     size_t lds = ((SURFACE ? 0 : (size_t)N * tc) + 3 * (size_t)N) * 4;
     if (lds < RF_TILE_THREADS * 12 * 4) lds = RF_TILE_THREADS * 12 * 4;
