@@ -1,9 +1,13 @@
-"""per-(kernel, grid) duration table from a rocprofv3 kernel trace CSV: python tools/trace_by_shape.py trace.csv steps [filter]"""
+"""per-(kernel, grid) duration table from a rocprofv3 kernel trace CSV:
+    python tools/trace_by_shape.py trace.csv <steps | auto> [filter]
+'auto': the number of steps is the number of concat_rows_kernel dispatches (one per forward)."""
 import csv, collections, sys
-f, steps = sys.argv[1], float(sys.argv[2])
+f = sys.argv[1]
+rows = list(csv.DictReader(open(f)))
+steps = float(sum("concat_rows_kernel" in r["Kernel_Name"] for r in rows)) if sys.argv[2] == "auto" else float(sys.argv[2])
 flt = sys.argv[3].split(",") if len(sys.argv) > 3 else None
 acc = collections.defaultdict(list)
-for r in csv.DictReader(open(f)):
+for r in rows:
     n = r["Kernel_Name"]
     if flt and not any(x in n for x in flt):
         continue
