@@ -87,19 +87,34 @@ __global__ __launch_bounds__(REV_THREADS) void rev_build_kernel(const int32_t* _
     }
     if (!EDGES_IN_LDS) __threadfence_block();
     __syncthreads();
-    // nearly sorted lists -> insertion sort per row; after the fill cnt[m] is the END of row m, its start the end of m-1
-    for (int m = tid; m < Nsrc; m += REV_THREADS) {
-        const int a = m ? cnt[m - 1] : 0, z = cnt[m];
-        for (int p = a + 1; p < z; ++p) {
-            const int v = ed[p];
-            int q = p - 1;
-            while (q >= a && ed[q] > v) { ed[q + 1] = ed[q]; --q; }
-            ed[q + 1] = v;
+    // after the fill cnt[m] is the END of row m, its start the end of row m-1
+    if (EDGES_IN_LDS && k == 1) {
+        // row maps (k = 1: few, long rows).  Ascending order by RANK: one thread per edge counts the smaller edge ids of its row (O(row length) LDS reads,
+        // parallel over edges) and writes the edge to its final global slot -- a thread-per-row insertion sort is a
+        // serial O(length^2) chain (18 us for 64 rows of ~16 edges)
+        for (int p = tid; p < E; p += REV_THREADS) {
+            const int e = led[p];
+            const int i = e / k, n = e - i * k;
+            const int m = ib[(size_t)i * kstride + n];
+            const int a = m ? cnt[m - 1] : 0, z = cnt[m];
+            int c = 0;
+            for (int q = a; q < z; ++q) c += led[q] < e ? 1 : 0;
+            edge[a + c] = e;
         }
-    }
-    if (EDGES_IN_LDS) {
-        __syncthreads();
-        for (int e = tid; e < E; e += REV_THREADS) edge[e] = led[e];
+    } else {
+        for (int m = tid; m < Nsrc; m += REV_THREADS) {    // nearly sorted lists (in LDS when they fit): insertion sort per row
+            const int a = m ? cnt[m - 1] : 0, z = cnt[m];
+            for (int p = a + 1; p < z; ++p) {
+                const int v = ed[p];
+                int q = p - 1;
+                while (q >= a && ed[q] > v) { ed[q + 1] = ed[q]; --q; }
+                ed[q + 1] = v;
+            }
+        }
+        if (EDGES_IN_LDS) {
+            __syncthreads();
+            for (int e = tid; e < E; e += REV_THREADS) edge[e] = led[e];
+        }
     }
 }
 
