@@ -1,18 +1,28 @@
 """Drop-in mirror of the reference's ``network/HSPose.py`` operator surface (HSPose.py:23-276).
 
 Same constructor, ``forward`` keyword set, ``output_dict`` keys and ``build_params`` as the reference.
-Built so far: the inference path (``FLAGS.train = 0``; evaluation/evaluate.py:91-106) and the
-depth -> cloud entry (``PC is None``, HSPose.py:39-48).  The training-only branches -- on-device
-augmentation (HSPose.py:185-256) and the four loss modules (``do_loss=True``, HSPose.py:84-181) -- are
-SURVEY 8f-1 and raise NotImplementedError here rather than silently doing something else; training the
-network itself (forward + backward of ``self.posenet``) is fully supported through ``PoseNet9D``.
+The inference path (``FLAGS.train = 0``; evaluation/evaluate.py:91-106), the depth -> cloud entry (``PC is None``,
+HSPose.py:39-48), the on-device augmentation (``FLAGS.train``, HSPose.py:53-61, hs_pose_amd/augment.py) and the
+training losses (``do_loss=True``, HSPose.py:84-181, hs_pose_amd/losses.py): ``forward`` returns ``output_dict``
+or ``(output_dict, loss_dict)`` with the four sub-dictionaries ``engine/train.py:84-90`` sums.
 """
 import torch
 import torch.nn as nn
 
+from .augment import data_augment
 from .config import FLAGS
+from .losses import control_loss, fs_net_loss, geo_transform_loss, prop_rot_loss, recon_6face_loss
 from .pc_sample import PC_sample
 from .PoseNet9D import PoseNet9D
+
+
+def get_gt_v(Rs, axis=2):
+    """green (y) and red (x) axes of the ground-truth rotations, R[:, :, 1] and R[:, :, 0], computed the reference's
+    way (tools/training_utils.py:59-73: R times a corner matrix, rows 1 and 2 of the transposed product)."""
+    bs = Rs.shape[0]
+    corners = torch.tensor([[0, 0, 1], [0, 1, 0], [1, 0, 0] if axis == 3 else [0, 0, 0]], dtype=torch.float, device=Rs.device)
+    gt_vec = torch.bmm(Rs, corners.view(1, 3, 3).repeat(bs, 1, 1)).transpose(2, 1).reshape(bs, -1)
+    return gt_vec[:, 3:6], gt_vec[:, 6:9]
 
 
 class HSPose(nn.Module):
@@ -20,6 +30,11 @@ class HSPose(nn.Module):
         super(HSPose, self).__init__()
         self.posenet = PoseNet9D()
         self.train_stage = train_stage
+        self.loss_recon = recon_6face_loss()
+        self.loss_fs_net = fs_net_loss()
+        self.loss_geo = geo_transform_loss()
+        self.loss_prop = prop_rot_loss()
+        self.name_fs_list, self.name_recon_list, self.name_geo_list, self.name_prop_list = control_loss(self.train_stage)
 
     def forward(self, PC=None, depth=None, obj_id=None, camK=None,
                 gt_R=None, gt_t=None, gt_s=None, mean_shape=None, gt_2D=None, sym=None, aug_bb=None,
@@ -39,9 +54,9 @@ class HSPose(nn.Module):
         sketch = None
         PC = PC.detach()
         if FLAGS.train:
-            raise NotImplementedError(
-                "HSPose.forward with FLAGS.train: on-device augmentation (HSPose.py:185-256) is SURVEY 8f-1 "
-                "(next); call self.posenet(PC, obj_id) for the network forward/backward")
+            with torch.no_grad():
+                PC, gt_R, gt_t, gt_s = self.data_augment(PC, gt_R, gt_t, gt_s, mean_shape, sym, aug_bb, aug_rt_t,
+                                                         aug_rt_r, model_point, nocs_scale, obj_id)
 
         recon, face_normal, face_dis, face_f, p_green_R, p_red_R, f_green_R, f_red_R, \
             Pred_T, Pred_s = self.posenet(PC, obj_id)
@@ -63,10 +78,38 @@ class HSPose(nn.Module):
         output_dict['gt_t'] = gt_t
         output_dict['gt_s'] = gt_s
 
-        if do_loss:
-            raise NotImplementedError("HSPose.forward(do_loss=True): the loss modules (HSPose.py:84-181) are "
-                                      "SURVEY 8f-1 (next)")
-        return output_dict
+        if not do_loss:
+            return output_dict
+
+        pred_fsnet_list = {'Rot1': p_green_R, 'Rot1_f': f_green_R, 'Rot2': p_red_R, 'Rot2_f': f_red_R, 'Recon': recon,
+                           'Tran': Pred_T, 'Size': Pred_s}
+        gt_green_v, gt_red_v = (None, None) if self.train_stage == 'Backbone_only' else get_gt_v(gt_R)
+        gt_fsnet_list = {'Rot1': gt_green_v, 'Rot2': gt_red_v, 'Recon': PC, 'Tran': gt_t, 'Size': gt_s}
+        fsnet_loss = self.loss_fs_net(self.name_fs_list, pred_fsnet_list, gt_fsnet_list, sym)
+
+        pred_prop_list = {'Recon': recon, 'Rot1': p_green_R, 'Rot2': p_red_R, 'Tran': Pred_T, 'Scale': Pred_s,
+                          'Rot1_f': f_green_R.detach(), 'Rot2_f': f_red_R.detach()}
+        gt_prop_list = {'Points': PC, 'R': gt_R, 'T': gt_t, 'Mean_shape': mean_shape}
+        prop_loss = self.loss_prop(self.name_prop_list, pred_prop_list, gt_prop_list, sym)
+
+        pred_recon_list = {'F_n': face_normal, 'F_d': face_dis, 'F_c': face_f, 'Rot1': p_green_R, 'Rot1_f': f_green_R.detach(),
+                           'Rot2': p_red_R, 'Rot2_f': f_red_R.detach(), 'Tran': Pred_T, 'Size': Pred_s}
+        gt_recon_list = {'R': gt_R, 'T': gt_t, 'Size': gt_s, 'Mean_shape': mean_shape, 'Points': PC}
+        recon_loss = self.loss_recon(self.name_recon_list, pred_recon_list, gt_recon_list, sym, obj_id)
+
+        pred_geo_list = {'Rot1': p_green_R, 'Rot2': p_red_R, 'Tran': Pred_T, 'Size': Pred_s, 'Rot1_f': f_green_R.detach(),
+                         'Rot2_f': f_red_R.detach()}
+        gt_geo_list = {'Points': PC, 'R': gt_R, 'T': gt_t, 'Mean_shape': mean_shape}
+        geo_loss = self.loss_geo(self.name_geo_list, pred_geo_list, gt_geo_list, sym)
+
+        loss_dict = {'fsnet_loss': fsnet_loss, 'recon_loss': recon_loss, 'geo_loss': geo_loss, 'prop_loss': prop_loss}
+        return output_dict, loss_dict
+
+    def data_augment(self, PC, gt_R, gt_t, gt_s, mean_shape, sym, aug_bb, aug_rt_t, aug_rt_r, model_point, nocs_scale,
+                     obj_ids, check_points=False):
+        """HSPose.py:185-256 (check_points: the reference's interactive visualisation, not reproduced)."""
+        return data_augment(PC, gt_R, gt_t, gt_s, mean_shape, sym, aug_bb, aug_rt_t, aug_rt_r, model_point, nocs_scale,
+                            obj_ids)
 
     def build_params(self, training_stage_freeze=None):
         """HSPose.py:258-275: one param group, lr = FLAGS.lr * FLAGS.lr_pose.  (The reference's 'pose'

@@ -22,6 +22,13 @@ class _Flags:
         sample_method='basic',  # config.py:44
         train=1,              # config.py:48
         batch_size=16,        # config.py:55
+        aug_pc_pro=0.2, aug_pc_r=0.2, aug_rt_pro=0.3, aug_bb_pro=0.3, aug_bc_pro=0.3,   # config.py:24-28
+        fsnet_loss_type='l1',                                                          # config.py:64
+        rot_1_w=8.0, rot_2_w=8.0, rot_regular=4.0, tran_w=8.0, size_w=8.0, recon_w=8.0, r_con_w=1.0,   # config.py:66-72
+        recon_n_w=3.0, recon_d_w=3.0, recon_v_w=1.0, recon_s_w=0.3, recon_f_w=1.0,      # config.py:74-78
+        recon_bb_r_w=1.0, recon_bb_t_w=1.0, recon_bb_s_w=1.0, recon_bb_self_w=1.0,      # config.py:79-82
+        geo_p_w=1.0, geo_s_w=10.0, geo_f_w=0.1,                                         # config.py:87-89
+        prop_pm_w=2.0, prop_sym_w=1.0, prop_r_reg_w=1.0,                                # config.py:91-93
         lr=1e-4,              # config.py:96
         lr_pose=1.0,          # config.py:98
     )

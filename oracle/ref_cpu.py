@@ -557,3 +557,84 @@ def generate_rt_inputs():
     sym = torch.zeros(Bn, 4)
     sym[::3, 0] = 1.0                                                         # bottle / bowl / can style symmetry
     return pg, pr, fg, fr, T, sym
+
+
+# ---------------------------------------------------------------------------------------------
+# closed-form inputs of the loss / augmentation fixtures (oracle/gen_golden_losses.py, tests)
+# ---------------------------------------------------------------------------------------------
+
+LOSS_SYM = [[1, 1, 0, 1], [1, 1, 0, 1], [0, 0, 0, 0], [1, 1, 1, 1], [0, 1, 0, 0], [0, 1, 0, 0], [1, 0, 0, 0]]
+LOSS_OBJ = [0, 1, 2, 3, 4, 5, 5]          # bottle, bowl, camera, can, laptop, mug with handle, mug without
+
+
+def loss_case(n_points: int = 96, seed: int = 4000):
+    """a batch of 7 objects (one per symmetry class of the dataset) with a plausible ground truth and network outputs
+    that are the ground truth plus noise.  Returns (gt, pred): dicts of tensors; pred tensors are fresh leaves."""
+    B, N = len(LOSS_OBJ), n_points
+    sym = torch.tensor(LOSS_SYM, dtype=torch.float32)
+    obj = torch.tensor(LOSS_OBJ, dtype=torch.float32)
+    q, r = torch.linalg.qr(hash_tensor((B, 3, 3), seed, 1.0))
+    q = q * torch.sign(torch.diagonal(r, dim1=-2, dim2=-1)).unsqueeze(-2)
+    gt_R = q * torch.sign(torch.linalg.det(q)).view(B, 1, 1)                      # proper rotations
+    gt_t = hash_tensor((B, 3), seed + 1, 0.1) + torch.tensor([0.0, 0.0, 0.8])
+    mean_shape = 0.15 + hash_tensor((B, 3), seed + 2, 0.05)
+    gt_s = hash_tensor((B, 3), seed + 3, 0.02)
+    size = gt_s + mean_shape
+    canon = hash_tensor((B, N, 3), seed + 4, 0.5) * size.unsqueeze(1)             # inside the box
+    PC = torch.matmul(canon, gt_R.transpose(1, 2)) + gt_t.unsqueeze(1)
+    gt = dict(PC=PC, gt_R=gt_R, gt_t=gt_t, gt_s=gt_s, mean_shape=mean_shape, sym=sym, obj_id=obj)
+
+    def leaf(t):
+        return t.clone().requires_grad_(True)
+    p_green = F.normalize(gt_R[:, :, 1] + hash_tensor((B, 3), seed + 5, 0.08), dim=1)
+    p_red = F.normalize(gt_R[:, :, 0] + hash_tensor((B, 3), seed + 6, 0.08), dim=1)
+    axes = gt_R.transpose(1, 2)                                                    # row a = axis a
+    order = [(1, 1.0), (0, 1.0), (2, 1.0), (0, -1.0), (2, -1.0), (1, -1.0)]       # network order y+ x+ z+ x- z- y-
+    fn = torch.stack([sg * axes[:, a] for a, sg in order], dim=1).unsqueeze(1).expand(B, N, 6, 3)
+    fn = F.normalize(fn + hash_tensor((B, N, 6, 3), seed + 7, 0.1), dim=-1)
+    fd = torch.stack([size[:, a].unsqueeze(1) / 2 - sg * canon[:, :, a] for a, sg in order], dim=2)
+    fd = fd + hash_tensor((B, N, 6), seed + 8, 0.01)
+    pred = dict(p_green_R=leaf(p_green), p_red_R=leaf(p_red),
+                f_green_R=leaf(torch.sigmoid(hash_tensor((B,), seed + 9, 2.0))),
+                f_red_R=leaf(torch.sigmoid(hash_tensor((B,), seed + 10, 2.0))),
+                Pred_T=leaf(gt_t + hash_tensor((B, 3), seed + 11, 0.01)),
+                Pred_s=leaf(gt_s + hash_tensor((B, 3), seed + 12, 0.01)),
+                recon=leaf(PC + hash_tensor((B, N, 3), seed + 13, 0.01)),
+                face_normal=leaf(fn), face_dis=leaf(fd),
+                face_f=leaf(torch.sigmoid(hash_tensor((B, N, 6), seed + 14, 2.0))))
+    return gt, pred
+
+
+def augment_case(n_points: int = 64, seed: int = 4100):
+    """inputs of the augmentation fixture: the loss batch plus per-sample augmentation parameters and model points."""
+    gt, _ = loss_case(n_points, seed)
+    B = gt["PC"].shape[0]
+    ang = hash_tensor((B, 3), seed + 20, 0.2)
+    cx, sx, cy, sy, cz, sz = torch.cos(ang[:, 0]), torch.sin(ang[:, 0]), torch.cos(ang[:, 1]), torch.sin(ang[:, 1]), \
+        torch.cos(ang[:, 2]), torch.sin(ang[:, 2])
+    zero, one = torch.zeros(B), torch.ones(B)
+    Rx = torch.stack([one, zero, zero, zero, cx, -sx, zero, sx, cx], dim=1).view(B, 3, 3)
+    Ry = torch.stack([cy, zero, sy, zero, one, zero, -sy, zero, cy], dim=1).view(B, 3, 3)
+    Rz = torch.stack([cz, -sz, zero, sz, cz, zero, zero, zero, one], dim=1).view(B, 3, 3)
+    gt.update(aug_bb=1.0 + hash_tensor((B, 3), seed + 21, 0.2), aug_rt_t=hash_tensor((B, 3), seed + 22, 0.02),
+              aug_rt_r=Rz @ Ry @ Rx, model_point=hash_tensor((B, 48, 3), seed + 23, 0.5),
+              nocs_scale=0.3 + hash_tensor((B,), seed + 24, 0.05))
+    return gt
+
+
+def hspose_train_case(B: int, N: int, seed: int):
+    """closed-form ground truth for the full-step fixture: the cloud and category ids of the stack fixtures
+    (hash cloud of 5 cm spread at 0.8 m) with a pose / size ground truth placed on it."""
+    pts = hash_tensor((B, N, 3), seed, 0.05)
+    pts[:, :, 2] += 0.8
+    import numpy as np
+    obj = torch.from_numpy((hash_unit(B, seed + 1) * 6).astype(np.int64)).float()
+    q, r = torch.linalg.qr(hash_tensor((B, 3, 3), seed + 30, 1.0))
+    q = q * torch.sign(torch.diagonal(r, dim1=-2, dim2=-1)).unsqueeze(-2)
+    gt_R = q * torch.sign(torch.linalg.det(q)).view(B, 1, 1)
+    table = torch.tensor(LOSS_SYM[:6], dtype=torch.float32)
+    return dict(PC=pts, obj_id=obj, gt_R=gt_R, gt_t=pts.mean(dim=1) + hash_tensor((B, 3), seed + 31, 0.01),
+                gt_s=hash_tensor((B, 3), seed + 32, 0.02), mean_shape=0.12 + hash_tensor((B, 3), seed + 33, 0.03),
+                sym=table[obj.long()], aug_bb=torch.ones(B, 3), aug_rt_t=torch.zeros(B, 3),
+                aug_rt_r=torch.eye(3).repeat(B, 1, 1), model_point=hash_tensor((B, 32, 3), seed + 34, 0.5),
+                nocs_scale=torch.full((B,), 0.3))

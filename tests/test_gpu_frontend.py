@@ -130,11 +130,11 @@ def test_hspose_eval_matches_posenet_fixture(dev, ref, flags, monkeypatch):
     assert (rt.cpu() - want).abs().max() < 1e-3                                 # 1e-4 inputs through acos
 
 
-def test_hspose_training_branches_say_what_is_missing(dev, flags):
+def test_hspose_branches_the_reference_does_not_implement(dev, flags):
+    """the depth entry exists only for 'PoseNet_only' (HSPose.py:49-50 raises otherwise); unknown stages have no loss set"""
     from hs_pose_amd.HSPose import HSPose
-    flags.train = 1
-    net = HSPose("PoseNet_only").to(dev)
-    with pytest.raises(NotImplementedError, match="8f-1"):
-        net(PC=torch.zeros(2, 64, 3, device=dev), obj_id=torch.zeros(2, 1, device=dev))
+    flags.train = 0
     with pytest.raises(NotImplementedError):
-        HSPose("Backbone_only").to(dev)(depth=torch.zeros(1, 1, 4, 4, device=dev))
+        HSPose("FSNet_only").to(dev)(depth=torch.zeros(1, 1, 4, 4, device=dev))
+    with pytest.raises(NotImplementedError):
+        HSPose("Backbone_only")
