@@ -24,7 +24,7 @@ def _conv_bn_relu_rows(seq, x, n_blocks):
     """Apply n_blocks x (Conv1d k=1, BatchNorm1d, ReLU) of an nn.Sequential to (R, C) rows."""
     for i in range(n_blocks):
         conv, bn = seq[3 * i], seq[3 * i + 1]
-        x = torch.relu(bn(F.linear(x, conv.weight.squeeze(-1), conv.bias)))
+        x = ops.bn_relu(F.linear(x, conv.weight.squeeze(-1), conv.bias), bn)         # fused BatchNorm + ReLU (norm.hip)
     return x
 
 
@@ -84,7 +84,7 @@ class FaceRecon(nn.Module):
                                   (fm_4, nearest_pool_2, 1), (one_hot, None, 2)])
 
         if FLAGS.train:
-            f_global = fm_4.max(1)[0]          # (FaceRecon.py:98 computes it unconditionally; only this branch reads it)
+            f_global = ops.points_max(fm_4)          # (FaceRecon.py:98 computes it unconditionally; only this branch reads it)
             rows = feat.reshape(bs * vertice_num, -1)
             h = _conv_bn_relu_rows(self.conv1d_block, rows, 3)                       # (B*N, 256)
             r = _conv_bn_relu_rows(self.recon_head, h, 1)

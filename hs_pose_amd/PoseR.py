@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .config import FLAGS
 
 
@@ -31,10 +32,10 @@ class _PointMLPHead(nn.Module):
     def forward_rows(self, x: "(B, N, f)"):
         b, n, c = x.shape
         h = x.reshape(b * n, c)
-        h = F.relu(self.bn1(F.linear(h, self.conv1.weight.squeeze(-1), self.conv1.bias)))
-        h = F.relu(self.bn2(F.linear(h, self.conv2.weight.squeeze(-1), self.conv2.bias)))
-        h = h.view(b, n, -1).max(dim=1)[0]                                       # (B,256)
-        h = F.relu(self.bn3(F.linear(h, self.conv3.weight.squeeze(-1), self.conv3.bias)))
+        h = ops.bn_relu(F.linear(h, self.conv1.weight.squeeze(-1), self.conv1.bias), self.bn1)   # fused BN + ReLU
+        h = ops.bn_relu(F.linear(h, self.conv2.weight.squeeze(-1), self.conv2.bias), self.bn2)
+        h = ops.points_max(h.view(b, n, -1))                                     # (B,256)
+        h = ops.bn_relu(F.linear(h, self.conv3.weight.squeeze(-1), self.conv3.bias), self.bn3)
         h = self.drop1(h)
         return F.linear(h, self.conv4.weight.squeeze(-1), self.conv4.bias).contiguous()
 

@@ -30,6 +30,8 @@ SIGNATURES = {
     "hsp_gather_max_bwd_csr": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "hsp_gather_max_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "hsp_gather_max_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "hsp_points_max_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "hsp_points_max_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "hsp_orl_workspace_bytes": (_sz, [_i, _i, _i]),
     "hsp_orl_global_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "hsp_colsum_rows": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),

@@ -7,9 +7,26 @@ perturbation, a linear "box cage" taper along y for bowls / mugs, and per-point 
 made in the reference's order on the tensors' device (``torch.rand``), so a seeded run consumes the generator
 identically.
 """
+import contextlib
+
 import torch
 
 from .config import FLAGS
+
+_noise_feed = None
+
+
+@contextlib.contextmanager
+def jitter_noise_feed(noise):
+    """Within the scope ``defor_3D_pc`` takes its per-point jitter factors from ``noise`` (a device tensor the caller
+    filled from ``torch.rand(pc.shape) * r`` on the CPU generator, as the reference draws it) instead of drawing: a
+    captured hipGraph cannot contain the host draw + upload (hs_pose_amd.graph.GraphedTrainStep)."""
+    global _noise_feed
+    prev, _noise_feed = _noise_feed, noise
+    try:
+        yield
+    finally:
+        _noise_feed = prev
 
 
 def _object_frame(pc, R, t):
@@ -23,7 +40,7 @@ def _camera_frame(pts, R, t):
 def defor_3D_bb_in_batch(pc, model_point, R, t, s, sym=None, aug_bb=None):
     """scale the object along its own axes by aug_bb (x and z share the mean factor when it is rotationally symmetric);
     data_augmentation.py:70-79."""
-    sym_bb = (aug_bb + aug_bb[:, [2, 1, 0]]) / 2.0
+    sym_bb = (aug_bb + aug_bb.flip(-1)) / 2.0                         # (x, y, z) + (z, y, x); no index upload: graph-capturable
     k = torch.where((sym[:, 0] == 1).unsqueeze(-1), sym_bb, aug_bb)
     pc_new = _camera_frame(_object_frame(pc, R, t) * k.unsqueeze(-2), R, t)
     return pc_new, s * k, model_point * k.unsqueeze(-2)
@@ -56,7 +73,7 @@ def defor_3D_pc(pc, gt_t, r=0.2, points_defor=None, return_defor=False):
     """every coordinate moves away from the object centre by a uniform fraction in [0, r); data_augmentation.py:137-144
     (the draw is made on the CPU generator and moved, like the reference's ``torch.rand(shape).to(device)``)."""
     if points_defor is None:
-        points_defor = torch.rand(pc.shape).to(pc.device) * r
+        points_defor = _noise_feed if _noise_feed is not None else torch.rand(pc.shape).to(pc.device) * r
     new_pc = pc + points_defor * (pc - gt_t.unsqueeze(1))
     return (new_pc, points_defor) if return_defor else new_pc
 

@@ -479,6 +479,70 @@ static int stream_grid(long long threads) {
     return (int)g;
 }
 
+// ---- max over the points of a cloud (the heads' torch.max(x, 2)[0]) ---------------------------------------------------
+// grid (ceil(C/64), B), 1024 threads = 16 row groups x 64 channels: wave g scans rows g, g+16, ... of its 64-channel strip
+// (256 B per wave per row), the 16 partial (value, first row) pairs fold through LDS.
+__global__ __launch_bounds__(1024) void points_max_fwd_kernel(const float* __restrict__ x, int N, int C,
+                                                              float* __restrict__ out, int32_t* __restrict__ arg) {
+    __shared__ float s_v[16][64];
+    __shared__ int s_i[16][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, b = blockIdx.y;
+    float best = -INFINITY;
+    int bi = INT_MAX;
+    if (c < C) {
+        const float* col = x + (size_t)b * N * C + c;
+        int n = g;
+        for (; n + 48 < N; n += 64) {                     // four rows in flight per lane
+            const float v0 = col[(size_t)n * C], v1 = col[(size_t)(n + 16) * C], v2 = col[(size_t)(n + 32) * C],
+                        v3 = col[(size_t)(n + 48) * C];
+            if (v0 > best || (v0 != v0 && best == best)) { best = v0; bi = n; }
+            if (v1 > best || (v1 != v1 && best == best)) { best = v1; bi = n + 16; }
+            if (v2 > best || (v2 != v2 && best == best)) { best = v2; bi = n + 32; }
+            if (v3 > best || (v3 != v3 && best == best)) { best = v3; bi = n + 48; }
+        }
+        for (; n < N; n += 16) {
+            const float v = col[(size_t)n * C];
+            if (v > best || (v != v && best == best)) { best = v; bi = n; }
+        }
+    }
+    s_v[g][lane] = best;
+    s_i[g][lane] = bi;
+    __syncthreads();
+    if (g == 0 && c < C) {
+#pragma unroll
+        for (int j = 1; j < 16; ++j) {
+            const float v = s_v[j][lane];
+            const int i = s_i[j][lane];
+            const bool vnan = v != v, bnan = best != best;
+            if ((vnan && !bnan) || (!bnan && v > best) || (vnan == bnan && v == best && i < bi) ||
+                (vnan && bnan && i < bi)) { best = v; bi = i; }
+        }
+        out[(size_t)b * C + c] = best;
+        arg[(size_t)b * C + c] = bi == INT_MAX ? 0 : bi;
+    }
+}
+
+// grad_x (B,N,C) written in one pass: grad_out[b,c] on the winning row, 0 elsewhere (no memset + scatter)
+__global__ __launch_bounds__(256) void points_max_bwd_kernel(const float* __restrict__ gout,
+                                                             const int32_t* __restrict__ arg, int N, int C4,
+                                                             long long total, float* __restrict__ gx) {
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(t % C4);
+        const long long r = t / C4;
+        const int n = (int)(r % N);
+        const size_t bc = (size_t)(r / N) * C4 + c4;
+        const int4 a = reinterpret_cast<const int4*>(arg)[bc];
+        const float4 g = reinterpret_cast<const float4*>(gout)[bc];
+        float4 o;
+        o.x = a.x == n ? g.x : 0.f;
+        o.y = a.y == n ? g.y : 0.f;
+        o.z = a.z == n ? g.z : 0.f;
+        o.w = a.w == n ? g.w : 0.f;
+        reinterpret_cast<float4*>(gx)[t] = o;
+    }
+}
+
 }  // namespace hsp
 
 using namespace hsp;
@@ -612,6 +676,23 @@ extern "C" int hsp_gather_max_bwd_csr(const float* grad_out, int grad_bcast, con
     const long long total = (long long)B * Nsrc * (C >> 2);
     hipLaunchKernelGGL(gather_max_bwd_csr_kernel, dim3(stream_grid(total)), dim3(256), 0, as_stream(stream), grad_out,
                        grad_bcast, argmax, rev_off, rev_edge, B, Nsrc, Nq, k, C, grad_feat);
+    return check_launch();
+}
+
+extern "C" int hsp_points_max_fwd(const float* x, int B, int N, int C, float* out, int32_t* argrow, hspStream_t stream) {
+    if (!x || !out || !argrow || B <= 0 || N <= 0 || C <= 0) return HSP_ERR_BAD_ARG;
+    hipLaunchKernelGGL(points_max_fwd_kernel, dim3((C + 63) / 64, B), dim3(1024), 0, as_stream(stream), x, N, C, out,
+                       argrow);
+    return check_launch();
+}
+
+extern "C" int hsp_points_max_bwd(const float* grad_out, const int32_t* argrow, int B, int N, int C, float* grad_x,
+                                  hspStream_t stream) {
+    if (!grad_out || !argrow || !grad_x || B <= 0 || N <= 0 || C <= 0) return HSP_ERR_BAD_ARG;
+    if (C & 3) return HSP_ERR_UNSUPPORTED;
+    const long long total = (long long)B * N * (C >> 2);
+    hipLaunchKernelGGL(points_max_bwd_kernel, dim3(stream_grid(total)), dim3(256), 0, as_stream(stream), grad_out,
+                       argrow, N, C >> 2, total, grad_x);
     return check_launch();
 }
 

@@ -7,9 +7,12 @@ two ``torch.randperm`` draws of the Pool_layers on the CPU default generator (gc
 BEFORE each replay, in the same order and on the same generator as the reference, and is uploaded into
 static index buffers the captured kernels read.
 """
+import os
+
 import torch
 
-from . import gcn3d, ops
+from . import augment, gcn3d, ops
+from .config import FLAGS
 
 
 def draw_pool_indices(n_points, rate=4, levels=2):
@@ -94,3 +97,107 @@ class GraphedStep:
             out.append(self.flat_grad[off:off + p.numel()].view_as(p))
             off += p.numel()
         return out
+
+
+class GraphedTrainStep:
+    """One full training step of engine/train.py:76-104 with the device work replayed as a hipGraph:
+
+        zero_grad -> HSPose.forward(do_loss=True) (augmentation, network, 19 losses) -> sum -> backward -> squared
+        gradient norm                                              [captured once, replayed]
+        optimizer.step() (clip coefficient applied inside) ; scheduler.step()      [one launch + host scalars]
+
+    Host work before each replay, in the reference's order on the CPU default generator: the jitter factors of
+    ``defor_3D_pc`` (``torch.rand(PC.shape) * aug_pc_r``) and the two Pool_layer ``randperm`` draws; the augmentation's
+    ``torch.rand(..., device=...)`` draws are made inside the graph by the device generator.  ``batch`` is a dict of
+    static device tensors with HSPose.forward's keyword names (``load_batch`` copies new data in); gradients land in
+    the fused optimizer's flat buffer.  Eagerly the step is CPU-bound (~2500 tiny launches in the losses alone).
+
+    The process must start with ``DEBUG_CLR_GRAPH_PACKET_CAPTURE=0`` in the environment (the constructor refuses to run
+    otherwise).  With ROCm 7.2's default AQL-packet capture of graph kernel nodes, ATen's multi-block reductions (the
+    semaphore-ordered global-reduce path: bias-gradient column sums over 16448 rows, ``max`` over the points) replay with
+    wrong results at B=16, N=1028 -- measured: a head's ``conv2.bias`` gradient of 17 instead of 2e-7, every other
+    parameter equal to the eager step to rounding; with the flag off all 19 losses and all gradients match eager.  The
+    kernel-only graph of ``GraphedStep`` is not affected and keeps the default.
+
+    Build it BEFORE the network's first eager backward: autograd binds each parameter's gradient accumulator to the
+    stream of its first use, and an accumulator bound to another stream than the capture stream is executed outside
+    the capture (the replayed graph then reads freed memory).  The warm-up iterations here run on the capture stream."""
+
+    def __init__(self, network, optimizer, batch, scheduler=None, max_norm=5, warmup=3):
+        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
+            raise RuntimeError("GraphedTrainStep: start the process with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (before the "
+                               "first HIP call) -- ATen reductions replay incorrectly under the packet-capture graph path")
+        self.net, self.opt, self.sched, self.max_norm = network, optimizer, scheduler, max_norm
+        self.batch = batch
+        PC = batch["PC"]
+        B, N, _ = PC.shape
+        self.n_points = N
+        dev = PC.device
+        self.noise = torch.zeros_like(PC)
+        self.pool_idx = [torch.empty(int(N / 4), dtype=torch.int32, device=dev),
+                         torch.empty(int(int(N / 4) / 4), dtype=torch.int32, device=dev)]
+        self.loss_dict, self.total = None, None
+        self._host_draws()
+        prev_timer = ops.set_timer(None)
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self._body()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._body()
+        finally:
+            ops.set_timer(prev_timer)
+
+    def _host_draws(self):
+        if FLAGS.train:
+            self.noise.copy_(torch.rand(self.noise.shape) * FLAGS.aug_pc_r)
+        for buf, idx in zip(self.pool_idx, draw_pool_indices(self.n_points)):
+            buf.copy_(idx.to(torch.int32))
+
+    def _body(self):
+        # Gradients are created INSIDE the capture (grad = None first) and then moved into the optimizer's flat buffer
+        # with one multi-tensor copy: accumulating straight into the pre-existing flat views makes autograd synchronise
+        # the capture stream with the stream those views were made on, and the replayed graph then waits forever.
+        params, views = self._params_and_views()
+        for p in params:
+            p.grad = None
+        with gcn3d.pool_index_feed(self.pool_idx), augment.jitter_noise_feed(self.noise):
+            _, ld = self.net(do_loss=True, **self.batch)
+        total = sum(ld['fsnet_loss'].values()) + sum(ld['recon_loss'].values()) + sum(ld['geo_loss'].values()) \
+            + sum(ld['prop_loss'].values())
+        total.backward()
+        torch._foreach_copy_(views, [p.grad if p.grad is not None else torch.zeros_like(p) for p in params])
+        for p, v in zip(params, views):
+            p.grad = v
+        self.opt.clip_grad_norm_(self.max_norm)             # device scalar; consumed by the step() outside the graph
+        self._gnorm_sq, self._max_norm = self.opt._gnorm_sq, self.opt._max_norm
+        self.loss_dict, self.total = ld, total
+
+    def _params_and_views(self):
+        params, views = [], []
+        for fg in self.opt._flat:
+            for p, o in zip(fg.params, fg.offsets):
+                params.append(p)
+                views.append(fg.view(fg.flat_g, p, o))
+        return params, views
+
+    def load_batch(self, batch):
+        for k, v in batch.items():
+            self.batch[k].copy_(v, non_blocking=True)
+
+    def run(self, check_nan=False):
+        """one training step; returns False when ``check_nan`` found a NaN loss (the reference's skip, train.py:91-95)."""
+        self._host_draws()
+        self.graph.replay()
+        if check_nan and bool(torch.isnan(self.total).any()):
+            return False
+        self.opt._gnorm_sq, self.opt._max_norm = self._gnorm_sq, self._max_norm
+        self.opt.step()
+        if self.sched is not None:
+            self.sched.step()
+        return True

@@ -82,14 +82,34 @@ def rot_mat_y_first(y, x):
     return torch.stack((x, y, z), dim=-1)
 
 
+def _rescale(res, kept, batch):
+    """res * batch / kept when any sample is kept, else res -- the reference's ``if valid_num > 0`` (a host round trip
+    there) as a select on the device."""
+    return res * torch.where(kept > 0, batch / kept.clamp(min=1).to(res.dtype), torch.ones_like(res))
+
+
 def _masked_mean_rescaled(values, keep):
     """mean over the batch of ``values`` with the dropped samples zeroed, rescaled by B / #kept when any is kept
     (the reference's way of averaging over the non-symmetric samples only)."""
-    kept = keep.sum()
     res = torch.where(keep, values, torch.zeros_like(values)).mean()
-    if kept > 0:
-        res = res * values.size(0) / kept
-    return res
+    return _rescale(res, keep.sum(), values.size(0))
+
+
+def _inverse3(m):
+    """inverse of (...,3,3) matrices.  On the GPU by cofactors (nine fused element-wise kernels): torch.inverse goes
+    through a batched LU in the solver library with a host synchronisation -- milliseconds for 48 matrices -- and so
+    does its backward.  On the CPU torch.inverse (the reference's call; keeps the CPU parity tests at 1e-6)."""
+    if not m.is_cuda:
+        return torch.inverse(m)
+    a, b, c = m[..., 0, 0], m[..., 0, 1], m[..., 0, 2]
+    d, e, f = m[..., 1, 0], m[..., 1, 1], m[..., 1, 2]
+    g, h, i = m[..., 2, 0], m[..., 2, 1], m[..., 2, 2]
+    A, B, C = e * i - f * h, c * h - b * i, b * f - c * e
+    D, E, Fc = f * g - d * i, a * i - c * g, c * d - a * f
+    G, H, I = d * h - e * g, b * g - a * h, a * e - b * d
+    det = a * A + b * D + c * G
+    adj = torch.stack([torch.stack([A, B, C], dim=-1), torch.stack([D, E, Fc], dim=-1), torch.stack([G, H, I], dim=-1)], dim=-2)
+    return adj / det.unsqueeze(-1).unsqueeze(-1)
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -141,12 +161,9 @@ class fs_net_loss(nn.Module):
         """red-axis regression over the non-symmetric samples (fs_net_loss.py:146-154; the result keeps the
         reference's shape (1,))."""
         keep = (sym[:, 0] == 0).unsqueeze(-1)
-        kept = keep.sum(dim=0)
         res = self.loss_func_Rot2(torch.where(keep, pred_v, torch.zeros_like(pred_v)),
                                   torch.where(keep, gt_v, torch.zeros_like(gt_v)))
-        if kept > 0:
-            res = res * pred_v.size(0) / kept
-        return res
+        return _rescale(res, keep.sum(dim=0), pred_v.size(0))
 
     def cal_loss_R_con(self, p_rot_g, p_rot_r, g_rot_g, g_rot_r, p_g_con, p_r_con, sym):
         """the confidences should equal exp(-13.7 |axis error|^2); the red one only where the axis is defined
@@ -189,10 +206,7 @@ class geo_transform_loss(nn.Module):
         keep = sym[:, 0] == 0
         x_pred = torch.where(keep.view(-1, 1), _dot(centred, p_rot_r.unsqueeze(1)), torch.zeros_like(canon[:, :, 0]))
         x_gt = torch.where(keep.view(-1, 1), canon[:, :, 0], torch.zeros_like(canon[:, :, 0]))
-        res_x = self.loss_func(x_pred, x_gt)
-        kept = keep.sum()
-        if kept > 0:
-            res_x = res_x * points.size(0) / kept
+        res_x = _rescale(self.loss_func(x_pred, x_gt), keep.sum(), points.size(0))
         return res_y + res_x
 
 
@@ -246,10 +260,11 @@ class prop_rot_loss(nn.Module):
         zero = torch.zeros_like(PC)
         canon = _to_object_frame(PC, gt_R, gt_t)
 
-        def back(flip):
-            pts = canon * torch.tensor(flip, dtype=canon.dtype, device=canon.device).reshape(-1, 3)
+        def back(pts):
             return torch.matmul(pts, gt_R.transpose(-2, -1)) + gt_t.unsqueeze(1)
-        target = torch.where(cls_yx, back([1, 1, -1]), zero) + torch.where(cls_y, back([-1, 1, -1]), zero) \
+        mirror_z = torch.cat([canon[..., :2], -canon[..., 2:]], dim=-1)                       # (x, y, -z)
+        turn_y = torch.cat([-canon[..., 0:1], canon[..., 1:2], -canon[..., 2:]], dim=-1)      # (-x, y, -z)
+        target = torch.where(cls_yx, back(mirror_z), zero) + torch.where(cls_y, back(turn_y), zero) \
             + torch.where(cls_none, PC, zero)
         recon = self.loss_func(target, torch.where(skip, torch.zeros_like(PC_re), PC_re))
 
@@ -270,7 +285,10 @@ class prop_rot_loss(nn.Module):
 # recon_6face_loss
 # ------------------------------------------------------------------------------------------------------------
 
-_FACE_ORDER = [1, 0, 2, 3, 5, 4]        # network order (y+, x+, z+, x-, z-, y-) -> (x+, y+, z+, x-, y-, z-)
+def _reorder_faces(x):
+    """network order (y+, x+, z+, x-, z-, y-) -> (x+, y+, z+, x-, y-, z-) along dim 2, i.e. x[:, :, [1, 0, 2, 3, 5, 4]],
+    by slices (a list index would upload an index tensor: not capturable in a hipGraph)."""
+    return torch.cat([x[:, :, 1:2], x[:, :, 0:1], x[:, :, 2:4], x[:, :, 5:6], x[:, :, 4:5]], dim=2)
 
 
 def _axis_sum(res, sym_flag, obj_ids, xz_only=False):
@@ -289,7 +307,7 @@ def fit_planes(points, weights):
     A = torch.cat([points[..., :2], torch.ones_like(points[..., :1])], dim=-1)
     At = A.transpose(-1, -2)
     w = weights.unsqueeze(-1)
-    X = torch.matmul(torch.inverse(torch.matmul(At, w * A)), torch.matmul(At, w * points[..., 2:3]))
+    X = torch.matmul(_inverse3(torch.matmul(At, w * A)), torch.matmul(At, w * points[..., 2:3]))
     a, b, c = X[..., 0, :], X[..., 1, :], X[..., 2, :]
     norm2 = a * a + b * b + 1.0
     dn = torch.cat([a * c, b * c, -c], dim=-1) / (norm2 + 1e-8)
@@ -329,9 +347,9 @@ class recon_6face_loss(nn.Module):
         coordinate a, and the confidence must be exp(-303.5 |n d - n_gt d_gt|^2).  All three are summed over the
         faces that are defined for the object, / 6 / B."""
         bs = pc.shape[0]
-        fn = face_normal[:, :, _FACE_ORDER]                     # (B,N,6,3)
-        fd = face_dis[:, :, _FACE_ORDER]                        # (B,N,6)
-        ff = face_f[:, :, _FACE_ORDER]
+        fn = _reorder_faces(face_normal)                        # (B,N,6,3)
+        fd = _reorder_faces(face_dis)                           # (B,N,6)
+        ff = _reorder_faces(face_f)
         coord = _to_object_frame(pc, gt_R, gt_t)                # (B,N,3)
         half = (gt_s + mean_shape).reshape(-1, 1, 3) / 2.0
         sym_flag = sym[:, 0]
@@ -371,17 +389,17 @@ class recon_6face_loss(nn.Module):
         bs = pc.shape[0]
         re_s = gt_s + mean_shape
         pre_s = p_s + mean_shape
-        fn = face_normal[:, :, _FACE_ORDER]
-        fd = face_dis[:, :, _FACE_ORDER]
-        fc = face_c[:, :, _FACE_ORDER]
+        fn = _reorder_faces(face_normal)
+        fd = _reorder_faces(face_dis)
+        fc = _reorder_faces(face_c)
         votes = pc.unsqueeze(-2) + fd.unsqueeze(-1) * fn                              # (B,N,6,3)
         sym_flag = sym[:, 0]
         vote_up, n_up, c_up = self._voted_planes(votes[:, :, :3], fc[:, :, :3], gt_t, gt_R, re_s, sym_flag, obj_ids)
         vote_dn, n_dn, c_dn = self._voted_planes(votes[:, :, 3:], fc[:, :, 3:], gt_t, -gt_R, re_s, sym_flag, obj_ids)
-        if any(bool(torch.any(torch.isnan(x))) for x in (n_up, n_dn, c_up, c_dn)):
-            print('nan found in cal_recon_loss_vote new_n/new_c')
-            nan = torch.tensor(float('nan'), device=vote_up.device, dtype=vote_up.dtype)
-            return nan, nan.clone(), nan.clone(), nan.clone(), nan.clone()
+        # a NaN in any fitted plane turns all five terms into NaN (recon_loss.py:632-639), which train.py then skips;
+        # done as a select: no host round trip per step
+        bad = torch.isnan(n_up).any() | torch.isnan(n_dn).any() | torch.isnan(c_up).any() | torch.isnan(c_dn).any()
+        poison = torch.where(bad, torch.full_like(vote_up, float('nan')), torch.zeros_like(vote_up))
         res_vote = (vote_dn + vote_up) / 6.0 / bs
         # r: the fitted normals against the frame built from the predicted axes
         new_y, new_x = vertical_axes(f_rot_g, f_rot_r, p_rot_g, p_rot_r)
@@ -397,7 +415,7 @@ class recon_6face_loss(nn.Module):
                  + _axis_sum(torch.abs(pre_s / 2.0 - dis_dn), sym_flag, obj_ids)) / 6.0 / bs
         # self-consistency of the fitted box
         parallel = _axis_sum(torch.mean(torch.abs(n_up + n_dn), dim=-1), sym_flag, obj_ids)
-        perp_up = _axis_sum(torch.abs((n_up[:, [1, 1, 1]] * n_up).sum(dim=-1)), sym_flag, obj_ids, xz_only=True)
-        perp_dn = _axis_sum(torch.abs((n_dn[:, [1, 1, 1]] * n_dn).sum(dim=-1)), sym_flag, obj_ids, xz_only=True)
+        perp_up = _axis_sum(torch.abs((n_up[:, 1:2] * n_up).sum(dim=-1)), sym_flag, obj_ids, xz_only=True)
+        perp_dn = _axis_sum(torch.abs((n_dn[:, 1:2] * n_dn).sum(dim=-1)), sym_flag, obj_ids, xz_only=True)
         res_self = (parallel + perp_up + perp_dn) / 6.0 / bs
-        return res_vote, res_r, res_t, res_s, res_self
+        return res_vote + poison, res_r + poison, res_t + poison, res_s + poison, res_self + poison

@@ -288,6 +288,37 @@ class _OrlGlobal(torch.autograd.Function):
         return gfeat, None, None
 
 
+class _PointsMax(torch.autograd.Function):
+    """(B,N,C) -> (B,C) max over the points of each cloud; the gradient goes to the first winning row."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x, torch.float32, "points_max.x")
+        B, N, C = x.shape
+        out = torch.empty(B, C, dtype=torch.float32, device=x.device)
+        arg = torch.empty(B, C, dtype=torch.int32, device=x.device)
+        _run("hsp_points_max_fwd", (_p(x), B, N, C, _p(out), _p(arg), _stream()), key=f"B{B}N{N}C{C}",
+             abytes=B * (4 * N * C + 8 * C))
+        ctx.save_for_backward(arg)
+        ctx.dims = (B, N, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        B, N, C = ctx.dims
+        g = _req(g, torch.float32, "points_max.grad")
+        gx = torch.empty(B, N, C, dtype=torch.float32, device=g.device)
+        _run("hsp_points_max_bwd", (_p(g), _p(arg), B, N, C, _p(gx), _stream()), key=f"B{B}N{N}C{C}",
+             abytes=B * (4 * N * C + 8 * C))
+        return gx
+
+
+def points_max(x):
+    """max over dim 1 of a point-major (B,N,C) tensor -> (B,C)   (the heads' torch.max(x, 2)[0])."""
+    return _PointsMax.apply(x)
+
+
 def gather_max(feat, idx, k, qsel=None):
     """max over the first k listed neighbours of each (selected) row -> (B,Nq,C)."""
     return _GatherMax.apply(feat, idx, qsel, k)

@@ -146,6 +146,15 @@ int hsp_gather_max_bwd_csr(const float *grad_out, int grad_bcast, const uint8_t 
                            const int32_t *rev_edge, int B, int Nsrc, int Nq, int k, int C, float *grad_feat,
                            hspStream_t stream);
 
+/* ---- max over the points of a cloud (the heads' global feature) ------------------------------
+ * replaces torch.max(x, 2, keepdim=True)[0]    PoseR.py:29 / :60, PoseTs.py:33, FaceRecon.py:98
+ * x (B,N,C) point-major; out (B,C) = max_n x[b,n,c]; argrow (B,C) int32 = the FIRST row attaining
+ * it (NaN counts as the maximum, as in ATen).  bwd: grad_x (B,N,C) is OVERWRITTEN with grad_out on
+ * the winning row and 0 elsewhere (C % 4 == 0). */
+int hsp_points_max_fwd(const float *x, int B, int N, int C, float *out, int32_t *argrow, hspStream_t stream);
+int hsp_points_max_bwd(const float *grad_out, const int32_t *argrow, int B, int N, int C, float *grad_x,
+                       hspStream_t stream);
+
 /* ORL global feature in one pass (get_ORL_global, gcn3d.py:211-218, before the repeat):
  * fg (B,C) = mean_i max_{n<k} feat[b, idx[b,i,n], :], argmax (B,N,C) uint8; the (B,N,C) max tensor is never
  * written.  idx (B,N,kstride).  ws: hsp_orl_workspace_bytes(B,N,C).  Backward: hsp_gather_max_bwd(grad_bcast=1). */

@@ -89,6 +89,12 @@ def orl_global(feature: Tensor, xyz: Tensor, k: int) -> Tensor:
     return g.mean(dim=1, keepdim=True).repeat(1, feature.shape[1], 1)
 
 
+def points_max(feature: Tensor) -> Tensor:
+    """(B,N,C) -> (B,C): the heads' max over the points, torch.max(x, 2, keepdim=True)[0] on the reference's (B,C,N)
+    layout (PoseR.py:29, :60; PoseTs.py:33; FaceRecon.py:98)."""
+    return torch.max(feature.transpose(1, 2), 2, keepdim=True)[0].squeeze(-1)
+
+
 def orl_forward(feature: Tensor, xyz: Tensor, k: int, conv2_w: Tensor) -> Tensor:
     """conv2(cat[feature, f_global]) + feature     (gcn3d.py:109-113, :183-187)."""
     fg = orl_global(feature, xyz, k)

@@ -97,6 +97,28 @@ def test_gather_max_fwd_bwd(dev, ref, B, N, C, k, kstride, nq):
     gclose(fg.grad, feat.grad, "gather_max dfeat")
 
 
+@pytest.mark.parametrize("B,N,C,ties", [(2, 200, 32, False), (16, 1028, 256, False), (3, 64, 512, True), (1, 17, 100, True),
+                                        (16, 1, 256, False)])
+def test_points_max_fwd_bwd(dev, ref, B, N, C, ties):
+    from hs_pose_amd import ops
+    feat = ref.hash_tensor((B, N, C), 24, 1.0)
+    if ties:                                    # relu-like plateaus: the gradient must go to the FIRST winning row
+        feat = (feat * 2).round().clamp_min(0.0)
+    feat.requires_grad_(True)
+    want = ref.points_max(feat)
+    up = ref.hash_tensor(tuple(want.shape), 25, 1.0)
+    (want * up).sum().backward()
+    if C % 4:
+        with torch.no_grad():
+            close(ops.points_max(feat.detach().to(dev)), want, tol=0, what="points_max out")
+        return
+    fg = feat.detach().clone().to(dev).requires_grad_(True)
+    got = ops.points_max(fg)
+    close(got, want, tol=0, what="points_max out")
+    (got * up.to(dev)).sum().backward()
+    close(fg.grad, feat.grad, tol=0, what="points_max dfeat")
+
+
 @pytest.mark.parametrize("deterministic", [False, True])
 def test_orl_global_fwd_bwd(dev, ref, monkeypatch, deterministic):
     from hs_pose_amd import ops
