@@ -61,6 +61,9 @@ class FaceRecon(nn.Module):
             self.face_head = nn.Sequential(*cbr(FLAGS.feat_face + 3, 512), *cbr(512, 256), *cbr(256, 128),
                                            nn.Conv1d(128, self.face_recon_num, 1))
 
+    keep_backward_cut = False
+    backward_cut = None
+
     def forward(self, vertices: "tensor (bs, vetice_num, 3)", cat_id: "tensor (bs, 1)"):
         """-> (recon (bs,N,3) | None, face (bs,N,face_recon_c) | None, feat (bs,N,1286))"""
         bs, vertice_num, _ = vertices.size()
@@ -72,7 +75,12 @@ class FaceRecon(nn.Module):
             v_pool_1, fm_pool_1 = self.pool_1(vertices, fm_1)
             k1 = min(k, v_pool_1.shape[1] // 8)
             fm_2 = ops.bn_relu(self.conv_2(v_pool_1, fm_pool_1, k1), self.bn2)
-            fm_3 = ops.bn_relu(self.conv_3(v_pool_1, fm_2, k1), self.bn3)
+            # The coarse levels and the concat read the fine levels through aliases (no kernels): every path from feat
+            # down to an alias stays above the others, so a backward pass can stop at them and be resumed
+            # (graph.py::GraphedStep(split=True) reduces the coarse levels' gradients while the fine levels still run).
+            a_0, a_1, a_2 = fm_0.view_as(fm_0), fm_1.view_as(fm_1), fm_2.view_as(fm_2)
+            self.backward_cut = (a_0, a_1, a_2) if self.keep_backward_cut else None   # holds the autograd graph: opt-in
+            fm_3 = ops.bn_relu(self.conv_3(v_pool_1, a_2, k1), self.bn3)
             v_pool_2, fm_pool_2 = self.pool_2(v_pool_1, fm_3)
             k2 = min(k, v_pool_2.shape[1] // 8)
             fm_4 = self.conv_4(v_pool_2, fm_pool_2, k2)
@@ -80,7 +88,7 @@ class FaceRecon(nn.Module):
         nearest_pool_1 = ops.nn1(vertices, v_pool_1)
         nearest_pool_2 = ops.nn1(vertices, v_pool_2)
         # nearest up-sampling of the coarse levels, the one-hot category columns and the concat in one kernel
-        feat = ops.assemble_feat([(fm_0, None, 0), (fm_1, None, 0), (fm_2, nearest_pool_1, 1), (fm_3, nearest_pool_1, 1),
+        feat = ops.assemble_feat([(a_0, None, 0), (a_1, None, 0), (a_2, nearest_pool_1, 1), (fm_3, nearest_pool_1, 1),
                                   (fm_4, nearest_pool_2, 1), (one_hot, None, 2)])
 
         if FLAGS.train:

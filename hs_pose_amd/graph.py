@@ -32,10 +32,16 @@ class GraphedStep:
     (``load_inputs`` copies new data in); parameter ``.grad`` tensors live in the graph's memory pool
     and are overwritten by every replay; ``feat`` is the static output."""
 
-    def __init__(self, face_recon, centred, obj, dfeat, warmup=3, flat_grads=False):
+    def __init__(self, face_recon, centred, obj, dfeat, warmup=3, flat_grads=False, split=False):
         """flat_grads=True additionally packs every parameter gradient into ONE contiguous buffer
         (``self.flat_grad``, one captured multi-tensor copy per step) so a data-parallel caller can
-        all-reduce the step's gradients with a single RCCL collective right after the replay."""
+        all-reduce the step's gradients with a single RCCL collective right after the replay.
+
+        split=True (implies flat_grads) captures the step as TWO graphs cut at ``face_recon.backward_cut``:
+        ``run_first()`` = zero_grad, forward and the backward of everything above the cut (conv_3, conv_4, bn3:
+        78 % of the gradient bytes, ready after the cheap coarse levels) packed into ``flat_late``; ``run_second()`` =
+        the backward of the fine levels packed into ``flat_early``.  The caller starts the all-reduce of ``flat_late``
+        between the two, so that exchange overlaps the N=1028 layers' backward."""
         self.net = face_recon
         self.centred, self.obj, self.dfeat = centred, obj, dfeat
         B, N, _ = centred.shape
@@ -45,8 +51,9 @@ class GraphedStep:
                          torch.empty(int(int(N / 4) / 4), dtype=torch.int32, device=dev)]
         self.params = [p for p in face_recon.parameters() if p.requires_grad]
         self.feat = None
-        self.flat_grad = None
-        if flat_grads:
+        self.flat_grad = self.flat_late = self.flat_early = None
+        self.split = bool(split)
+        if flat_grads or split:
             self.flat_grad = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
         self._upload_pool_indices()
         prev_timer = ops.set_timer(None)               # HIP events cannot be recorded inside a capture
@@ -54,13 +61,26 @@ class GraphedStep:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
+                if split:
+                    self._find_late_params()
                 for _ in range(warmup):
-                    self._body()
+                    if split:
+                        self._body_first()
+                        self._body_second()
+                    else:
+                        self._body()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self._body()
+            if split:
+                self.graph2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self._body_first()
+                with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
+                    self._body_second()
+            else:
+                with torch.cuda.graph(self.graph):
+                    self._body()
         finally:
             ops.set_timer(prev_timer)
 
@@ -70,10 +90,46 @@ class GraphedStep:
         with gcn3d.pool_index_feed(self.pool_idx):
             _, _, feat = self.net(self.centred, self.obj)
         feat.backward(self.dfeat)
-        self.feat = feat
+        self.feat = feat.detach()                       # (keeping the autograd graph alive would pin its accumulators' streams)
         if self.flat_grad is not None:
             torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params],
                       out=self.flat_grad)
+
+    # ---- the step cut in two (split=True) -------------------------------------------------------------------------
+    def _find_late_params(self):
+        """late = the parameters the cut tensors do not depend on (their gradients are complete after the first part).
+        ``flat_grad`` is laid out [late | early] so each part is one contiguous all-reduce."""
+        self.net.keep_backward_cut = True
+        with gcn3d.pool_index_feed(self.pool_idx):
+            _, _, feat = self.net(self.centred, self.obj)
+        cut = list(self.net.backward_cut)
+        self.net.backward_cut = None
+        below = torch.autograd.grad(cut, self.params, [torch.zeros_like(c) for c in cut], allow_unused=True)
+        self.late = [p for p, g in zip(self.params, below) if g is None]
+        self.early = [p for p, g in zip(self.params, below) if g is not None]
+        del feat, below
+        n_late = sum(p.numel() for p in self.late)
+        self.flat_late, self.flat_early = self.flat_grad[:n_late], self.flat_grad[n_late:]
+        self.params = self.late + self.early           # grad_views() follows the flat layout
+
+    def _body_first(self):
+        for p in self.params:
+            p.grad = None
+        with gcn3d.pool_index_feed(self.pool_idx):
+            _, _, feat = self.net(self.centred, self.obj)
+        self.feat = feat.detach()
+        cut = list(self.net.backward_cut)
+        self.net.backward_cut = None
+        grads = torch.autograd.grad(feat, cut + self.late, self.dfeat, allow_unused=True)
+        self._cut, self._cut_grads = cut, list(grads[:len(cut)])
+        torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1) for p, g in zip(self.late, grads[len(cut):])],
+                  out=self.flat_late)
+
+    def _body_second(self):
+        torch.autograd.backward(self._cut, self._cut_grads, inputs=self.early)
+        torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.early],
+                  out=self.flat_early)
+        self._cut = self._cut_grads = None
 
     def _upload_pool_indices(self):
         for buf, idx in zip(self.pool_idx, draw_pool_indices(self.n_points)):
@@ -88,7 +144,19 @@ class GraphedStep:
         """one step: draw + upload the pool indices (host RNG, reference order), replay the graph."""
         self._upload_pool_indices()
         self.graph.replay()
+        if self.split:
+            self.graph2.replay()
         return self.feat
+
+    def run_first(self):
+        """split=True: pool indices, forward, backward above the cut -> ``flat_late`` is final"""
+        self._upload_pool_indices()
+        self.graph.replay()
+        return self.feat
+
+    def run_second(self):
+        """split=True: the rest of the backward -> ``flat_early`` is final"""
+        self.graph2.replay()
 
     def grad_views(self):
         """per-parameter views into flat_grad (after an all-reduce these ARE the averaged gradients)"""
