@@ -269,3 +269,67 @@ class GraphedTrainStep:
         if self.sched is not None:
             self.sched.step()
         return True
+
+
+class GraphedInference:
+    """The timed body of the reference's evaluation loop (evaluation/evaluate.py:90-106) as one hipGraph, for a fixed
+    number of instances per call:
+
+        output_dict = network(PC, obj_id, mean_shape, sym)         # eval mode: BatchNorm on running statistics
+        pred_RT = generate_RT([p_green_R, p_red_R], [f_green_R, f_red_R], Pred_T, mode='vec', sym)
+        pred_s = Pred_s + mean_shape
+
+    ``PC`` (n,N,3), ``obj_id`` (n,) or (n,1), ``mean_shape`` (n,3), ``sym`` (n,4) are static device buffers
+    (``load`` copies new data in); ``run()`` draws the two Pool_layer permutations on the host generator like the
+    reference's forward does, replays, and returns the static ``(pred_RT (n,4,4), pred_s (n,3), output_dict)``.
+    A detector producing a varying instance count keeps one object per count (a capture is a few ms)."""
+
+    def __init__(self, network, PC, obj_id, mean_shape, sym, warmup=2):
+        from .geom_utils import generate_RT
+        self.net, self._generate_RT = network, generate_RT
+        self.PC, self.obj_id, self.mean_shape, self.sym = PC, obj_id, mean_shape, sym
+        n, N, _ = PC.shape
+        self.n_points = N
+        dev = PC.device
+        self.pool_idx = [torch.empty(int(N / 4), dtype=torch.int32, device=dev),
+                         torch.empty(int(int(N / 4) / 4), dtype=torch.int32, device=dev)]
+        if network.training:
+            raise RuntimeError("GraphedInference: put the network in eval() mode first")
+        self._draw()
+        prev_timer = ops.set_timer(None)
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self._body()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._body()
+        finally:
+            ops.set_timer(prev_timer)
+
+    def _draw(self):
+        for buf, idx in zip(self.pool_idx, draw_pool_indices(self.n_points)):
+            buf.copy_(idx.to(torch.int32))
+
+    @torch.no_grad()
+    def _body(self):
+        with gcn3d.pool_index_feed(self.pool_idx):
+            out = self.net(PC=self.PC, obj_id=self.obj_id, mean_shape=self.mean_shape, sym=self.sym)
+        self.pred_RT = self._generate_RT([out['p_green_R'], out['p_red_R']], [out['f_green_R'], out['f_red_R']],
+                                         out['Pred_T'], mode='vec', sym=self.sym)
+        self.pred_s = out['Pred_s'] + self.mean_shape
+        self.output_dict = out
+
+    def load(self, PC=None, obj_id=None, mean_shape=None, sym=None):
+        for dst, src in ((self.PC, PC), (self.obj_id, obj_id), (self.mean_shape, mean_shape), (self.sym, sym)):
+            if src is not None:
+                dst.copy_(src, non_blocking=True)
+
+    def run(self):
+        self._draw()
+        self.graph.replay()
+        return self.pred_RT, self.pred_s, self.output_dict

@@ -58,3 +58,45 @@ def test_graphed_step_matches_eager(dev, B, N, mode):
         assert err <= 2e-5 * gmax, f"{k}: |graph - eager| {err:.3e}, max|grad| {gmax:.3e}"
     if mode == "split":                                 # the cut: coarse levels first, and they carry most of the bytes
         assert graphed.flat_late.numel() > graphed.flat_early.numel() > 0
+
+
+@pytest.mark.parametrize("n", [1, 5])
+def test_graphed_inference_matches_eager(dev, n):
+    """evaluate.py's timed body (eval-mode forward + generate_RT) replayed from a graph == issued eagerly"""
+    from hs_pose_amd import gcn3d
+    from hs_pose_amd.config import FLAGS
+    from hs_pose_amd.geom_utils import generate_RT
+    from hs_pose_amd.graph import GraphedInference
+    from hs_pose_amd.HSPose import HSPose
+    FLAGS.reset()
+    FLAGS.train = 0
+    torch.manual_seed(0)
+    net = HSPose("PoseNet_only").to(dev)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():                       # non-trivial running statistics
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+    net.eval()
+    N = 1028
+    PC = (torch.randn(n, N, 3, generator=g) * 0.05 + torch.tensor([0.0, 0.0, 0.8])).to(dev)
+    obj = torch.randint(0, 6, (n,), generator=g).to(dev)
+    mean_shape = (torch.rand(n, 3, generator=g) * 0.2 + 0.1).to(dev)
+    sym = torch.zeros(n, 4, dtype=torch.int32)
+    sym[::2, 0] = 1
+    sym = sym.to(dev)
+    torch.manual_seed(21)
+    graphed = GraphedInference(net, PC, obj, mean_shape, sym)
+    for _ in range(2):
+        RT_g, s_g, out_g = graphed.run()
+    torch.cuda.synchronize()
+    with torch.no_grad(), gcn3d.pool_index_feed([p.clone() for p in graphed.pool_idx]):
+        out = net(PC=PC, obj_id=obj, mean_shape=mean_shape, sym=sym)
+        RT = generate_RT([out['p_green_R'], out['p_red_R']], [out['f_green_R'], out['f_red_R']], out['Pred_T'],
+                         mode='vec', sym=sym)
+    assert RT_g.shape == (n, 4, 4) and s_g.shape == (n, 3)
+    for k in ('p_green_R', 'p_red_R', 'f_green_R', 'f_red_R', 'Pred_T', 'Pred_s'):
+        assert (out_g[k] - out[k]).abs().max().item() <= 1e-5, k
+    assert (RT_g - RT).abs().max().item() <= 1e-5
+    assert (s_g - (out['Pred_s'] + mean_shape)).abs().max().item() <= 1e-6
