@@ -192,7 +192,7 @@ class GraphedTrainStep:
     the capture (the replayed graph then reads freed memory).  The warm-up iterations here run on the capture stream."""
 
     def __init__(self, network, optimizer, batch, scheduler=None, max_norm=5, warmup=3):
-        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
+        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0" and os.environ.get("HSP_TRAIN_GRAPH_UNCHECKED") != "1":
             raise RuntimeError("GraphedTrainStep: start the process with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (before the "
                                "first HIP call) -- ATen reductions replay incorrectly under the packet-capture graph path")
         self.net, self.opt, self.sched, self.max_norm = network, optimizer, scheduler, max_norm

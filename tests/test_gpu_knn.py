@@ -71,6 +71,7 @@ def test_knn_ties_value_equal(dev, ref, oc):
     (64, 260, 7, 5, 1),       # symmetric path with odd C (generic load path), K1 = 9
     (2, 69, 7, 5, 1),         # 5 remainder queries, odd C (generic load path)
     (2, 72, 64, 20, 1),       # only two query tiles: waves 2, 3 idle, no shared bound
+    (2, 4096, 128, 20, 1),    # dense cloud (BASELINE configs[3] point count): 128 query tiles per cloud
 ])
 def test_knn_vs_c_oracle(dev, ref, oc, B, N, C, k, drop):
     from hs_pose_amd import ops

@@ -30,7 +30,21 @@ def gclose(a, b, what=""):
     assert err <= 1e-4 * scale, f"{what}: grad max abs err {err:.3e} vs scale {scale:.3e}"
 
 
-@pytest.mark.parametrize("B,N,k,S,K", [(2, 128, 8, 3, 16), (1, 257, 20, 7, 128), (3, 64, 8, 7, 512), (9, 40, 4, 2, 8)])
+def gclose_kinks(a, b, what="", max_outliers=8):
+    """gradient check for the dense-cloud cases: 1e-4 of the gradient's scale everywhere except a handful of entries.
+    With N*k*S*C ~ 10^8 arg-max decisions per launch a near-tie is decided differently by two correct fp32 evaluations
+    now and then (tools/oracle_sensitivity.py: the CPU oracle disagrees with its own float64 run in the same way); one
+    flipped winner moves one summand of one column of dD (3 entries) or between two rows of dfm."""
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    scale = max(b.abs().max().item(), 1e-12)
+    err = (a - b).abs()
+    out = int((err > 1e-4 * scale).sum().item())
+    assert out <= max_outliers, f"{what}: {out} entries beyond 1e-4 of the scale (max err {err.max().item():.3e}, scale {scale:.3e})"
+    assert err.max().item() <= 2e-2 * scale, f"{what}: grad max abs err {err.max().item():.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("B,N,k,S,K", [(2, 128, 8, 3, 16), (1, 257, 20, 7, 128), (3, 64, 8, 7, 512), (9, 40, 4, 2, 8),
+                                       (1, 4096, 20, 7, 128)])          # dense cloud (BASELINE configs[3] point count)
 def test_rf_surface_fwd_bwd(dev, ref, B, N, k, S, K):
     from hs_pose_amd import ops
     xyz = ref.hash_tensor((B, N, 3), 1, 0.1)
@@ -43,12 +57,12 @@ def test_rf_surface_fwd_bwd(dev, ref, B, N, k, S, K):
     got = ops.rf_surface(xyz.to(dev), idx.int().to(dev), Dg, S)
     close(got, want, what="rf_surface out")
     (got * up.to(dev)).sum().backward()
-    gclose(Dg.grad, D.grad, "rf_surface dD")
+    (gclose_kinks if N >= 2048 else gclose)(Dg.grad, D.grad, "rf_surface dD")
 
 
 @pytest.mark.parametrize("deterministic", [False, True])
 @pytest.mark.parametrize("B,N,k,S,Cin,C", [(2, 128, 8, 3, 16, 32), (1, 257, 20, 7, 128, 128), (2, 64, 8, 7, 256, 512),
-                                           (10, 48, 5, 2, 8, 12), (1, 1028, 20, 7, 32, 128)])
+                                           (10, 48, 5, 2, 8, 12), (1, 1028, 20, 7, 32, 128), (1, 4096, 20, 7, 32, 128)])
 def test_rf_conv_fwd_bwd(dev, ref, monkeypatch, B, N, k, S, Cin, C, deterministic):
     """both backward forms: column-tile LDS scatter (default) and CSR gather (HSP_DETERMINISTIC=1)"""
     from hs_pose_amd import ops
@@ -72,11 +86,13 @@ def test_rf_conv_fwd_bwd(dev, ref, monkeypatch, B, N, k, S, Cin, C, deterministi
     got = ops.rf_conv(xyz.to(dev), idx.int().to(dev), Dg, fmg, S)
     close(got, want, what="rf_conv out")
     (got * up.to(dev)).sum().backward()
-    gclose(fmg.grad, fm.grad, "rf_conv dfm")
-    gclose(Dg.grad, D.grad, "rf_conv dD")
+    check = gclose_kinks if N >= 2048 else gclose
+    check(fmg.grad, fm.grad, "rf_conv dfm")
+    check(Dg.grad, D.grad, "rf_conv dD")
 
 
 @pytest.mark.parametrize("B,N,C,k,kstride,nq", [(2, 200, 32, 4, 20, 50), (3, 64, 512, 8, 8, None), (1, 1028, 128, 20, 20, None),
+                                                (1, 4096, 128, 20, 20, None), (1, 4096, 128, 4, 20, 1024),
                                                 (2, 257, 256, 4, 20, 64)])
 def test_gather_max_fwd_bwd(dev, ref, B, N, C, k, kstride, nq):
     from hs_pose_amd import ops
