@@ -25,6 +25,16 @@ def draw_pool_indices(n_points, rate=4, levels=2):
     return out
 
 
+
+def upload_pool_indices(bufs, n_points):
+    """draw the Pool_layer permutations (host generator, reference order) and queue their upload on the current
+    stream WITHOUT blocking the host: the copy comes from pinned staging memory (PyTorch's host allocator keeps the
+    block until the copy has run), stream-ordered after the previous replay and before the next, so the host can
+    enqueue step i+1 while step i is still running."""
+    for buf, idx in zip(bufs, draw_pool_indices(n_points)):
+        buf.copy_(idx.to(torch.int32).pin_memory(), non_blocking=True)
+
+
 class GraphedStep:
     """step = zero_grad; (_, _, feat) = face_recon(centred, obj); feat.backward(dfeat)   as one hipGraph.
 
@@ -132,8 +142,7 @@ class GraphedStep:
         self._cut = self._cut_grads = None
 
     def _upload_pool_indices(self):
-        for buf, idx in zip(self.pool_idx, draw_pool_indices(self.n_points)):
-            buf.copy_(idx.to(torch.int32), non_blocking=False)
+        upload_pool_indices(self.pool_idx, self.n_points)
 
     def load_inputs(self, centred=None, obj=None, dfeat=None):
         for dst, src in ((self.centred, centred), (self.obj, obj), (self.dfeat, dfeat)):
@@ -224,8 +233,7 @@ class GraphedTrainStep:
     def _host_draws(self):
         if FLAGS.train:
             self.noise.copy_(torch.rand(self.noise.shape) * FLAGS.aug_pc_r)
-        for buf, idx in zip(self.pool_idx, draw_pool_indices(self.n_points)):
-            buf.copy_(idx.to(torch.int32))
+        upload_pool_indices(self.pool_idx, self.n_points)
 
     def _body(self):
         # Gradients are created INSIDE the capture (grad = None first) and then moved into the optimizer's flat buffer
@@ -312,8 +320,7 @@ class GraphedInference:
             ops.set_timer(prev_timer)
 
     def _draw(self):
-        for buf, idx in zip(self.pool_idx, draw_pool_indices(self.n_points)):
-            buf.copy_(idx.to(torch.int32))
+        upload_pool_indices(self.pool_idx, self.n_points)
 
     @torch.no_grad()
     def _body(self):
