@@ -502,6 +502,12 @@ def _rf_conv_bwd_raw(xyz, idx, directions, fm, arg, gF3, S):
     return gfm, gd
 
 
+def _scaled_mm(a, b, alpha):
+    """alpha * (a @ b) with the scale in the GEMM epilogue (no separate element-wise kernel)"""
+    out = torch.empty(a.shape[0], b.shape[1], dtype=a.dtype, device=a.device)
+    return torch.addmm(out, a, b, beta=0.0, alpha=alpha, out=out)
+
+
 class _HSLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste3, w_conv23):
@@ -547,10 +553,10 @@ class _HSLayer(torch.autograd.Function):
         gt = colsum_rows(g)                                                    # (B,C) = sum_i g
         g_conv2 = torch.empty_like(w_conv2)
         wgrad(g2, F2, out=g_conv2[:, :C])                                      # gWa, written in place (ldc = 2C)
-        g_conv2[:, C:] = gt.t() @ fg                                           # gWb (tiny)
+        torch.mm(gt.t(), fg, out=g_conv2[:, C:])                               # gWb (tiny), straight into its column block
         gF3 = torch.empty(B, N, C, dtype=torch.float32, device=g.device)
         torch.mm(g2, Wa, out=gF3.view(B * N, C))                               # g Wa ...
-        _orl_bwd_accumulate_raw((gt @ Wb) / N, idx_x, arg_o, k, gF3, extra=g)  # ... + g + ORL scatter, one pass
+        _orl_bwd_accumulate_raw(_scaled_mm(gt, Wb, 1.0 / N), idx_x, arg_o, k, gF3, extra=g)  # ... + g + ORL scatter, one pass
         gfm, gD = _rf_conv_bwd_raw(xyz, idx_f, directions, fm.view(B, N, -1), arg, gF3, S)
         gfm2 = gfm.view(B * N, -1)
         gW, gb = wgrad(X2, gfm2, colsum=True)                                  # X^T gfm and the bias gradient
@@ -604,10 +610,10 @@ class _SurfaceLayer(torch.autograd.Function):
         gt = colsum_rows(g)
         g_conv2 = torch.empty_like(w_conv2)
         wgrad(g2, F2, out=g_conv2[:, :C])
-        g_conv2[:, C:] = gt.t() @ fg
+        torch.mm(gt.t(), fg, out=g_conv2[:, C:])
         gF3 = torch.empty(B, N, C, dtype=torch.float32, device=g.device)
         torch.mm(g2, Wa, out=gF3.view(B * N, C))
-        _orl_bwd_accumulate_raw((gt @ Wb) / N, idx_x, arg_o, k, gF3, extra=g)
+        _orl_bwd_accumulate_raw(_scaled_mm(gt, Wb, 1.0 / N), idx_x, arg_o, k, gF3, extra=g)
         gD = torch.empty_like(directions)
         L = lib()
         wsb = L.hsp_rf_bwd_scatter_workspace_bytes(B, SC)
