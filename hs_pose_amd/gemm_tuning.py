@@ -45,3 +45,13 @@ def enable(tune_missing=True, max_tuning_ms=30):
         pass
     _enabled = True
     return work
+
+
+def save(path=None):
+    """write the merged table (shipped entries + what this process tuned) -- how hs_pose_amd/tuning/ is regenerated:
+    HSP_TUNABLEOP_OUT=<file> python tools/bench_train_step.py ; python tools/bench_infer.py ; python bench.py"""
+    path = path or os.environ.get("HSP_TUNABLEOP_OUT")
+    fn = getattr(torch.cuda.tunable, "write_file", None)    # (this torch build appends to the file as it tunes)
+    if _enabled and path and fn is not None:
+        fn(path)
+    return path

@@ -49,14 +49,33 @@ def _to_object_frame(points, R, t):
     return torch.matmul(points - t.unsqueeze(1), R)
 
 
+_CONSTS = {}
+
+
+def _const(name, ref, build):
+    """small constant tensors, built once per (device, dtype) -- outside any graph capture (first eager call)"""
+    key = (name, ref.device, ref.dtype)
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = build().to(device=ref.device, dtype=ref.dtype)
+    return t
+
+
+def _skew_basis():
+    b = torch.zeros(3, 3, 3)                      # [k]x = sum_a axis[a] * b[a]:  [[0,-z,y],[z,0,-x],[-y,x,0]]
+    b[2, 0, 1], b[1, 0, 2], b[2, 1, 0], b[0, 1, 2], b[1, 2, 0], b[0, 2, 1] = -1, 1, 1, -1, -1, 1
+    return b.reshape(3, 9)
+
+
 def _rodrigues(axis, s, c):
-    """rotation matrices (B,3,3) about unit axes (B,3) with sin / cos (B,1) (tools/rot_utils.py:67-75)."""
-    x, y, z = axis[:, 0:1], axis[:, 1:2], axis[:, 2:3]
-    t = 1 - c
-    rows = [torch.cat([x * x * t + c, x * y * t - z * s, x * z * t + y * s], dim=-1),
-            torch.cat([y * x * t + z * s, y * y * t + c, y * z * t - x * s], dim=-1),
-            torch.cat([x * z * t - y * s, z * y * t + x * s, z * z * t + c], dim=-1)]
-    return torch.stack(rows, dim=-2)
+    """rotation matrices (B,3,3) about unit axes (B,3) with sin / cos (B,1) (tools/rot_utils.py:67-75):
+    R = (1-c) k k^T + c I + s [k]x, assembled from three (B,3,3) terms instead of nine scalar expressions.  Entry by
+    entry this is the reference's arithmetic -- (x*y)*(1-c) (+ c | - z*s | + y*s), the other terms being exact zeros --
+    in 8 kernels instead of ~75."""
+    t = (1 - c).unsqueeze(-1)
+    outer = axis.unsqueeze(-1) * axis.unsqueeze(-2)
+    K = torch.matmul(axis, _const("skew", axis, _skew_basis)).view(-1, 3, 3)
+    return (outer * t + _const("eye3", axis, lambda: torch.eye(3)) * c.unsqueeze(-1)) + K * s.unsqueeze(-1)
 
 
 def vertical_axes(c1, c2, y, z):
@@ -72,6 +91,23 @@ def vertical_axes(c1, c2, y, z):
     new_y = torch.matmul(_rodrigues(axis, torch.sin(th_y), torch.cos(th_y)), y.unsqueeze(-1)).squeeze(-1)
     new_z = torch.matmul(_rodrigues(axis, torch.sin(-th_z), torch.cos(-th_z)), z.unsqueeze(-1)).squeeze(-1)
     return new_y, new_z
+
+
+_va_memo = None
+
+
+def vertical_axes_shared(c1, c2, y, z):
+    """vertical_axes for the call the property loss and the voting loss both make on the same network outputs
+    (prop_loss.py:163, recon_loss.py:640): computed once per forward, the second caller gets the same autograd nodes.
+    The entry is keyed on the identity of the axis tensors (kept referenced, so an id cannot be reused) and the storage of
+    the detached confidences; a new forward replaces it."""
+    global _va_memo
+    key = (id(y), id(z), c1.data_ptr(), c2.data_ptr(), y._version, z._version, torch.is_grad_enabled())
+    if _va_memo is not None and _va_memo[0] == key:
+        return _va_memo[2]
+    out = vertical_axes(c1, c2, y, z)
+    _va_memo = (key, (y, z, c1, c2), out)
+    return out
 
 
 def rot_mat_y_first(y, x):
@@ -242,7 +278,7 @@ class prop_rot_loss(nn.Module):
         against the same under the ground-truth pose (prop_loss.py:156-189)."""
         canon = _to_object_frame(points, g_R, g_t)
         ys, xs = vertical_axes(f_g_vec, torch.full_like(f_g_vec, 1e-5), p_g_vec, g_R[..., 0])
-        yn, xn = vertical_axes(f_g_vec, f_r_vec, p_g_vec, p_r_vec)
+        yn, xn = vertical_axes_shared(f_g_vec, f_r_vec, p_g_vec, p_r_vec)
         symmetric = (sym[:, 0] == 1).unsqueeze(-1)
         p_R = rot_mat_y_first(torch.where(symmetric, ys, yn), torch.where(symmetric, xs, xn))
         return self.loss_func(torch.matmul(points - p_t.unsqueeze(1), p_R), canon)
@@ -291,13 +327,18 @@ def _reorder_faces(x):
     return torch.cat([x[:, :, 1:2], x[:, :, 0:1], x[:, :, 2:4], x[:, :, 5:6], x[:, :, 4:5]], dim=2)
 
 
-def _axis_sum(res, sym_flag, obj_ids, xz_only=False):
-    """sum over the batch of the per-axis residuals res (B,3): y always, z without rotational symmetry, x
-    without rotational symmetry and not for the mug (recon_loss.py:545-553)."""
-    zero = torch.zeros_like(res[:, 0])
-    x = torch.where(torch.logical_and(sym_flag == 0, obj_ids != 5), res[:, 0], zero).sum()
-    z = torch.where(sym_flag == 0, res[:, 2], zero).sum()
-    return x + z if xz_only else x + res[:, 1].sum() + z
+def _axis_mask(sym_flag, obj_ids):
+    """(B,3) bool: which axis residuals count -- y always, z without rotational symmetry, x without rotational
+    symmetry and not for the mug (recon_loss.py:545-553).  Built once per loss call."""
+    no_rot = sym_flag == 0
+    return torch.stack([torch.logical_and(no_rot, obj_ids != 5), torch.ones_like(no_rot), no_rot], dim=-1)
+
+
+def _axis_sum(res, mask, xz_only=False):
+    """sum over the batch of the per-axis residuals res (B,3) that count (same order as the reference: per-axis sums over
+    the batch, then x + y + z)."""
+    s = torch.where(mask, res, 0.0).sum(dim=0)
+    return s[0] + s[2] if xz_only else s[0] + s[1] + s[2]
 
 
 def fit_planes(points, weights):
@@ -353,6 +394,7 @@ class recon_6face_loss(nn.Module):
         coord = _to_object_frame(pc, gt_R, gt_t)                # (B,N,3)
         half = (gt_s + mean_shape).reshape(-1, 1, 3) / 2.0
         sym_flag = sym[:, 0]
+        axis_mask = _axis_mask(sym_flag, obj_ids)
         axes = gt_R.transpose(-1, -2).unsqueeze(1)              # (B,1,3,3): row a = axis a in the camera frame
         res_n = res_d = res_c = 0.0
         for sign, sl in ((1.0, slice(0, 3)), (-1.0, slice(3, 6))):
@@ -362,13 +404,13 @@ class recon_6face_loss(nn.Module):
             r = torch.mean(1.0 - cos, dim=1)                    # (B,3)
             xz = torch.where(sym_flag == 0, r[:, 0] + r[:, 2], torch.zeros_like(r[:, 0]))
             res_n = res_n + r[:, 1].sum() + xz.sum()
-            res_d = res_d + _axis_sum(torch.mean(torch.abs(fd[:, :, sl] - d_gt), dim=1), sym_flag, obj_ids)
+            res_d = res_d + _axis_sum(torch.mean(torch.abs(fd[:, :, sl] - d_gt), dim=1), axis_mask)
             err = torch.norm(fn[:, :, sl] * fd[:, :, sl].unsqueeze(-1) - n_gt * d_gt.unsqueeze(-1), dim=-1)
             conf = torch.exp(-303.5 * err * err)
-            res_c = res_c + _axis_sum(torch.mean(torch.abs(conf - ff[:, :, sl]), dim=1), sym_flag, obj_ids)
+            res_c = res_c + _axis_sum(torch.mean(torch.abs(conf - ff[:, :, sl]), dim=1), axis_mask)
         return res_n / 6 / bs, res_d / 6 / bs, res_c / 6 / bs
 
-    def _voted_planes(self, on_plane, conf, gt_t, gt_R_signed, re_s, sym_flag, obj_ids):
+    def _voted_planes(self, on_plane, conf, gt_t, gt_R_signed, re_s, axis_mask):
         """fit the three +a (or -a) faces through the points pushed onto them, orient the normals like the ground
         truth, and compare the fitted foot points with the true ones (recon_loss.py:555-577)."""
         n, dn, c = fit_planes(on_plane.transpose(1, 2), conf.transpose(-1, -2))      # (B,3,3), (B,3,3), (B,3,1)
@@ -378,7 +420,7 @@ class recon_6face_loss(nn.Module):
         c = torch.where(flip, -c, c)
         face_centre = gt_t.unsqueeze(-2) + axes * re_s.unsqueeze(-1) / 2.0
         dn_gt = axes * (-(axes * face_centre).sum(dim=-1, keepdim=True))
-        return _axis_sum(torch.mean(torch.abs(dn - dn_gt), dim=-1), sym_flag, obj_ids), n, c
+        return _axis_sum(torch.mean(torch.abs(dn - dn_gt), dim=-1), axis_mask), n, c
 
     def cal_recon_loss_vote(self, pc, face_normal, face_dis, face_c, p_rot_g, f_rot_g, p_rot_r, f_rot_r, p_t, p_s,
                             gt_R, gt_t, gt_s, mean_shape, sym, obj_ids, save_path=None):
@@ -393,29 +435,29 @@ class recon_6face_loss(nn.Module):
         fd = _reorder_faces(face_dis)
         fc = _reorder_faces(face_c)
         votes = pc.unsqueeze(-2) + fd.unsqueeze(-1) * fn                              # (B,N,6,3)
-        sym_flag = sym[:, 0]
-        vote_up, n_up, c_up = self._voted_planes(votes[:, :, :3], fc[:, :, :3], gt_t, gt_R, re_s, sym_flag, obj_ids)
-        vote_dn, n_dn, c_dn = self._voted_planes(votes[:, :, 3:], fc[:, :, 3:], gt_t, -gt_R, re_s, sym_flag, obj_ids)
+        axis_mask = _axis_mask(sym[:, 0], obj_ids)
+        vote_up, n_up, c_up = self._voted_planes(votes[:, :, :3], fc[:, :, :3], gt_t, gt_R, re_s, axis_mask)
+        vote_dn, n_dn, c_dn = self._voted_planes(votes[:, :, 3:], fc[:, :, 3:], gt_t, -gt_R, re_s, axis_mask)
         # a NaN in any fitted plane turns all five terms into NaN (recon_loss.py:632-639), which train.py then skips;
         # done as a select: no host round trip per step
         bad = torch.isnan(n_up).any() | torch.isnan(n_dn).any() | torch.isnan(c_up).any() | torch.isnan(c_dn).any()
         poison = torch.where(bad, torch.full_like(vote_up, float('nan')), torch.zeros_like(vote_up))
         res_vote = (vote_dn + vote_up) / 6.0 / bs
         # r: the fitted normals against the frame built from the predicted axes
-        new_y, new_x = vertical_axes(f_rot_g, f_rot_r, p_rot_g, p_rot_r)
+        new_y, new_x = vertical_axes_shared(f_rot_g, f_rot_r, p_rot_g, p_rot_r)
         frame = torch.stack([new_x, new_y, torch.cross(new_x, new_y, dim=-1)], dim=-2)
-        res_r = (_axis_sum(torch.mean(torch.abs(n_up - frame), dim=-1), sym_flag, obj_ids)
-                 + _axis_sum(torch.mean(torch.abs(n_dn + frame), dim=-1), sym_flag, obj_ids)) / 6.0 / bs
+        res_r = (_axis_sum(torch.mean(torch.abs(n_up - frame), dim=-1), axis_mask)
+                 + _axis_sum(torch.mean(torch.abs(n_dn + frame), dim=-1), axis_mask)) / 6.0 / bs
         # t: the predicted centre is equally far from opposite faces
         dis_up = torch.abs((n_up * p_t.unsqueeze(-2)).sum(dim=-1, keepdim=True) + c_up).squeeze(-1)
         dis_dn = torch.abs((n_dn * p_t.unsqueeze(-2)).sum(dim=-1, keepdim=True) + c_dn).squeeze(-1)
-        res_t = _axis_sum(torch.abs(dis_dn - dis_up), sym_flag, obj_ids) / 6.0 / bs
+        res_t = _axis_sum(torch.abs(dis_dn - dis_up), axis_mask) / 6.0 / bs
         # s: and half the predicted size away from each
-        res_s = (_axis_sum(torch.abs(pre_s / 2.0 - dis_up), sym_flag, obj_ids)
-                 + _axis_sum(torch.abs(pre_s / 2.0 - dis_dn), sym_flag, obj_ids)) / 6.0 / bs
+        res_s = (_axis_sum(torch.abs(pre_s / 2.0 - dis_up), axis_mask)
+                 + _axis_sum(torch.abs(pre_s / 2.0 - dis_dn), axis_mask)) / 6.0 / bs
         # self-consistency of the fitted box
-        parallel = _axis_sum(torch.mean(torch.abs(n_up + n_dn), dim=-1), sym_flag, obj_ids)
-        perp_up = _axis_sum(torch.abs((n_up[:, 1:2] * n_up).sum(dim=-1)), sym_flag, obj_ids, xz_only=True)
-        perp_dn = _axis_sum(torch.abs((n_dn[:, 1:2] * n_dn).sum(dim=-1)), sym_flag, obj_ids, xz_only=True)
+        parallel = _axis_sum(torch.mean(torch.abs(n_up + n_dn), dim=-1), axis_mask)
+        perp_up = _axis_sum(torch.abs((n_up[:, 1:2] * n_up).sum(dim=-1)), axis_mask, xz_only=True)
+        perp_dn = _axis_sum(torch.abs((n_dn[:, 1:2] * n_dn).sum(dim=-1)), axis_mask, xz_only=True)
         res_self = (parallel + perp_up + perp_dn) / 6.0 / bs
         return res_vote + poison, res_r + poison, res_t + poison, res_s + poison, res_self + poison

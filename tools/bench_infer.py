@@ -62,6 +62,8 @@ def main():
                          "clouds_per_s": round(n * args.images / dt, 1)}
         print(json.dumps(res))
 
+    gemm_tuning.save()                           # only with HSP_TUNABLEOP_OUT set
+
 
 if __name__ == "__main__":
     main()

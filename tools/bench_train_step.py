@@ -97,6 +97,8 @@ def main():
                       "batch": args.batch, "points": args.points, "ms_per_step": round(1e3 * dt / args.steps, 3),
                       "clouds_per_s": round(args.batch * args.steps / dt, 1), "last_total_loss": float(total.detach())}))
 
+    gemm_tuning.save()                           # only with HSP_TUNABLEOP_OUT set
+
 
 if __name__ == "__main__":
     main()
