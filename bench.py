@@ -93,10 +93,16 @@ def main():
     ap.add_argument("--no-gemm-tuning", action="store_true", help="leave hipBLASLt/rocBLAS on their default heuristics")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result: libraries that write to fd 1 themselves (RCCL prints a version
+    # banner there, flushed at exit) are sent to stderr
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     from hs_pose_amd import ops
     from hs_pose_amd.config import FLAGS
     from hs_pose_amd.FaceRecon import FaceRecon
-    from hs_pose_amd.parallel import GradReducer, init_distributed
+    from hs_pose_amd.parallel import GradReducer, graphed_step_with_exchange, init_distributed
 
     rank, world, device = init_distributed()
     assert device.type == "cuda", "bench.py measures the HIP path; it needs a GPU"
@@ -129,10 +135,11 @@ def main():
         # the host, before each replay.  Data parallel: the captured step also packs all gradients into one
         # flat buffer, which is mean-all-reduced with a single RCCL collective after every replay.
         from hs_pose_amd.graph import GraphedStep
-        # More than one rank: the step is captured as two graphs cut below the coarse levels, so that the all-reduce of
-        # their gradients (78 % of the bytes) runs on RCCL's stream while the N=1028 layers' backward is still going.
-        want_split = use_dist and (world > 1 or os.environ.get("HSP_SPLIT_GRAPH") == "1") \
-            and os.environ.get("HSP_SPLIT_GRAPH") != "0"
+        # HSP_SPLIT_GRAPH=1: the step captured as two graphs cut below the coarse levels, so that the all-reduce of their
+        # gradients (78 % of the bytes) runs on RCCL's stream under the N=1028 layers' backward.  Opt-in: with a 1-rank
+        # group the second graph launch + the asynchronous work cost 0.15 ms per step on this runtime, about what the
+        # overlap can hide of a 12.4 MB exchange over xGMI, so the default is ONE all-reduce.
+        want_split = use_dist and os.environ.get("HSP_SPLIT_GRAPH") == "1"
         for split in ([True, False] if want_split else [False]):
             try:
                 graphed = GraphedStep(net, centred, obj, dfeat, flat_grads=use_dist, split=split)
@@ -144,19 +151,10 @@ def main():
         reducer = GradReducer(params)                      # bucketed all-reduce launched from autograd hooks
 
     def graphed_step():
-        if graphed.split:
-            graphed.run_first()
-            late = dist.all_reduce(graphed.flat_late, op=dist.ReduceOp.SUM, async_op=True)
-            graphed.run_second()                           # overlaps the exchange above
-            early = dist.all_reduce(graphed.flat_early, op=dist.ReduceOp.SUM, async_op=True)
-            late.wait()
-            early.wait()
-            graphed.flat_grad.mul_(1.0 / world)
-            return
-        graphed.run()
         if use_dist:
-            dist.all_reduce(graphed.flat_grad, op=dist.ReduceOp.SUM)
-            graphed.flat_grad.mul_(1.0 / world)
+            graphed_step_with_exchange(graphed, world)         # hs_pose_amd/parallel.py
+        else:
+            graphed.run()
 
     step = graphed_step if graphed is not None else eager_step
 
@@ -235,13 +233,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"HS stack (FaceRecon backbone -> feat) fwd+bwd, B={B}/GPU N={N} fp32, "
                                    f"train-mode BN, random-init weights (BASELINE configs[1] shape)",
-                       "global_batch": world * B, "points": N, "parallelism": f"dp{world}", "hipgraph": graphed is not None, "grad_exchange": ("none" if world == 1 else "2 all-reduces, first overlapped with backward" if graphed is not None and graphed.split else "1 all-reduce after backward" if graphed is not None else "bucketed, hook-driven"),
+                       "global_batch": world * B, "points": N, "parallelism": f"dp{world}", "hipgraph": graphed is not None, "split_graph": bool(graphed is not None and graphed.split), "grad_exchange": ("none" if world == 1 else "2 all-reduces, first overlapped with backward" if graphed is not None and graphed.split else "1 all-reduce after backward" if graphed is not None else "bucketed, hook-driven"),
                        "libhsp_ms_per_step": round(hsp_ms, 4)},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_sample)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=result_out, flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

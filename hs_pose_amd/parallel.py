@@ -127,3 +127,26 @@ class GradReducer:
         for h in self._handles:
             h.remove()
         self._handles = []
+
+
+def graphed_step_with_exchange(graphed, world, group=None):
+    """one data-parallel step of a graph-replayed network (hs_pose_amd.graph.GraphedStep): replay, mean the gradients
+    over the ranks in the step's flat buffer.
+
+    split form (``graphed.split``): ``run_first()`` leaves the coarse levels' gradients final in ``flat_late`` -- their
+    all-reduce is started asynchronously (RCCL's own stream) and runs under ``run_second()``, the fine levels' backward;
+    only the second, small exchange is exposed.  Otherwise one all-reduce over ``flat_grad`` after the replay.  Every
+    rank issues the same collectives in the same order."""
+    if not getattr(graphed, "split", False):
+        graphed.run()
+        if world > 1 or dist.is_initialized():
+            dist.all_reduce(graphed.flat_grad, op=dist.ReduceOp.SUM, group=group)
+            graphed.flat_grad.mul_(1.0 / world)
+        return
+    graphed.run_first()
+    late = dist.all_reduce(graphed.flat_late, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    graphed.run_second()                                   # overlaps the exchange above
+    early = dist.all_reduce(graphed.flat_early, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    late.wait()
+    early.wait()
+    graphed.flat_grad.mul_(1.0 / world)

@@ -70,6 +70,66 @@ def test_grad_reducer_world2_gloo():
     assert got == [(0, "ok"), (1, "ok")]
 
 
+class _FakeGraphedStep:
+    """stands in for hs_pose_amd.graph.GraphedStep on the CPU: the same buffers and entry points, gradients made up"""
+
+    def __init__(self, rank, split):
+        self.split = split
+        self.flat_grad = torch.zeros(1000)
+        self.flat_late, self.flat_early = self.flat_grad[:700], self.flat_grad[700:]
+        self.rank, self.step, self.calls = rank, 0, []
+
+    def _grads(self):
+        g = torch.Generator().manual_seed(100 * self.step + self.rank)
+        return torch.randn(1000, generator=g)
+
+    def run(self):
+        self.calls.append("run")
+        self.flat_grad.copy_(self._grads())
+        self.step += 1
+
+    def run_first(self):
+        self.calls.append("first")
+        self.flat_late.copy_(self._grads()[:700])
+
+    def run_second(self):
+        self.calls.append("second")
+        self.flat_early.copy_(self._grads()[700:])
+        self.step += 1
+
+
+def _worker_graphed(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from hs_pose_amd.parallel import graphed_step_with_exchange, init_distributed
+    init_distributed()
+    for split in (False, True):
+        fake = _FakeGraphedStep(rank, split)
+        for step in range(3):
+            graphed_step_with_exchange(fake, world)
+            want = sum(torch.randn(1000, generator=torch.Generator().manual_seed(100 * step + r)) for r in range(world)) / world
+            assert torch.allclose(fake.flat_grad, want, rtol=1e-6, atol=1e-7), (split, step)
+        assert fake.calls == (["first", "second"] * 3 if split else ["run"] * 3)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, "ok"))
+
+
+def test_graphed_step_exchange_world2_gloo():
+    """the gradient exchange bench.py uses around the graph replays (one all-reduce, or two with the first overlapped):
+    flat buffer == mean over the ranks, every step"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_graphed, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got == [(0, "ok"), (1, "ok")]
+    assert all(p.exitcode == 0 for p in procs)
+
+
 def test_shard_range_covers_batch():
     from hs_pose_amd.parallel import shard_range
     for n in (1, 7, 16, 128, 129):
