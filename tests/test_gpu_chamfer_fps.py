@@ -48,3 +48,21 @@ def test_fps_golden_and_oracle(dev, ref, oc):
     assert np.array_equal(ops.fps(pts.to(dev), 257).cpu().numpy(), oc.fps_f32(pts.numpy(), 257))
     pts = ref.hash_tensor((2, 3000, 3), 83, 0.2)
     assert np.array_equal(ops.fps(pts.to(dev), 100).cpu().numpy(), oc.fps_f32(pts.numpy(), 100))
+
+
+@pytest.mark.parametrize("B,N,m", [(3, 50, 50), (2, 128, 40), (2, 129, 129), (16, 1028, 256), (2, 1281, 300), (2, 2048, 128),
+                                   (3, 4096, 1024), (1, 5000, 200), (1, 12288, 64), (1, 13000, 64)])
+def test_fps_every_launch_shape(dev, ref, oc, B, N, m):
+    """each register-resident instantiation (threads x points per thread), the LDS limit and the generic kernel behind it:
+    bit-exact picks against the C oracle"""
+    from hs_pose_amd import ops
+    pts = ref.hash_tensor((B, N, 3), 84 + N, 0.2)
+    assert np.array_equal(ops.fps(pts.to(dev), m).cpu().numpy(), oc.fps_f32(pts.numpy(), m))
+
+
+def test_fps_duplicate_points(dev, ref, oc):
+    """tiled clouds: after the distinct points are exhausted every distance-to-set is 0 and the first index wins"""
+    from hs_pose_amd import ops
+    base = ref.hash_tensor((2, 100, 3), 90, 0.2)
+    pts = torch.cat([base, base, base[:, :56]], dim=1).contiguous()         # 256 points, 100 distinct
+    assert np.array_equal(ops.fps(pts.to(dev), 180).cpu().numpy(), oc.fps_f32(pts.numpy(), 180))
