@@ -14,34 +14,66 @@
 
 namespace hsp {
 
-#define PC_THREADS 1024
+#define PC_CHUNK 4096          // pixels per workgroup: 256 threads x 16 consecutive pixels (row-major order is kept)
 
-// one workgroup per image: row-major stream compaction of {p : mask[p] > 0 && depth[p] > 0}
-__global__ __launch_bounds__(PC_THREADS) void pc_compact_kernel(const float* __restrict__ mask,
-                                                                const float* __restrict__ depth, int HW,
-                                                                int32_t* __restrict__ pix,
-                                                                int32_t* __restrict__ count) {
-    __shared__ int part[PC_THREADS];
-    const int b = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ bool pc_valid(float m, float d) { return m * (d > 0.f ? 1.f : 0.f) > 0.f; }
+
+// row-major stream compaction of {p : mask[p] > 0 && depth[p] > 0}, many workgroups per image, two launches:
+//   pc_count_kernel   grid (nchunk, B): valid pixels of each 4096-pixel chunk -> cnt[b][chunk]
+//   pc_write_kernel   grid (nchunk, B): offset = sum of the earlier chunks' counts, scan inside the chunk, ids written;
+//                                       the last chunk's workgroup writes the image's total
+// (one workgroup per image moved 75 GB/s: 16 workgroups on 256 CUs)
+__global__ __launch_bounds__(256) void pc_count_kernel(const float* __restrict__ mask, const float* __restrict__ depth,
+                                                       int HW, int nchunk, int32_t* __restrict__ cnt) {
+    __shared__ int wsum[4];
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     const float* mb = mask + (size_t)b * HW;
     const float* db = depth + (size_t)b * HW;
-    const int per = (HW + PC_THREADS - 1) / PC_THREADS;
-    const int lo = min(tid * per, HW), hi = min(lo + per, HW);
+    const int lo = min(chunk * PC_CHUNK + tid * 16, HW), hi = min(lo + 16, HW);
     int c = 0;
-    for (int p = lo; p < hi; ++p) c += (mb[p] * (db[p] > 0.f ? 1.f : 0.f) > 0.f) ? 1 : 0;
-    part[tid] = c;
+    for (int p = lo; p < hi; ++p) c += pc_valid(mb[p], db[p]) ? 1 : 0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m);
+    if ((tid & 63) == 0) wsum[tid >> 6] = c;
     __syncthreads();
-    for (int d = 1; d < PC_THREADS; d <<= 1) {
-        const int v = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    if (tid == 0) cnt[(size_t)b * nchunk + chunk] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+__global__ __launch_bounds__(256) void pc_write_kernel(const float* __restrict__ mask, const float* __restrict__ depth,
+                                                       int HW, int nchunk, const int32_t* __restrict__ cnt,
+                                                       int32_t* __restrict__ pix, int32_t* __restrict__ count) {
+    __shared__ int red[4];
+    __shared__ int wpre[4];
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    // offset of this chunk = sum of the counts of the image's earlier chunks
+    int part = 0;
+    for (int c = tid; c < chunk; c += 256) part += cnt[(size_t)b * nchunk + c];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m);
+    if (lane == 0) red[wv] = part;
+    const float* mb = mask + (size_t)b * HW;
+    const float* db = depth + (size_t)b * HW;
+    const int lo = min(chunk * PC_CHUNK + tid * 16, HW), hi = min(lo + 16, HW);
+    unsigned bits = 0;
+    for (int p = lo; p < hi; ++p) bits |= (pc_valid(mb[p], db[p]) ? 1u : 0u) << (p - lo);
+    const int c = __popc(bits);
+    int incl = c;                                            // inclusive scan inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
     }
-    int off = tid ? part[tid - 1] : 0;
+    if (lane == 63) wpre[wv] = incl;
+    __syncthreads();
+    const int base = (red[0] + red[1]) + (red[2] + red[3]);
+    int woff = 0;
+    for (int w = 0; w < wv; ++w) woff += wpre[w];
+    int off = base + woff + incl - c;
     int32_t* out = pix + (size_t)b * HW;
     for (int p = lo; p < hi; ++p)
-        if (mb[p] * (db[p] > 0.f ? 1.f : 0.f) > 0.f) out[off++] = p;
-    if (tid == PC_THREADS - 1) count[b] = part[tid];
+        if ((bits >> (p - lo)) & 1u) out[off++] = p;
+    if (chunk == nchunk - 1 && tid == 255) count[b] = base + woff + incl;
 }
 
 // PC[b,s,:] = ( (u - cx) * d / fx, (v - cy) * d / fy, d ) / 1000   for pixel pix[b, choose[b,s]]
@@ -144,10 +176,23 @@ __global__ __launch_bounds__(64) void generate_rt_kernel(const float* __restrict
 
 using namespace hsp;
 
+extern "C" size_t hsp_pc_compact_workspace_bytes(int B, int HW) {
+    if (B <= 0 || HW <= 0) return 0;
+    return (size_t)B * ((HW + PC_CHUNK - 1) / PC_CHUNK) * sizeof(int32_t);
+}
+
 extern "C" int hsp_pc_compact(const float* mask, const float* depth, int B, int HW, int32_t* pix, int32_t* count,
-                              hspStream_t stream) {
+                              void* ws, size_t ws_bytes, hspStream_t stream) {
     if (!mask || !depth || !pix || !count || B <= 0 || HW <= 0) return HSP_ERR_BAD_ARG;
-    hipLaunchKernelGGL(pc_compact_kernel, dim3(B), dim3(PC_THREADS), 0, as_stream(stream), mask, depth, HW, pix, count);
+    if (!ws || ws_bytes < hsp_pc_compact_workspace_bytes(B, HW)) return HSP_ERR_WORKSPACE;
+    const int nchunk = (HW + PC_CHUNK - 1) / PC_CHUNK;
+    if (nchunk > 65535) return HSP_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    int32_t* cnt = reinterpret_cast<int32_t*>(ws);
+    hipLaunchKernelGGL(pc_count_kernel, dim3(nchunk, B), dim3(256), 0, st, mask, depth, HW, nchunk, cnt);
+    int rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(pc_write_kernel, dim3(nchunk, B), dim3(256), 0, st, mask, depth, HW, nchunk, cnt, pix, count);
     return check_launch();
 }
 

@@ -878,7 +878,10 @@ def pc_compact(mask, depth):
     B, HW = mask.shape
     pix = torch.empty(B, HW, dtype=torch.int32, device=mask.device)
     count = torch.empty(B, dtype=torch.int32, device=mask.device)
-    _run("hsp_pc_compact", (_p(mask), _p(depth), B, HW, _p(pix), _p(count), _stream()),
+    L = lib()
+    wsb = L.hsp_pc_compact_workspace_bytes(B, HW)
+    ws = _ws(wsb, mask.device)
+    _run("hsp_pc_compact", (_p(mask), _p(depth), B, HW, _p(pix), _p(count), _p(ws), wsb, _stream()),
          key=f"B{B}HW{HW}", abytes=B * HW * 12)
     return pix, count
 

@@ -239,8 +239,9 @@ int hsp_bn_relu_bwd(const float *x, const float *dy, int R, int C, const float *
  * hsp_pc_gather back-projects the chosen pixels: pc (B,S,3) = ((u-cx)*d/fx, (v-cy)*d/fy, d) / 1000,
  * coor2d (B,2,HW), camK (B,3,3), choose (B,S) int32.
  */
+size_t hsp_pc_compact_workspace_bytes(int B, int HW);   /* per-chunk counts of the two-launch compaction */
 int hsp_pc_compact(const float *mask, const float *depth, int B, int HW, int32_t *pix, int32_t *count,
-                   hspStream_t stream);
+                   void *ws, size_t ws_bytes, hspStream_t stream);
 int hsp_pc_gather(const float *depth, const float *coor2d, const float *camK, const int32_t *pix,
                   const int32_t *choose, int B, int HW, int S, float *pc, hspStream_t stream);
 

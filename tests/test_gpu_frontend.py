@@ -24,7 +24,7 @@ def test_pc_compact_is_row_major_boolean_indexing(dev, ref):
         assert np.array_equal(pix[b, :len(want)].cpu().numpy(), want)          # integer work: bit-exact
 
 
-@pytest.mark.parametrize("HW", [1, 63, 1024, 1025, 65536, 256 * 256 + 7])
+@pytest.mark.parametrize("HW", [1, 63, 1024, 1025, 4095, 4096, 4097, 65536, 256 * 256 + 7, 480 * 640])
 def test_pc_compact_sizes(dev, ref, HW):
     from hs_pose_amd import ops
     m = (ref.hash_tensor((2, HW), 31, 0.5, 0.5) > 0.4).float()
@@ -34,6 +34,18 @@ def test_pc_compact_sizes(dev, ref, HW):
         want = ref.valid_pixels(m[b], d[b]).numpy()
         assert int(count[b]) == len(want)
         assert np.array_equal(pix[b, :len(want)].cpu().numpy(), want)
+
+
+def test_pc_compact_all_and_none(dev, ref):
+    """every pixel valid (the ids fill the whole row) and no pixel valid (count 0), several chunks per image"""
+    from hs_pose_amd import ops
+    HW = 3 * 4096 + 100
+    ones = torch.ones(2, HW)
+    depth = torch.full((2, HW), 700.0)
+    depth[1] = 0.0
+    pix, count = ops.pc_compact(ones.to(dev), depth.to(dev))
+    assert count.cpu().tolist() == [HW, 0]
+    assert torch.equal(pix[0].cpu(), torch.arange(HW, dtype=torch.int32))
 
 
 def test_pc_sample_matches_reference(dev, ref, flags):
