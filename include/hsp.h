@@ -147,7 +147,7 @@ int hsp_gather_max_bwd_csr(const float *grad_out, int grad_bcast, const uint8_t 
                            hspStream_t stream);
 
 /* ---- max over the points of a cloud (the heads' global feature) ------------------------------
- * replaces torch.max(x, 2, keepdim=True)[0]    PoseR.py:29 / :60, PoseTs.py:33, FaceRecon.py:98
+ * replaces torch.max(x, 2, keepdim=True)[0]    PoseR.py:30 / :61, PoseTs.py:35, FaceRecon.py:98
  * x (B,N,C) point-major; out (B,C) = max_n x[b,n,c]; argrow (B,C) int32 = the FIRST row attaining
  * it (NaN counts as the maximum, as in ATen).  bwd: grad_x (B,N,C) is OVERWRITTEN with grad_out on
  * the winning row and 0 elsewhere (C % 4 == 0). */

@@ -91,7 +91,7 @@ def orl_global(feature: Tensor, xyz: Tensor, k: int) -> Tensor:
 
 def points_max(feature: Tensor) -> Tensor:
     """(B,N,C) -> (B,C): the heads' max over the points, torch.max(x, 2, keepdim=True)[0] on the reference's (B,C,N)
-    layout (PoseR.py:29, :60; PoseTs.py:33; FaceRecon.py:98)."""
+    layout (PoseR.py:30, :61; PoseTs.py:35; FaceRecon.py:98)."""
     return torch.max(feature.transpose(1, 2), 2, keepdim=True)[0].squeeze(-1)
 
 
