@@ -24,7 +24,7 @@ def _conv_bn_relu_rows(seq, x, n_blocks):
     """Apply n_blocks x (Conv1d k=1, BatchNorm1d, ReLU) of an nn.Sequential to (R, C) rows."""
     for i in range(n_blocks):
         conv, bn = seq[3 * i], seq[3 * i + 1]
-        x = ops.bn_relu(F.linear(x, conv.weight.squeeze(-1), conv.bias), bn)         # fused BatchNorm + ReLU (norm.hip)
+        x = ops.bn_relu(ops.linear_rows(x, conv.weight.squeeze(-1), conv.bias), bn)         # fused BatchNorm + ReLU (norm.hip)
     return x
 
 
@@ -97,11 +97,11 @@ class FaceRecon(nn.Module):
             h = _conv_bn_relu_rows(self.conv1d_block, rows, 3)                       # (B*N, 256)
             r = _conv_bn_relu_rows(self.recon_head, h, 1)
             last = self.recon_head[3]
-            recon = F.linear(r, last.weight.squeeze(-1), last.bias).view(bs, vertice_num, -1)
+            recon = ops.linear_rows(r, last.weight.squeeze(-1), last.bias).view(bs, vertice_num, -1)
             face_in = torch.cat([f_global.unsqueeze(1).expand(-1, vertice_num, -1).reshape(bs * vertice_num, -1), h,
                                  vertices.reshape(bs * vertice_num, 3)], dim=1)
             f = _conv_bn_relu_rows(self.face_head, face_in, 3)
             last = self.face_head[9]
-            face = F.linear(f, last.weight.squeeze(-1), last.bias).view(bs, vertice_num, -1)
+            face = ops.linear_rows(f, last.weight.squeeze(-1), last.bias).view(bs, vertice_num, -1)
             return recon, face, feat
         return None, None, feat

@@ -56,8 +56,12 @@ class HSPose(nn.Module):
                 PC, gt_R, gt_t, gt_s = self.data_augment(PC, gt_R, gt_t, gt_s, mean_shape, sym, aug_bb, aug_rt_t,
                                                          aug_rt_r, model_point, nocs_scale, obj_id)
 
-        recon, face_normal, face_dis, face_f, p_green_R, p_red_R, f_green_R, f_red_R, \
-            Pred_T, Pred_s = self.posenet(PC, obj_id)
+        runner = self.graphed_posenet
+        if runner is not None and self.training and torch.is_grad_enabled() and PC.shape == runner.PC.shape:
+            net_out = runner(PC, obj_id)                      # two hipGraph replays behind one autograd node
+        else:
+            net_out = self.posenet(PC, obj_id)
+        recon, face_normal, face_dis, face_f, p_green_R, p_red_R, f_green_R, f_red_R, Pred_T, Pred_s = net_out
 
         output_dict['mask'] = obj_mask
         output_dict['sketch'] = sketch
@@ -102,6 +106,16 @@ class HSPose(nn.Module):
 
         loss_dict = {'fsnet_loss': fsnet_loss, 'recon_loss': recon_loss, 'geo_loss': geo_loss, 'prop_loss': prop_loss}
         return output_dict, loss_dict
+
+    graphed_posenet = None
+
+    def enable_graphed_posenet(self, PC, obj_id):
+        """capture ``posenet`` forward / backward for training batches of this shape (hs_pose_amd.graph.GraphedNetwork);
+        ``forward`` then replays the graphs whenever a training batch has that shape and runs eagerly otherwise.
+        Call it before the first eager backward of the network, with FLAGS.train set as in training."""
+        from .graph import GraphedNetwork
+        object.__setattr__(self, "graphed_posenet", GraphedNetwork(self.posenet, PC, obj_id))
+        return self.graphed_posenet
 
     def data_augment(self, PC, gt_R, gt_t, gt_s, mean_shape, sym, aug_bb, aug_rt_t, aug_rt_r, model_point, nocs_scale,
                      obj_ids, check_points=False):

@@ -32,12 +32,12 @@ class _PointMLPHead(nn.Module):
     def forward_rows(self, x: "(B, N, f)"):
         b, n, c = x.shape
         h = x.reshape(b * n, c)
-        h = ops.bn_relu(F.linear(h, self.conv1.weight.squeeze(-1), self.conv1.bias), self.bn1)   # fused BN + ReLU
-        h = ops.bn_relu(F.linear(h, self.conv2.weight.squeeze(-1), self.conv2.bias), self.bn2)
+        h = ops.bn_relu(ops.linear_rows(h, self.conv1.weight.squeeze(-1), self.conv1.bias), self.bn1)   # fused BN + ReLU
+        h = ops.bn_relu(ops.linear_rows(h, self.conv2.weight.squeeze(-1), self.conv2.bias), self.bn2)
         h = ops.points_max(h.view(b, n, -1))                                     # (B,256)
-        h = ops.bn_relu(F.linear(h, self.conv3.weight.squeeze(-1), self.conv3.bias), self.bn3)
+        h = ops.bn_relu(ops.linear_rows(h, self.conv3.weight.squeeze(-1), self.conv3.bias), self.bn3)
         h = self.drop1(h)
-        return F.linear(h, self.conv4.weight.squeeze(-1), self.conv4.bias).contiguous()
+        return ops.linear_rows(h, self.conv4.weight.squeeze(-1), self.conv4.bias).contiguous()
 
     def forward(self, x: "(B, f, N)"):
         return self.forward_rows(x.transpose(1, 2))

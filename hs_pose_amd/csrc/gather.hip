@@ -144,6 +144,27 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     }
 }
 
+// the same first stage for widths the float4 form does not take (C not a multiple of 4, or C/4 not dividing 256;
+// C <= 256): thread = (row lane, column), consecutive threads read consecutive words
+__global__ __launch_bounds__(256) void colsum_partial_scalar_kernel(const float* __restrict__ x, int N, int C,
+                                                                    float* __restrict__ part, int nchunk, int rows) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int RL = 256 / C;
+    const int col = tid % C, rl = tid / C;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int r0 = chunk * rows, r1 = min(N, r0 + rows);
+    float s = 0.f;
+    if (rl < RL)
+        for (int i = r0 + rl; i < r1; i += RL) s += x[((size_t)b * N + i) * C + col];
+    red[tid] = s;
+    __syncthreads();
+    if (rl == 0) {
+        for (int l = 1; l < RL; ++l) s += red[l * C + col];
+        part[((size_t)b * nchunk + chunk) * C + col] = s;
+    }
+}
+
 // feat rows assembled from column segments (reference FaceRecon.py:100-107: nearest up-sampling gathers,
 // one-hot category columns and torch.cat) in ONE pass: segment s of row (b,i) comes from
 //   kind 0: src[(b*N + i)*w + c]      kind 1: src[(b*Ns + idx[b*N+i])*w + c]      kind 2: src[b*w + c]
@@ -462,8 +483,10 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float* __res
 
 // points per chunk for the two-stage per-cloud reductions: enough chunks to fill the chip, at least one
 // row per row-lane, at most ORL_ROWS (the workspace is sized for the smallest chunk count = ORL_ROWS rows)
+static bool colsum_vec4(int C) { return !(C & 3) && !(256 % (C >> 2)); }
+
 static int chunk_rows(int B, int N, int C) {
-    const int RL = 256 / (C >> 2);
+    const int RL = colsum_vec4(C) ? 256 / (C >> 2) : (C <= 256 ? 256 / C : 1);
     long long r = ((long long)B * N + 511) / 512;           // ~512 workgroups ...
     if (r < (N + 31) / 32) r = (N + 31) / 32;               // ... but at most 32 chunks per cloud for the serial fold
     if (r < RL) r = RL;
@@ -697,7 +720,7 @@ extern "C" int hsp_points_max_bwd(const float* grad_out, const int32_t* argrow, 
 }
 
 extern "C" size_t hsp_orl_workspace_bytes(int B, int N, int C) {
-    if (B <= 0 || N <= 0 || C <= 0 || (C & 3) || (256 % (C >> 2))) return 0;
+    if (B <= 0 || N <= 0 || C <= 0 || (!colsum_vec4(C) && C > 256)) return 0;
     const int rows = chunk_rows(B, N, C);
     return (size_t)B * ((N + rows - 1) / rows) * C * sizeof(float);
 }
@@ -719,13 +742,16 @@ extern "C" int hsp_orl_global_fwd(const float* feat, const int32_t* idx, int B, 
 extern "C" int hsp_colsum_rows(const float* x, int B, int N, int C, float* out, void* ws, size_t ws_bytes,
                                hspStream_t stream) {
     if (!x || !out || B <= 0 || N <= 0 || C <= 0) return HSP_ERR_BAD_ARG;
-    if ((C & 3) || (256 % (C >> 2))) return HSP_ERR_UNSUPPORTED;
+    if (!colsum_vec4(C) && C > 256) return HSP_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < hsp_orl_workspace_bytes(B, N, C)) return HSP_ERR_WORKSPACE;
     hipStream_t st = as_stream(stream);
     const int rows = chunk_rows(B, N, C);
     const int nchunk = (N + rows - 1) / rows;
     float* part = reinterpret_cast<float*>(ws);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, x, N, C, part, nchunk, rows);
+    if (colsum_vec4(C))
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, x, N, C, part, nchunk, rows);
+    else
+        hipLaunchKernelGGL(colsum_partial_scalar_kernel, dim3(nchunk, B), dim3(256), 0, st, x, N, C, part, nchunk, rows);
     hipLaunchKernelGGL(chunk_fold_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, B, nchunk, C, 1.0f, out);
     return check_launch();
 }

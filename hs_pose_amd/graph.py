@@ -340,3 +340,94 @@ class GraphedInference:
         self._draw()
         self.graph.replay()
         return self.pred_RT, self.pred_s, self.output_dict
+
+
+class _GraphedNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, runner, anchor):
+        ctx.runner = runner
+        runner.graph_fwd.replay()
+        outs = tuple(o.detach() for o in runner.outs)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        r = ctx.runner
+        for buf, g in zip(r.gouts, gouts):
+            if g is None:
+                buf.zero_()
+            else:
+                buf.copy_(g)
+        r.graph_bwd.replay()
+        have = [(p, g) for p, g in zip(r.params, r.pgrads) if g is not None]
+        acc = [(p.grad, g) for p, g in have if p.grad is not None]
+        if acc:
+            torch._foreach_add_([a for a, _ in acc], [g for _, g in acc])
+        for p, g in have:
+            if p.grad is None:
+                p.grad = g.clone()
+        return None, None
+
+
+class GraphedNetwork:
+    """``posenet(PC, obj_id)`` of a training step as two hipGraphs behind ONE autograd node: the forward graph produces
+    the ten network outputs in static buffers, the backward graph takes their gradients from static buffers and leaves
+    the parameter gradients in static buffers, which the node adds into ``p.grad`` with one multi-tensor add.  Losses,
+    augmentation and the optimizer stay eager (they are not part of the captured region), so this is the part of
+    ``engine/train.py``'s step that is pure kernels + library GEMMs: ~400 launches and their autograd bookkeeping become
+    two replays.  The network's Conv1d(k=1) layers go through ``ops.linear_rows`` (bias gradient by the column-sum
+    kernels), BatchNorm through ``ops.bn_relu`` and the max over points through ``ops.points_max``, so the captured
+    graphs contain no ATen multi-block reduction (see GraphedTrainStep for why that matters on ROCm 7.2).
+
+    ``runner = GraphedNetwork(net.posenet, PC, obj_id)`` (example inputs of the step's shape, B and N fixed);
+    ``outs = runner(PC, obj_id)`` inside the usual step, ``loss.backward()`` as usual.  The Pool_layer permutations are
+    drawn on the host generator before every replay, dropout uses the device generator inside the graph."""
+
+    def __init__(self, posenet, PC, obj_id, warmup=3):
+        self.net = posenet
+        self.PC = PC.detach().clone()
+        self.obj_id = obj_id.detach().clone()
+        B, N, _ = PC.shape
+        self.n_points = N
+        dev = PC.device
+        self.pool_idx = [torch.empty(int(N / 4), dtype=torch.int32, device=dev),
+                         torch.empty(int(int(N / 4) / 4), dtype=torch.int32, device=dev)]
+        self.params = [p for p in posenet.parameters() if p.requires_grad]
+        self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+        upload_pool_indices(self.pool_idx, N)
+        prev_timer = ops.set_timer(None)
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    outs = self._forward()
+                    live = [o for o in outs if o is not None and o.requires_grad]
+                    torch.autograd.grad(live, self.params, [torch.zeros_like(o) for o in live], allow_unused=True)
+                del outs, live
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph_fwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_fwd):
+                outs = self._forward()
+            self.none_mask = [o is None for o in outs]
+            self.outs = [o for o in outs if o is not None]
+            self.gouts = [torch.zeros_like(o) for o in self.outs]
+            self.graph_bwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_bwd, pool=self.graph_fwd.pool()):
+                self.pgrads = list(torch.autograd.grad(self.outs, self.params, self.gouts, allow_unused=True))
+        finally:
+            ops.set_timer(prev_timer)
+
+    def _forward(self):
+        with gcn3d.pool_index_feed(self.pool_idx):
+            return self.net(self.PC, self.obj_id)
+
+    def __call__(self, PC, obj_id):
+        if PC.shape != self.PC.shape:
+            raise RuntimeError(f"GraphedNetwork was captured for {tuple(self.PC.shape)}, got {tuple(PC.shape)}")
+        self.PC.copy_(PC)
+        self.obj_id.copy_(obj_id.reshape(self.obj_id.shape))
+        upload_pool_indices(self.pool_idx, self.n_points)
+        live = iter(_GraphedNetFn.apply(self, self._anchor))
+        return tuple(None if isnone else next(live) for isnone in self.none_mask)

@@ -352,7 +352,11 @@ def _wgrad_library(A2, B2, out, colsum):
         torch.mm(A2.t(), B2, out=out)
     else:
         out.copy_(A2.t() @ B2)
-    return (out, B2.sum(dim=0)) if colsum else out
+    if not colsum:
+        return out
+    if B2.is_contiguous():                                   # two-stage kernel: no ATen multi-block reduction
+        return out, colsum_rows(B2.view(1, B2.shape[0], B2.shape[1])).view(-1)
+    return out, B2.sum(dim=0)
 
 
 def _wgrad_custom(A2, B2, out, colsum):
@@ -432,7 +436,7 @@ def _residual_bias(out3, f3, t2):
 def colsum_rows(x3):
     """(B,C) = x3.sum(dim=1) for a contiguous (B,N,C) fp32 tensor: deterministic two-stage column sum"""
     B, N, C = x3.shape
-    if C % 4 or 256 % (C // 4) or not x3.is_contiguous():
+    if ((C % 4 or 256 % (C // 4)) and C > 256) or not x3.is_contiguous():
         return x3.sum(dim=1)
     out = torch.empty(B, C, dtype=torch.float32, device=x3.device)
     L = lib()
@@ -633,6 +637,41 @@ def hs_layer(xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste, w_con
 def surface_layer(xyz, idx_x, k, S, directions, w_ste, w_conv2):
     """HSlayer_surface.forward (gcn3d.py:79-90) given the xyz neighbour index (exactly k columns)."""
     return _SurfaceLayer.apply(xyz, idx_x, k, S, directions, w_ste, w_conv2)
+
+
+class _LinearRows(torch.autograd.Function):
+    """y = x W^T + b over point rows (the Conv1d(k=1) layers of the heads, PoseR.py:27-36 / PoseTs.py:32-44 /
+    FaceRecon.py:38-66): library GEMMs for y and dx, the parameter-gradient kernel for dW with the bias gradient as its
+    fused column sum (or the two-stage column-sum kernel) -- no ATen multi-block reduction anywhere, which keeps the node
+    replayable inside a hipGraph (graph.py::GraphedNetwork)."""
+
+    @staticmethod
+    def forward(ctx, x2, weight, bias):
+        x2 = _req(x2, torch.float32, "linear_rows.x")
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias = bias is not None
+        return torch.addmm(bias, x2, weight.t()) if bias is not None else torch.mm(x2, weight.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, weight = ctx.saved_tensors
+        g = _req(g, torch.float32, "linear_rows.grad")
+        gx = torch.mm(g, weight) if ctx.needs_input_grad[0] else None
+        R, Cout = g.shape
+        gb = None
+        if Cout % 64 == 0 and x2.shape[1] % 64 == 0:
+            gwt, gb = wgrad(x2, g, colsum=True)                 # (Cin, Cout) = dW^T, column sums of g = db
+            gw = gwt.t()
+        else:
+            gw = torch.mm(g.t(), x2)
+            if ctx.has_bias:
+                gb = colsum_rows(g.view(1, R, Cout)).view(Cout)
+        return gx, gw, (gb if ctx.has_bias else None)
+
+
+def linear_rows(x2, weight, bias=None):
+    """F.linear(x2, weight, bias) for (R, Cin) rows with a graph-replayable backward."""
+    return _LinearRows.apply(x2, weight, bias)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -100,3 +100,72 @@ def test_graphed_inference_matches_eager(dev, n):
         assert (out_g[k] - out[k]).abs().max().item() <= 1e-5, k
     assert (RT_g - RT).abs().max().item() <= 1e-5
     assert (s_g - (out['Pred_s'] + mean_shape)).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("B,N", [(4, 256), (16, 1028)])
+def test_graphed_posenet_training_step_matches_eager(dev, B, N):
+    """HSPose.forward(do_loss=True) with posenet replayed from its two hipGraphs (GraphedNetwork; losses eager) against
+    the all-eager step on a twin network: all loss terms, every parameter gradient, the parameters after the Ranger step.
+    Default runtime settings (graph packet capture on)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import ref_cpu as oc
+    from hs_pose_amd import gcn3d
+    from hs_pose_amd.config import FLAGS
+    from hs_pose_amd.HSPose import HSPose
+    from hs_pose_amd.train import TrainDriver
+    FLAGS.reset()
+    FLAGS.train = 1
+    FLAGS.aug_bb_pro = FLAGS.aug_rt_pro = FLAGS.aug_bc_pro = FLAGS.aug_pc_pro = -1.0
+    keys = ("PC", "obj_id", "gt_R", "gt_t", "gt_s", "mean_shape", "sym", "aug_bb", "aug_rt_t", "aug_rt_r", "model_point",
+            "nocs_scale")
+    case = {k: v.to(dev) for k, v in oc.hspose_train_case(B, N, 7).items()}
+    batch = {k: case[k] for k in keys}
+
+    def make():
+        torch.manual_seed(0)
+        net = HSPose("PoseNet_only").to(dev).train()
+        for m in net.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        return net, TrainDriver(net, total_iters=1000, check_nan=False)
+
+    def total_of(ld):
+        return sum(sum(d.values()) for d in ld.values())
+
+    try:
+        net_g, drv_g = make()
+        torch.manual_seed(3)
+        runner = net_g.enable_graphed_posenet(batch["PC"], batch["obj_id"])
+        for _ in range(2):                                      # replays must not accumulate state across steps
+            drv_g.optimizer.zero_grad()
+            _, ld_g = net_g(do_loss=True, **batch)
+            total_of(ld_g).backward()
+        torch.cuda.synchronize()
+        pool = [p.clone() for p in runner.pool_idx]
+        grads_g = {k: p.grad.detach().clone() for k, p in net_g.named_parameters()}
+
+        net_e, drv_e = make()
+        with gcn3d.pool_index_feed(pool):
+            _, ld_e = net_e(do_loss=True, **batch)
+        drv_e.optimizer.zero_grad()
+        total_of(ld_e).backward()
+        torch.cuda.synchronize()
+        for g in ld_e:
+            for k in ld_e[g]:
+                a, b = float(ld_e[g][k]), float(ld_g[g][k])
+                assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), f"loss {g}.{k}: eager {a} graph {b}"
+        gmax = max(p.grad.abs().max().item() for p in net_e.parameters() if p.grad is not None)
+        for k, p in net_e.named_parameters():
+            if p.grad is None:
+                continue
+            err = (p.grad - grads_g[k]).abs().max().item()
+            assert err <= 1e-4 * gmax, f"grad {k}: |diff| {err:.3e} vs max|grad| {gmax:.3e}"
+        for drv in (drv_g, drv_e):
+            drv.optimizer.clip_grad_norm_(5)
+            drv.optimizer.step()
+        pe = dict(net_e.named_parameters())
+        for k, p in net_g.named_parameters():
+            assert (p - pe[k]).abs().max().item() <= 1e-5 * max(1.0, p.abs().max().item()), k
+    finally:
+        FLAGS.reset()

@@ -10,7 +10,7 @@ import sys
 import time
 
 # read by the HIP runtime when it starts: GraphedTrainStep needs it (see hs_pose_amd/graph.py)
-if "--no-graph" not in sys.argv:
+if "--no-graph" not in sys.argv and "--graph-net" not in sys.argv:
     os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--points", type=int, default=1028)
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly (CPU-bound) instead of replaying a hipGraph")
+    ap.add_argument("--graph-net", action="store_true", help="eager step with posenet forward/backward replayed from two hipGraphs")
     args = ap.parse_args()
     from hs_pose_amd import gemm_tuning
     from hs_pose_amd.config import FLAGS
@@ -51,7 +52,9 @@ def main():
         return total
 
     graphed = None
-    if not args.no_graph:
+    if args.graph_net:
+        net.enable_graphed_posenet(case["PC"], case["obj_id"])
+    if not args.no_graph and not args.graph_net:
         from hs_pose_amd.graph import GraphedTrainStep
         # (no eager step first: the network's first backward has to run on the capture stream -- see GraphedTrainStep)
         batch = {k: case[k] for k in ("PC", "obj_id", "gt_R", "gt_t", "gt_s", "mean_shape", "sym", "aug_bb", "aug_rt_t",
@@ -93,7 +96,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(json.dumps({"unit": "U3 full training step (HSPose do_loss + backward + clip + Ranger), "
-                              + ("hipGraph replay" if graphed is not None else "eager"),
+                              + ("hipGraph replay" if graphed is not None else "eager, posenet graphed" if args.graph_net else "eager"),
                       "batch": args.batch, "points": args.points, "ms_per_step": round(1e3 * dt / args.steps, 3),
                       "clouds_per_s": round(args.batch * args.steps / dt, 1), "last_total_loss": float(total.detach())}))
 
