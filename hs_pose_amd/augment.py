@@ -11,6 +11,8 @@ import contextlib
 
 import torch
 
+from . import staging
+
 from .config import FLAGS
 
 _noise_feed = None
@@ -69,11 +71,19 @@ def defor_3D_bc_in_batch(pc, R, t, s, model_point, nocs_scale):
     return pc_new, s_new, ey_up, ey_down
 
 
+def _host_rand(like):
+    """``torch.rand(shape).to(device)`` of the reference (CPU default generator), uploaded through the pinned staging ring
+    (hs_pose_amd/staging.py) so the host does not wait for the previous training step."""
+    if not like.is_cuda:
+        return torch.rand(like.shape)
+    return staging.upload(lambda buf: torch.rand(like.shape, out=buf), like.shape, torch.float32, like.device)
+
+
 def defor_3D_pc(pc, gt_t, r=0.2, points_defor=None, return_defor=False):
     """every coordinate moves away from the object centre by a uniform fraction in [0, r); data_augmentation.py:137-144
     (the draw is made on the CPU generator and moved, like the reference's ``torch.rand(shape).to(device)``)."""
     if points_defor is None:
-        points_defor = _noise_feed if _noise_feed is not None else torch.rand(pc.shape).to(pc.device) * r
+        points_defor = _noise_feed if _noise_feed is not None else _host_rand(pc) * r
     new_pc = pc + points_defor * (pc - gt_t.unsqueeze(1))
     return (new_pc, points_defor) if return_defor else new_pc
 

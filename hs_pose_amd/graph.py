@@ -11,7 +11,7 @@ import os
 
 import torch
 
-from . import augment, gcn3d, ops
+from . import augment, gcn3d, ops, staging
 from .config import FLAGS
 
 
@@ -28,11 +28,11 @@ def draw_pool_indices(n_points, rate=4, levels=2):
 
 def upload_pool_indices(bufs, n_points):
     """draw the Pool_layer permutations (host generator, reference order) and queue their upload on the current
-    stream WITHOUT blocking the host: the copy comes from pinned staging memory (PyTorch's host allocator keeps the
-    block until the copy has run), stream-ordered after the previous replay and before the next, so the host can
-    enqueue step i+1 while step i is still running."""
+    stream WITHOUT blocking the host: the copy comes from a ring of pinned staging buffers (hs_pose_amd/staging.py),
+    stream-ordered after the previous replay and before the next, so the host can enqueue step i+1 while step i is still
+    running."""
     for buf, idx in zip(bufs, draw_pool_indices(n_points)):
-        buf.copy_(idx.to(torch.int32).pin_memory(), non_blocking=True)
+        staging.upload(lambda pinned, idx=idx: pinned.copy_(idx), buf.shape, torch.int32, buf.device, out=buf)
 
 
 class GraphedStep:
