@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_u3
 rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/tools/bench_train_step.py --steps 10 --warmup 3 --no-graph > $O/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/tools/bench_train_step.py --steps 10 --warmup 3 ${U3_MODE:---no-graph} > $O/bench.log 2>&1
 tail -1 $O/bench.log
 cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/u3_kernel_stats.csv
 python - $O/u3_kernel_stats.csv <<'PY'
