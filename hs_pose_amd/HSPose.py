@@ -56,8 +56,8 @@ class HSPose(nn.Module):
                 PC, gt_R, gt_t, gt_s = self.data_augment(PC, gt_R, gt_t, gt_s, mean_shape, sym, aug_bb, aug_rt_t,
                                                          aug_rt_r, model_point, nocs_scale, obj_id)
 
-        runner = self.graphed_posenet
-        if runner is not None and self.training and torch.is_grad_enabled() and PC.shape == runner.PC.shape:
+        runner = self.graphed_posenet.get(tuple(PC.shape)) if self.graphed_posenet else None
+        if runner is not None and self.training and torch.is_grad_enabled():
             net_out = runner(PC, obj_id)                      # two hipGraph replays behind one autograd node
         else:
             net_out = self.posenet(PC, obj_id)
@@ -111,11 +111,14 @@ class HSPose(nn.Module):
 
     def enable_graphed_posenet(self, PC, obj_id):
         """capture ``posenet`` forward / backward for training batches of this shape (hs_pose_amd.graph.GraphedNetwork);
-        ``forward`` then replays the graphs whenever a training batch has that shape and runs eagerly otherwise.
+        ``forward`` then replays the graphs whenever a training batch has a captured shape and runs eagerly otherwise
+        (call it once per shape, e.g. also for the last, smaller batch of an epoch).
         Call it before the first eager backward of the network, with FLAGS.train set as in training."""
         from .graph import GraphedNetwork
-        object.__setattr__(self, "graphed_posenet", GraphedNetwork(self.posenet, PC, obj_id))
-        return self.graphed_posenet
+        runners = dict(self.graphed_posenet or {})
+        runners[tuple(PC.shape)] = GraphedNetwork(self.posenet, PC, obj_id)
+        object.__setattr__(self, "graphed_posenet", runners)
+        return runners[tuple(PC.shape)]
 
     def data_augment(self, PC, gt_R, gt_t, gt_s, mean_shape, sym, aug_bb, aug_rt_t, aug_rt_r, model_point, nocs_scale,
                      obj_ids, check_points=False):

@@ -167,5 +167,10 @@ def test_graphed_posenet_training_step_matches_eager(dev, B, N):
         pe = dict(net_e.named_parameters())
         for k, p in net_g.named_parameters():
             assert (p - pe[k]).abs().max().item() <= 1e-5 * max(1.0, p.abs().max().item()), k
+        # a batch of another shape (the last one of an epoch) takes the eager path of the same network
+        small = {k: (v[:B - 1] if torch.is_tensor(v) and v.shape[:1] == (B,) else v) for k, v in batch.items()}
+        _, ld_s = net_g(do_loss=True, **small)
+        assert torch.isfinite(total_of(ld_s)).all()
+        total_of(ld_s).backward()
     finally:
         FLAGS.reset()
