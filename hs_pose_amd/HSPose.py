@@ -16,6 +16,10 @@ from .pc_sample import PC_sample
 from .PoseNet9D import PoseNet9D
 
 
+_NET_OUTPUTS = ('recon', 'face_normal', 'face_dis', 'face_f', 'p_green_R', 'p_red_R', 'f_green_R', 'f_red_R', 'Pred_T',
+                'Pred_s')
+
+
 def get_gt_v(Rs, axis=2):
     """green (y) and red (x) axes of the ground-truth rotations, R[:, :, 1] and R[:, :, 0] (tools/training_utils.py:59-73
     multiplies R by a 0/1 corner matrix and picks rows of the transposed product: the same numbers, exactly)."""
@@ -61,48 +65,33 @@ class HSPose(nn.Module):
             net_out = runner(PC, obj_id)                      # two hipGraph replays behind one autograd node
         else:
             net_out = self.posenet(PC, obj_id)
-        recon, face_normal, face_dis, face_f, p_green_R, p_red_R, f_green_R, f_red_R, Pred_T, Pred_s = net_out
-
-        output_dict['mask'] = obj_mask
-        output_dict['sketch'] = sketch
-        output_dict['recon'] = recon
-        output_dict['PC'] = PC
-        output_dict['face_normal'] = face_normal
-        output_dict['face_dis'] = face_dis
-        output_dict['face_f'] = face_f
-        output_dict['p_green_R'] = p_green_R
-        output_dict['p_red_R'] = p_red_R
-        output_dict['f_green_R'] = f_green_R
-        output_dict['f_red_R'] = f_red_R
-        output_dict['Pred_T'] = Pred_T
-        output_dict['Pred_s'] = Pred_s
-        output_dict['gt_R'] = gt_R
-        output_dict['gt_t'] = gt_t
-        output_dict['gt_s'] = gt_s
-
+        out = dict(zip(_NET_OUTPUTS, net_out))
+        # the reference's 16 keys in its order (HSPose.py:67-82): mask / sketch are always None in this training stage
+        output_dict.update(mask=obj_mask, sketch=sketch, recon=out['recon'], PC=PC)
+        output_dict.update({k: out[k] for k in _NET_OUTPUTS[1:]})
+        output_dict.update(gt_R=gt_R, gt_t=gt_t, gt_s=gt_s)
         if not do_loss:
             return output_dict
 
-        pred_fsnet_list = {'Rot1': p_green_R, 'Rot1_f': f_green_R, 'Rot2': p_red_R, 'Rot2_f': f_red_R, 'Recon': recon,
-                           'Tran': Pred_T, 'Size': Pred_s}
-        gt_green_v, gt_red_v = (None, None) if self.train_stage == 'Backbone_only' else get_gt_v(gt_R)
-        gt_fsnet_list = {'Rot1': gt_green_v, 'Rot2': gt_red_v, 'Recon': PC, 'Tran': gt_t, 'Size': gt_s}
-        fsnet_loss = self.loss_fs_net(self.name_fs_list, pred_fsnet_list, gt_fsnet_list, sym)
+        # the four loss modules read their inputs from dictionaries keyed as in the reference (HSPose.py:84-160); the axis
+        # confidences enter every loss except fs_net's own confidence terms as constants (detached)
+        axes = {'Rot1': out['p_green_R'], 'Rot2': out['p_red_R']}
+        conf = {'Rot1_f': out['f_green_R'], 'Rot2_f': out['f_red_R']}
+        conf_const = {k: v.detach() for k, v in conf.items()}
+        pose = {'Tran': out['Pred_T'], 'Size': out['Pred_s']}
+        gt_pose = {'Points': PC, 'R': gt_R, 'T': gt_t, 'Mean_shape': mean_shape}
+        green_gt, red_gt = (None, None) if self.train_stage == 'Backbone_only' else get_gt_v(gt_R)
 
-        pred_prop_list = {'Recon': recon, 'Rot1': p_green_R, 'Rot2': p_red_R, 'Tran': Pred_T, 'Scale': Pred_s,
-                          'Rot1_f': f_green_R.detach(), 'Rot2_f': f_red_R.detach()}
-        gt_prop_list = {'Points': PC, 'R': gt_R, 'T': gt_t, 'Mean_shape': mean_shape}
-        prop_loss = self.loss_prop(self.name_prop_list, pred_prop_list, gt_prop_list, sym)
-
-        pred_recon_list = {'F_n': face_normal, 'F_d': face_dis, 'F_c': face_f, 'Rot1': p_green_R, 'Rot1_f': f_green_R.detach(),
-                           'Rot2': p_red_R, 'Rot2_f': f_red_R.detach(), 'Tran': Pred_T, 'Size': Pred_s}
-        gt_recon_list = {'R': gt_R, 'T': gt_t, 'Size': gt_s, 'Mean_shape': mean_shape, 'Points': PC}
-        recon_loss = self.loss_recon(self.name_recon_list, pred_recon_list, gt_recon_list, sym, obj_id)
-
-        pred_geo_list = {'Rot1': p_green_R, 'Rot2': p_red_R, 'Tran': Pred_T, 'Size': Pred_s, 'Rot1_f': f_green_R.detach(),
-                         'Rot2_f': f_red_R.detach()}
-        gt_geo_list = {'Points': PC, 'R': gt_R, 'T': gt_t, 'Mean_shape': mean_shape}
-        geo_loss = self.loss_geo(self.name_geo_list, pred_geo_list, gt_geo_list, sym)
+        fsnet_loss = self.loss_fs_net(self.name_fs_list, {**axes, **conf, **pose, 'Recon': out['recon']},
+                                      {'Rot1': green_gt, 'Rot2': red_gt, 'Recon': PC, 'Tran': gt_t, 'Size': gt_s}, sym)
+        prop_loss = self.loss_prop(self.name_prop_list,
+                                   {**axes, **conf_const, 'Recon': out['recon'], 'Tran': out['Pred_T'], 'Scale': out['Pred_s']},
+                                   gt_pose, sym)
+        recon_loss = self.loss_recon(self.name_recon_list,
+                                     {**axes, **conf_const, **pose, 'F_n': out['face_normal'], 'F_d': out['face_dis'],
+                                      'F_c': out['face_f']},
+                                     {**gt_pose, 'Size': gt_s}, sym, obj_id)
+        geo_loss = self.loss_geo(self.name_geo_list, {**axes, **conf_const, **pose}, gt_pose, sym)
 
         loss_dict = {'fsnet_loss': fsnet_loss, 'recon_loss': recon_loss, 'geo_loss': geo_loss, 'prop_loss': prop_loss}
         return output_dict, loss_dict
