@@ -150,3 +150,20 @@ def graphed_step_with_exchange(graphed, world, group=None):
     late.wait()
     early.wait()
     graphed.flat_grad.mul_(1.0 / world)
+
+
+def mean_flat_gradients(buffers, group=None):
+    """gradient mean over the ranks for gradients that already live in flat buffers (the fused optimizer keeps one per
+    parameter group, hs_pose_amd/solver.py): one asynchronous all-reduce per buffer, then the 1/world scale.  A no-op
+    without a process group or with a single rank."""
+    if not dist.is_initialized():
+        return
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=True) for b in buffers]
+    for w in works:
+        w.wait()
+    inv = 1.0 / world
+    for b in buffers:
+        b.mul_(inv)

@@ -12,15 +12,23 @@ optimizer of ``hs_pose_amd.solver``:
 import math
 
 import torch
+import torch.distributed as dist
 
 from .config import FLAGS
+from .parallel import mean_flat_gradients
 from .solver import build_lr_rate, build_optimizer
 
 
 class TrainDriver:
     def __init__(self, network, optimizer=None, scheduler=None, total_iters=None, accumulate=None, max_norm=5,
-                 check_nan=True, global_step=0):
+                 check_nan=True, global_step=0, data_parallel=None):
+        """data_parallel (default: whenever torch.distributed is initialised with more than one rank): after every
+        backward the gradients -- already in the optimizer's flat buffers -- are averaged over the ranks with one RCCL
+        all-reduce per parameter group, before clipping (the reference trains on a single device, train.py:23)."""
         self.network = network
+        if data_parallel is None:
+            data_parallel = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.data_parallel = bool(data_parallel)
         self.optimizer = optimizer if optimizer is not None else build_optimizer(network.build_params(training_stage_freeze=[]))
         if scheduler is None:
             if total_iters is None:
@@ -41,6 +49,8 @@ class TrainDriver:
             self.skipped += 1
             return False
         total_loss.backward()
+        if self.data_parallel:                                 # one process per GPU: gradient mean over the ranks
+            mean_flat_gradients([fg.flat_g for fg in self.optimizer._flat])
         self.optimizer.clip_grad_norm_(self.max_norm)
         if self.global_step % self.accumulate == 0:
             self.optimizer.step()

@@ -109,6 +109,11 @@ def _worker_graphed(rank, world, port, q):
             want = sum(torch.randn(1000, generator=torch.Generator().manual_seed(100 * step + r)) for r in range(world)) / world
             assert torch.allclose(fake.flat_grad, want, rtol=1e-6, atol=1e-7), (split, step)
         assert fake.calls == (["first", "second"] * 3 if split else ["run"] * 3)
+    # the training driver's exchange: flat gradient buffers (one per parameter group) averaged in place
+    from hs_pose_amd.parallel import mean_flat_gradients
+    bufs = [torch.full((50,), float(rank + 1)), torch.arange(7, dtype=torch.float32) * (rank + 1)]
+    mean_flat_gradients(bufs)
+    assert torch.allclose(bufs[0], torch.full((50,), 1.5)) and torch.allclose(bufs[1], torch.arange(7, dtype=torch.float32) * 1.5)
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, "ok"))
