@@ -219,7 +219,7 @@ def main():
                       f"-> {d['abytes'] / (d['avg_us'] * 1e-6) / 1e9:8.1f} GB/s", file=sys.stderr)
             print(f"libhsp kernels {hsp_ms:.3f} ms/step of {1e3 * dt / args.steps:.3f} ms/step", file=sys.stderr)
         line = {
-            "metric": "point-clouds/sec (N=1028) HS-layer fwd+bwd",
+            "metric": f"point-clouds/sec (N={N}) HS-layer fwd+bwd",     # BASELINE.json's metric at the default N=1028
             "value": round(world * B * args.steps / dt, 2),
             "unit": "point-clouds/sec",
             "n_gpus": world,
