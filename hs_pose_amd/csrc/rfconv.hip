@@ -130,11 +130,21 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_kernel(const float* __restr
                     }
                     // ... and that winner's support value fm[b,m*,C+j]: the backward's direction gradient reads it
                     // as a stream instead of gathering 4-byte values from N rows (4x the HBM traffic, measured)
-                    if (WF) *reinterpret_cast<float4*>(fwin + pt * SC + j) = wf;
+                    // fwin / argrow / out are write-once streams read again only by the backward: non-temporal stores keep
+                    // them from evicting the cloud's fm rows (the gather's working set) from the XCD's L2
+                    if (WF) {
+                        float* fw = fwin + pt * SC + j;
+                        __builtin_nontemporal_store(wf.x, fw); __builtin_nontemporal_store(wf.y, fw + 1);
+                        __builtin_nontemporal_store(wf.z, fw + 2); __builtin_nontemporal_store(wf.w, fw + 3);
+                    }
                     *reinterpret_cast<float4*>(smax + j) = best;
                     // the winning SOURCE ROW m* = idx[b,i,n*] (uint16): the backward needs neither idx nor n
-                    *reinterpret_cast<ushort4*>(argrow + pt * SC + j) =
-                        make_ushort4((unsigned short)sIdx[a0], (unsigned short)sIdx[a1], (unsigned short)sIdx[a2], (unsigned short)sIdx[a3]);
+                    {
+                        const unsigned lo = (unsigned)sIdx[a0] | ((unsigned)sIdx[a1] << 16);
+                        const unsigned hi = (unsigned)sIdx[a2] | ((unsigned)sIdx[a3] << 16);
+                        unsigned* ap = reinterpret_cast<unsigned*>(argrow + pt * SC + j);
+                        __builtin_nontemporal_store(lo, ap); __builtin_nontemporal_store(hi, ap + 1);
+                    }
                 }
             }
             __syncthreads();
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_kernel(const float* __restr
                 for (int sp = 1; sp < S; ++sp) s = add_rn(s, smax[sp * C + c]);
                 float v = __fdiv_rn(s, invS_div);
                 if (!SURFACE) v = add_rn(fm[pt * fstride + c], v);
-                out[pt * C + c] = v;
+                __builtin_nontemporal_store(v, out + pt * C + c);
             }
         }
     }
