@@ -174,3 +174,21 @@ def test_graphed_posenet_training_step_matches_eager(dev, B, N):
         total_of(ld_s).backward()
     finally:
         FLAGS.reset()
+
+
+def test_staging_ring_uploads_in_order(dev):
+    """hs_pose_amd/staging.py: values pass through unchanged, slots are reused only after their upload has run, the
+    host-side generator order is the caller's"""
+    from hs_pose_amd import staging
+    torch.manual_seed(5)
+    want = [torch.rand(33, 3) for _ in range(11)]            # more uploads than ring slots
+    torch.manual_seed(5)
+    got = []
+    sink = torch.zeros(33, 3, device=dev)
+    for i in range(11):
+        x = staging.upload(lambda buf: torch.rand(33, 3, out=buf), (33, 3), torch.float32, dev,
+                           out=sink if i % 2 else None, ring=3)
+        got.append(x.clone())
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a.cpu(), b)
