@@ -1,11 +1,19 @@
-"""hipGraph capture of one HS-stack training step (forward + backward) for launch-bound batch sizes.
+"""hipGraph capture of the launch-bound steps of the path.
 
-At B=16, N=1028 a step is ~350 kernel launches of 5-100 us each; issued eagerly from Python the GPU
-idles between them.  ``GraphedStep`` captures zero_grad -> forward -> backward once (static shapes,
-static input / gradient buffers) and replays it.  The only host work of the reference's forward -- the
-two ``torch.randperm`` draws of the Pool_layers on the CPU default generator (gcn3d.py:243) -- happens
-BEFORE each replay, in the same order and on the same generator as the reference, and is uploaded into
-static index buffers the captured kernels read.
+* ``GraphedStep``       -- one HS-stack training step (zero_grad, forward, backward): what ``bench.py`` times.  At B=16,
+  N=1028 it is ~185 launches of 5-100 us; issued eagerly from Python the GPU idles between them.  Optionally packs the
+  gradients into one flat buffer for the data-parallel exchange, or splits the step in two graphs so that the first
+  all-reduce overlaps the rest of the backward.
+* ``GraphedNetwork``    -- ``posenet`` forward / backward of the FULL model as two graphs behind one autograd node, for
+  ``engine/train.py``'s step (losses and optimizer stay eager).
+* ``GraphedInference``  -- the timed body of ``evaluation/evaluate.py`` (eval forward + generate_RT).
+* ``GraphedTrainStep``  -- the whole training step incl. the losses as one graph (checked, but needs a runtime flag and
+  is slower than the above on ROCm 7.2; kept as the capture-safe reference form).
+
+Static shapes, static input / gradient buffers.  The only host work of the reference's forward -- the two
+``torch.randperm`` draws of the Pool_layers on the CPU default generator (gcn3d.py:243) -- happens BEFORE each replay,
+in the same order and on the same generator as the reference, and is uploaded into static index buffers the captured
+kernels read.
 """
 import os
 
