@@ -22,6 +22,10 @@ import torch
 from . import augment, gcn3d, ops, staging
 from .config import FLAGS
 
+# Other threads of the process (RCCL's watchdog polling events, the autograd engine's workers) may call into HIP while
+# this thread captures: only this thread's calls are checked against the capture.
+_CAPTURE = {"capture_error_mode": "thread_local"}
+
 
 def draw_pool_indices(n_points, rate=4, levels=2):
     """consume the CPU default generator exactly like FaceRecon's two Pool_layers (FaceRecon.py:91,96)."""
@@ -92,12 +96,12 @@ class GraphedStep:
             self.graph = torch.cuda.CUDAGraph()
             if split:
                 self.graph2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
+                with torch.cuda.graph(self.graph, **_CAPTURE):
                     self._body_first()
-                with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
+                with torch.cuda.graph(self.graph2, pool=self.graph.pool(), **_CAPTURE):
                     self._body_second()
             else:
-                with torch.cuda.graph(self.graph):
+                with torch.cuda.graph(self.graph, **_CAPTURE):
                     self._body()
         finally:
             ops.set_timer(prev_timer)
@@ -233,7 +237,7 @@ class GraphedTrainStep:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, **_CAPTURE):
                 self._body()
         finally:
             ops.set_timer(prev_timer)
@@ -322,7 +326,7 @@ class GraphedInference:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, **_CAPTURE):
                 self._body()
         finally:
             ops.set_timer(prev_timer)
@@ -416,13 +420,13 @@ class GraphedNetwork:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph_fwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_fwd):
+            with torch.cuda.graph(self.graph_fwd, **_CAPTURE):
                 outs = self._forward()
             self.none_mask = [o is None for o in outs]
             self.outs = [o for o in outs if o is not None]
             self.gouts = [torch.zeros_like(o) for o in self.outs]
             self.graph_bwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_bwd, pool=self.graph_fwd.pool()):
+            with torch.cuda.graph(self.graph_bwd, pool=self.graph_fwd.pool(), **_CAPTURE):
                 self.pgrads = list(torch.autograd.grad(self.outs, self.params, self.gouts, allow_unused=True))
         finally:
             ops.set_timer(prev_timer)
