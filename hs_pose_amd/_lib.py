@@ -59,6 +59,7 @@ SIGNATURES = {
     "hsp_chamfer_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "hsp_fps_workspace_bytes": (_sz, [_i, _i]),
     "hsp_fps_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "hsp_fps_f64": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
 }
 
 

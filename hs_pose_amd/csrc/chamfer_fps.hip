@@ -160,7 +160,9 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(const float* __restric
         for (int k = 0; k < PPT; ++k) {
             const int j = tid + k * THREADS;
             const float dx = sub_rn(px[k], cx), dy = sub_rn(py[k], cy), dz = sub_rn(pz[k], cz);
-            const float d = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
+            // numpy on a float32 cloud: fp32 (x*x + y*y) + z*z, then a correctly rounded fp32 sqrt (eval_utils.py:73-84);
+            // the sqrt folds neighbouring d^2 values into exact ties that argmax breaks by index, so it cannot be skipped
+            const float d = __fsqrt_rn(add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz)));
             const float v = fminf(dt[k], d);
             dt[k] = v;
             const unsigned long long kk = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(~j);
@@ -195,39 +197,49 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(const float* __restric
 // each round = distance update + workgroup arg-max (max value, then lowest index).
 #define FPS_THREADS 1024
 
-__global__ __launch_bounds__(FPS_THREADS) void fps_generic_kernel(const float* __restrict__ xyz, int N, int n_samples,
-                                                                  int32_t* __restrict__ sel, float* __restrict__ dts) {
-    __shared__ float sv[FPS_THREADS / HSP_WAVE];
+template <typename T> __device__ __forceinline__ T fps_dist(T dx, T dy, T dz);
+template <> __device__ __forceinline__ float fps_dist<float>(float dx, float dy, float dz) {
+    return __fsqrt_rn(add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz)));
+}
+template <> __device__ __forceinline__ double fps_dist<double>(double dx, double dy, double dz) {
+    return __dsqrt_rn(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz)));
+}
+
+// T = float: any N (distances in a global workspace); T = double: the reference helper's own dtype (it is called on
+// float64 mesh vertices, tools/eval_utils.py:122-140) -- numpy's float64 arithmetic step for step.
+template <typename T>
+__global__ __launch_bounds__(FPS_THREADS) void fps_generic_kernel(const T* __restrict__ xyz, int N, int n_samples,
+                                                                  int32_t* __restrict__ sel, T* __restrict__ dts) {
+    __shared__ T sv[FPS_THREADS / HSP_WAVE];
     __shared__ int si[FPS_THREADS / HSP_WAVE];
     __shared__ int scur;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
-    const float* p = xyz + (size_t)b * N * 3;
-    float* dt = dts + (size_t)b * N;
-    for (int j = tid; j < N; j += FPS_THREADS) dt[j] = INFINITY;
+    const T* p = xyz + (size_t)b * N * 3;
+    T* dt = dts + (size_t)b * N;
+    for (int j = tid; j < N; j += FPS_THREADS) dt[j] = (T)INFINITY;
     int cur = 0;
     for (int s = 0; s < n_samples; ++s) {
         if (tid == 0) sel[(size_t)b * n_samples + s] = cur;
-        const float cx = p[cur * 3], cy = p[cur * 3 + 1], cz = p[cur * 3 + 2];
-        float bv = -1.0f;
+        const T cx = p[cur * 3], cy = p[cur * 3 + 1], cz = p[cur * 3 + 2];
+        T bv = (T)-1.0;
         int bi = INT_MAX;
         for (int j = tid; j < N; j += FPS_THREADS) {
-            const float dx = sub_rn(p[j * 3], cx), dy = sub_rn(p[j * 3 + 1], cy), dz = sub_rn(p[j * 3 + 2], cz);
-            const float d = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
-            float v = dt[j];
+            const T d = fps_dist<T>(p[j * 3] - cx, p[j * 3 + 1] - cy, p[j * 3 + 2] - cz);
+            T v = dt[j];
             if (d < v) { v = d; dt[j] = d; }
             if (v > bv) { bv = v; bi = j; }          // j ascends per lane: strict '>' keeps the first max
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(bv, off);
+            const T ov = __shfl_xor(bv, off);
             const int oi = __shfl_xor(bi, off);
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
         if ((tid & 63) == 0) { sv[tid >> 6] = bv; si[tid >> 6] = bi; }
         __syncthreads();
         if (tid == 0) {
-            float fv = sv[0];
+            T fv = sv[0];
             int fi = si[0];
             for (int w = 1; w < FPS_THREADS / HSP_WAVE; ++w)
                 if (sv[w] > fv || (sv[w] == fv && si[w] < fi)) { fv = sv[w]; fi = si[w]; }
@@ -299,7 +311,16 @@ extern "C" int hsp_fps_f32(const float* xyz, int B, int N, int n_samples, int32_
         FPS_REG(1024, 12);
     }
 #undef FPS_REG
-    hipLaunchKernelGGL(fps_generic_kernel, dim3(B), dim3(FPS_THREADS), 0, st, xyz, N, n_samples, sel,
+    hipLaunchKernelGGL(fps_generic_kernel<float>, dim3(B), dim3(FPS_THREADS), 0, st, xyz, N, n_samples, sel,
                        reinterpret_cast<float*>(ws));
+    return check_launch();
+}
+
+extern "C" int hsp_fps_f64(const double* xyz, int B, int N, int n_samples, int32_t* sel, void* ws, size_t ws_bytes,
+                           hspStream_t stream) {
+    if (!xyz || !sel || B <= 0 || N <= 0 || n_samples <= 0 || n_samples > N) return HSP_ERR_BAD_ARG;
+    if (!ws || ws_bytes < 2 * hsp_fps_workspace_bytes(B, N)) return HSP_ERR_WORKSPACE;
+    hipLaunchKernelGGL(fps_generic_kernel<double>, dim3(B), dim3(FPS_THREADS), 0, as_stream(stream), xyz, N, n_samples,
+                       sel, reinterpret_cast<double*>(ws));
     return check_launch();
 }

@@ -10,6 +10,7 @@
 //   quad   = ATen row-sum order (quad_kernel below), dist = ((inner*-2)+quad[j])+quad[i]
 //   select = ascending (distance, index); strict '<' keeps the lower index on exact ties.
 #include "common.h"
+#include <float.h>
 
 namespace hsp {
 
@@ -66,10 +67,14 @@ struct TopList {
 // T-way tournament merge of sorted lists held in LDS.  The T lanes of one query are adjacent
 // lanes of a wave; lane `sub` walks list `my_list`.  Writes ranks [drop, drop+k) of the union as
 // indices to out_row, or (PAIRS) all k+drop ranks as (distance, index) pairs to out_pairs.
+// A list slot that was never filled (non-finite distances are never inserted: `v < d` is false for NaN / +inf) still
+// holds the sentinel index INT_MAX; it is replaced by `fallback` (a valid row, the query itself) before it is written,
+// so a NaN / Inf input row can never turn into an out-of-range neighbour index downstream (the reference's topk also
+// returns valid indices there; the NaN shows up in the loss and engine/train.py:91-95 skips the batch).
 template <int K1, int T, bool PAIRS = false>
 __device__ __forceinline__ void merge_write(const int2* __restrict__ lists, int my_list, int sub, int k,
                                             int drop, bool valid, int32_t* __restrict__ out_row,
-                                            int2* __restrict__ out_pairs = nullptr) {
+                                            int nrows, int fallback, int2* __restrict__ out_pairs = nullptr) {
     const int2* mine = lists + (size_t)my_list * K1;
     int ptr = 0;
     int2 h = mine[0];
@@ -101,7 +106,7 @@ __device__ __forceinline__ void merge_write(const int2* __restrict__ lists, int 
         if (PAIRS) {
             if (sub == 0) out_pairs[r] = make_int2(__float_as_int(bd), bi);
         } else if (valid && sub == 0 && r >= drop) {
-            out_row[r - drop] = bi;
+            out_row[r - drop] = (unsigned)bi < (unsigned)nrows ? bi : fallback;
         }
     }
 }
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ x, 
     }
     __syncthreads();                       // every lane is done with pts: reuse the LDS for the lists
     top.store(lists + (size_t)tid * K1);   // each lane re-reads only its own list: no further barrier
-    merge_write<K1, T>(lists, tid, t, k, drop, valid, idx + ((size_t)b * N + (valid ? q : 0)) * k);
+    merge_write<K1, T>(lists, tid, t, k, drop, valid, idx + ((size_t)b * N + (valid ? q : 0)) * k, N, valid ? q : 0);
 }
 
 __device__ __forceinline__ unsigned sortable_key(float f) {
@@ -198,8 +203,8 @@ __global__ __launch_bounds__(256) void knn3_wave_kernel(const float* __restrict_
             const float4 c = pts[j < N ? j : N - 1];
             const float inner = dot3_chain(qp.x, qp.y, qp.z, c.x, c.y, c.z);
             const float dv = add_rn(add_rn(mul_rn(inner, -2.0f), c.w), qp.w);
-            d[s] = j < N ? dv : INFINITY;
-            lmin = fminf(lmin, d[s]);
+            d[s] = j < N ? fminf(dv, FLT_MAX) : INFINITY;       // NaN / +inf of a real row -> FLT_MAX: still selectable, so
+            lmin = fminf(lmin, d[s]);                           // every output slot is written with a valid index
         }
         // the m-th smallest of the 64 lane minima: m distinct candidates are <= tau
         const unsigned key = sortable_key(lmin);
@@ -406,7 +411,9 @@ __device__ __forceinline__ void knn_select_wave(const float* dl, int2* sv, int N
     const int lane = threadIdx.x & 63;
     const int m = k + drop;
     float lmin = INFINITY;
-    for (int j = lane; j < N; j += 64) lmin = fminf(lmin, dl[j]);
+    // real rows with a NaN / +inf distance count as FLT_MAX (ties by index): m valid candidates always exist, every
+    // output slot is written (see merge_write)
+    for (int j = lane; j < N; j += 64) lmin = fminf(lmin, fminf(dl[j], FLT_MAX));
     // radix select, most significant bit first: the m-th smallest of the 64 keys
     const unsigned key = sortable_key(lmin);
     unsigned prefix = 0;
@@ -421,7 +428,7 @@ __device__ __forceinline__ void knn_select_wave(const float* dl, int2* sv, int N
     int n = 0;
     for (int j0 = 0; j0 < N; j0 += 64) {
         const int j = j0 + lane;
-        const float d = j < N ? dl[j] : INFINITY;
+        const float d = j < N ? fminf(dl[j], FLT_MAX) : INFINITY;
         const bool keep = j < N && d <= tau;
         const unsigned long long bal = __ballot(keep);
         if (keep) sv[n + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(__float_as_int(d), j);
@@ -789,7 +796,7 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
     const int src = (ml >> 1) * 64 + (ml & 1) * 32 + mq;
     const int oq = q0 + mq;
     const bool ovalid = oq < N;
-    merge_write<K1, 8>(lists, src, ml, k, drop, ovalid, idx + ((size_t)b * N + (ovalid ? oq : 0)) * k);
+    merge_write<K1, 8>(lists, src, ml, k, drop, ovalid, idx + ((size_t)b * N + (ovalid ? oq : 0)) * k, N, ovalid ? oq : 0);
 }
 
 // ------------------------------------------------------------------------------------------------

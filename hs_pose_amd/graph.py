@@ -47,6 +47,27 @@ def upload_pool_indices(bufs, n_points):
         staging.upload(lambda pinned, idx=idx: pinned.copy_(idx), buf.shape, torch.int32, buf.device, out=buf)
 
 
+class _preserve_bn_stats:
+    """Warm-up forwards run the live network in train mode on the EXAMPLE batch; without this their BatchNorm
+    running_mean / running_var / num_batches_tracked updates would leak into the model (and its checkpoints) although
+    no training step has happened.  The buffers are snapshotted on entry and restored on exit (after the capture, which
+    executes nothing), so a captured object starts from exactly the state the eager path would have."""
+
+    def __init__(self, module):
+        self.bufs = [b for m in module.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)
+                     for b in (m.running_mean, m.running_var, m.num_batches_tracked) if b is not None]
+
+    def __enter__(self):
+        self.saved = [b.detach().clone() for b in self.bufs]
+        return self
+
+    def __exit__(self, *exc):
+        torch.cuda.synchronize()
+        for b, s_ in zip(self.bufs, self.saved):
+            b.copy_(s_)
+        return False
+
+
 class GraphedStep:
     """step = zero_grad; (_, _, feat) = face_recon(centred, obj); feat.backward(dfeat)   as one hipGraph.
 
@@ -79,6 +100,7 @@ class GraphedStep:
             self.flat_grad = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
         self._upload_pool_indices()
         prev_timer = ops.set_timer(None)               # HIP events cannot be recorded inside a capture
+        keep = _preserve_bn_stats(face_recon).__enter__()
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -104,6 +126,7 @@ class GraphedStep:
                 with torch.cuda.graph(self.graph, **_CAPTURE):
                     self._body()
         finally:
+            keep.__exit__()
             ops.set_timer(prev_timer)
 
     def _body(self):
@@ -228,6 +251,7 @@ class GraphedTrainStep:
         self.loss_dict, self.total = None, None
         self._host_draws()
         prev_timer = ops.set_timer(None)
+        keep = _preserve_bn_stats(network).__enter__()
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -240,6 +264,7 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.graph, **_CAPTURE):
                 self._body()
         finally:
+            keep.__exit__()
             ops.set_timer(prev_timer)
 
     def _host_draws(self):
@@ -392,7 +417,9 @@ class GraphedNetwork:
     graphs contain no ATen multi-block reduction (see GraphedTrainStep for why that matters on ROCm 7.2).
 
     ``runner = GraphedNetwork(net.posenet, PC, obj_id)`` (example inputs of the step's shape, B and N fixed);
-    ``outs = runner(PC, obj_id)`` inside the usual step, ``loss.backward()`` as usual.  The Pool_layer permutations are
+    ``outs = runner(PC, obj_id)`` inside the usual step, ``loss.backward()`` as usual.  The returned tensors ALIAS the
+    graph's static output buffers: the next call overwrites them -- ``clone()`` anything kept across steps.  Constructing
+    the object leaves the BatchNorm running statistics untouched (warm-up runs are rolled back).  The Pool_layer permutations are
     drawn on the host generator before every replay, dropout uses the device generator inside the graph."""
 
     def __init__(self, posenet, PC, obj_id, warmup=3):
@@ -408,6 +435,7 @@ class GraphedNetwork:
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)
         upload_pool_indices(self.pool_idx, N)
         prev_timer = ops.set_timer(None)
+        keep = _preserve_bn_stats(posenet).__enter__()
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -429,6 +457,7 @@ class GraphedNetwork:
             with torch.cuda.graph(self.graph_bwd, pool=self.graph_fwd.pool(), **_CAPTURE):
                 self.pgrads = list(torch.autograd.grad(self.outs, self.params, self.gouts, allow_unused=True))
         finally:
+            keep.__exit__()
             ops.set_timer(prev_timer)
 
     def _forward(self):

@@ -891,15 +891,17 @@ def chamfer(xyz1, xyz2):
 
 
 def fps(xyz, n_samples):
-    """int32 (B,n_samples) farthest-point-sampling indices per cloud (first pick = index 0)."""
-    xyz = _req(xyz.detach(), torch.float32, "fps.xyz")
+    """int32 (B,n_samples) farthest-point-sampling indices per cloud (first pick = index 0); float32 or float64 clouds,
+    computed in the cloud's own dtype like the numpy helper does (tools/eval_utils.py:73-84,107-119)."""
+    f64 = isinstance(xyz, torch.Tensor) and xyz.dtype == torch.float64
+    xyz = _req(xyz.detach(), torch.float64 if f64 else torch.float32, "fps.xyz")
     B, N, _ = xyz.shape
     sel = torch.empty(B, n_samples, dtype=torch.int32, device=xyz.device)
     L = lib()
-    wsb = L.hsp_fps_workspace_bytes(B, N)
+    wsb = L.hsp_fps_workspace_bytes(B, N) * (2 if f64 else 1)
     ws = _ws(wsb, xyz.device)
-    _run("hsp_fps_f32", (_p(xyz), B, N, n_samples, _p(sel), _p(ws), wsb, _stream()),
-         key=f"B{B}N{N}n{n_samples}", abytes=B * (12 * N + 4 * n_samples))
+    _run("hsp_fps_f64" if f64 else "hsp_fps_f32", (_p(xyz), B, N, n_samples, _p(sel), _p(ws), wsb, _stream()),
+         key=f"B{B}N{N}n{n_samples}", abytes=B * ((24 if f64 else 12) * N + 4 * n_samples))
     return sel
 
 

@@ -62,7 +62,10 @@ class _FlatGroup:
                 rows += [(o + r * rl, rl, 1) for r in range(p.shape[0])]
             else:
                 rows += [(o + c, min(_ROW_CHUNK, n - c), 0) for c in range(0, n, _ROW_CHUNK)]
-        self.flat_s.copy_(self.flat_p)                         # slow_buffer starts as a copy of the weights
+        # slow_buffer is filled from the weights at the FIRST step(), like the reference creates it lazily
+        # (ranger2020.py:168-170): weights loaded between construction and the first step must be what Lookahead
+        # interpolates towards, not the random init that was live when the optimizer was built
+        self.slow_ready = False
         tab = np.zeros(len(rows), dtype=np.dtype([("offset", np.int64), ("len", np.int32), ("gc", np.int32)]))
         for i, (o, l, gc) in enumerate(rows):
             tab[i] = (o, l, gc)
@@ -153,6 +156,23 @@ class Ranger(Optimizer):
                 v.copy_(p.grad)
                 p.grad = v
 
+    def sync_grads(self):
+        """make the flat gradient buffers current: a backward that replaced a ``.grad`` (first accumulation into a None
+        grad) is copied back into its flat view.  Call before reading ``flat_g`` directly (data-parallel all-reduce)."""
+        for fg in self._flat:
+            self._collect_grads(fg)
+
+    def scale_grads_by_clip_(self):
+        """apply the pending clip coefficient to the gradients IN PLACE now (instead of inside the next step()): what the
+        reference's clip_grad_norm_ does on iterations that accumulate without stepping (engine/train.py:103-104).
+        Device-side, no host synchronisation."""
+        if self._gnorm_sq is None:
+            return
+        coef = torch.clamp(self._max_norm / (self._gnorm_sq.sqrt() + 1e-6), max=1.0)
+        for fg in self._flat:
+            fg.flat_g.mul_(coef)
+        self._gnorm_sq = None
+
     def clip_grad_norm_(self, max_norm):
         """torch.nn.utils.clip_grad_norm_(all parameters, max_norm) (engine/train.py:99): the squared norm is reduced
         on the device and the coefficient min(1, max_norm / (norm + 1e-6)) is applied INSIDE the next step() --
@@ -177,6 +197,9 @@ class Ranger(Optimizer):
         loss = None
         for group, fg in zip(self.param_groups, self._flat):
             self._collect_grads(fg)
+            if not fg.slow_ready:                                  # first step of this group: slow weights = weights now
+                fg.flat_s.copy_(fg.flat_p)
+                fg.slow_ready = True
             st0 = self.state[fg.params[0]]
             step = int(st0["step"]) + 1
             beta1, beta2 = group["betas"]
@@ -199,6 +222,8 @@ class Ranger(Optimizer):
         """accepts checkpoints of the reference Ranger (per-parameter tensors): values are copied into the flat state."""
         super().load_state_dict(state_dict)
         for fg in self._flat:
+            # a checkpoint written after >= 1 step carries every slow_buffer; one without them leaves the lazy fill armed
+            fg.slow_ready = all("slow_buffer" in self.state[p] for p in fg.params)
             for p, o in zip(fg.params, fg.offsets):
                 st = self.state[p]
                 for name, flat in (("exp_avg", fg.flat_m), ("exp_avg_sq", fg.flat_v), ("slow_buffer", fg.flat_s)):

@@ -2,7 +2,9 @@
 optimizer of ``hs_pose_amd.solver``:
 
   total_loss NaN -> the iteration is skipped (counters advance, nothing else happens)       train.py:91-95
-  backward; clip_grad_norm_(network.parameters(), 5) after EVERY backward                    train.py:98-99,103-104
+  backward; clip_grad_norm_(network.parameters(), 5) after EVERY backward -- on iterations that only accumulate the
+  coefficient is applied to the accumulated gradients in place, like the reference's in-place clip; on stepping
+  iterations it is folded into the fused optimizer step                                      train.py:98-99,103-104
   optimizer.step(); scheduler.step(); optimizer.zero_grad() when global_step % accumulate == 0   train.py:97-102
   checkpoint = {'seed','epoch','posenet_state_dict','scheduler','optimizer'}                 train.py:115-123
 
@@ -32,7 +34,8 @@ class TrainDriver:
         self.optimizer = optimizer if optimizer is not None else build_optimizer(network.build_params(training_stage_freeze=[]))
         if scheduler is None:
             if total_iters is None:
-                total_iters = int(getattr(FLAGS, "train_steps", 1500)) * int(getattr(FLAGS, "total_epoch", 150))
+                acc = int(accumulate if accumulate is not None else getattr(FLAGS, "accumulate", 1))
+                total_iters = int(getattr(FLAGS, "train_steps", 1500)) * int(getattr(FLAGS, "total_epoch", 150)) // acc   # train.py:51
             scheduler = build_lr_rate(self.optimizer, total_iters=total_iters)
         self.scheduler = scheduler
         self.accumulate = int(accumulate if accumulate is not None else getattr(FLAGS, "accumulate", 1))
@@ -50,12 +53,15 @@ class TrainDriver:
             return False
         total_loss.backward()
         if self.data_parallel:                                 # one process per GPU: gradient mean over the ranks
+            self.optimizer.sync_grads()                        # (a backward may have re-created .grad outside the flat buffer)
             mean_flat_gradients([fg.flat_g for fg in self.optimizer._flat])
         self.optimizer.clip_grad_norm_(self.max_norm)
         if self.global_step % self.accumulate == 0:
             self.optimizer.step()
             self.scheduler.step()
             self.optimizer.zero_grad()
+        else:
+            self.optimizer.scale_grads_by_clip_()              # accumulate-only iteration: clip in place (train.py:103-104)
         self.global_step += 1
         return True
 
@@ -70,10 +76,11 @@ class TrainDriver:
         }
 
     def load_checkpoint(self, ckpt):
-        """resume (engine/train.py:46-57 loads model weights; optimizer / scheduler state restored when present)."""
+        """resume (engine/train.py:53-59: model weights, optimizer and scheduler state when present); returns the epoch
+        to START from, i.e. the checkpoint's epoch + 1 like the reference's ``s_epoch``."""
         self.network.load_state_dict(ckpt['posenet_state_dict'])
         if 'optimizer' in ckpt:
             self.optimizer.load_state_dict(ckpt['optimizer'])
         if 'scheduler' in ckpt:
             self.scheduler.load_state_dict(ckpt['scheduler'])
-        return ckpt.get('epoch', 0)
+        return ckpt.get('epoch', -1) + 1

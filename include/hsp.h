@@ -293,11 +293,17 @@ int hsp_chamfer_bwd(const float *xyz1, const float *xyz2, const int32_t *idx1, c
 
 /* ---- farthest point sampling -----------------------------------------------------------------
  * replaces farthest_point_sampling(points, n)         tools/eval_utils.py:107-119 (per cloud)
- * xyz (B,N,3) -> sel (B,n_samples): start at 0, running min of squared fp32 distances, first maximum wins.
- * ws: hsp_fps_workspace_bytes(B,N).
+ * xyz (B,N,3) -> sel (B,n_samples): start at 0, running min of the Euclidean distances, first maximum wins.
+ * The arithmetic follows the dtype the numpy helper is called with (eval_utils.py:73-84):
+ *   hsp_fps_f32 -- a float32 cloud: (x*x + y*y) + z*z and a correctly rounded sqrt, all in fp32;
+ *   hsp_fps_f64 -- a float64 cloud (what tools/eval_utils.py:122-140 passes): the same in fp64.
+ * The sqrt is part of the contract: it creates exact ties that the first-maximum rule resolves by index.
+ * ws: hsp_fps_workspace_bytes(B,N) for f32, twice that for f64.
  */
 size_t hsp_fps_workspace_bytes(int B, int N);
 int hsp_fps_f32(const float *xyz, int B, int N, int n_samples, int32_t *sel, void *ws, size_t ws_bytes,
+                hspStream_t stream);
+int hsp_fps_f64(const double *xyz, int B, int N, int n_samples, int32_t *sel, void *ws, size_t ws_bytes,
                 hspStream_t stream);
 
 #ifdef __cplusplus

@@ -40,7 +40,7 @@ from datasets.load_data import PoseDataset as RefDataset  # noqa: E402
 import ref_cpu as oc  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
-torch.set_num_threads(8)
+torch.set_num_threads(1)
 
 
 frontend_inputs = oc.frontend_inputs

@@ -109,7 +109,7 @@ save("losses_augment", green=g.numpy(), red=r.numpy(), **aug)
 print("full step: HSPose.forward(do_loss=True), closed-form weights, B=4 N=256")
 import network.fs_net_repo.gcn3d as rg
 
-torch.set_num_threads(8)
+torch.set_num_threads(1)      # bit-reproducible regeneration (threaded MKL reductions are not)
 B, N, seed = 4, 256, 73
 FLAGS.train = 1
 FLAGS.aug_bb_pro = FLAGS.aug_rt_pro = FLAGS.aug_bc_pro = FLAGS.aug_pc_pro = -1.0       # augmentation never fires

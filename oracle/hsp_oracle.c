@@ -269,8 +269,10 @@ void hsp_oracle_fps_f64(const double *pts, int B, int N, int n_samples, int32_t 
     free(dts);
 }
 
-/* fp32 variant with the same rule set, the arithmetic the HIP kernel uses:
- * squared distances (monotone in the sqrt form), fp32, (dx*dx + dy*dy) + dz*dz without fma. */
+/* The same helper called on a float32 array: numpy then computes diff, diff**2, the sum over the three coordinates
+ * ((x*x + y*y) + z*z, sequential) and np.sqrt all in fp32 (eval_utils.py:73-84).  The square root matters: it maps
+ * neighbouring fp32 values of d^2 to the SAME fp32 distance about half the time, and np.argmax then takes the first of
+ * them -- a squared-distance rule picks a different point there (pinned by tests/golden/fps_*: the lattice cloud). */
 void hsp_oracle_fps_f32(const float *pts, int B, int N, int n_samples, int32_t *sel) {
     float *dts = (float *)malloc(sizeof(float) * (size_t)N);
     for (int b = 0; b < B; b++) {
@@ -284,7 +286,8 @@ void hsp_oracle_fps_f32(const float *pts, int B, int N, int n_samples, int32_t *
                 volatile float dx = p[j * 3] - p[cur * 3], dy = p[j * 3 + 1] - p[cur * 3 + 1], dz = p[j * 3 + 2] - p[cur * 3 + 2];
                 volatile float xx = dx * dx, yy = dy * dy, zz = dz * dz;
                 volatile float s1 = xx + yy;
-                volatile float d = s1 + zz;
+                volatile float d2 = s1 + zz;
+                volatile float d = sqrtf(d2);
                 if (d < dts[j]) dts[j] = d;
                 if (dts[j] > best) { best = dts[j]; arg = j; }
             }

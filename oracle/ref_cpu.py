@@ -644,3 +644,45 @@ def hspose_train_case(B: int, N: int, seed: int):
                 sym=table[obj.long()], aug_bb=torch.ones(B, 3), aug_rt_t=torch.zeros(B, 3),
                 aug_rt_r=torch.eye(3).repeat(B, 1, 1), model_point=hash_tensor((B, 32, 3), seed + 34, 0.5),
                 nocs_scale=torch.full((B,), 0.3))
+
+
+# ------------------------------------------------------------------------------------------------
+# closed-form inputs of the Chamfer / FPS fixtures (oracle/gen_golden_chamfer_fps.py writes the reference's
+# outputs for exactly these; the tests re-create them)
+# ------------------------------------------------------------------------------------------------
+CHAMFER_CASES = ["chamfer_100_50", "chamfer_257_1028", "chamfer_ties", "chamfer_1_7"]
+FPS_CASES = ["fps_512_64", "fps_1028_256", "fps_lattice_512_128", "fps_dups_300_40"]
+
+
+def chamfer_case(name: str):
+    """(xyz1 (B,n,3), xyz2 (B,m,3), grad_dist1 (B,n), grad_dist2 (B,m)) fp32"""
+    if name == "chamfer_100_50":                                   # SURVEY 8c's case
+        x1, x2 = hash_tensor((2, 100, 3), 91, 0.5), hash_tensor((2, 50, 3), 92, 0.5)
+    elif name == "chamfer_257_1028":                               # the hot path's level sizes, object scale
+        x1, x2 = hash_tensor((2, 257, 3), 95, 0.05), hash_tensor((2, 1028, 3), 96, 0.05)
+    elif name == "chamfer_ties":                                   # exact ties: duplicated points on a coarse lattice
+        x1 = torch.round(hash_tensor((1, 96, 3), 97, 2.0) * 2) / 2
+        x2 = torch.round(hash_tensor((1, 160, 3), 98, 2.0) * 2) / 2
+        x2[:, 100:140] = x2[:, 20:60]
+    elif name == "chamfer_1_7":                                    # n == 1, ragged tiny
+        x1, x2 = hash_tensor((3, 1, 3), 99, 1.0), hash_tensor((3, 7, 3), 100, 1.0)
+    else:
+        raise KeyError(name)
+    B, n, m = x1.shape[0], x1.shape[1], x2.shape[1]
+    return x1.contiguous(), x2.contiguous(), hash_tensor((B, n), 93, 1.0), hash_tensor((B, m), 94, 1.0)
+
+
+def fps_case(name: str):
+    """(points (N,3) float64 numpy -- cast to float32 for the fp32 rule --, n_samples)"""
+    if name == "fps_512_64":
+        return hash_tensor((512, 3), 81, 1.0).double().numpy(), 64
+    if name == "fps_1028_256":                                     # object-scale cloud at the hot path's N
+        return (hash_tensor((1028, 3), 82, 0.05) + torch.tensor([0.0, 0.0, 0.8])).double().numpy(), 256
+    if name == "fps_lattice_512_128":                              # 8x8x8 lattice, every point moved by a few ulps
+        g = torch.stack(torch.meshgrid(torch.arange(8.), torch.arange(8.), torch.arange(8.), indexing="ij"), -1).reshape(-1, 3)
+        return (g + 3.0 + hash_tensor((512, 3), 83, 2.0 ** -20)).double().numpy(), 128
+    if name == "fps_dups_300_40":                                  # duplicated points: zero distances, index ties
+        p = hash_tensor((300, 3), 84, 1.0)
+        p[150:300] = p[0:150]
+        return p.double().numpy(), 40
+    raise KeyError(name)

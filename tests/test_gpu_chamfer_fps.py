@@ -28,6 +28,39 @@ def test_chamfer_fwd_bwd(dev, ref, oc, B, n, m):
         assert err <= 1e-5 * max(1.0, np.abs(want).max()), err     # atomics: order differs, values agree
 
 
+@pytest.mark.parametrize("name", ["chamfer_100_50", "chamfer_257_1028", "chamfer_ties", "chamfer_1_7"])
+def test_chamfer_reference_extension_golden(dev, ref, name):
+    """against fixtures written by the reference's own chamfer_distance.cpp (oracle/_ref/cd_ref.so, CPU entry points):
+    distances and arg-mins bit-exact (same fp32 expression, strict <: first minimum, also on the exact ties of
+    chamfer_ties), gradients to 1e-6 of scale (the kernel's atomics sum in another order than the serial scatter)."""
+    from hs_pose_amd import ops
+    g = golden(name)
+    x1, x2, u1, u2 = ref.chamfer_case(name)
+    a, b = x1.to(dev).requires_grad_(True), x2.to(dev).requires_grad_(True)
+    d1, d2, i1, i2 = ops.chamfer(a, b)
+    assert np.array_equal(i1.cpu().numpy(), g["idx1"].astype(np.int32)) and np.array_equal(i2.cpu().numpy(), g["idx2"].astype(np.int32))
+    assert np.array_equal(d1.detach().cpu().numpy(), g["dist1"]) and np.array_equal(d2.detach().cpu().numpy(), g["dist2"])
+    ((d1 * u1.to(dev)).sum() + (d2 * u2.to(dev)).sum()).backward()
+    for got, want in ((a.grad, g["gx1"]), (b.grad, g["gx2"])):
+        err = np.abs(got.cpu().numpy() - want).max()
+        assert err <= 1e-6 * max(1.0, np.abs(want).max()), (name, err)
+
+
+@pytest.mark.parametrize("name", ["fps_512_64", "fps_1028_256", "fps_lattice_512_128", "fps_dups_300_40"])
+def test_fps_reference_helper_golden(dev, ref, name):
+    """the picks of tools/eval_utils.py:107-119 on the float32 cloud (hsp_fps_f32) and on the float64 cloud
+    (hsp_fps_f64), bit-exact -- including the perturbed lattice, where only the sqrt'ed-distance rule gets them"""
+    from hs_pose_amd import ops
+    g = golden(name)
+    pts, ns = ref.fps_case(name)
+    p64 = torch.from_numpy(pts).unsqueeze(0)
+    assert np.array_equal(ops.fps(p64.float().to(dev), ns).cpu().numpy()[0], g["sel_f32"].astype(np.int32))
+    assert np.array_equal(ops.fps(p64.to(dev), ns).cpu().numpy()[0], g["sel_f64"].astype(np.int32))
+    two = torch.cat([p64, p64.flip(1)], dim=0).contiguous()                   # batched: clouds are independent
+    sel = ops.fps(two.to(dev), ns).cpu().numpy()
+    assert np.array_equal(sel[0], g["sel_f64"].astype(np.int32)) and sel[1][0] == 0
+
+
 def test_chamfer_module_surface(dev, ref):
     from hs_pose_amd.chamfer import ChamferDistance
     a = ref.hash_tensor((1, 100, 3), 95, 1.0).to(dev)
@@ -43,7 +76,7 @@ def test_fps_golden_and_oracle(dev, ref, oc):
     g = golden("fps_512_64")
     pts = ref.hash_tensor((512, 3), 81, 1.0).unsqueeze(0)
     sel = ops.fps(pts.to(dev), 64).cpu().numpy()
-    assert np.array_equal(sel[0], g["sel"].astype(np.int32))          # == the reference's numpy helper
+    assert np.array_equal(sel[0], g["sel_f32"].astype(np.int32))      # == the reference's numpy helper on this fp32 cloud
     pts = ref.hash_tensor((5, 1028, 3), 82, 0.2)
     assert np.array_equal(ops.fps(pts.to(dev), 257).cpu().numpy(), oc.fps_f32(pts.numpy(), 257))
     pts = ref.hash_tensor((2, 3000, 3), 83, 0.2)

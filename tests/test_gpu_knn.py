@@ -139,3 +139,27 @@ def test_knn_full_size_properties(dev, ref):
     back = perm[idx_p][:, inv]
     same = (back.sort(dim=2)[0] == idx.sort(dim=2)[0]).all(dim=2).float().mean().item()
     assert same > 0.999
+
+
+@pytest.mark.parametrize("B,N,C,k", [(2, 1028, 3, 20), (2, 257, 3, 20), (1, 48, 3, 8), (2, 1028, 128, 20),
+                                     (2, 257, 256, 20), (2, 260, 64, 20), (1, 4096, 3, 20)])
+def test_knn_non_finite_rows_give_valid_indices(dev, ref, B, N, C, k):
+    """NaN / Inf input rows (diverging training, a bad depth pixel) must never become out-of-range neighbour indices:
+    the consumers (rf conv gathers, CSR builds) use them unclamped.  Rows without non-finite values keep exact results
+    w.r.t. the finite rows; every index stays in [0, N)."""
+    from hs_pose_amd import ops
+    x = ref.hash_tensor((B, N, C), 123, 1.0)
+    bad = [3, N // 2, N - 1]
+    x[0, bad[0]] = float("nan")
+    x[0, bad[1], 0] = float("inf")
+    x[-1, bad[2], C - 1] = float("-inf")
+    idx = ops.knn(x.to(dev), k)
+    # downstream consumers of the index run without faulting
+    f = torch.zeros(B, N, 8, device=dev)
+    ops.gather_max(f, idx, k)
+    torch.cuda.synchronize()
+    idx = idx.cpu().numpy()
+    assert idx.min() >= 0 and idx.max() < N
+    # a cloud made of NaN only: still valid indices
+    idx = ops.knn(torch.full((1, N, C), float("nan"), device=dev), k).cpu().numpy()
+    assert idx.min() >= 0 and idx.max() < N

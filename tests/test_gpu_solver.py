@@ -38,6 +38,26 @@ def test_fused_ranger_matches_reference(dev, ref, name):
         assert np.abs(st["slow_buffer"].cpu().numpy() - g[f"final.slow{i}"]).max() <= 2e-6
 
 
+def test_slow_buffer_is_taken_at_the_first_step(dev, ref):
+    """weights loaded AFTER the optimizer was built (pretrained checkpoint without optimizer state) are what Lookahead
+    interpolates towards at step k=6 -- the reference creates slow_buffer lazily at its first step (ranger2020.py:168-170)."""
+    from hs_pose_amd.solver import Ranger, clip_grad_norm_
+    g, c = golden("solver_ranger_default"), CASES["solver_ranger_default"]
+    params = [torch.nn.Parameter(torch.randn_like(t).to(dev)) for t in ref.opt_case_tensors(0)]     # "random init"
+    opt = Ranger(params, lr=c["lr"], **c["kw"])
+    with torch.no_grad():
+        for p, t in zip(params, ref.opt_case_tensors(0)):
+            p.copy_(t.to(dev))                                 # "load_state_dict" after construction
+    for step in range(1, c["nsteps"] + 1):
+        for p, gr in zip(params, ref.opt_case_tensors(step)):
+            p.grad.copy_(gr.to(dev))
+        clip_grad_norm_(opt, c["max_norm"])
+        opt.step()
+    for i, p in enumerate(params):
+        assert np.abs(p.detach().cpu().numpy() - g[f"s{c['nsteps']}.p{i}"]).max() <= 2e-6
+        assert np.abs(opt.state[p]["slow_buffer"].cpu().numpy() - g[f"final.slow{i}"]).max() <= 2e-6
+
+
 def test_gradients_replaced_by_autograd_are_picked_up(dev, ref):
     """a first backward after ``p.grad = None`` makes a fresh .grad tensor: step() copies it back into the flat buffer."""
     from hs_pose_amd.solver import Ranger
@@ -135,6 +155,9 @@ def test_train_driver_loop_semantics(dev, flags, tmp_path):
     assert drv.global_step == 1 and drv.skipped == 1 and torch.equal(w, w0) and float(w.grad.abs().max()) == 0.0
     assert drv.step(loss_of(1.0)) is True                      # global_step 1: accumulate only
     assert drv.global_step == 2 and torch.equal(w, w0) and float(w.grad.abs().max()) > 0.0
+    # ... and was clipped IN PLACE like the reference's clip_grad_norm_ on accumulate-only iterations (train.py:103-104)
+    total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in net.parameters()))
+    assert abs(float(total) - 5.0) < 1e-3
     lr_before = drv.optimizer.param_groups[0]["lr"]
     assert drv.step(loss_of(1.0)) is True                      # global_step 2: optimizer + scheduler + zero_grad
     assert not torch.equal(w, w0) and float(w.grad.abs().max()) == 0.0
@@ -145,7 +168,7 @@ def test_train_driver_loop_semantics(dev, flags, tmp_path):
     torch.save(ck, path)
     net2 = HSPose("PoseNet_only").to(dev)
     drv2 = TrainDriver(net2, total_iters=100, accumulate=2)
-    assert drv2.load_checkpoint(torch.load(path, weights_only=False)) == 7
+    assert drv2.load_checkpoint(torch.load(path, weights_only=False)) == 8     # the epoch to resume FROM (train.py:56)
     assert torch.equal(net2.posenet.ts.conv1.weight, w)
     assert drv2.optimizer.state[net2.posenet.ts.conv1.weight]["step"] == 1
     assert drv2.scheduler.last_epoch == drv.scheduler.last_epoch

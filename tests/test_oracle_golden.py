@@ -6,6 +6,17 @@ import torch
 
 from conftest import golden
 
+
+@pytest.fixture(autouse=True)
+def _one_thread():
+    """the fixtures are written with ONE torch thread (oracle/gen_golden.py: bit-reproducible regeneration); the
+    restatement is held to 1e-6 here, which threaded MKL reductions + train-mode BN on 4 rows can exceed"""
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    yield
+    torch.set_num_threads(n)
+
+
 KNN_CASES = ["knn_xyz_1028", "knn_xyz_257", "knn_xyz_64_k8", "knn_xyz_1028_k4", "knn_feat128_1028",
              "knn_feat128_257", "knn_feat256_257", "knn_feat256_64_k8", "knn_feat16_128_k8", "knn_feat32_16_k2",
              "knn_relu_feat128_257"]
@@ -144,9 +155,35 @@ def test_fps_oracles(ref, oc):
     assert np.array_equal(oc.fps_f32(pts.numpy()[None], 64)[0], g["sel"].astype(np.int32))
 
 
+@pytest.mark.parametrize("name", ["chamfer_100_50", "chamfer_257_1028", "chamfer_ties", "chamfer_1_7"])
+def test_chamfer_oracle_equals_reference_extension(ref, oc, name):
+    """fixtures written by the reference's OWN chamfer_distance.cpp (compiled as is into oracle/_ref/cd_ref.so, CPU entry
+    points forward / backward, .cpp:59-87,114-177; oracle/gen_golden_chamfer_fps.py): the C restatement returns the same
+    distances, arg-mins (first minimum wins, also on exact ties) and gradients bit for bit."""
+    g = golden(name)
+    x1, x2, g1, g2 = ref.chamfer_case(name)
+    d1, d2, i1, i2 = oc.chamfer_fwd(x1.numpy(), x2.numpy())
+    assert np.array_equal(i1, g["idx1"].astype(np.int32)) and np.array_equal(i2, g["idx2"].astype(np.int32))
+    assert np.array_equal(d1, g["dist1"]) and np.array_equal(d2, g["dist2"])
+    gx1, gx2 = oc.chamfer_bwd(x1.numpy(), x2.numpy(), i1, i2, g1.numpy(), g2.numpy())
+    assert np.array_equal(gx1, g["gx1"]) and np.array_equal(gx2, g["gx2"])
+
+
+@pytest.mark.parametrize("name", ["fps_512_64", "fps_1028_256", "fps_lattice_512_128", "fps_dups_300_40"])
+def test_fps_oracle_equals_reference_helper(ref, oc, name):
+    """fixtures written by tools/eval_utils.py:107-119 called on float64 and on float32 arrays (numpy computes in the
+    array's dtype, sqrt included): both C restatements equal it; on the perturbed lattice a squared-distance fp32 rule
+    would pick other points (recorded in the fixture), so the sqrt is part of the contract."""
+    g = golden(name)
+    pts, ns = ref.fps_case(name)
+    assert np.array_equal(oc.fps_f64(pts[None], ns)[0], g["sel_f64"].astype(np.int32))
+    assert np.array_equal(oc.fps_f32(pts[None].astype(np.float32), ns)[0], g["sel_f32"].astype(np.int32))
+    if name == "fps_lattice_512_128":
+        assert not np.array_equal(g["sel_f32_squared_rule"], g["sel_f32"])
+
+
 def test_chamfer_oracle_vs_bruteforce(ref, oc):
-    """the C restatement of chamfer_distance.cpp:59-177 against an independent torch formulation
-    (the reference extension itself needs nvcc for its .cu half -- see DESIGN.md)."""
+    """the C restatement of chamfer_distance.cpp:59-177 against an independent torch formulation as well"""
     x1 = ref.hash_tensor((2, 100, 3), 91, 0.5).requires_grad_(True)
     x2 = ref.hash_tensor((2, 50, 3), 92, 0.5).requires_grad_(True)
     d1, d2, i1, i2 = oc.chamfer_fwd(x1.detach().numpy(), x2.detach().numpy())
