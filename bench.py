@@ -31,7 +31,32 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
 MFMA_F32_PEAK_TFLOPS = 157.3   # same guide: v_mfma_f32_32x32x2_f32 dense peak (= the fp32 vector rate)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01", "traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # same guide: dense bf16 MFMA peak
+# HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/refresh_profiles.sh)
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02", "traffic.json")
+
+
+def u1_algorithmic(N, k=20, S=7):
+    """(bytes, GEMM-shaped flops) per cloud of unit U1 forward+backward, SURVEY.md 8(d): every (N,k,S*C) and (N,N)
+    intermediate counts as zero; each layer input read once, output written once, the (N,S*Cout) support tensor and the
+    graph-conv feature written + read once, int32 indices written + read once, feat written once; backward = 2x forward.
+    GEMM-shaped flops = fm GEMM + feature-space distance tiles + STE + conv2 per layer (1.57 GFLOP forward at N=1028).
+    The byte model is normalised to SURVEY's 31.1 MB/cloud forward at N=1028 (it gives 29.6 MB there: the survey also
+    counts the pools' / up-sampling's small reads)."""
+    def model(n0):
+        n1 = int(n0 / 4); n2 = int(n1 / 4)
+        k1, k2 = min(k, n1 // 8), min(k, n2 // 8)
+        by = n0 * (12 + 4 * 128 + 8 * 128 + 8 * k)                                       # conv_0
+        fl = n0 * 2 * (3 * 128 + 256 * 128)
+        for n, cin, cout, kk in ((n0, 128, 128, k), (n1, 128, 256, k1), (n1, 256, 256, k1), (n2, 256, 512, k2)):
+            by += n * (4 * cin + 8 * S * cout + 4 * cout + 8 * cout + 16 * kk)
+            fl += 2 * n * (cin * (S + 1) * cout + n * cin + cin * cout + 2 * cout * cout)
+        by += 4 * n0 * 128 + n1 * (4 * 128 + 12) + 4 * n1 * 256 + n2 * (4 * 256 + 12)   # pools
+        by += 4 * n0 * 1286                                                              # feat
+        return by, fl
+    by, fl = model(N)
+    by1028, _ = model(1028)
+    return 3 * by * (31.1e6 / by1028), 3 * fl
 
 
 def make_inputs(B, N, device, seed=0):
@@ -169,12 +194,28 @@ def main():
     timer = ops.KernelTimer() if rank == 0 else None
     if graphed is None:
         ops.set_timer(timer)                            # eager: per-kernel HIP events inside the timed region
+    # per-step HIP events on the stream the step is issued on (hipEvent timing, median of >= 50 steps)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         step()
+        evs[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
     ops.set_timer(None)
+    step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
+    extra = max(0, 50 - args.steps)                     # the median is always over >= 50 steps; `value` stays the K-step wall clock
+    if extra:
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(extra + 1)]
+        evs[0].record()
+        for i in range(extra):
+            step()
+            evs[i + 1].record()
+        fence()
+        step_ms += [evs[i].elapsed_time(evs[i + 1]) for i in range(extra)]
+    step_ms.sort()
+    median_ms = step_ms[len(step_ms) // 2]
     if graphed is not None and rank == 0:
         # HIP events cannot be recorded inside a graph replay: the per-kernel durations of the roofline
         # line come from the same K steps issued eagerly right after the timed region (same kernels, same
@@ -192,8 +233,9 @@ def main():
 
     if rank == 0:
         summ = timer.summary()
-        # dominant kernel = the C-ABI call with the largest total time in the timed region
-        (kname, kkey), kd = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
+        # dominant kernel = the single C-ABI launch with the longest average duration (per launch, not per shape key:
+        # two layers that share a shape are two launches)
+        (kname, kkey), kd = max(summ.items(), key=lambda kv: kv[1]["avg_us"])
         hsp_ms = sum(d["total_ms"] for d in summ.values()) / args.steps
         if kd.get("aflops", 0) > 0:       # GEMM-shaped kernel (feature-space distance tiles / weight gradient): MFMA roofline
             achieved = kd["aflops"] / (kd["avg_us"] * 1e-6) / 1e12
@@ -210,8 +252,18 @@ def main():
             with open(TRAFFIC_JSON) as f:
                 tj = json.load(f)
             roof["traffic"] = tj.get(f"{kname}[{kkey}]", {}).get("hbm_bytes_per_launch")
+            roof["traffic_source"] = "profiles/r02/traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE passes of this command)"
         except Exception:
             pass
+        roof["avg_us_source"] = ("HIP events around the call, in the timed region" if graphed is None else
+                                 "HIP events around the call, the same K steps re-issued eagerly right after the timed "
+                                 "graph replays (events cannot be recorded inside a replay)")
+        ubytes, uflops = u1_algorithmic(N)
+        step_s = median_ms * 1e-3
+        step_roof = {"algorithmic_bytes_per_cloud": round(ubytes), "gemm_flops_per_cloud": round(uflops),
+                     "step_hbm_frac": round(B * ubytes / step_s / 1e9 / HBM_PEAK_GBS, 5),
+                     "step_mfma_frac": round(B * uflops / step_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 5),
+                     "mfma_peak_tflops": MFMA_F32_PEAK_TFLOPS}
         if args.breakdown:
             for (n_, k_), d in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
                 print(f"{n_:22s} {k_:28s} calls/step {d['calls'] / args.steps:4.1f}  avg {d['avg_us']:9.1f} us  "
@@ -226,6 +278,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "ms_per_step_median": round(median_ms, 4),          # HIP-event median over max(K, 50) steps
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -236,6 +289,7 @@ def main():
                        "global_batch": world * B, "points": N, "parallelism": f"dp{world}", "hipgraph": graphed is not None, "split_graph": bool(graphed is not None and graphed.split), "grad_exchange": ("none" if world == 1 else "2 all-reduces, first overlapped with backward" if graphed is not None and graphed.split else "1 all-reduce after backward" if graphed is not None else "bucketed, hook-driven"),
                        "libhsp_ms_per_step": round(hsp_ms, 4)},
             "roofline": roof,
+            "step_roofline": step_roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_sample)

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(const float* __restric
             const float dx = sub_rn(px[k], cx), dy = sub_rn(py[k], cy), dz = sub_rn(pz[k], cz);
             // numpy on a float32 cloud: fp32 (x*x + y*y) + z*z, then a correctly rounded fp32 sqrt (eval_utils.py:73-84);
             // the sqrt folds neighbouring d^2 values into exact ties that argmax breaks by index, so it cannot be skipped
-            const float d = __fsqrt_rn(add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz)));
+            const float d = sqrtf(add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz)));   // (__fsqrt_rn is the 1-ulp native sqrt)
             const float v = fminf(dt[k], d);
             dt[k] = v;
             const unsigned long long kk = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(~j);
@@ -199,10 +199,10 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(const float* __restric
 
 template <typename T> __device__ __forceinline__ T fps_dist(T dx, T dy, T dz);
 template <> __device__ __forceinline__ float fps_dist<float>(float dx, float dy, float dz) {
-    return __fsqrt_rn(add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz)));
+    return sqrtf(add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz)));      // correctly rounded (ocml)
 }
 template <> __device__ __forceinline__ double fps_dist<double>(double dx, double dy, double dz) {
-    return __dsqrt_rn(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz)));
+    return sqrt(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz)));
 }
 
 // T = float: any N (distances in a global workspace); T = double: the reference helper's own dtype (it is called on

@@ -1,5 +1,7 @@
 """GPU parity of the whole HS stack / PoseNet9D against the reference's golden outputs (pose/size
 outputs within 1e-4, BASELINE north_star) and of the backward of unit U1 (feat -> all HS parameters)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -7,6 +9,15 @@ import torch
 from conftest import golden
 
 pytestmark = pytest.mark.gpu
+
+# Free-running (no teacher forcing) bounds at N=1028.  Yardstick: the CPU oracle's OWN drift when its input moves by
+# 1 ulp (tools/oracle_free_running_sensitivity.py, 3 noise seeds): eval-mode BN -> rows with identical neighbour sets per
+# HS layer 0.87 / 0.60-0.67 / 0.33-0.40 / 0.27-0.41, pose / size outputs move by up to 7.9e-4; train-mode BN (one
+# re-routed row reaches every row) -> 0.86 / 0.62-0.65 / 0.39-0.41 / 0.66-0.70 and up to 9.8e-2.  Measured on the GPU
+# (round 2): 0.92 / 0.69 / 0.43 / 0.41 with 8.8e-4, and 0.92 / 0.83 / 0.64 / 0.82 with 6.3e-2 -- inside the reference's
+# own conditioning.  Bounds = ~3x / ~2x the oracle's worst drift; agreement floors below every oracle-vs-oracle figure.
+FREE_RUNNING_BOUND = {"stack_eval_1028": 3e-3, "stack_evalflags_trainbn_1028": 2e-1}
+FREE_RUNNING_AGREE = {"stack_eval_1028": (0.8, 0.5, 0.25, 0.2), "stack_evalflags_trainbn_1028": (0.8, 0.5, 0.25, 0.4)}
 
 OUT_NAMES = ["recon", "face_normal", "face_dis", "face_f", "p_green_R", "p_red_R", "f_green_R", "f_red_R", "Pred_T", "Pred_s"]
 
@@ -196,3 +207,54 @@ def test_bench_data_parallel_path_smoke(dev, split):
     assert line["config"]["hipgraph"] is True and line["value"] > 0 and line["n_gpus"] == 1
     assert ("capture (split=True) failed" not in out.stderr) and line["config"]["split_graph"] is (split == "1")
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs on the node (RCCL over xGMI)")
+def test_rccl_two_ranks(dev):
+    """ready for the first multi-GPU lease: 2 RCCL ranks under torchrun -- (a) tests/_rccl_two_rank_check.py: after the
+    graphed step's exchange ``flat_grad`` == mean of the per-rank gradients, both exchange forms; (b) bench.py --gpus 2
+    prints one line with n_gpus == 2 and weak-scaled work."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    run = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
+    out = subprocess.run(run + ["--master-port", "29561", os.path.join(root, "tests", "_rccl_two_rank_check.py")], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "RCCL_TWO_RANK_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+    print(out.stdout)
+    out = subprocess.run(run + ["--master-port", "29562", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup",
+                                "2", "--batch", "4", "--points", "256", "--no-cpu-baseline", "--no-gemm-tuning"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8 and line["scaling"] == "weak" and line["value"] > 0
+
+
+@pytest.mark.parametrize("name", ["stack_eval_1028", "stack_evalflags_trainbn_1028"])
+def test_posenet9d_free_running_1028(dev, ref, flags, monkeypatch, name):
+    """What the product returns WITHOUT teacher forcing at the config-2 cloud size (N=1028): the network's own
+    feature-space neighbour sets are used; agreement with the reference's recorded sets and the pose / size errors are
+    reported (DESIGN.md section 2.2 quotes them) and held to a stated bound.  Where every neighbour row agrees the strict
+    1e-4 applies; otherwise the outputs differ by what a few re-routed neighbours (and, under train-mode BatchNorm over
+    B*N rows, their spread to every row) are worth -- the reference moves by the same order under 1-ulp input noise
+    (tools/oracle_sensitivity.py)."""
+    g = golden(name)
+    train_flag, B, N, seed, bn_training = (int(v) for v in g["meta"])
+    net = _build(ref, flags, dev, train_flag, bool(bn_training))
+    pts, obj = _inputs(ref, B, N, seed, dev)
+    watch = ForcedFeatKnn(monkeypatch, g, dev, force=False)
+    torch.manual_seed(1)
+    outs = dict(zip(OUT_NAMES, net(pts, obj)))
+    errs = {n_: _maxerr(outs[n_], g["out." + n_]) for n_ in OUT_NAMES[4:]}
+    exact = min(watch.agree) == 1.0
+    print(f"FREE-RUNNING {name}: rows with the reference's neighbour set per HS layer {[round(a, 4) for a in watch.agree]}; "
+          f"max abs error {({k_: float(f'{v:.2e}') for k_, v in errs.items()})}")
+    report = os.environ.get("HSP_REPORT_DIR")
+    if report:
+        import json
+        with open(os.path.join(report, f"free_running_{name}.json"), "w") as f:
+            json.dump({"agree_rows_per_layer": watch.agree, "max_abs_err": errs}, f, indent=1)
+    assert all(a >= f for a, f in zip(watch.agree, FREE_RUNNING_AGREE[name])), watch.agree
+    bound = 1e-4 if exact else FREE_RUNNING_BOUND[name]
+    for n_, e in errs.items():
+        assert e <= bound, f"{name} {n_}: {e:.3e} > {bound}"
