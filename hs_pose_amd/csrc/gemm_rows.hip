@@ -12,19 +12,29 @@
 //   y   = x W^T + b / gx = g W                      the Conv1d(k=1) layers of the heads (PoseR.py:16-39, PoseTs.py:18-45,
 //                                                   FaceRecon.py:37-68)
 //
-// Structure: a 256-thread workgroup (4 waves as 2x2) owns a BM x BN tile of C (128x128 or 64x64: the row counts of this
-// path are 257 * 2^j, so tile shape is chosen per call by how evenly the tiles fill 256 CUs); K is walked in blocks of
-// 128 BYTES per row (32 fp32 / 64 bf16) staged through LDS: global -> registers (in flight under the MFMAs of the
-// previous block) -> LDS, double-buffered, one barrier per block.  The LDS image is the same for both types: rows of
-// 128 data bytes + 16 pad bytes (144-byte pitch: the 16 lanes of a ds_read_b128 group hit 16 different 16-byte slots),
-// read at row*144 + 32*step + 16*(lane>>5), which hands every lane
+// Structure: persistent 256-thread workgroups (4 waves as 2x2), each walking its share of the BM x BN tiles of C
+// (128x128 or 64x64: the row counts of this path are 257 * 2^j, so the shape is chosen per call by how evenly the tiles
+// fill 256 CUs).  K is walked in blocks of 128 BYTES per row (32 fp32 / 64 bf16) through a double-buffered LDS stage, ONE
+// barrier per block; the (tile, k-block) iteration space of a workgroup is flattened, so the first block of the next tile
+// is already in flight while the current tile finishes and is written out (with K = 128 a tile is only four blocks long:
+// an un-overlapped prologue per tile cost as much as the MFMAs).
+// Staging: when every operand is 16-byte aligned, global -> LDS directly (global_load_lds_dwordx4, no staging registers,
+// no ds_write); otherwise global -> registers (4-byte pieces, any alignment) -> ds_write after the block's MFMAs.
+// LDS image, identical for both types: tile rows of 128 bytes = 8 chunks of 16 bytes, chunk c of row r stored at
+// position c ^ ((r >> 1) & 7): the 16 lanes of a ds_read_b128 group (16 different rows, same c) hit 16 different
+// 16-byte slots, and a wave's LDS-DMA destination stays lane-linear (the permutation is applied to the SOURCE address).
+// Reads at row*128 + ((2*step + (lane>>5)) ^ key)*16 hand every lane
 //   fp32: 4 consecutive k  -> 4 x v_mfma_f32_32x32x2_f32  (k pairs (j, j+4): the k order inside a block is permuted
 //                              identically for A and B, the sum is the same set of products)
 //   bf16: 8 consecutive k  -> 1 x v_mfma_f32_32x32x16_bf16
-// "nn" operands (k-major rows, fp32 only) are staged as [k][n] and read with ds_read_b32 (lanes = consecutive n).
-// Rows past M / columns past N are clamped on load and masked on store; k past K is zero-filled in the loader, so any
-// K (3, 771, 1286, 1289 ...) and any operand alignment (runtime vector width 16/8/4 bytes) is accepted.
+// "nn" operands (k-major rows, fp32 only) are staged as [k][n] rows and read with ds_read_b32 (lanes = consecutive n).
+// Rows past M / columns past N are clamped on load and masked on store; in the ragged last block of K the operands are
+// zeroed as they are read from LDS, so any K (3, 771, 1286, 1289 ...) is accepted.
+// Tile order: tm fastest inside groups of 16 row panels, then tn -- the ~128 tiles an XCD works on at a time form a
+// 16 x 8 rectangle that shares 16 A panels and 8 B panels in that XCD's L2.
 #include "common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace hsp {
 
@@ -33,8 +43,8 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 struct GemmRowsArgs {
     const void* A1; const void* B1; const void* A2; const void* B2;
-    int lda1, ldb1, K1, va1, vb1;          // v*: bytes per staging load the operand's alignment allows (16, 8, 4, 2)
-    int lda2, ldb2, K2, va2, vb2;
+    int lda1, ldb1, K1;
+    int lda2, ldb2, K2;
     void* C; int ldc;
     int M, N;
     const float* bias;                     // (N) fp32 or null
@@ -43,7 +53,7 @@ struct GemmRowsArgs {
     int tiles_m, tiles_n;
 };
 
-#define GR_PITCH 144                       // LDS bytes per tile row (128 data + 16 pad)
+#define GR_TM_GROUP 16                     // row panels per tile-order group
 
 __device__ __forceinline__ float bf16_to_f32(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {              // round to nearest even; NaN stays NaN
@@ -53,79 +63,58 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {              //
     return (unsigned short)(u >> 16);
 }
 
-// 16 bytes of row `p` starting at element k0 (EPC = 16 / ES elements), elements at or past K zero-filled.
-// vb = bytes per load the operand's alignment allows (host: base pointer and row pitch are multiples of it).  A full
-// chunk is fetched in 16 / vb pieces; the ragged chunk at the end of K element by element, so nothing past element
-// K-1 is ever touched unless vb == 16 (then the pitch is a multiple of 16 bytes and the chunk lies inside the row).
-template <int ES>   // element size in bytes (4: fp32, 2: bf16)
-__device__ __forceinline__ uint4 load_chunk_guarded(const char* __restrict__ p, int k0, int K, int vb) {
-    constexpr int EPC = 16 / ES;
-    unsigned w[4] = {0u, 0u, 0u, 0u};
-    if (k0 >= K) return make_uint4(0u, 0u, 0u, 0u);
-    const char* q = p + (size_t)k0 * ES;
-    const bool full = k0 + EPC <= K;
-    if (vb == 16) {
-        const uint4 v = *reinterpret_cast<const uint4*>(q);
-        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-        if (!full) {
-            const int keep = K - k0;                            // 1 .. EPC-1 elements survive
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (ES == 4) w[e] = e < keep ? w[e] : 0u;
-                else w[e] &= (2 * e < keep ? 0x0000ffffu : 0u) | (2 * e + 1 < keep ? 0xffff0000u : 0u);
-            }
-        }
-    } else if (full && vb == 8) {
-        const uint2 a = *reinterpret_cast<const uint2*>(q);
-        const uint2 b = *reinterpret_cast<const uint2*>(q + 8);
-        w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y;
-    } else if (full && (vb == 4 || ES == 4)) {
-        const unsigned* u = reinterpret_cast<const unsigned*>(q);
-        w[0] = u[0]; w[1] = u[1]; w[2] = u[2]; w[3] = u[3];
-    } else if (ES == 4) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (k0 + e < K) w[e] = *reinterpret_cast<const unsigned*>(q + 4 * e);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (k0 + e < K) w[e >> 1] |= (unsigned)*reinterpret_cast<const unsigned short*>(q + 2 * e) << (16 * (e & 1));
-    }
-    return make_uint4(w[0], w[1], w[2], w[3]);
+// 16 bytes, global -> LDS, no registers: every lane supplies its own source address, the destination is
+// lds_wave_base + lane * 16 (lds_wave_base must be wave-uniform)
+__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
 // T: float or unsigned short (bf16 bits).  WM, WN: 32x32 MFMA tiles per wave along M / N (block tile = 64*WM x 64*WN).
-// LB1 / LB2: layout of B1 / B2 -- 1 "nt" (N,K) k contiguous, 2 "nn" (K,N) n contiguous (fp32 only), 0 (LB2) = no 2nd source
-template <typename T, int WM, int WN, int LB1, int LB2>
+// LB1 / LB2: layout of B1 / B2 -- 1 "nt" (N,K) k contiguous, 2 "nn" (K,N) n contiguous (fp32 only), 0 (LB2) = no 2nd source.
+// GLDS: every operand 16-byte aligned (base and row pitch) -> LDS-DMA staging; else 4-byte pieces through registers.
+template <typename T, int WM, int WN, int LB1, int LB2, int MODE>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
+    constexpr bool GLDS = MODE == 2;             // MODE 2: LDS-DMA, 1: registers, 16-byte loads, 0: registers, 4-byte pieces
     constexpr int ES = sizeof(T);
     constexpr int EPC = 16 / ES;                 // elements per 16-byte chunk
     constexpr int BKE = 128 / ES;                // k elements per block
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    constexpr int A_BYTES = BM * GR_PITCH;
-    constexpr int NN_PITCH = (BN + 4) * 4;       // "nn" tile: 32 k-rows of BN fp32 + pad
-    constexpr int B_BYTES = (BN * GR_PITCH > 32 * NN_PITCH) ? BN * GR_PITCH : 32 * NN_PITCH;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;      // ("nn": 32 k-rows of BN fp32 -- the same size)
     constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int NN_PITCH = BN * 4;
+    constexpr int NA = BM / 32, NB = BN / 32;    // staging pieces per thread (16-byte chunks)
     static_assert(LB1 == 1 || (LB1 == 2 && ES == 4), "nn operands are fp32 only");
     static_assert(LB2 == 0 || LB2 == 1 || (LB2 == 2 && ES == 4), "nn operands are fp32 only");
+    static_assert(MODE != 0 || ES == 4, "bf16 operands must be 16-byte aligned");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave >> 1) * 32 * WM, wn0 = (wave & 1) * 32 * WN;
     const int li = lane & 31, lh = lane >> 5;
+    const int key = (li >> 1) & 7;               // swizzle key of the rows this lane reads (tile row offsets are multiples of 32)
 
-    // tile of this workgroup: XCD-aware (block b runs on XCD b % 8): each XCD walks a contiguous range of tiles, tn
-    // fastest, so the workgroups sharing an A row panel share one L2 (bijective for any tile count)
+    // ---- tiles of this workgroup.  Workgroups b = x (mod 8) run on XCD x: it takes a contiguous range of the ordered
+    // tile list, and its workgroups take every (gridDim/8)-th tile of that range, so the tiles in flight on an XCD are
+    // consecutive in the order below.
     const int ntiles = g.tiles_m * g.tiles_n;
-    int tile;
-    {
-        const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
-        const int q = ntiles >> 3, r = ntiles & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per = gridDim.x >> 3;      // gridDim.x is a multiple of 8
+    const int q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int x_first = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int x_count = q8 + (xcd < r8 ? 1 : 0);
+    const int my_count = idx < x_count ? (x_count - idx + per - 1) / per : 0;
+    if (my_count == 0) return;
+
+    auto tile_origin = [&](int i, int& m0, int& n0) {
+        // ordered tile id -> (tm, tn): groups of GR_TM_GROUP row panels; inside a group tm fastest, then tn
+        const int o = x_first + idx + i * per;
+        const int gsz = GR_TM_GROUP * g.tiles_n;
+        const int grp = o / gsz, rem = o - grp * gsz;
+        const int gh = min(GR_TM_GROUP, g.tiles_m - grp * GR_TM_GROUP);          // panels in this (maybe last, shorter) group
+        const int tn = rem / gh, tm = grp * GR_TM_GROUP + (rem - tn * gh);
+        m0 = tm * BM; n0 = tn * BN;
+    };
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -139,196 +128,245 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
     const int T2 = LB2 ? (g.K2 + BKE - 1) / BKE : 0;
     const int TT = T1 + T2;
 
-    uint4 ra[BM / 32], rb[BN / 32];
-    // staging roles: A (and "nt" B): thread -> 16-byte chunk (tid & 7) of rows (tid >> 3) + 32 p
-    const int s_row = tid >> 3, s_chunk = tid & 7;
+    // ---- staging ---------------------------------------------------------------------------------------------------
+    // thread -> 16-byte chunk p = tid & 7 (physical position) of tile rows (tid >> 3) + 32 j; logical chunk = p ^ rowkey.
+    // In LDS-DMA mode wave w's 64 lanes are exactly rows 8w .. 8w+7 (+ 32 j) x 8 chunks = 1024 contiguous LDS bytes.
+    const int s_row = tid >> 3, s_p = tid & 7;
+    const int s_c = s_p ^ ((s_row >> 1) & 7);                 // (rows s_row + 32 j share the key)
+    uint4 ra[GLDS ? 1 : NA], rb[GLDS ? 1 : NB];
 
-    auto fetch = [&](int t) {
+    auto src_of = [&](int t, const char*& A, const char*& B, int& lda, int& ldb, int& K, int& kb, int& lb) {
         const bool second = LB2 && t >= T1;
-        const char* A = reinterpret_cast<const char*>(second ? g.A2 : g.A1);
-        const char* B = reinterpret_cast<const char*>(second ? g.B2 : g.B1);
-        const int lda = second ? g.lda2 : g.lda1, ldb = second ? g.ldb2 : g.ldb1, K = second ? g.K2 : g.K1;
-        const int va = second ? g.va2 : g.va1, vb = second ? g.vb2 : g.vb1;
-        const int kb = (second ? t - T1 : t) * BKE;
-        const int lb = (LB2 == 0 || LB1 == LB2) ? LB1 : (second ? LB2 : LB1);
-#pragma unroll
-        for (int p = 0; p < BM / 32; ++p) {
-            const int row = min(m0 + s_row + 32 * p, g.M - 1);
-            ra[p] = load_chunk_guarded<ES>(A + (size_t)row * lda * ES, kb + s_chunk * EPC, K, va);
-        }
-        if (lb == 1) {
-#pragma unroll
-            for (int p = 0; p < BN / 32; ++p) {
-                const int col = min(n0 + s_row + 32 * p, g.N - 1);
-                rb[p] = load_chunk_guarded<ES>(B + (size_t)col * ldb * ES, kb + s_chunk * EPC, K, vb);
-            }
+        A = reinterpret_cast<const char*>(second ? g.A2 : g.A1);
+        B = reinterpret_cast<const char*>(second ? g.B2 : g.B1);
+        lda = second ? g.lda2 : g.lda1; ldb = second ? g.ldb2 : g.ldb1; K = second ? g.K2 : g.K1;
+        kb = (second ? t - T1 : t) * BKE;
+        lb = (LB2 == 0 || LB1 == LB2) ? LB1 : (second ? LB2 : LB1);
+    };
+    // 16 bytes as four 4-byte pieces, no branches (a piece at or past `lim` is redirected to element 0: garbage, zeroed
+    // when it is read from LDS)
+    auto load4 = [&](const char* row, int e0, int lim) {
+        if constexpr (MODE == 1) {
+            return *reinterpret_cast<const uint4*>(row + (size_t)(e0 < lim ? e0 : 0) * ES);
         } else {
-            // "nn": chunk q = tid + 256 p of the 32 x BN tile: k row q / (BN/4), 4 columns at 4 * (q % (BN/4))
+            unsigned w[4];
 #pragma unroll
-            for (int p = 0; p < BN / 32; ++p) {
-                const int q = tid + 256 * p;
-                const int kr = q / (BN / 4), nc = (q - kr * (BN / 4)) * 4;
-                const int k = kb + kr;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (k < K) v = load_chunk_guarded<ES>(B + (size_t)k * ldb * ES, n0 + nc, g.N, vb);
-                rb[p] = v;
-            }
+            for (int e = 0; e < 4; ++e) w[e] = *reinterpret_cast<const unsigned*>(row + (size_t)(e0 + e < lim ? e0 + e : 0) * 4);
+            return make_uint4(w[0], w[1], w[2], w[3]);
         }
     };
-    auto stash = [&](int t) {
-        char* sa = smem + (t & 1) * STAGE;
+    auto issue = [&](int t, int m0, int n0, int buf) {       // loads of k-block t of tile (m0, n0) -> stage `buf`
+        const char *A, *B; int lda, ldb, K, kb, lb;
+        src_of(t, A, B, lda, ldb, K, kb, lb);
+        char* sa = smem + buf * STAGE;
         char* sb = sa + A_BYTES;
-        const bool second = LB2 && t >= T1;
-        const int lb = (LB2 == 0 || LB1 == LB2) ? LB1 : (second ? LB2 : LB1);
+        const int k0 = kb + s_c * EPC;
+        const int k0c = k0 < K ? k0 : 0;                     // (a chunk that starts before K lies inside the 16-byte-multiple pitch)
 #pragma unroll
-        for (int p = 0; p < BM / 32; ++p)
-            *reinterpret_cast<uint4*>(sa + (s_row + 32 * p) * GR_PITCH + s_chunk * 16) = ra[p];
+        for (int j = 0; j < NA; ++j) {
+            const int row = min(m0 + s_row + 32 * j, g.M - 1);
+            const char* src = A + (size_t)row * lda * ES;
+            if constexpr (GLDS) glds16(src + (size_t)k0c * ES, sa + (wave * 8 + 32 * j) * 128);
+            else ra[j] = load4(src, k0, K);
+        }
         if (lb == 1) {
 #pragma unroll
-            for (int p = 0; p < BN / 32; ++p)
-                *reinterpret_cast<uint4*>(sb + (s_row + 32 * p) * GR_PITCH + s_chunk * 16) = rb[p];
+            for (int j = 0; j < NB; ++j) {
+                const int col = min(n0 + s_row + 32 * j, g.N - 1);
+                const char* src = B + (size_t)col * ldb * ES;
+                if constexpr (GLDS) glds16(src + (size_t)k0c * ES, sb + (wave * 8 + 32 * j) * 128);
+                else rb[j] = load4(src, k0, K);
+            }
         } else {
+            // "nn": the tile is 32 k-rows of BN fp32, linear; thread -> 16 bytes at byte (tid + 256 j) * 16
 #pragma unroll
-            for (int p = 0; p < BN / 32; ++p) {
-                const int q = tid + 256 * p;
-                const int kr = q / (BN / 4), nc = (q - kr * (BN / 4)) * 4;
-                *reinterpret_cast<uint4*>(sb + kr * NN_PITCH + nc * 4) = rb[p];
+            for (int j = 0; j < NB; ++j) {
+                const int off = (tid + 256 * j) * 16;
+                const int kr = off / NN_PITCH, nc = (off - kr * NN_PITCH) >> 2;
+                const int k = kb + kr < K ? kb + kr : 0;
+                const char* src = B + (size_t)k * ldb * 4;
+                if constexpr (GLDS) glds16(src + (size_t)(n0 + nc < g.N ? n0 + nc : 0) * 4, sb + (wave * 64 + 256 * j) * 16);
+                else rb[j] = load4(src, n0 + nc, g.N);
             }
         }
     };
-    auto compute = [&](int t) {
-        const char* sa = smem + (t & 1) * STAGE;
+    auto stash = [&](int t, int buf) {                       // register mode: staged registers -> LDS
+        if constexpr (!GLDS) {
+            char* sa = smem + buf * STAGE;
+            char* sb = sa + A_BYTES;
+            const bool second = LB2 && t >= T1;
+            const int lb = (LB2 == 0 || LB1 == LB2) ? LB1 : (second ? LB2 : LB1);
+#pragma unroll
+            for (int j = 0; j < NA; ++j) *reinterpret_cast<uint4*>(sa + (s_row + 32 * j) * 128 + s_p * 16) = ra[j];
+            if (lb == 1) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) *reinterpret_cast<uint4*>(sb + (s_row + 32 * j) * 128 + s_p * 16) = rb[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) *reinterpret_cast<uint4*>(sb + (tid + 256 * j) * 16) = rb[j];
+            }
+        }
+    };
+
+    // ---- MFMAs of one k-block.  MASK: the ragged last block of a source -- operands at k >= kvalid are zeroed
+    auto mma_block = [&](int buf, int lb, int kvalid, auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        const char* sa = smem + buf * STAGE;
         const char* sb = sa + A_BYTES;
-        const bool second = LB2 && t >= T1;
-        const int lb = (LB2 == 0 || LB1 == LB2) ? LB1 : (second ? LB2 : LB1);
-        const char* pa = sa + (wm0 + li) * GR_PITCH + 16 * lh;
-        if (lb == 1) {
-            const char* pb = sb + (wn0 + li) * GR_PITCH + 16 * lh;
+        const char* pa = sa + (wm0 + li) * 128;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                uint4 a[WM], b[WN];
+        for (int s = 0; s < 4; ++s) {
+            const int coff = ((2 * s + lh) ^ key) << 4;
+            uint4 a[WM];
 #pragma unroll
-                for (int x = 0; x < WM; ++x) a[x] = *reinterpret_cast<const uint4*>(pa + x * 32 * GR_PITCH + 32 * s);
+            for (int x = 0; x < WM; ++x) a[x] = *reinterpret_cast<const uint4*>(pa + x * 32 * 128 + coff);
+            if (ES == 4) {
+                float b[WN][4];
+                if (lb == 1) {
+                    const char* pb = sb + (wn0 + li) * 128 + coff;
 #pragma unroll
-                for (int y = 0; y < WN; ++y) b[y] = *reinterpret_cast<const uint4*>(pb + y * 32 * GR_PITCH + 32 * s);
-                if (ES == 4) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int x = 0; x < WM; ++x)
-#pragma unroll
-                            for (int y = 0; y < WN; ++y) {
-                                const unsigned au = j == 0 ? a[x].x : j == 1 ? a[x].y : j == 2 ? a[x].z : a[x].w;
-                                const unsigned bu = j == 0 ? b[y].x : j == 1 ? b[y].y : j == 2 ? b[y].z : b[y].w;
-                                acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(au), __uint_as_float(bu),
-                                                                                 acc[x][y], 0, 0, 0);
-                            }
+                    for (int y = 0; y < WN; ++y) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(pb + y * 32 * 128);
+                        b[y][0] = __uint_as_float(v.x); b[y][1] = __uint_as_float(v.y);
+                        b[y][2] = __uint_as_float(v.z); b[y][3] = __uint_as_float(v.w);
+                    }
                 } else {
+                    const char* pb = sb + (8 * s + 4 * lh) * NN_PITCH + (wn0 + li) * 4;
 #pragma unroll
-                    for (int x = 0; x < WM; ++x)
+                    for (int y = 0; y < WN; ++y)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) b[y][j] = *reinterpret_cast<const float*>(pb + j * NN_PITCH + y * 128);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool live = !MASK || 8 * s + 4 * lh + j < kvalid;
+#pragma unroll
+                    for (int x = 0; x < WM; ++x) {
+                        const unsigned au = j == 0 ? a[x].x : j == 1 ? a[x].y : j == 2 ? a[x].z : a[x].w;
+                        const float av = live ? __uint_as_float(au) : 0.f;
 #pragma unroll
                         for (int y = 0; y < WN; ++y)
-                            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[x]),
-                                                                                __builtin_bit_cast(bf16x8, b[y]), acc[x][y],
-                                                                                0, 0, 0);
+                            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, live ? b[y][j] : 0.f, acc[x][y], 0, 0, 0);
+                    }
                 }
+            } else {
+                const char* pb = sb + (wn0 + li) * 128 + coff;
+                uint4 b[WN];
+#pragma unroll
+                for (int y = 0; y < WN; ++y) b[y] = *reinterpret_cast<const uint4*>(pb + y * 32 * 128);
+                if (MASK) {
+                    const int keep = kvalid - (16 * s + 8 * lh);              // of this lane's 8 elements
+                    auto m = [&](uint4 v) {
+                        unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[e] &= (2 * e < keep ? 0x0000ffffu : 0u) | (2 * e + 1 < keep ? 0xffff0000u : 0u);
+                        return make_uint4(w[0], w[1], w[2], w[3]);
+                    };
+#pragma unroll
+                    for (int x = 0; x < WM; ++x) a[x] = m(a[x]);
+#pragma unroll
+                    for (int y = 0; y < WN; ++y) b[y] = m(b[y]);
+                }
+#pragma unroll
+                for (int x = 0; x < WM; ++x)
+#pragma unroll
+                    for (int y = 0; y < WN; ++y)
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[x]),
+                                                                            __builtin_bit_cast(bf16x8, b[y]), acc[x][y], 0, 0, 0);
             }
-        } else if (ES == 4) {
-            // "nn" B tile [k][n]: lane reads B[k = 8 s + 4 lh + j][wn0 + 32 y + li]
-            const char* pb = sb + (4 * lh) * NN_PITCH + (wn0 + li) * 4;
+        }
+    };
+    auto compute = [&](int t, int buf) {
+        const bool second = LB2 && t >= T1;
+        const int lb = (LB2 == 0 || LB1 == LB2) ? LB1 : (second ? LB2 : LB1);
+        const int K = second ? g.K2 : g.K1;
+        const int kvalid = K - (second ? t - T1 : t) * BKE;
+        if (kvalid >= BKE) mma_block(buf, lb, BKE, std::false_type{});
+        else mma_block(buf, lb, kvalid, std::true_type{});
+    };
+
+    // ---- write a finished tile: accumulator r of (x,y) <-> row wm0 + 32x + (r&3) + 8(r>>2) + 4 lh, column wn0 + 32y + li
+    auto epilogue = [&](int m0, int n0) {
+        const int rpc = g.rows_per_cloud;
+        int c0 = 0, nb = 0x7fffffff;                      // per-cloud bias: cloud boundaries by comparison, no per-row division
+        if (g.cbias) { c0 = m0 / rpc; nb = (c0 + 1) * rpc; }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                uint4 a[WM];
-                float b[WN][4];
+        for (int y = 0; y < WN; ++y) {
+            const int col = n0 + wn0 + 32 * y + li;
+            const bool cok = col < g.N;
+            const float bv = (g.bias && cok) ? g.bias[col] : 0.f;
 #pragma unroll
-                for (int x = 0; x < WM; ++x) a[x] = *reinterpret_cast<const uint4*>(pa + x * 32 * GR_PITCH + 32 * s);
+            for (int x = 0; x < WM; ++x) {
 #pragma unroll
-                for (int y = 0; y < WN; ++y)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        b[y][j] = *reinterpret_cast<const float*>(pb + (8 * s + j) * NN_PITCH + y * 128);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int x = 0; x < WM; ++x)
-#pragma unroll
-                        for (int y = 0; y < WN; ++y) {
-                            const unsigned au = j == 0 ? a[x].x : j == 1 ? a[x].y : j == 2 ? a[x].z : a[x].w;
-                            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(au), b[y][j], acc[x][y], 0, 0, 0);
-                        }
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm0 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    float v = acc[x][y][r] + bv;
+                    acc[x][y][r] = 0.f;
+                    if (!cok || row >= g.M) continue;
+                    if (g.resid) {
+                        if (ES == 4) v += reinterpret_cast<const float*>(g.resid)[(size_t)row * g.ldr + col];
+                        else v += bf16_to_f32(reinterpret_cast<const unsigned short*>(g.resid)[(size_t)row * g.ldr + col]);
+                    }
+                    if (g.cbias) {
+                        int c = c0;
+                        if (row >= nb) c = c0 + 1 + (row - nb) / rpc;      // rare: the tile spans clouds
+                        v += g.cbias[(size_t)c * g.N + col];
+                    }
+                    if (ES == 4) reinterpret_cast<float*>(g.C)[(size_t)row * g.ldc + col] = v;
+                    else reinterpret_cast<unsigned short*>(g.C)[(size_t)row * g.ldc + col] = f32_to_bf16(v);
+                }
             }
         }
     };
 
-    fetch(0);
-    stash(0);
+    // ---- the flattened (tile, k-block) walk: stage it+1 while block `it` is multiplied
+    int m0, n0, nm0, nn0;
+    tile_origin(0, m0, n0);
+    issue(0, m0, n0, 0);
+    stash(0, 0);
     __syncthreads();
-    for (int t = 0; t < TT; ++t) {
-        if (t + 1 < TT) fetch(t + 1);            // global loads in flight under this block's MFMAs
-        __builtin_amdgcn_sched_barrier(0);       // (hipcc would sink the loads next to their use in stash())
-        compute(t);
+    int ti = 0, t = 0;
+    const int total = my_count * TT;
+    for (int it = 0; it < total; ++it) {
+        int nt = t + 1, nti = ti;
+        nm0 = m0; nn0 = n0;
+        if (nt == TT) { nt = 0; nti = ti + 1; if (nti < my_count) tile_origin(nti, nm0, nn0); }
+        const bool more = it + 1 < total;
+        if (more) issue(nt, nm0, nn0, (it + 1) & 1);          // in flight under this block's MFMAs
+        __builtin_amdgcn_sched_barrier(0);                   // (hipcc would sink register-mode loads next to their use)
+        compute(t, it & 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < TT) stash(t + 1);            // the other buffer: last read in iteration t-1, before the barrier below
-        __syncthreads();
-    }
-
-    // epilogue: accumulator r of tile (x,y) <-> row wm0 + 32x + (r&3) + 8(r>>2) + 4 lh, column wn0 + 32y + li
-    T* C = reinterpret_cast<T*>(g.C);
-    const T* R = reinterpret_cast<const T*>(g.resid);
-    // per-cloud bias: rows of this tile lie in clouds c0, c0+1, ... ; boundaries by comparison (no per-row division)
-    int c0 = 0, nb = 0x7fffffff;
-    const int rpc = g.rows_per_cloud;
-    if (g.cbias) { c0 = m0 / rpc; nb = (c0 + 1) * rpc; }
-#pragma unroll
-    for (int y = 0; y < WN; ++y) {
-        const int col = n0 + wn0 + 32 * y + li;
-        if (col >= g.N) continue;
-        const float bv = g.bias ? g.bias[col] : 0.f;
-#pragma unroll
-        for (int x = 0; x < WM; ++x) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm0 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row >= g.M) continue;
-                float v = acc[x][y][r] + bv;
-                if (g.resid) {
-                    if (ES == 4) v += reinterpret_cast<const float*>(R)[(size_t)row * g.ldr + col];
-                    else v += bf16_to_f32(reinterpret_cast<const unsigned short*>(R)[(size_t)row * g.ldr + col]);
-                }
-                if (g.cbias) {
-                    int c = c0;
-                    if (row >= nb) c = c0 + 1 + (row - nb) / rpc;      // rare (tile spans clouds): the division is off the hot path
-                    v += g.cbias[(size_t)c * g.N + col];
-                }
-                if (ES == 4) reinterpret_cast<float*>(C)[(size_t)row * g.ldc + col] = v;
-                else reinterpret_cast<unsigned short*>(C)[(size_t)row * g.ldc + col] = f32_to_bf16(v);
-            }
-        }
+        if (t == TT - 1) epilogue(m0, n0);
+        if (more) stash(nt, (it + 1) & 1);                   // the other stage: last read in iteration it-1, before the barrier below
+        __syncthreads();                                     // (waits for the LDS-DMA / ds_write of stage it+1 as well)
+        t = nt; ti = nti; m0 = nm0; n0 = nn0;
     }
 }
 
-// bytes per staging load an operand allows: base pointer, row pitch (bytes) and 16 all share the factor
-static int vec_bytes(const void* p, int ld_elems, int es) {
-    const size_t a = reinterpret_cast<size_t>(p);
-    const size_t pitch = (size_t)ld_elems * es;
-    for (int v = 16; v > es; v >>= 1)
-        if (a % v == 0 && pitch % v == 0) return v;
-    return es;
+// 16-byte alignment of an operand (base pointer and row pitch)
+static bool aligned16(const void* p, int ld_elems, int es) {
+    return reinterpret_cast<size_t>(p) % 16 == 0 && ((size_t)ld_elems * es) % 16 == 0;
 }
 
-template <typename T, int WM, int WN>
+template <typename T, int WM, int WN, int MODE>
 static int launch_cfg(const GemmRowsArgs& a, int lb1, int lb2, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int ES = sizeof(T);
     GemmRowsArgs g = a;
     g.tiles_m = (a.M + BM - 1) / BM;
     g.tiles_n = (a.N + BN - 1) / BN;
-    constexpr size_t nn = (size_t)32 * (BN + 4) * 4, nt = (size_t)BN * GR_PITCH;
-    const size_t lds = 2 * ((size_t)BM * GR_PITCH + (nn > nt ? nn : nt));
-    const dim3 grid(g.tiles_m * g.tiles_n), block(256);
+    const size_t lds = 2 * (size_t)(BM + BN) * 128;
+    // persistent grid: as many workgroups as stay resident (LDS: 160 KiB per CU), a multiple of 8 (XCDs), no more than tiles
+    const int per_cu = (int)((160 * 1024) / lds) > 4 ? 4 : (int)((160 * 1024) / lds);
+    long long nb = (long long)HSP_NUM_CU * per_cu;
+    const long long tiles = (long long)g.tiles_m * g.tiles_n;
+    if (const char* e = getenv("HSP_GEMM_PERSIST")) { if (e[0] == '0') nb = tiles; }        // profiling override: one tile per workgroup
+    if (nb > tiles) nb = tiles;
+    nb = (nb + 7) / 8 * 8;
+    const dim3 grid((unsigned)nb), block(256);
 #define GR_LAUNCH(L1, L2)                                                                                               \
     do {                                                                                                               \
-        auto kern = gemm_rows_kernel<T, WM, WN, L1, L2>;                                                               \
+        auto kern = gemm_rows_kernel<T, WM, WN, L1, L2, MODE>;                                                         \
         static bool attr_set = false;                                                                                  \
         if (!attr_set) {                                                                                               \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
@@ -339,19 +377,26 @@ static int launch_cfg(const GemmRowsArgs& a, int lb1, int lb2, hipStream_t st) {
         hipLaunchKernelGGL(kern, grid, block, lds, st, g);                                                             \
         return check_launch();                                                                                         \
     } while (0)
+    // layouts on this path: X W ("nn"), x W^T ("nt"), X Wste^T + F Wa^T ("nt" + "nt"), g Wste + gfm W^T ("nn" + "nt")
     if constexpr (ES == 4) {
         if (lb1 == 1 && lb2 == 0) GR_LAUNCH(1, 0);
         if (lb1 == 2 && lb2 == 0) GR_LAUNCH(2, 0);
         if (lb1 == 1 && lb2 == 1) GR_LAUNCH(1, 1);
-        if (lb1 == 1 && lb2 == 2) GR_LAUNCH(1, 2);
         if (lb1 == 2 && lb2 == 1) GR_LAUNCH(2, 1);
-        if (lb1 == 2 && lb2 == 2) GR_LAUNCH(2, 2);
     } else {
         if (lb1 == 1 && lb2 == 0) GR_LAUNCH(1, 0);
         if (lb1 == 1 && lb2 == 1) GR_LAUNCH(1, 1);
     }
 #undef GR_LAUNCH
     return HSP_ERR_UNSUPPORTED;
+}
+
+template <typename T, int WM, int WN>
+static int launch_mode(const GemmRowsArgs& a, int lb1, int lb2, int mode, hipStream_t st) {
+    if (mode == 2) return launch_cfg<T, WM, WN, 2>(a, lb1, lb2, st);
+    if (mode == 1) return launch_cfg<T, WM, WN, 1>(a, lb1, lb2, st);
+    if constexpr (sizeof(T) == 4) return launch_cfg<T, WM, WN, 0>(a, lb1, lb2, st);
+    return HSP_ERR_UNSUPPORTED;                    // bf16 operands: 16-byte aligned rows
 }
 
 // tile shape: the one whose tiles fill the 256 CUs most evenly (cost = tiles per CU, rounded up, x tile area; the small
@@ -379,17 +424,35 @@ static int gemm_rows_dispatch(const void* A1, int lda1, const void* B1, int ldb1
     if (ES == 2 && (l1 == 1 || (two && l2 == 1))) return HSP_ERR_UNSUPPORTED;     // bf16: "nt" operands only
     GemmRowsArgs g{};
     g.A1 = A1; g.B1 = B1; g.lda1 = lda1; g.ldb1 = ldb1; g.K1 = K1;
-    g.va1 = vec_bytes(A1, lda1, ES); g.vb1 = vec_bytes(B1, ldb1, ES);
+    bool glds = aligned16(A1, lda1, ES) && aligned16(B1, ldb1, ES);
     if (two) {
         g.A2 = A2; g.B2 = B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;
-        g.va2 = vec_bytes(A2, lda2, ES); g.vb2 = vec_bytes(B2, ldb2, ES);
+        glds = glds && aligned16(A2, lda2, ES) && aligned16(B2, ldb2, ES);
     }
+    if (!glds && ES == 4) {                                    // register mode reads 4-byte pieces
+        const void* ps[4] = {A1, B1, A2, B2};
+        for (const void* q : ps)
+            if (reinterpret_cast<size_t>(q) % 4) return HSP_ERR_UNSUPPORTED;
+    }
+    // a dual-source call whose second source is a (K,N)-with-(N,K) pair is issued with the sources swapped
+    // (the sum is commutative), which keeps the instantiated layout pairs to ("nt","nt") and ("nn","nt")
     g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.bias = bias; g.resid = resid; g.ldr = ldr; g.cbias = cbias;
     g.rows_per_cloud = rpc > 0 ? rpc : 1;
-    const int lb1 = l1 == 0 ? 1 : 2, lb2 = two ? (l2 == 0 ? 1 : 2) : 0;
+    int lb1 = l1 == 0 ? 1 : 2, lb2 = two ? (l2 == 0 ? 1 : 2) : 0;
+    if (two && lb1 == 1 && lb2 == 2) {
+        const void* t; int ti;
+        t = g.A1; g.A1 = g.A2; g.A2 = t;  t = g.B1; g.B1 = g.B2; g.B2 = t;
+        ti = g.lda1; g.lda1 = g.lda2; g.lda2 = ti;  ti = g.ldb1; g.ldb1 = g.ldb2; g.ldb2 = ti;  ti = g.K1; g.K1 = g.K2; g.K2 = ti;
+        lb1 = 2; lb2 = 1;
+    }
+    if (two && lb1 == 2 && lb2 == 2) return HSP_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);
-    if (prefer_small_tile(M, N)) return launch_cfg<T, 1, 1>(g, lb1, lb2, st);
-    return launch_cfg<T, 2, 2>(g, lb1, lb2, st);
+    bool small = prefer_small_tile(M, N);
+    if (const char* e = getenv("HSP_GEMM_TILE")) small = e[0] == 's' ? true : e[0] == 'l' ? false : small;   // profiling override
+    int mode = glds ? 1 : 0;                                   // aligned: 16-byte register staging (LDS-DMA measured slower here)
+    if (const char* e = getenv("HSP_GEMM_GLDS")) { if (glds && e[0] == '1') mode = 2; }                        // profiling override
+    if (small) return launch_mode<T, 1, 1>(g, lb1, lb2, mode, st);
+    return launch_mode<T, 2, 2>(g, lb1, lb2, mode, st);
 }
 
 }  // namespace hsp

@@ -413,6 +413,61 @@ def wgrad(A2, B2, out=None, colsum=False):
     return _wgrad_custom(A2, B2, out, colsum) if choice == "custom" else _wgrad_library(A2, B2, out, colsum)
 
 
+def _ld(t):
+    """leading dimension (elements) of a 2-D tensor whose rows are contiguous"""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise HspError("gemm_rows: operands must be 2-D with contiguous rows (stride(1) == 1)")
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def gemm_rows(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=None, cloud_bias=None, rows_per_cloud=0,
+              out=None):
+    """out (M,N) = A1 @ op(B1) [+ A2 @ op(B2)] [+ bias] [+ resid] [+ cloud_bias[row // rows_per_cloud]]   (csrc/gemm_rows.hip)
+
+    op(B) = B^T for a (N,K) weight (``nn=False``: a Linear / Conv1d(k=1) weight) or B for a (K,N) matrix (``nn=True``:
+    HS_layer.weights).  fp32 or bf16 (all of A, B, resid, out alike; bias / cloud_bias always fp32; bf16 takes (N,K)
+    operands only).  Operands may be row-strided views (column blocks of wider tensors)."""
+    dt = A1.dtype
+    if dt not in (torch.float32, torch.bfloat16):
+        raise HspError(f"gemm_rows: fp32 or bf16 operands, got {dt}")
+    for t_, nm in ((A1, "A1"), (B1, "B1"), (A2, "A2"), (B2, "B2"), (resid, "resid"), (out, "out")):
+        if t_ is not None and (not t_.is_cuda or t_.dtype != dt):
+            raise HspError(f"gemm_rows.{nm}: expected a {dt} GPU tensor")
+    M, K1 = A1.shape
+    N = B1.shape[1] if nn1 else B1.shape[0]
+    if (B1.shape[0] if nn1 else B1.shape[1]) != K1:
+        raise HspError("gemm_rows: A1 / B1 inner dimensions differ")
+    K2 = 0
+    if A2 is not None:
+        K2 = A2.shape[1]
+        if A2.shape[0] != M or (B2.shape[1] if nn2 else B2.shape[0]) != N or (B2.shape[0] if nn2 else B2.shape[1]) != K2:
+            raise HspError("gemm_rows: second source has the wrong shape")
+    if out is None:
+        out = torch.empty(M, N, dtype=dt, device=A1.device)
+    for t_ in (bias, cloud_bias):
+        if t_ is not None and (t_.dtype != torch.float32 or not t_.is_cuda or not t_.is_contiguous()):
+            raise HspError("gemm_rows: bias / cloud_bias must be contiguous fp32 GPU tensors")
+    flops = 2 * M * N * (K1 + K2)
+    es = 4 if dt == torch.float32 else 2
+    ab = es * (M * (K1 + K2) + N * (K1 + K2) + M * N * (2 if resid is not None else 1))
+    key = f"M{M}N{N}K{K1}" + (f"+{K2}" if K2 else "")
+    if dt == torch.float32:
+        _run("hsp_gemm_rows_f32", (_p(A1), _ld(A1), _p(B1), _ld(B1), 1 if nn1 else 0, K1,
+                                   _p(A2), _ld(A2) if A2 is not None else 0, _p(B2), _ld(B2) if B2 is not None else 0,
+                                   1 if nn2 else 0, K2, M, N, _p(bias), _p(resid), _ld(resid) if resid is not None else 0,
+                                   _p(cloud_bias), int(rows_per_cloud), _p(out), _ld(out), _stream()),
+             key=key, abytes=ab, aflops=flops)
+    else:
+        if nn1 or nn2:
+            raise HspError("gemm_rows: bf16 operands must be (N,K) (pass the transposed copy)")
+        _run("hsp_gemm_rows_bf16", (_p(A1), _ld(A1), _p(B1), _ld(B1), K1,
+                                    _p(A2), _ld(A2) if A2 is not None else 0, _p(B2), _ld(B2) if B2 is not None else 0, K2,
+                                    M, N, _p(bias), _p(resid), _ld(resid) if resid is not None else 0, _p(cloud_bias),
+                                    int(rows_per_cloud), _p(out), _ld(out), _stream()),
+             key=key + "bf16", abytes=ab, aflops=flops)
+    return out
+
+
 def _orl_fwd_raw(F3, idx_x, k):
     """(fg (B,C), argmax (B,N,C) uint8): mean over points of the neighbourhood max, one pass, no (B,N,C) max tensor"""
     B, N, C = F3.shape
