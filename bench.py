@@ -287,7 +287,11 @@ def main():
             "config": {"workload": f"HS stack (FaceRecon backbone -> feat) fwd+bwd, B={B}/GPU N={N} fp32, "
                                    f"train-mode BN, random-init weights (BASELINE configs[1] shape)",
                        "global_batch": world * B, "points": N, "parallelism": f"dp{world}", "hipgraph": graphed is not None, "split_graph": bool(graphed is not None and graphed.split), "grad_exchange": ("none" if world == 1 else "2 all-reduces, first overlapped with backward" if graphed is not None and graphed.split else "1 all-reduce after backward" if graphed is not None else "bucketed, hook-driven"),
-                       "libhsp_ms_per_step": round(hsp_ms, 4)},
+                       "libhsp_ms_per_step": round(hsp_ms, 4),
+                       # dense per-point products: hand-written csrc/gemm_rows.hip vs the BLAS library, per composite shape
+                       "gemm": {"mode": ops.GEMM_MODE,
+                                "own": sorted(k_ for k_, v_ in ops.gemm_choices().items() if v_ == "own"),
+                                "library": sorted(k_ for k_, v_ in ops.gemm_choices().items() if v_ == "library")}},
             "roofline": roof,
             "step_roofline": step_roof,
         }

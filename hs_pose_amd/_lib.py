@@ -40,8 +40,8 @@ SIGNATURES = {
     "hsp_gather_rows_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "hsp_gather_rows_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "hsp_gather_rows_bwd_csr": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "hsp_gemm_rows_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
-    "hsp_gemm_rows_bf16": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
+    "hsp_gemm_rows_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, ctypes.c_float, _vp, _i, _vp]),
+    "hsp_gemm_rows_bf16": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, ctypes.c_float, _vp, _i, _vp]),
     "hsp_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
     "hsp_wgrad_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     "hsp_bn_workspace_bytes": (_sz, [_i, _i]),

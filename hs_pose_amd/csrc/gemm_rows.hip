@@ -50,6 +50,7 @@ struct GemmRowsArgs {
     const float* bias;                     // (N) fp32 or null
     const void* resid; int ldr;            // (M,N) of the output type or null
     const float* cbias; int rows_per_cloud;  // (ceil(M / rows_per_cloud), N) fp32 or null
+    float alpha;                           // scales the accumulated products (before bias / resid / cloud bias)
     int tiles_m, tiles_n;
 };
 
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm0 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    float v = acc[x][y][r] + bv;
+                    float v = g.alpha * acc[x][y][r] + bv;
                     acc[x][y][r] = 0.f;
                     if (!cok || row >= g.M) continue;
                     if (g.resid) {
@@ -412,7 +413,7 @@ static bool prefer_small_tile(int M, int N) {
 template <typename T>
 static int gemm_rows_dispatch(const void* A1, int lda1, const void* B1, int ldb1, int l1, int K1, const void* A2, int lda2,
                               const void* B2, int ldb2, int l2, int K2, int M, int N, const float* bias, const void* resid,
-                              int ldr, const float* cbias, int rpc, void* C, int ldc, hspStream_t stream) {
+                              int ldr, const float* cbias, int rpc, float alpha, void* C, int ldc, hspStream_t stream) {
     constexpr int ES = sizeof(T);
     if (!A1 || !B1 || !C || M <= 0 || N <= 0 || K1 <= 0 || lda1 < K1 || ldc < N) return HSP_ERR_BAD_ARG;
     if (l1 != 0 && l1 != 1) return HSP_ERR_BAD_ARG;
@@ -438,6 +439,7 @@ static int gemm_rows_dispatch(const void* A1, int lda1, const void* B1, int ldb1
     // (the sum is commutative), which keeps the instantiated layout pairs to ("nt","nt") and ("nn","nt")
     g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.bias = bias; g.resid = resid; g.ldr = ldr; g.cbias = cbias;
     g.rows_per_cloud = rpc > 0 ? rpc : 1;
+    g.alpha = alpha;
     int lb1 = l1 == 0 ? 1 : 2, lb2 = two ? (l2 == 0 ? 1 : 2) : 0;
     if (two && lb1 == 1 && lb2 == 2) {
         const void* t; int ti;
@@ -462,15 +464,15 @@ using namespace hsp;
 extern "C" int hsp_gemm_rows_f32(const float* A1, int lda1, const float* B1, int ldb1, int b1_layout, int K1,
                                  const float* A2, int lda2, const float* B2, int ldb2, int b2_layout, int K2, int M, int N,
                                  const float* bias, const float* resid, int ldr, const float* cloud_bias,
-                                 int rows_per_cloud, float* C, int ldc, hspStream_t stream) {
+                                 int rows_per_cloud, float alpha, float* C, int ldc, hspStream_t stream) {
     return gemm_rows_dispatch<float>(A1, lda1, B1, ldb1, b1_layout, K1, A2, lda2, B2, ldb2, b2_layout, K2, M, N, bias, resid,
-                                     ldr, cloud_bias, rows_per_cloud, C, ldc, stream);
+                                     ldr, cloud_bias, rows_per_cloud, alpha, C, ldc, stream);
 }
 
 extern "C" int hsp_gemm_rows_bf16(const hsp_bf16_t* A1, int lda1, const hsp_bf16_t* B1, int ldb1, int K1,
                                   const hsp_bf16_t* A2, int lda2, const hsp_bf16_t* B2, int ldb2, int K2, int M, int N,
                                   const float* bias, const hsp_bf16_t* resid, int ldr, const float* cloud_bias,
-                                  int rows_per_cloud, hsp_bf16_t* C, int ldc, hspStream_t stream) {
+                                  int rows_per_cloud, float alpha, hsp_bf16_t* C, int ldc, hspStream_t stream) {
     return gemm_rows_dispatch<unsigned short>(A1, lda1, B1, ldb1, 0, K1, A2, lda2, B2, ldb2, 0, K2, M, N, bias, resid, ldr,
-                                              cloud_bias, rows_per_cloud, C, ldc, stream);
+                                              cloud_bias, rows_per_cloud, alpha, C, ldc, stream);
 }

@@ -399,7 +399,7 @@ def wgrad(A2, B2, out=None, colsum=False):
           and A2.stride(0) % 2 == 0 and B2.stride(0) % 2 == 0 and A2.dtype == torch.float32 and A2.is_cuda)
     if not ok or WGRAD_MODE == "library":
         return _wgrad_library(A2, B2, out, colsum)
-    if WGRAD_MODE == "custom":
+    if WGRAD_MODE == "custom" or GEMM_MODE == "own":
         return _wgrad_custom(A2, B2, out, colsum)
     key = (M, N, K, bool(colsum))
     choice = _wgrad_choice.get(key)
@@ -421,8 +421,8 @@ def _ld(t):
 
 
 def gemm_rows(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=None, cloud_bias=None, rows_per_cloud=0,
-              out=None):
-    """out (M,N) = A1 @ op(B1) [+ A2 @ op(B2)] [+ bias] [+ resid] [+ cloud_bias[row // rows_per_cloud]]   (csrc/gemm_rows.hip)
+              out=None, alpha=1.0):
+    """out (M,N) = alpha * (A1 @ op(B1) [+ A2 @ op(B2)]) [+ bias] [+ resid] [+ cloud_bias[row // rows_per_cloud]]   (csrc/gemm_rows.hip)
 
     op(B) = B^T for a (N,K) weight (``nn=False``: a Linear / Conv1d(k=1) weight) or B for a (K,N) matrix (``nn=True``:
     HS_layer.weights).  fp32 or bf16 (all of A, B, resid, out alike; bias / cloud_bias always fp32; bf16 takes (N,K)
@@ -455,7 +455,7 @@ def gemm_rows(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=N
         _run("hsp_gemm_rows_f32", (_p(A1), _ld(A1), _p(B1), _ld(B1), 1 if nn1 else 0, K1,
                                    _p(A2), _ld(A2) if A2 is not None else 0, _p(B2), _ld(B2) if B2 is not None else 0,
                                    1 if nn2 else 0, K2, M, N, _p(bias), _p(resid), _ld(resid) if resid is not None else 0,
-                                   _p(cloud_bias), int(rows_per_cloud), _p(out), _ld(out), _stream()),
+                                   _p(cloud_bias), int(rows_per_cloud), float(alpha), _p(out), _ld(out), _stream()),
              key=key, abytes=ab, aflops=flops)
     else:
         if nn1 or nn2:
@@ -463,9 +463,105 @@ def gemm_rows(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=N
         _run("hsp_gemm_rows_bf16", (_p(A1), _ld(A1), _p(B1), _ld(B1), K1,
                                     _p(A2), _ld(A2) if A2 is not None else 0, _p(B2), _ld(B2) if B2 is not None else 0, K2,
                                     M, N, _p(bias), _p(resid), _ld(resid) if resid is not None else 0, _p(cloud_bias),
-                                    int(rows_per_cloud), _p(out), _ld(out), _stream()),
+                                    int(rows_per_cloud), float(alpha), _p(out), _ld(out), _stream()),
              key=key + "bf16", abytes=ab, aflops=flops)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# dense per-point products of a layer: the hand-written fused kernel (csrc/gemm_rows.hip) or the BLAS library through
+# torch.  HSP_GEMM = own | library | auto (default): "auto" times both forms of a composite once per shape (outside any
+# graph capture, on the real buffers -- both forms write the same result) and keeps the faster; "own" runs no library
+# GEMM at all on the layer path.  ``gemm_choices()`` reports what was picked.
+# ------------------------------------------------------------------------------------------------
+GEMM_MODE = os.environ.get("HSP_GEMM", "auto")
+_gemm_choice = {}
+
+
+def gemm_choices():
+    """{composite[shape]: "own" | "library"} decided so far (bench.py prints the tally)"""
+    return dict(_gemm_choice)
+
+
+def _pick(key, own_fn, lib_fn):
+    if GEMM_MODE == "own":
+        return own_fn()
+    if GEMM_MODE == "library":
+        return lib_fn()
+    choice = _gemm_choice.get(key)
+    if choice is None:
+        if torch.cuda.is_current_stream_capturing() or _timer is not None:
+            return own_fn()                                   # cannot time here; decided on a later eager call
+        t_own = _time_us(own_fn)
+        t_lib = _time_us(lib_fn)
+        # (isolated timings flatter the fused form slightly -- inside the step's graph the library's picks are warm -- so it
+        # has to win by a margin)
+        choice = _gemm_choice[key] = "own" if t_own <= 0.9 * t_lib else "library"
+    return own_fn() if choice == "own" else lib_fn()
+
+
+def _fm_rows(X2, weights, bias, out=None):
+    """fm = X W + b   (gcn3d.py:171)"""
+    R, Cin = X2.shape
+    if out is None:
+        out = torch.empty(R, weights.shape[1], dtype=X2.dtype, device=X2.device)
+    return _pick(f"fm[R{R}K{Cin}N{weights.shape[1]}]",
+                 lambda: gemm_rows(X2, weights, True, bias=bias, out=out),
+                 lambda: torch.addmm(bias, X2, weights, out=out))
+
+
+def _layer_out_rows(x2, w_ste, F2, Wa, t2, out3):
+    """out = x Wste^T + F Wa^T + F + t[cloud]   (gcn3d.py:149,186,156): one fused launch, or GEMM + GEMM + residual pass"""
+    B, N, C = out3.shape
+    out = out3.view(B * N, C)
+
+    def lib():
+        torch.mm(x2, w_ste.t(), out=out)
+        out.addmm_(F2, Wa.t())
+        _residual_bias(out3, F2.view(B, N, C), t2)
+        return out3
+    def own():
+        gemm_rows(x2, w_ste, False, F2, Wa, False, resid=F2, cloud_bias=t2.contiguous(), rows_per_cloud=N, out=out)
+        return out3
+    return _pick(f"out[R{B * N}K{x2.shape[1]}+{C}N{C}]", own, lib)
+
+
+def _mm_nn(g2, W, out=None, alpha=1.0):
+    """alpha * (g @ W) for a row-strided (K,N) matrix W"""
+    R, K = g2.shape
+    if out is None:
+        out = torch.empty(R, W.shape[1], dtype=g2.dtype, device=g2.device)
+
+    def lib():
+        if alpha == 1.0:
+            return torch.mm(g2, W, out=out)
+        return torch.addmm(out, g2, W, beta=0.0, alpha=alpha, out=out)
+    return _pick(f"nn[R{R}K{K}N{W.shape[1]}]", lambda: gemm_rows(g2, W, True, out=out, alpha=alpha), lib)
+
+
+def _mm_nt(x2, W, bias=None, out=None):
+    """x @ W^T (+ bias) for a (N,K) weight"""
+    R, K = x2.shape
+    if out is None:
+        out = torch.empty(R, W.shape[0], dtype=x2.dtype, device=x2.device)
+
+    def lib():
+        if bias is not None:
+            return torch.addmm(bias, x2, W.t(), out=out)
+        return torch.mm(x2, W.t(), out=out)
+    return _pick(f"nt[R{R}K{K}N{W.shape[0]}{'b' if bias is not None else ''}]",
+                 lambda: gemm_rows(x2, W, False, bias=bias, out=out), lib)
+
+
+def _grad_in_rows(g2, w_ste, gfm2, weights, out):
+    """gX = g Wste + gfm W^T   (input gradient of gcn3d.py:149 and :171)"""
+    R = g2.shape[0]
+
+    def lib():
+        torch.mm(g2, w_ste, out=out)
+        return out.addmm_(gfm2, weights.t())
+    return _pick(f"gx[R{R}K{g2.shape[1]}+{gfm2.shape[1]}N{out.shape[1]}]",
+                 lambda: gemm_rows(g2, w_ste, True, gfm2, weights, False, out=out), lib)
 
 
 def _orl_fwd_raw(F3, idx_x, k):
@@ -582,7 +678,7 @@ class _HSLayer(torch.autograd.Function):
         SC = directions.shape[1]
         C = SC // S
         X2 = X.view(B * N, Cin)
-        fm = torch.addmm(bias, X2, weights)                                    # (BN, (S+1)C)
+        fm = _fm_rows(X2, weights, bias)                                       # (BN, (S+1)C)
         need_bwd = any(ctx.needs_input_grad)
         F3, arg, fwin = _rf_conv_fwd_raw(xyz, idx_f, directions, fm.view(B, N, -1), S, need_bwd)
         if fwin is not None:
@@ -591,10 +687,8 @@ class _HSLayer(torch.autograd.Function):
         fg, arg_o = _orl_fwd_raw(F3, idx_x, k)                                 # (B,C)
         F2 = F3.view(B * N, C)
         out3 = torch.empty(B, N, C, dtype=torch.float32, device=X.device)      # (returned as is: not a view)
-        out = out3.view(B * N, C)
-        torch.mm(X2, w_ste.t(), out=out)                                       # X Wste^T
-        out.addmm_(F2, w_conv2[:, :C].t())                                     # + F Wa^T
-        _residual_bias(out3, F3, fg @ w_conv2[:, C:].t())                      # + F + t[b]   (one pass)
+        t2 = _mm_nt(fg, w_conv2[:, C:])                                        # (B,C): the per-cloud half of conv2
+        _layer_out_rows(X2, w_ste, F2, w_conv2[:, :C], t2, out3)               # X Wste^T + F Wa^T + F + t[b]
         ctx.save_for_backward(xyz, X, idx_f, idx_x, fm, arg, F3, arg_o, fg, weights, directions, w_ste3, w_conv23)
         ctx.k, ctx.S = k, S
         return out3
@@ -612,18 +706,16 @@ class _HSLayer(torch.autograd.Function):
         gt = colsum_rows(g)                                                    # (B,C) = sum_i g
         g_conv2 = torch.empty_like(w_conv2)
         wgrad(g2, F2, out=g_conv2[:, :C])                                      # gWa, written in place (ldc = 2C)
-        torch.mm(gt.t(), fg, out=g_conv2[:, C:])                               # gWb (tiny), straight into its column block
+        wgrad(gt, fg, out=g_conv2[:, C:])                                      # gWb = gt^T fg (tiny), straight into its column block
         gF3 = torch.empty(B, N, C, dtype=torch.float32, device=g.device)
-        torch.mm(g2, Wa, out=gF3.view(B * N, C))                               # g Wa ...
-        _orl_bwd_accumulate_raw(_scaled_mm(gt, Wb, 1.0 / N), idx_x, arg_o, k, gF3, extra=g)  # ... + g + ORL scatter, one pass
+        _mm_nn(g2, Wa, out=gF3.view(B * N, C))                                 # g Wa ...
+        _orl_bwd_accumulate_raw(_mm_nn(gt, Wb, alpha=1.0 / N), idx_x, arg_o, k, gF3, extra=g)  # ... + g + ORL scatter, one pass
         gfm, gD = _rf_conv_bwd_raw(xyz, idx_f, directions, fm.view(B, N, -1), arg, gF3, S)
         gfm2 = gfm.view(B * N, -1)
         gW, gb = wgrad(X2, gfm2, colsum=True)                                  # X^T gfm and the bias gradient
         g_ste = wgrad(g2, X2)
         gX3 = torch.empty(B, N, Cin, dtype=torch.float32, device=g.device)
-        gXv = gX3.view(B * N, Cin)
-        torch.mm(g2, w_ste, out=gXv)
-        gXv.addmm_(gfm2, weights.t())
+        _grad_in_rows(g2, w_ste, gfm2, weights, gX3.view(B * N, Cin))          # g Wste + gfm W^T
         return None, gX3, None, None, None, None, gW, gb, gD, g_ste.unsqueeze_(-1), g_conv2.unsqueeze_(-1)
 
 
@@ -648,10 +740,8 @@ class _SurfaceLayer(torch.autograd.Function):
         fg, arg_o = _orl_fwd_raw(F3, idx_x, k)
         F2, x2 = F3.view(B * N, C), xyz.view(B * N, 3)
         out3 = torch.empty(B, N, C, dtype=torch.float32, device=xyz.device)
-        out = out3.view(B * N, C)
-        torch.mm(x2, w_ste.t(), out=out)
-        out.addmm_(F2, w_conv2[:, :C].t())
-        _residual_bias(out3, F3, fg @ w_conv2[:, C:].t())
+        t2 = _mm_nt(fg, w_conv2[:, C:])
+        _layer_out_rows(x2, w_ste, F2, w_conv2[:, :C], t2, out3)
         ctx.save_for_backward(xyz, idx_x, arg, F3, arg_o, fg, directions, w_conv23)
         ctx.k, ctx.S = k, S
         return out3
@@ -669,10 +759,10 @@ class _SurfaceLayer(torch.autograd.Function):
         gt = colsum_rows(g)
         g_conv2 = torch.empty_like(w_conv2)
         wgrad(g2, F2, out=g_conv2[:, :C])
-        torch.mm(gt.t(), fg, out=g_conv2[:, C:])
+        wgrad(gt, fg, out=g_conv2[:, C:])
         gF3 = torch.empty(B, N, C, dtype=torch.float32, device=g.device)
-        torch.mm(g2, Wa, out=gF3.view(B * N, C))
-        _orl_bwd_accumulate_raw(_scaled_mm(gt, Wb, 1.0 / N), idx_x, arg_o, k, gF3, extra=g)
+        _mm_nn(g2, Wa, out=gF3.view(B * N, C))
+        _orl_bwd_accumulate_raw(_mm_nn(gt, Wb, alpha=1.0 / N), idx_x, arg_o, k, gF3, extra=g)
         gD = torch.empty_like(directions)
         L = lib()
         wsb = L.hsp_rf_bwd_scatter_workspace_bytes(B, SC)
@@ -705,13 +795,13 @@ class _LinearRows(torch.autograd.Function):
         x2 = _req(x2, torch.float32, "linear_rows.x")
         ctx.save_for_backward(x2, weight)
         ctx.has_bias = bias is not None
-        return torch.addmm(bias, x2, weight.t()) if bias is not None else torch.mm(x2, weight.t())
+        return _mm_nt(x2, weight, bias)
 
     @staticmethod
     def backward(ctx, g):
         x2, weight = ctx.saved_tensors
         g = _req(g, torch.float32, "linear_rows.grad")
-        gx = torch.mm(g, weight) if ctx.needs_input_grad[0] else None
+        gx = _mm_nn(g, weight) if ctx.needs_input_grad[0] else None
         R, Cout = g.shape
         gb = None
         if Cout % 64 == 0 and x2.shape[1] % 64 == 0:

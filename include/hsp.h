@@ -205,7 +205,7 @@ int hsp_gather_rows_bwd_csr(const float *grad_out, int grad_stride, const int32_
  *                                                  resid = feature, cloud_bias = f_global Wb^T per cloud)
  *   their input gradients (g Wa ; g Wste + gfm W^T)                          autograd of the above
  *   Conv1d(Cin, Cout, 1) of the heads                                       PoseR.py:16-39, PoseTs.py:18-45, FaceRecon.py:37-68
- * C (M,N) = A1 (M,K1) op(B1) [+ A2 (M,K2) op(B2)] [+ bias (N)] [+ resid (M,N)] [+ cloud_bias[row / rows_per_cloud] (N)]
+ * C (M,N) = alpha * (A1 (M,K1) op(B1) [+ A2 (M,K2) op(B2)]) [+ bias (N)] [+ resid (M,N)] [+ cloud_bias[row / rows_per_cloud] (N)]
  * b?_layout 0 = "nt": B is (N,K), k contiguous (a Linear / Conv1d weight);  1 = "nn": B is (K,N) (HS_layer.weights).
  * A2 == NULL: single source.  Leading dimensions in elements; any K, any alignment (aligned operands stage 16 bytes
  * per load).  fp32: v_mfma_f32_32x32x2_f32 (exact fp32).  bf16: v_mfma_f32_32x32x16_bf16, fp32 accumulate, "nt"
@@ -214,11 +214,11 @@ int hsp_gather_rows_bwd_csr(const float *grad_out, int grad_stride, const int32_
 int hsp_gemm_rows_f32(const float *A1, int lda1, const float *B1, int ldb1, int b1_layout, int K1,
                       const float *A2, int lda2, const float *B2, int ldb2, int b2_layout, int K2, int M, int N,
                       const float *bias, const float *resid, int ldr, const float *cloud_bias, int rows_per_cloud,
-                      float *C, int ldc, hspStream_t stream);
+                      float alpha, float *C, int ldc, hspStream_t stream);
 int hsp_gemm_rows_bf16(const hsp_bf16_t *A1, int lda1, const hsp_bf16_t *B1, int ldb1, int K1,
                        const hsp_bf16_t *A2, int lda2, const hsp_bf16_t *B2, int ldb2, int K2, int M, int N,
                        const float *bias, const hsp_bf16_t *resid, int ldr, const float *cloud_bias,
-                       int rows_per_cloud, hsp_bf16_t *C, int ldc, hspStream_t stream);
+                       int rows_per_cloud, float alpha, hsp_bf16_t *C, int ldc, hspStream_t stream);
 
 /* ---- weight-gradient GEMM ---------------------------------------------------------------------
  * replaces the parameter-gradient matmuls autograd runs for `feature_map @ self.weights + self.bias`
