@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="clouds per GPU")
     ap.add_argument("--points", type=int, default=1028)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="feature storage of the HS stack: f32 = BASELINE configs[1] (the headline); bf16 = configs[3] "
+                         "(run it as --dtype bf16 --points 4096 --batch 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16, help="clouds in the CPU-baseline sample (one per-GPU batch)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
@@ -140,9 +143,14 @@ def main():
     FLAGS.reset(); FLAGS.train = 0                      # U1: backbone only (feat), no train-only heads
     torch.manual_seed(0)
     net = FaceRecon().to(device).train()
+    bf16 = args.dtype == "bf16"
+    if bf16:
+        net.set_feature_dtype(torch.bfloat16)           # bf16 feature rows / fm / gradients, bf16 MFMA products (ops_bf16.py)
     params = [p for p in net.parameters()]
     reducer = None                                     # eager fallback only (hooks must not exist during capture)
     centred, obj, dfeat = make_inputs(B, N, device, seed=rank)
+    if bf16:
+        dfeat = dfeat.bfloat16()
     torch.manual_seed(1 + rank)                         # Pool_layer randperm stream (per rank)
 
     def eager_step():
@@ -259,11 +267,17 @@ def main():
                                  "HIP events around the call, the same K steps re-issued eagerly right after the timed "
                                  "graph replays (events cannot be recorded inside a replay)")
         ubytes, uflops = u1_algorithmic(N)
+        if bf16:
+            ubytes *= 0.5                                      # every feature tensor of the byte model is stored in 2 bytes
+        mfma_peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
+        if roof["bound"] == "mfma" and bf16:
+            roof["peak"] = mfma_peak
+            roof["frac"] = round(roof["achieved"] / mfma_peak, 5)
         step_s = median_ms * 1e-3
         step_roof = {"algorithmic_bytes_per_cloud": round(ubytes), "gemm_flops_per_cloud": round(uflops),
                      "step_hbm_frac": round(B * ubytes / step_s / 1e9 / HBM_PEAK_GBS, 5),
-                     "step_mfma_frac": round(B * uflops / step_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 5),
-                     "mfma_peak_tflops": MFMA_F32_PEAK_TFLOPS}
+                     "step_mfma_frac": round(B * uflops / step_s / 1e12 / mfma_peak, 5),
+                     "mfma_peak_tflops": mfma_peak}
         if args.breakdown:
             for (n_, k_), d in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
                 print(f"{n_:22s} {k_:28s} calls/step {d['calls'] / args.steps:4.1f}  avg {d['avg_us']:9.1f} us  "
@@ -282,10 +296,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"HS stack (FaceRecon backbone -> feat) fwd+bwd, B={B}/GPU N={N} fp32, "
-                                   f"train-mode BN, random-init weights (BASELINE configs[1] shape)",
+            "config": {"workload": f"HS stack (FaceRecon backbone -> feat) fwd+bwd, B={B}/GPU N={N} "
+                                   + ("bf16 feature storage + bf16 MFMA products, fp32 geometry / accumulation / parameters, "
+                                      "train-mode BN, random-init weights (BASELINE configs[3] shape when B=64 N=4096)" if bf16 else
+                                      "fp32, train-mode BN, random-init weights (BASELINE configs[1] shape)"),
                        "global_batch": world * B, "points": N, "parallelism": f"dp{world}", "hipgraph": graphed is not None, "split_graph": bool(graphed is not None and graphed.split), "grad_exchange": ("none" if world == 1 else "2 all-reduces, first overlapped with backward" if graphed is not None and graphed.split else "1 all-reduce after backward" if graphed is not None else "bucketed, hook-driven"),
                        "libhsp_ms_per_step": round(hsp_ms, 4),
                        # dense per-point products: hand-written csrc/gemm_rows.hip vs the BLAS library, per composite shape

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import gcn3d, ops
+from . import gcn3d, ops, ops_bf16
 from .config import FLAGS
 
 
@@ -63,24 +63,51 @@ class FaceRecon(nn.Module):
 
     keep_backward_cut = False
     backward_cut = None
+    feature_dtype = torch.float32
+    _bf16 = None
+
+    def set_feature_dtype(self, dtype):
+        """torch.bfloat16: the HS stack stores its feature rows, ``fm`` and activation gradients in bf16 and runs its dense
+        products on the bf16 matrix cores (BASELINE configs[3]; hs_pose_amd/ops_bf16.py says what stays fp32); ``feat``
+        comes out bf16.  The parameters stay fp32 masters -- call again after anything that re-seats them (moving the
+        module, building the fused optimizer).  torch.float32 restores the default path."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("feature dtype: torch.float32 or torch.bfloat16")
+        self.feature_dtype = dtype
+        self.conv_0.out_dtype = dtype
+        for layer in (self.conv_1, self.conv_2, self.conv_3):          # BatchNorm follows: fp32 rows out of the bf16 layer
+            layer.out_fp32 = dtype == torch.bfloat16
+        self._bf16 = None
+        if dtype == torch.bfloat16:
+            if FLAGS.train:
+                raise NotImplementedError("bf16 feature rows: the HS stack (feat); the train-only heads take fp32 rows")
+            specs = [(self.conv_0.conv2.weight.squeeze(-1), True, True)]
+            for layer in (self.conv_1, self.conv_2, self.conv_3, self.conv_4):
+                specs += [(layer.weights, True, True), (layer.STE_layer.weight.squeeze(-1), True, True),
+                          (layer.conv2.weight.squeeze(-1), True, True)]
+            self._bf16 = ops_bf16.Bf16Params(specs)
+        return self
 
     def forward(self, vertices: "tensor (bs, vetice_num, 3)", cat_id: "tensor (bs, 1)"):
         """-> (recon (bs,N,3) | None, face (bs,N,face_recon_c) | None, feat (bs,N,1286))"""
         bs, vertice_num, _ = vertices.size()
         one_hot = torch.zeros(bs, FLAGS.obj_c, device=vertices.device).scatter_(1, cat_id.view(-1, 1).long(), 1)
         k = self.neighbor_num
+        if self._bf16 is not None:
+            self._bf16.refresh()                      # fp32 master weights -> this step's bf16 working copies (one launch)
         with gcn3d.knn_scope():
             fm_0 = F.relu(self.conv_0(vertices, k), inplace=True)
-            fm_1 = ops.bn_relu(self.conv_1(vertices, fm_0, k), self.bn1)
+            od = self.feature_dtype if self.feature_dtype == torch.bfloat16 else None
+            fm_1 = ops.bn_relu(self.conv_1(vertices, fm_0, k), self.bn1, out_dtype=od)
             v_pool_1, fm_pool_1 = self.pool_1(vertices, fm_1)
             k1 = min(k, v_pool_1.shape[1] // 8)
-            fm_2 = ops.bn_relu(self.conv_2(v_pool_1, fm_pool_1, k1), self.bn2)
+            fm_2 = ops.bn_relu(self.conv_2(v_pool_1, fm_pool_1, k1), self.bn2, out_dtype=od)
             # The coarse levels and the concat read the fine levels through aliases (no kernels): every path from feat
             # down to an alias stays above the others, so a backward pass can stop at them and be resumed
             # (graph.py::GraphedStep(split=True) reduces the coarse levels' gradients while the fine levels still run).
             a_0, a_1, a_2 = fm_0.view_as(fm_0), fm_1.view_as(fm_1), fm_2.view_as(fm_2)
             self.backward_cut = (a_0, a_1, a_2) if self.keep_backward_cut else None   # holds the autograd graph: opt-in
-            fm_3 = ops.bn_relu(self.conv_3(v_pool_1, a_2, k1), self.bn3)
+            fm_3 = ops.bn_relu(self.conv_3(v_pool_1, a_2, k1), self.bn3, out_dtype=od)
             v_pool_2, fm_pool_2 = self.pool_2(v_pool_1, fm_3)
             k2 = min(k, v_pool_2.shape[1] // 8)
             fm_4 = self.conv_4(v_pool_2, fm_pool_2, k2)

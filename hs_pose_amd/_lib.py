@@ -40,8 +40,29 @@ SIGNATURES = {
     "hsp_gather_rows_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "hsp_gather_rows_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "hsp_gather_rows_bwd_csr": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "hsp_gemm_rows_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, ctypes.c_float, _vp, _i, _vp]),
-    "hsp_gemm_rows_bf16": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, ctypes.c_float, _vp, _i, _vp]),
+    "hsp_gemm_rows_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, ctypes.c_float, _vp, _vp, _vp, _i, _vp]),
+    "hsp_gemm_rows_bf16": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, ctypes.c_float, _vp, _vp, _vp, _i, _i, _vp]),
+    "hsp_bn_relu_fwd_mixed": (_i, [_vp, _i, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "hsp_bn_relu_apply_mixed": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "hsp_bn_relu_bwd_mixed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "hsp_cast_params_bf16": (_i, [_vp, _i, _i, _vp]),
+    "hsp_knn_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "hsp_rf_surface_fwd_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "hsp_rf_surface_bwd_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "hsp_rf_conv_wants_fwin_bf16": (_i, [_i, _i, _i]),
+    "hsp_rf_conv_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "hsp_rf_conv_bwd_scatter_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "hsp_gather_max_fwd_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "hsp_gather_max_bwd_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "hsp_orl_global_fwd_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "hsp_colsum_rows_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "hsp_concat_rows_pitched": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
+    "hsp_concat_rows_bf16": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
+    "hsp_gather_rows_bwd_csr_bf16": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "hsp_wgrad_bf16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
+    "hsp_bn_relu_fwd_bf16": (_i, [_vp, _i, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "hsp_bn_relu_apply_bf16": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "hsp_bn_relu_bwd_bf16": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "hsp_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
     "hsp_wgrad_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     "hsp_bn_workspace_bytes": (_sz, [_i, _i]),

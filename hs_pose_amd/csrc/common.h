@@ -65,4 +65,53 @@ __device__ __forceinline__ float3 unit_dir_fast(float px, float py, float pz, fl
     return make_float3(dx * inv, dy * inv, dz * inv);
 }
 
+// ------------------------------------------------------------------------------------------------
+// feature storage type of a kernel: fp32, or bfloat16 bits (BASELINE configs[3]: features / fm / gradients stored in
+// bf16, every kernel still computes in fp32 -- loads widen, stores round to nearest even).  xyz, support directions
+// and theta never go through these (gcn3d.py:57,59 keeps them fp32).
+// ------------------------------------------------------------------------------------------------
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ unsigned f32_to_bf16_bits(float f) {            // round to nearest even; NaN stays NaN
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+template <typename FT> struct Feat;
+template <> struct Feat<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+    static __device__ __forceinline__ void st_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }
+    static __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+    static __device__ __forceinline__ void st4_nt(float* p, float4 v) {
+        __builtin_nontemporal_store(v.x, p); __builtin_nontemporal_store(v.y, p + 1);
+        __builtin_nontemporal_store(v.z, p + 2); __builtin_nontemporal_store(v.w, p + 3);
+    }
+    static __device__ __forceinline__ float rnd(float v) { return v; }        // value as it will read back from storage
+};
+template <> struct Feat<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_bits_to_f32(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = (bf16_t)f32_to_bf16_bits(v); }
+    static __device__ __forceinline__ void st_nt(bf16_t* p, float v) { __builtin_nontemporal_store((bf16_t)f32_to_bf16_bits(v), p); }
+    static __device__ __forceinline__ float4 ld4(const bf16_t* p) {                                  // 8-byte aligned
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                           __uint_as_float(u.y & 0xffff0000u));
+    }
+    static __device__ __forceinline__ uint2 pack4(float4 v) {
+        return make_uint2(f32_to_bf16_bits(v.x) | (f32_to_bf16_bits(v.y) << 16), f32_to_bf16_bits(v.z) | (f32_to_bf16_bits(v.w) << 16));
+    }
+    static __device__ __forceinline__ void st4(bf16_t* p, float4 v) { *reinterpret_cast<uint2*>(p) = pack4(v); }
+    static __device__ __forceinline__ void st4_nt(bf16_t* p, float4 v) {
+        const uint2 u = pack4(v);
+        unsigned* q = reinterpret_cast<unsigned*>(p);
+        __builtin_nontemporal_store(u.x, q); __builtin_nontemporal_store(u.y, q + 1);
+    }
+    static __device__ __forceinline__ float rnd(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
+};
+
 }  // namespace hsp

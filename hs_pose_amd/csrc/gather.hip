@@ -8,13 +8,15 @@
 //             the concatenated feature tensor (FaceRecon.py:107).
 // All are pure HBM/L2 streaming kernels: one lane per float4 of a row, 16-byte accesses.
 #include "common.h"
+#include <type_traits>
 
 namespace hsp {
 
 // running max / first arg-max over the k neighbour rows nb[0..k) of a float4 column group.  8 neighbours per
 // pass: their rows are gathered together while the next 8 indices are already in flight (index -> row is a
 // dependent pair of L2 round trips; one neighbour at a time, unrolled by 4, cost 10 of them per point at k = 20)
-__device__ __forceinline__ void gather_max_rows(const float* __restrict__ fb, const int32_t* __restrict__ nb, int k,
+template <typename FT>
+__device__ __forceinline__ void gather_max_rows(const FT* __restrict__ fb, const int32_t* __restrict__ nb, int k,
                                                 int C, float4& best, int& a0, int& a1, int& a2, int& a3) {
     constexpr int NB = 8;
     int cur[NB], nxt[NB];
@@ -25,7 +27,7 @@ __device__ __forceinline__ void gather_max_rows(const float* __restrict__ fb, co
         for (int u = 0; u < NB; ++u) nxt[u] = nb[min(n0 + NB + u, k - 1)];
         float4 f[NB];
 #pragma unroll
-        for (int u = 0; u < NB; ++u) f[u] = *reinterpret_cast<const float4*>(fb + (size_t)cur[u] * C);
+        for (int u = 0; u < NB; ++u) f[u] = Feat<FT>::ld4(fb + (size_t)cur[u] * C);
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const int n = n0 + u;
@@ -43,11 +45,12 @@ __device__ __forceinline__ void gather_max_rows(const float* __restrict__ fb, co
 
 
 // one thread per (query row, float4 column group); grid-stride
-__global__ __launch_bounds__(256) void gather_max_fwd_kernel(const float* __restrict__ feat,
+template <typename FT>
+__global__ __launch_bounds__(256) void gather_max_fwd_kernel(const FT* __restrict__ feat,
                                                              const int32_t* __restrict__ idx,
                                                              const int32_t* __restrict__ qsel, int B, int Nsrc,
                                                              int Nidx, int Nq, int k, int kstride, int C,
-                                                             float* __restrict__ out,
+                                                             FT* __restrict__ out,
                                                              uint8_t* __restrict__ argmax) {
     const int cq = C >> 2;
     const long long total = (long long)B * Nq * cq;
@@ -58,11 +61,11 @@ __global__ __launch_bounds__(256) void gather_max_fwd_kernel(const float* __rest
         const int b = (int)(row / Nq);
         const int qi = qsel ? qsel[q] : q;
         const int32_t* nb = idx + ((size_t)b * Nidx + qi) * kstride;
-        const float* fb = feat + (size_t)b * Nsrc * C + (g << 2);
+        const FT* fb = feat + (size_t)b * Nsrc * C + (g << 2);
         float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        gather_max_rows(fb, nb, k, C, best, a0, a1, a2, a3);
-        *reinterpret_cast<float4*>(out + row * C + (g << 2)) = best;
+        gather_max_rows<FT>(fb, nb, k, C, best, a0, a1, a2, a3);
+        Feat<FT>::st4(out + row * C + (g << 2), best);
         *reinterpret_cast<uchar4*>(argmax + row * C + (g << 2)) =
             make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
     }
@@ -75,7 +78,8 @@ __global__ __launch_bounds__(256) void gather_max_fwd_kernel(const float* __rest
 // to part[b][chunk][C]; orl_finalize_kernel folds the chunks (deterministic).  The (B,N,C) max tensor of
 // the reference is never written.
 #define ORL_ROWS 128         // upper bound of points per chunk
-__global__ __launch_bounds__(256) void orl_partial_kernel(const float* __restrict__ feat,
+template <typename FT>
+__global__ __launch_bounds__(256) void orl_partial_kernel(const FT* __restrict__ feat,
                                                           const int32_t* __restrict__ idx, int N, int k,
                                                           int kstride, int C, uint8_t* __restrict__ argmax,
                                                           float* __restrict__ part, int nchunk, int rows) {
@@ -85,13 +89,13 @@ __global__ __launch_bounds__(256) void orl_partial_kernel(const float* __restric
     const int g = tid % cq, rl = tid / cq, RL = 256 / cq;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int r0 = chunk * rows, r1 = min(N, r0 + rows);
-    const float* fb = feat + (size_t)b * N * C + (g << 2);
+    const FT* fb = feat + (size_t)b * N * C + (g << 2);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = r0 + rl; i < r1; i += RL) {
         const int32_t* nb = idx + ((size_t)b * N + i) * kstride;
         float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        gather_max_rows(fb, nb, k, C, best, a0, a1, a2, a3);
+        gather_max_rows<FT>(fb, nb, k, C, best, a0, a1, a2, a3);
         *reinterpret_cast<uchar4*>(argmax + ((size_t)b * N + i) * C + (g << 2)) =
             make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
         s.x += best.x; s.y += best.y; s.z += best.z; s.w += best.w;
@@ -123,7 +127,8 @@ __global__ __launch_bounds__(256) void chunk_fold_kernel(const float* __restrict
 }
 
 // part[b][chunk][c] = sum of x[b][i][c] over the chunk's rows (first stage of a per-cloud column sum)
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int N, int C,
+template <typename FT>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const FT* __restrict__ x, int N, int C,
                                                              float* __restrict__ part, int nchunk, int rows) {
     __shared__ float4 red[256];
     const int cq = C >> 2;
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     const int r0 = chunk * rows, r1 = min(N, r0 + rows);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = r0 + rl; i < r1; i += RL) {
-        const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)b * N + i) * C + (g << 2));
+        const float4 v = Feat<FT>::ld4(x + ((size_t)b * N + i) * C + (g << 2));
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     red[tid] = s;
@@ -168,23 +173,31 @@ __global__ __launch_bounds__(256) void colsum_partial_scalar_kernel(const float*
 // feat rows assembled from column segments (reference FaceRecon.py:100-107: nearest up-sampling gathers,
 // one-hot category columns and torch.cat) in ONE pass: segment s of row (b,i) comes from
 //   kind 0: src[(b*N + i)*w + c]      kind 1: src[(b*Ns + idx[b*N+i])*w + c]      kind 2: src[b*w + c]
-struct ConcatSeg { const float* src; const int32_t* idx; int width; int kind; int nsrc; int col0; };
+// (bf16 build: kind 0 / 1 sources are bf16 like the output, kind 2 -- the per-cloud one-hot row -- stays fp32 and is
+// rounded on the way in; W is the output ROW PITCH, which may exceed the sum of the widths: padding columns stay untouched)
+struct ConcatSeg { const void* src; const int32_t* idx; int width; int kind; int nsrc; int col0; };
 struct ConcatDesc { ConcatSeg seg[8]; int nseg; int even; };
 
-__global__ __launch_bounds__(256) void concat_rows_kernel(ConcatDesc d, int B, int N, int W, float* __restrict__ out) {
+template <typename FT>
+__global__ __launch_bounds__(256) void concat_rows_kernel(ConcatDesc d, int B, int N, int W, FT* __restrict__ out) {
+    using Pair = typename std::conditional<sizeof(FT) == 4, float2, unsigned>::type;       // two elements
     const long long rows = (long long)B * N;
     for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
         const int b = (int)(row / N);
-        float* o = out + (size_t)row * W;
+        FT* o = out + (size_t)row * W;
         for (int s = 0; s < d.nseg; ++s) {
             const ConcatSeg sg = d.seg[s];
-            const float* src;
-            if (sg.kind == 0) src = sg.src + (size_t)row * sg.width;
-            else if (sg.kind == 1) src = sg.src + ((size_t)b * sg.nsrc + sg.idx[row]) * sg.width;
-            else src = sg.src + (size_t)b * sg.width;
-            if (d.even) {       // every width / column offset / row stride even: 8-byte accesses
-                const float2* s2 = reinterpret_cast<const float2*>(src);
-                float2* o2 = reinterpret_cast<float2*>(o + sg.col0);
+            if (sg.kind == 2) {
+                const float* src = reinterpret_cast<const float*>(sg.src) + (size_t)b * sg.width;
+                for (int c = threadIdx.x; c < sg.width; c += 256) Feat<FT>::st(o + sg.col0 + c, src[c]);
+                continue;
+            }
+            const FT* src = reinterpret_cast<const FT*>(sg.src);
+            if (sg.kind == 0) src += (size_t)row * sg.width;
+            else src += ((size_t)b * sg.nsrc + sg.idx[row]) * sg.width;
+            if (d.even) {       // every width / column offset / row stride even: two elements per access
+                const Pair* s2 = reinterpret_cast<const Pair*>(src);
+                Pair* o2 = reinterpret_cast<Pair*>(o + sg.col0);
                 for (int c = threadIdx.x; c < (sg.width >> 1); c += 256) o2[c] = s2[c];
             } else {
                 for (int c = threadIdx.x; c < sg.width; c += 256) o[sg.col0 + c] = src[c];
@@ -226,14 +239,16 @@ __global__ __launch_bounds__(256) void gather_max_bwd_kernel(const float* __rest
 // branch is exactly reproducible.  MODE 0: arg-max routed (gather_max), MODE 1: plain row scatter
 // (gather_rows: nearest-neighbour up-sampling backward, many queries per source row).
 // grid (C/TC, B), block 256, dynamic LDS = Nsrc*TC*4
-template <int TC, int MODE>
-__global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const float* __restrict__ gout, int gstride,
+// FT: storage type of gout (per-query gradients) / gfeat / extra; the broadcast row `gbc` (B,C) is always fp32
+template <int TC, int MODE, typename FT>
+__global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const FT* __restrict__ gout, const float* __restrict__ gbc,
+                                                               int gstride,
                                                                int gbcast, const int32_t* __restrict__ idx,
                                                                int idx_shared, const int32_t* __restrict__ qsel,
                                                                const uint8_t* __restrict__ argmax, int Nsrc,
                                                                int Nidx, int Nq, int kstride, int C,
-                                                               float* __restrict__ gfeat, int accumulate,
-                                                               const float* __restrict__ extra) {
+                                                               FT* __restrict__ gfeat, int accumulate,
+                                                               const FT* __restrict__ extra) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* acc = reinterpret_cast<float*>(smem);
     int* cnt = reinterpret_cast<int*>(smem);
@@ -257,8 +272,16 @@ __global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const float* __re
                     const size_t row = (size_t)b * Nq + q;
                     const int m = idx_shared ? idx[q] : idx[row];
                     // rows of a column block of a wider tensor are only 8-byte aligned (stride 1286): two float2 loads
-                    const float2 g01 = *reinterpret_cast<const float2*>(gout + row * gstride + j);
-                    const float2 g23 = *reinterpret_cast<const float2*>(gout + row * gstride + j + 2);
+                    float2 g01, g23;
+                    if constexpr (sizeof(FT) == 4) {
+                        g01 = *reinterpret_cast<const float2*>(gout + row * gstride + j);
+                        g23 = *reinterpret_cast<const float2*>(gout + row * gstride + j + 2);
+                    } else {                                          // (rows of a bf16 column block: 4-byte aligned)
+                        const unsigned u0 = *reinterpret_cast<const unsigned*>(gout + row * gstride + j);
+                        const unsigned u1 = *reinterpret_cast<const unsigned*>(gout + row * gstride + j + 2);
+                        g01 = make_float2(__uint_as_float(u0 << 16), __uint_as_float(u0 & 0xffff0000u));
+                        g23 = make_float2(__uint_as_float(u1 << 16), __uint_as_float(u1 & 0xffff0000u));
+                    }
                     float* a = acc + m * TC + cg * 4;
                     if (g01.x != 0.f) atomicAdd(a + 0, g01.x);
                     if (g01.y != 0.f) atomicAdd(a + 1, g01.y);
@@ -277,7 +300,7 @@ __global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const float* __re
                 const int qi = qsel ? qsel[q] : q;
                 nb[u] = idx + ((size_t)b * Nidx + qi) * kstride;
                 am[u] = *reinterpret_cast<const uchar4*>(argmax + row * C + j);
-                gv[u] = gbcast ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(gout + row * gstride + j);
+                gv[u] = gbcast ? make_float4(0.f, 0.f, 0.f, 0.f) : Feat<FT>::ld4(gout + row * gstride + j);
             }
             int m0[FL], m1[FL], m2[FL], m3[FL];
 #pragma unroll
@@ -305,7 +328,7 @@ __global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const float* __re
     // first dependent add (one element per iteration left the 2-3 loads of each store as a serial latency chain:
     // 23 of the kernel's 31 us at B=16 N=1028 C=128)
     float4 gb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (MODE == 0 && gbcast) gb = *reinterpret_cast<const float4*>(gout + (size_t)b * C + j);   // (q % G == cg for all of a thread's q)
+    if (MODE == 0 && gbcast) gb = *reinterpret_cast<const float4*>(gbc + (size_t)b * C + j);   // (q % G == cg for all of a thread's q)
     const int total = Nsrc * G;
     for (int q0 = tid; q0 < total; q0 += 256 * FL) {
         float4 o[FL], x[FL];
@@ -314,8 +337,8 @@ __global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const float* __re
             const int q = min(q0 + u * 256, total - 1);
             const int m = q / G, g4 = q - m * G;
             const size_t off = ((size_t)b * Nsrc + m) * C + j0 + g4 * 4;
-            o[u] = accumulate ? *reinterpret_cast<const float4*>(gfeat + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-            x[u] = extra ? *reinterpret_cast<const float4*>(extra + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            o[u] = accumulate ? Feat<FT>::ld4(gfeat + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            x[u] = extra ? Feat<FT>::ld4(extra + off) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < FL; ++u) {
@@ -331,7 +354,7 @@ __global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const float* __re
                 }
                 if (accumulate) { v.x += o[u].x; v.y += o[u].y; v.z += o[u].z; v.w += o[u].w; }
                 if (extra) { v.x += x[u].x; v.y += x[u].y; v.z += x[u].z; v.w += x[u].w; }
-                *reinterpret_cast<float4*>(gfeat + ((size_t)b * Nsrc + m) * C + j0 + g4 * 4) = v;
+                Feat<FT>::st4(gfeat + ((size_t)b * Nsrc + m) * C + j0 + g4 * 4, v);
             }
         }
     }
@@ -361,21 +384,21 @@ static int pick_scatter_cols(int Nsrc, int C) {
     return 0;
 }
 
-template <int MODE>
-static int launch_scatter_tile(int tc, const float* gout, int gstride, int gbcast, const int32_t* idx, int idx_shared,
-                               const int32_t* qsel, const uint8_t* argmax, int B, int Nsrc, int Nidx, int Nq,
-                               int kstride, int C, float* gfeat, int accumulate, const float* extra, hipStream_t st) {
+template <int MODE, typename FT>
+static int launch_scatter_tile(int tc, const FT* gout, const float* gbc, int gstride, int gbcast, const int32_t* idx,
+                               int idx_shared, const int32_t* qsel, const uint8_t* argmax, int B, int Nsrc, int Nidx, int Nq,
+                               int kstride, int C, FT* gfeat, int accumulate, const FT* extra, hipStream_t st) {
     const size_t lds = (size_t)Nsrc * tc * 4;
     dim3 grid(C / tc, B);
 #define SC_LAUNCH(TC)                                                                                              \
     {                                                                                                              \
-        auto kern = scatter_tile_bwd_kernel<TC, MODE>;                                                             \
+        auto kern = scatter_tile_bwd_kernel<TC, MODE, FT>;                                                             \
         if (lds > 64 * 1024) {                                                                                     \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
             if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }                                 \
         }                                                                                                          \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, gout, gstride, gbcast, idx, idx_shared, qsel, argmax, Nsrc, \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, gout, gbc, gstride, gbcast, idx, idx_shared, qsel, argmax, Nsrc, \
                            Nidx, Nq, kstride, C, gfeat, accumulate, extra);                                        \
     }
     if (tc == 16) SC_LAUNCH(16) else if (tc == 8) SC_LAUNCH(8) else SC_LAUNCH(4)
@@ -570,39 +593,69 @@ __global__ __launch_bounds__(256) void points_max_bwd_kernel(const float* __rest
 
 using namespace hsp;
 
-extern "C" int hsp_gather_max_fwd(const float* feat, const int32_t* idx, const int32_t* qsel, int B, int Nsrc,
-                                  int Nidx, int Nq, int k, int kstride, int C, float* out, uint8_t* argmax,
-                                  hspStream_t stream) {
+template <typename FT>
+static int gather_max_fwd_impl(const FT* feat, const int32_t* idx, const int32_t* qsel, int B, int Nsrc,
+                               int Nidx, int Nq, int k, int kstride, int C, FT* out, uint8_t* argmax,
+                               hspStream_t stream) {
     if (!feat || !idx || !out || !argmax || B <= 0 || Nsrc <= 0 || Nidx <= 0 || Nq <= 0 || k <= 0 || kstride < k || C <= 0)
         return HSP_ERR_BAD_ARG;
     if (!qsel && Nq != Nidx) return HSP_ERR_BAD_ARG;
     if ((C & 3) || k > 255) return HSP_ERR_UNSUPPORTED;
     const long long total = (long long)B * Nq * (C >> 2);
-    hipLaunchKernelGGL(gather_max_fwd_kernel, dim3(stream_grid(total)), dim3(256), 0, as_stream(stream), feat, idx,
+    hipLaunchKernelGGL(gather_max_fwd_kernel<FT>, dim3(stream_grid(total)), dim3(256), 0, as_stream(stream), feat, idx,
                        qsel, B, Nsrc, Nidx, Nq, k, kstride, C, out, argmax);
     return check_launch();
 }
+extern "C" int hsp_gather_max_fwd(const float* feat, const int32_t* idx, const int32_t* qsel, int B, int Nsrc,
+                                  int Nidx, int Nq, int k, int kstride, int C, float* out, uint8_t* argmax,
+                                  hspStream_t stream) {
+    return gather_max_fwd_impl<float>(feat, idx, qsel, B, Nsrc, Nidx, Nq, k, kstride, C, out, argmax, stream);
+}
+extern "C" int hsp_gather_max_fwd_bf16(const hsp_bf16_t* feat, const int32_t* idx, const int32_t* qsel, int B, int Nsrc,
+                                       int Nidx, int Nq, int k, int kstride, int C, hsp_bf16_t* out, uint8_t* argmax,
+                                       hspStream_t stream) {
+    return gather_max_fwd_impl<bf16_t>(feat, idx, qsel, B, Nsrc, Nidx, Nq, k, kstride, C, out, argmax, stream);
+}
 
-extern "C" int hsp_gather_max_bwd(const float* grad_out, int grad_bcast, const int32_t* idx, const int32_t* qsel,
-                                  const uint8_t* argmax, int B, int Nsrc, int Nidx, int Nq, int kstride, int C,
-                                  float* grad_feat, int accumulate, const float* extra, hspStream_t stream) {
+template <typename FT>
+static int gather_max_bwd_impl(const void* grad_out, int grad_bcast, const int32_t* idx, const int32_t* qsel,
+                               const uint8_t* argmax, int B, int Nsrc, int Nidx, int Nq, int kstride, int C,
+                               FT* grad_feat, int accumulate, const FT* extra, hspStream_t stream) {
     if (!grad_out || !idx || !argmax || !grad_feat || B <= 0 || Nsrc <= 0 || Nidx <= 0 || Nq <= 0 || kstride <= 0 || C <= 0)
         return HSP_ERR_BAD_ARG;
     if (!qsel && Nq != Nidx) return HSP_ERR_BAD_ARG;
     if (C & 3) return HSP_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);
+    // the per-query gradient has the feature type; the broadcast row (ORL: d fg / N per cloud) is always fp32
     if (const int tc = pick_scatter_cols(Nsrc, C))
-        return launch_scatter_tile<0>(tc, grad_out, C, grad_bcast, idx, 0, qsel, argmax, B, Nsrc, Nidx, Nq, kstride, C,
-                                      grad_feat, accumulate, extra, st);
-    if (extra) return HSP_ERR_UNSUPPORTED;                 // the global-atomic fallback has no fused add
-    if (!accumulate) {
-        hipError_t e = hipMemsetAsync(grad_feat, 0, (size_t)B * Nsrc * C * sizeof(float), st);
-        if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
+        return launch_scatter_tile<0, FT>(tc, grad_bcast ? nullptr : reinterpret_cast<const FT*>(grad_out),
+                                          grad_bcast ? reinterpret_cast<const float*>(grad_out) : nullptr, C, grad_bcast, idx, 0,
+                                          qsel, argmax, B, Nsrc, Nidx, Nq, kstride, C, grad_feat, accumulate, extra, st);
+    if constexpr (sizeof(FT) == 4) {
+        if (extra) return HSP_ERR_UNSUPPORTED;             // the global-atomic fallback has no fused add
+        if (!accumulate) {
+            hipError_t e = hipMemsetAsync(grad_feat, 0, (size_t)B * Nsrc * C * sizeof(float), st);
+            if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
+        }
+        const long long total = (long long)B * Nq * (C >> 2);
+        hipLaunchKernelGGL(gather_max_bwd_kernel, dim3(stream_grid(total)), dim3(256), 0, st,
+                           reinterpret_cast<const float*>(grad_out), grad_bcast, idx, qsel, argmax, B, Nsrc, Nidx, Nq, kstride, C,
+                           grad_feat);
+        return check_launch();
     }
-    const long long total = (long long)B * Nq * (C >> 2);
-    hipLaunchKernelGGL(gather_max_bwd_kernel, dim3(stream_grid(total)), dim3(256), 0, st, grad_out, grad_bcast, idx,
-                       qsel, argmax, B, Nsrc, Nidx, Nq, kstride, C, grad_feat);
-    return check_launch();
+    return HSP_ERR_UNSUPPORTED;                            // bf16: the LDS tile form only (Nsrc * 16 bytes <= 144 KiB)
+}
+extern "C" int hsp_gather_max_bwd(const float* grad_out, int grad_bcast, const int32_t* idx, const int32_t* qsel,
+                                  const uint8_t* argmax, int B, int Nsrc, int Nidx, int Nq, int kstride, int C,
+                                  float* grad_feat, int accumulate, const float* extra, hspStream_t stream) {
+    return gather_max_bwd_impl<float>(grad_out, grad_bcast, idx, qsel, argmax, B, Nsrc, Nidx, Nq, kstride, C, grad_feat,
+                                      accumulate, extra, stream);
+}
+extern "C" int hsp_gather_max_bwd_bf16(const void* grad_out, int grad_bcast, const int32_t* idx, const int32_t* qsel,
+                                       const uint8_t* argmax, int B, int Nsrc, int Nidx, int Nq, int kstride, int C,
+                                       hsp_bf16_t* grad_feat, int accumulate, const hsp_bf16_t* extra, hspStream_t stream) {
+    return gather_max_bwd_impl<bf16_t>(grad_out, grad_bcast, idx, qsel, argmax, B, Nsrc, Nidx, Nq, kstride, C, grad_feat,
+                                       accumulate, extra, stream);
 }
 
 extern "C" int hsp_gather_rows_fwd(const float* feat, const int32_t* idx, int idx_shared, int B, int Nsrc, int Nq,
@@ -628,8 +681,8 @@ extern "C" int hsp_gather_rows_bwd(const float* grad_out, int grad_stride, const
     hipStream_t st = as_stream(stream);
     if ((C & 3) == 0 && (grad_stride & 1) == 0 && (reinterpret_cast<uintptr_t>(grad_out) & 7) == 0)
         if (const int tc = pick_scatter_cols(Nsrc, C))
-            return launch_scatter_tile<1>(tc, grad_out, grad_stride, 0, idx, idx_shared, nullptr, nullptr, B, Nsrc, Nq,
-                                          Nq, 1, C, grad_feat, 0, nullptr, st);
+            return launch_scatter_tile<1, float>(tc, grad_out, nullptr, grad_stride, 0, idx, idx_shared, nullptr, nullptr, B,
+                                                 Nsrc, Nq, Nq, 1, C, grad_feat, 0, nullptr, st);
     hipError_t e = hipMemsetAsync(grad_feat, 0, (size_t)B * Nsrc * C * sizeof(float), st);
     if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
     const long long total = (long long)B * Nq * C;
@@ -642,11 +695,12 @@ extern "C" int hsp_gather_rows_bwd(const float* grad_out, int grad_stride, const
 // SOURCE row m and sums the gradient rows of the queries that selected it, in ascending query order (no atomics,
 // bit-reproducible), reading every gradient row segment whole.  The column-tile scatter form reads a 64-byte
 // slice of every 5 KB gradient row per tile: 30-45 us where this takes under 10.
-__global__ __launch_bounds__(256) void gather_rows_bwd_csr_kernel(const float* __restrict__ gout, int gstride,
+template <typename FT>
+__global__ __launch_bounds__(256) void gather_rows_bwd_csr_kernel(const FT* __restrict__ gout, int gstride,
                                                                   const int32_t* __restrict__ rev_off,
                                                                   const int32_t* __restrict__ rev_edge, int B,
                                                                   int Nsrc, int Nq, int C,
-                                                                  float* __restrict__ gfeat) {
+                                                                  FT* __restrict__ gfeat) {
     const int pairs = C >> 1;                               // float2 columns (gradient rows are 8-byte aligned)
     const int tpr = pairs < 256 ? pairs : 256;              // threads per row
     const int RB = 256 / tpr;
@@ -657,7 +711,7 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_csr_kernel(const float* _
     const int32_t* off = rev_off + (size_t)b * (Nsrc + 1);
     const int32_t* edge = rev_edge + (size_t)b * Nq;
     const int o0 = off[m], o1 = off[m + 1];
-    const float* gb = gout + (size_t)b * Nq * gstride;
+    const FT* gb = gout + (size_t)b * Nq * gstride;
     for (int p = t; p < pairs; p += tpr) {
         float2 acc = make_float2(0.f, 0.f);
         for (int e = o0; e < o1; e += 4) {                  // 4 rows in flight, added in edge order
@@ -665,29 +719,47 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_csr_kernel(const float* _
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int q = edge[min(e + u, o1 - 1)];
-                v[u] = *reinterpret_cast<const float2*>(gb + (size_t)q * gstride + 2 * p);
+                if constexpr (sizeof(FT) == 4) {
+                    v[u] = *reinterpret_cast<const float2*>(gb + (size_t)q * gstride + 2 * p);
+                } else {
+                    const unsigned w = *reinterpret_cast<const unsigned*>(gb + (size_t)q * gstride + 2 * p);
+                    v[u] = make_float2(__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u));
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (e + u < o1) { acc.x += v[u].x; acc.y += v[u].y; }
         }
-        *reinterpret_cast<float2*>(gfeat + (size_t)row * C + 2 * p) = acc;
+        if constexpr (sizeof(FT) == 4) *reinterpret_cast<float2*>(gfeat + (size_t)row * C + 2 * p) = acc;
+        else *reinterpret_cast<unsigned*>(gfeat + (size_t)row * C + 2 * p) = f32_to_bf16_bits(acc.x) | (f32_to_bf16_bits(acc.y) << 16);
     }
 }
 
-extern "C" int hsp_gather_rows_bwd_csr(const float* grad_out, int grad_stride, const int32_t* rev_off,
-                                       const int32_t* rev_edge, int B, int Nsrc, int Nq, int C, float* grad_feat,
-                                       hspStream_t stream) {
+template <typename FT>
+static int gather_rows_bwd_csr_impl(const FT* grad_out, int grad_stride, const int32_t* rev_off,
+                                    const int32_t* rev_edge, int B, int Nsrc, int Nq, int C, FT* grad_feat,
+                                    hspStream_t stream) {
     if (!grad_out || !rev_off || !rev_edge || !grad_feat || B <= 0 || Nsrc <= 0 || Nq <= 0 || C <= 0 || grad_stride < C)
         return HSP_ERR_BAD_ARG;
-    if ((C & 1) || (grad_stride & 1) || (reinterpret_cast<uintptr_t>(grad_out) & 7) || (256 % ((C >> 1) < 256 ? (C >> 1) : 256)))
-        return HSP_ERR_UNSUPPORTED;                         // float2 columns, whole rows per workgroup
+    if ((C & 1) || (grad_stride & 1) || (reinterpret_cast<uintptr_t>(grad_out) & (2 * sizeof(FT) - 1)) ||
+        (256 % ((C >> 1) < 256 ? (C >> 1) : 256)))
+        return HSP_ERR_UNSUPPORTED;                         // two-element columns, whole rows per workgroup
     const int tpr = (C >> 1) < 256 ? (C >> 1) : 256;
     const int RB = 256 / tpr;
     const long long rows = (long long)B * Nsrc;
-    hipLaunchKernelGGL(gather_rows_bwd_csr_kernel, dim3((unsigned)((rows + RB - 1) / RB)), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(gather_rows_bwd_csr_kernel<FT>, dim3((unsigned)((rows + RB - 1) / RB)), dim3(256), 0, as_stream(stream),
                        grad_out, grad_stride, rev_off, rev_edge, B, Nsrc, Nq, C, grad_feat);
     return check_launch();
+}
+extern "C" int hsp_gather_rows_bwd_csr(const float* grad_out, int grad_stride, const int32_t* rev_off,
+                                       const int32_t* rev_edge, int B, int Nsrc, int Nq, int C, float* grad_feat,
+                                       hspStream_t stream) {
+    return gather_rows_bwd_csr_impl<float>(grad_out, grad_stride, rev_off, rev_edge, B, Nsrc, Nq, C, grad_feat, stream);
+}
+extern "C" int hsp_gather_rows_bwd_csr_bf16(const hsp_bf16_t* grad_out, int grad_stride, const int32_t* rev_off,
+                                            const int32_t* rev_edge, int B, int Nsrc, int Nq, int C, hsp_bf16_t* grad_feat,
+                                            hspStream_t stream) {
+    return gather_rows_bwd_csr_impl<bf16_t>(grad_out, grad_stride, rev_off, rev_edge, B, Nsrc, Nq, C, grad_feat, stream);
 }
 
 extern "C" int hsp_gather_max_bwd_csr(const float* grad_out, int grad_bcast, const uint8_t* argmax,
@@ -725,8 +797,9 @@ extern "C" size_t hsp_orl_workspace_bytes(int B, int N, int C) {
     return (size_t)B * ((N + rows - 1) / rows) * C * sizeof(float);
 }
 
-extern "C" int hsp_orl_global_fwd(const float* feat, const int32_t* idx, int B, int N, int k, int kstride, int C,
-                                  float* fg, uint8_t* argmax, void* ws, size_t ws_bytes, hspStream_t stream) {
+template <typename FT>
+static int orl_global_fwd_impl(const FT* feat, const int32_t* idx, int B, int N, int k, int kstride, int C,
+                               float* fg, uint8_t* argmax, void* ws, size_t ws_bytes, hspStream_t stream) {
     if (!feat || !idx || !fg || !argmax || B <= 0 || N <= 0 || k <= 0 || kstride < k || C <= 0) return HSP_ERR_BAD_ARG;
     if ((C & 3) || (256 % (C >> 2)) || k > 255) return HSP_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < hsp_orl_workspace_bytes(B, N, C)) return HSP_ERR_WORKSPACE;
@@ -734,9 +807,17 @@ extern "C" int hsp_orl_global_fwd(const float* feat, const int32_t* idx, int B, 
     const int rows = chunk_rows(B, N, C);
     const int nchunk = (N + rows - 1) / rows;
     float* part = reinterpret_cast<float*>(ws);
-    hipLaunchKernelGGL(orl_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, feat, idx, N, k, kstride, C, argmax, part, nchunk, rows);
+    hipLaunchKernelGGL(orl_partial_kernel<FT>, dim3(nchunk, B), dim3(256), 0, st, feat, idx, N, k, kstride, C, argmax, part, nchunk, rows);
     hipLaunchKernelGGL(chunk_fold_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, B, nchunk, C, 1.0f / (float)N, fg);
     return check_launch();
+}
+extern "C" int hsp_orl_global_fwd(const float* feat, const int32_t* idx, int B, int N, int k, int kstride, int C,
+                                  float* fg, uint8_t* argmax, void* ws, size_t ws_bytes, hspStream_t stream) {
+    return orl_global_fwd_impl<float>(feat, idx, B, N, k, kstride, C, fg, argmax, ws, ws_bytes, stream);
+}
+extern "C" int hsp_orl_global_fwd_bf16(const hsp_bf16_t* feat, const int32_t* idx, int B, int N, int k, int kstride, int C,
+                                       float* fg, uint8_t* argmax, void* ws, size_t ws_bytes, hspStream_t stream) {
+    return orl_global_fwd_impl<bf16_t>(feat, idx, B, N, k, kstride, C, fg, argmax, ws, ws_bytes, stream);
 }
 
 extern "C" int hsp_colsum_rows(const float* x, int B, int N, int C, float* out, void* ws, size_t ws_bytes,
@@ -749,15 +830,30 @@ extern "C" int hsp_colsum_rows(const float* x, int B, int N, int C, float* out, 
     const int nchunk = (N + rows - 1) / rows;
     float* part = reinterpret_cast<float*>(ws);
     if (colsum_vec4(C))
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, x, N, C, part, nchunk, rows);
+        hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(nchunk, B), dim3(256), 0, st, x, N, C, part, nchunk, rows);
     else
         hipLaunchKernelGGL(colsum_partial_scalar_kernel, dim3(nchunk, B), dim3(256), 0, st, x, N, C, part, nchunk, rows);
     hipLaunchKernelGGL(chunk_fold_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, B, nchunk, C, 1.0f, out);
     return check_launch();
 }
 
-extern "C" int hsp_concat_rows(int nseg, const float* const* src, const int32_t* const* idx, const int* width,
-                               const int* kind, const int* nsrc, int B, int N, float* out, hspStream_t stream) {
+extern "C" int hsp_colsum_rows_bf16(const hsp_bf16_t* x, int B, int N, int C, float* out, void* ws, size_t ws_bytes,
+                                    hspStream_t stream) {
+    if (!x || !out || B <= 0 || N <= 0 || C <= 0) return HSP_ERR_BAD_ARG;
+    if (!colsum_vec4(C)) return HSP_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < hsp_orl_workspace_bytes(B, N, C)) return HSP_ERR_WORKSPACE;
+    hipStream_t st = as_stream(stream);
+    const int rows = chunk_rows(B, N, C);
+    const int nchunk = (N + rows - 1) / rows;
+    float* part = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, dim3(nchunk, B), dim3(256), 0, st, x, N, C, part, nchunk, rows);
+    hipLaunchKernelGGL(chunk_fold_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, B, nchunk, C, 1.0f, out);
+    return check_launch();
+}
+
+template <typename FT>
+static int concat_rows_impl(int nseg, const void* const* src, const int32_t* const* idx, const int* width,
+                            const int* kind, const int* nsrc, int B, int N, FT* out, int out_pitch, hspStream_t stream) {
     if (nseg <= 0 || nseg > 8 || !src || !width || !kind || !out || B <= 0 || N <= 0) return HSP_ERR_BAD_ARG;
     ConcatDesc d;
     d.nseg = nseg;
@@ -772,14 +868,34 @@ extern "C" int hsp_concat_rows(int nseg, const float* const* src, const int32_t*
         d.seg[s].col0 = col;
         col += width[s];
     }
-    d.even = 1;
+    if (out_pitch < col) return HSP_ERR_BAD_ARG;
+    d.even = (out_pitch & 1) ? 0 : 1;
     for (int s = 0; s < nseg; ++s)
-        if ((width[s] & 1) || (reinterpret_cast<uintptr_t>(src[s]) & 7)) d.even = 0;
-    if (reinterpret_cast<uintptr_t>(out) & 7) d.even = 0;
+        if (kind[s] != 2 && ((width[s] & 1) || (d.seg[s].col0 & 1) || (reinterpret_cast<uintptr_t>(src[s]) & (2 * sizeof(FT) - 1))))
+            d.even = 0;
+    if (reinterpret_cast<uintptr_t>(out) & (2 * sizeof(FT) - 1)) d.even = 0;
     const long long rows = (long long)B * N;
     const int grid = (int)(rows < 8192 ? rows : 8192);
-    hipLaunchKernelGGL(concat_rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), d, B, N, col, out);
+    hipLaunchKernelGGL(concat_rows_kernel<FT>, dim3(grid), dim3(256), 0, as_stream(stream), d, B, N, out_pitch, out);
     return check_launch();
+}
+extern "C" int hsp_concat_rows(int nseg, const float* const* src, const int32_t* const* idx, const int* width,
+                               const int* kind, const int* nsrc, int B, int N, float* out, hspStream_t stream) {
+    int col = 0;
+    for (int s = 0; s < nseg && s < 8 && width; ++s) col += width[s];
+    return concat_rows_impl<float>(nseg, reinterpret_cast<const void* const*>(src), idx, width, kind, nsrc, B, N, out, col, stream);
+}
+/* the same with an explicit output row pitch (>= sum of widths: padding columns are left untouched) and, in the bf16
+ * form, bf16 kind-0 / kind-1 sources with fp32 kind-2 (per-cloud) sources */
+extern "C" int hsp_concat_rows_pitched(int nseg, const float* const* src, const int32_t* const* idx, const int* width,
+                                       const int* kind, const int* nsrc, int B, int N, float* out, int out_pitch,
+                                       hspStream_t stream) {
+    return concat_rows_impl<float>(nseg, reinterpret_cast<const void* const*>(src), idx, width, kind, nsrc, B, N, out, out_pitch, stream);
+}
+extern "C" int hsp_concat_rows_bf16(int nseg, const void* const* src, const int32_t* const* idx, const int* width,
+                                    const int* kind, const int* nsrc, int B, int N, hsp_bf16_t* out, int out_pitch,
+                                    hspStream_t stream) {
+    return concat_rows_impl<bf16_t>(nseg, src, idx, width, kind, nsrc, B, N, out, out_pitch, stream);
 }
 
 extern "C" int hsp_residual_bias(float* out, const float* f, const float* t, int B, int N, int C, hspStream_t stream) {

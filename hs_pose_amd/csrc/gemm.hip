@@ -29,9 +29,11 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // KB = 4: they take 4 consecutive K slices of ONE tile and fold their accumulators through LDS (fixed order), so
 //         a small output with a long K (128x128 <- 16448 rows) can be cut into hundreds of slices -- enough waves to
 //         fill the chip -- without multiplying the partial sums the reduce kernel has to read.
-template <bool COLSUM, int KB>
-__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ A, int lda,
-                                                    const float* __restrict__ B, int ldb, int M, int N, int K,
+// FT: storage type of A and B (float, or bf16_t: the pair of columns a lane owns is one 4-byte load, widened to fp32 --
+// the products still run on the fp32 MFMA, exact and in the same order as for fp32 operands)
+template <bool COLSUM, int KB, typename FT>
+__global__ __launch_bounds__(256) void wgrad_kernel(const FT* __restrict__ A, int lda,
+                                                    const FT* __restrict__ B, int ldb, int M, int N, int K,
                                                     int SK, int kslice, float* __restrict__ part,
                                                     float* __restrict__ cs_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -57,11 +59,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ A,
     // operands by raw buffer loads: descriptor over the whole matrix, per-lane byte offset fixed for the kernel
     // (row parity h, columns 2i, 2i+1 of the tile), row pair selected by a scalar offset -> no vector address
     // arithmetic in the loop, and rows >= K (ragged end of the last slice; slices are multiples of 8 rows) read 0
+    constexpr int ES = sizeof(FT);
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(A), 0, (int)((((size_t)K - 1) * lda + M) * 4), 0x00020000);
+        const_cast<FT*>(A), 0, (int)((((size_t)K - 1) * lda + M) * ES), 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(B), 0, (int)((((size_t)K - 1) * ldb + N) * 4), 0x00020000);
-    const int va = (h * lda + m0 + 2 * i) * 4, vb = (h * ldb + n0 + 2 * i) * 4;
+        const_cast<FT*>(B), 0, (int)((((size_t)K - 1) * ldb + N) * ES), 0x00020000);
+    const int va = (h * lda + m0 + 2 * i) * ES, vb = (h * ldb + n0 + 2 * i) * ES;
     f32x16 c00, c01, c10, c11;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
@@ -73,10 +76,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ A,
     auto load_group = [&](int kk, float2 (&aa)[WG_UNROLL], float2 (&bb)[WG_UNROLL]) {
 #pragma unroll
         for (int u = 0; u < WG_UNROLL; ++u) {
-            const auto x = __builtin_amdgcn_raw_buffer_load_b64(ra, va, (kk + 2 * u) * lda * 4, 0);
-            const auto y = __builtin_amdgcn_raw_buffer_load_b64(rb, vb, (kk + 2 * u) * ldb * 4, 0);
-            aa[u] = make_float2(__int_as_float(x[0]), __int_as_float(x[1]));
-            bb[u] = make_float2(__int_as_float(y[0]), __int_as_float(y[1]));
+            if constexpr (ES == 4) {
+                const auto x = __builtin_amdgcn_raw_buffer_load_b64(ra, va, (kk + 2 * u) * lda * 4, 0);
+                const auto y = __builtin_amdgcn_raw_buffer_load_b64(rb, vb, (kk + 2 * u) * ldb * 4, 0);
+                aa[u] = make_float2(__int_as_float(x[0]), __int_as_float(x[1]));
+                bb[u] = make_float2(__int_as_float(y[0]), __int_as_float(y[1]));
+            } else {
+                const unsigned x = __builtin_amdgcn_raw_buffer_load_b32(ra, va, (kk + 2 * u) * lda * 2, 0);
+                const unsigned y = __builtin_amdgcn_raw_buffer_load_b32(rb, vb, (kk + 2 * u) * ldb * 2, 0);
+                aa[u] = make_float2(__uint_as_float(x << 16), __uint_as_float(x & 0xffff0000u));
+                bb[u] = make_float2(__uint_as_float(y << 16), __uint_as_float(y & 0xffff0000u));
+            }
         }
     };
     auto mma_group = [&](const float2 (&aa)[WG_UNROLL], const float2 (&bb)[WG_UNROLL]) {
@@ -249,25 +259,26 @@ extern "C" size_t hsp_wgrad_workspace_bytes(int M, int N, int K) {
     return (size_t)(sk / kb) * ((size_t)M * N + N) * sizeof(float);
 }
 
-template <bool COLSUM>
-static int wgrad_launch(const float* A, int lda, const float* B, int ldb, int M, int N, int K, int sk, int ks, int kb,
+template <bool COLSUM, typename FT>
+static int wgrad_launch(const FT* A, int lda, const FT* B, int ldb, int M, int N, int K, int sk, int ks, int kb,
                         float* part, float* cs_part, hipStream_t st) {
     const int tiles = (M >> 6) * (N >> 6);
     if (kb == 1) {
-        hipLaunchKernelGGL((wgrad_kernel<COLSUM, 1>), dim3((tiles * sk + 3) / 4), dim3(256), 0, st, A, lda, B, ldb, M, N, K,
+        hipLaunchKernelGGL((wgrad_kernel<COLSUM, 1, FT>), dim3((tiles * sk + 3) / 4), dim3(256), 0, st, A, lda, B, ldb, M, N, K,
                            sk, ks, part, cs_part);
         return check_launch();
     }
     const size_t lds = (size_t)4 * 4 * 16 * 64 * sizeof(float) + (size_t)4 * 64 * sizeof(float2);
-    auto kern = wgrad_kernel<COLSUM, 4>;
+    auto kern = wgrad_kernel<COLSUM, 4, FT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
     hipLaunchKernelGGL(kern, dim3(tiles * (sk / 4)), dim3(256), lds, st, A, lda, B, ldb, M, N, K, sk, ks, part, cs_part);
     return check_launch();
 }
 
-extern "C" int hsp_wgrad_f32(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc,
-                             float* colsum_B, void* ws, size_t ws_bytes, hspStream_t stream) {
+template <typename FT>
+static int wgrad_impl(const FT* A, int lda, const FT* B, int ldb, int M, int N, int K, float* C, int ldc,
+                      float* colsum_B, void* ws, size_t ws_bytes, hspStream_t stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda < M || ldb < N || ldc < N) return HSP_ERR_BAD_ARG;
     if ((M & 63) || (N & 63) || (lda & 1) || (ldb & 1)) return HSP_ERR_UNSUPPORTED;   // 64x64 wave tiles, float2 loads
     if (!ws || ws_bytes < hsp_wgrad_workspace_bytes(M, N, K)) return HSP_ERR_WORKSPACE;
@@ -277,11 +288,21 @@ extern "C" int hsp_wgrad_f32(const float* A, int lda, const float* B, int ldb, i
     float* part = reinterpret_cast<float*>(ws);
     float* cs_part = part + (size_t)nparts * M * N;
     hipStream_t st = as_stream(stream);
-    int rc = colsum_B ? wgrad_launch<true>(A, lda, B, ldb, M, N, K, sk, ks, kb, part, cs_part, st)
-                      : wgrad_launch<false>(A, lda, B, ldb, M, N, K, sk, ks, kb, part, cs_part, st);
+    int rc = colsum_B ? wgrad_launch<true, FT>(A, lda, B, ldb, M, N, K, sk, ks, kb, part, cs_part, st)
+                      : wgrad_launch<false, FT>(A, lda, B, ldb, M, N, K, sk, ks, kb, part, cs_part, st);
     if (rc) return rc;
     const long long total = (long long)M * (N >> 2) + (colsum_B ? (N >> 2) : 0);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, part, nparts, M, N, C,
                        ldc, cs_part, colsum_B);
     return check_launch();
+}
+
+extern "C" int hsp_wgrad_f32(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc,
+                             float* colsum_B, void* ws, size_t ws_bytes, hspStream_t stream) {
+    return wgrad_impl<float>(A, lda, B, ldb, M, N, K, C, ldc, colsum_B, ws, ws_bytes, stream);
+}
+/* bf16 point rows in, fp32 parameter gradient out */
+extern "C" int hsp_wgrad_bf16(const hsp_bf16_t* A, int lda, const hsp_bf16_t* B, int ldb, int M, int N, int K, float* C,
+                              int ldc, float* colsum_B, void* ws, size_t ws_bytes, hspStream_t stream) {
+    return wgrad_impl<bf16_t>(A, lda, B, ldb, M, N, K, C, ldc, colsum_B, ws, ws_bytes, stream);
 }

@@ -51,6 +51,8 @@ struct GemmRowsArgs {
     const void* resid; int ldr;            // (M,N) of the output type or null
     const float* cbias; int rows_per_cloud;  // (ceil(M / rows_per_cloud), N) fp32 or null
     float alpha;                           // scales the accumulated products (before bias / resid / cloud bias)
+    const float* xyz3; const float* w3;    // rank-3 fp32 update + xyz3[row] . w3[col] ((M,3), (N,3)) or null
+    int c_f32;                             // bf16 operands: write C as fp32 (a tensor that feeds BatchNorm keeps its mantissa)
     int tiles_m, tiles_n;
 };
 
@@ -296,6 +298,8 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
             const int col = n0 + wn0 + 32 * y + li;
             const bool cok = col < g.N;
             const float bv = (g.bias && cok) ? g.bias[col] : 0.f;
+            float w30 = 0.f, w31 = 0.f, w32 = 0.f;
+            if (g.xyz3 && cok) { w30 = g.w3[col * 3]; w31 = g.w3[col * 3 + 1]; w32 = g.w3[col * 3 + 2]; }
 #pragma unroll
             for (int x = 0; x < WM; ++x) {
 #pragma unroll
@@ -308,12 +312,16 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
                         if (ES == 4) v += reinterpret_cast<const float*>(g.resid)[(size_t)row * g.ldr + col];
                         else v += bf16_to_f32(reinterpret_cast<const unsigned short*>(g.resid)[(size_t)row * g.ldr + col]);
                     }
+                    if (g.xyz3) {      // the K = 3 product on raw fp32 coordinates (HSlayer_surface's STE, gcn3d.py:85)
+                        const float* p3 = g.xyz3 + (size_t)row * 3;
+                        v += __fmaf_rn(p3[2], w32, __fmaf_rn(p3[1], w31, p3[0] * w30));
+                    }
                     if (g.cbias) {
                         int c = c0;
                         if (row >= nb) c = c0 + 1 + (row - nb) / rpc;      // rare: the tile spans clouds
                         v += g.cbias[(size_t)c * g.N + col];
                     }
-                    if (ES == 4) reinterpret_cast<float*>(g.C)[(size_t)row * g.ldc + col] = v;
+                    if (ES == 4 || g.c_f32) reinterpret_cast<float*>(g.C)[(size_t)row * g.ldc + col] = v;
                     else reinterpret_cast<unsigned short*>(g.C)[(size_t)row * g.ldc + col] = f32_to_bf16(v);
                 }
             }
@@ -413,7 +421,8 @@ static bool prefer_small_tile(int M, int N) {
 template <typename T>
 static int gemm_rows_dispatch(const void* A1, int lda1, const void* B1, int ldb1, int l1, int K1, const void* A2, int lda2,
                               const void* B2, int ldb2, int l2, int K2, int M, int N, const float* bias, const void* resid,
-                              int ldr, const float* cbias, int rpc, float alpha, void* C, int ldc, hspStream_t stream) {
+                              int ldr, const float* cbias, int rpc, float alpha, const float* xyz3, const float* w3, void* C, int ldc,
+                              int c_f32, hspStream_t stream) {
     constexpr int ES = sizeof(T);
     if (!A1 || !B1 || !C || M <= 0 || N <= 0 || K1 <= 0 || lda1 < K1 || ldc < N) return HSP_ERR_BAD_ARG;
     if (l1 != 0 && l1 != 1) return HSP_ERR_BAD_ARG;
@@ -440,6 +449,9 @@ static int gemm_rows_dispatch(const void* A1, int lda1, const void* B1, int ldb1
     g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.bias = bias; g.resid = resid; g.ldr = ldr; g.cbias = cbias;
     g.rows_per_cloud = rpc > 0 ? rpc : 1;
     g.alpha = alpha;
+    if ((xyz3 == nullptr) != (w3 == nullptr)) return HSP_ERR_BAD_ARG;
+    g.xyz3 = xyz3; g.w3 = w3;
+    g.c_f32 = c_f32;
     int lb1 = l1 == 0 ? 1 : 2, lb2 = two ? (l2 == 0 ? 1 : 2) : 0;
     if (two && lb1 == 1 && lb2 == 2) {
         const void* t; int ti;
@@ -457,22 +469,63 @@ static int gemm_rows_dispatch(const void* A1, int lda1, const void* B1, int ldb1
     return launch_mode<T, 2, 2>(g, lb1, lb2, mode, st);
 }
 
+// ---- fp32 master parameters -> bf16 working copies, all tensors of a step in ONE launch --------------------------------
+// entry e: src (rows, cols) fp32 with row pitch ld -> dst (rows, cols) bf16 and / or dstT (cols, rows) bf16 (the (N,K) form
+// the bf16 GEMM wants of a (K,N) matrix).  32 x 32 tiles through LDS: both copies are written in 64-byte row segments.
+__global__ __launch_bounds__(256) void cast_params_kernel(const HspCastDesc* __restrict__ tab, int n) {
+    __shared__ float tile[32][33];
+    int e = 0;
+    while (e + 1 < n && (int)blockIdx.x >= tab[e + 1].tile0) ++e;
+    const HspCastDesc d = tab[e];
+    const int t = (int)blockIdx.x - d.tile0;
+    const int tcols = (d.cols + 31) >> 5;
+    const int r0 = (t / tcols) * 32, c0 = (t % tcols) * 32;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    bf16_t* dst = reinterpret_cast<bf16_t*>(d.dst);
+    bf16_t* dstT = reinterpret_cast<bf16_t*>(d.dstT);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ly + 8 * j, c = c0 + lx;
+        float v = 0.f;
+        if (r < d.rows && c < d.cols) {
+            v = d.src[(size_t)r * d.ld + c];
+            if (dst) dst[(size_t)r * d.cols + c] = (bf16_t)f32_to_bf16_bits(v);
+        }
+        tile[ly + 8 * j][lx] = v;
+    }
+    if (!dstT) return;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + ly + 8 * j, r = r0 + lx;
+        if (r < d.rows && c < d.cols) dstT[(size_t)c * d.rows + r] = (bf16_t)f32_to_bf16_bits(tile[lx][ly + 8 * j]);
+    }
+}
+
 }  // namespace hsp
 
 using namespace hsp;
 
+extern "C" int hsp_cast_params_bf16(const HspCastDesc* table_dev, int n, int total_tiles, hspStream_t stream) {
+    if (!table_dev || n <= 0 || total_tiles <= 0) return HSP_ERR_BAD_ARG;
+    hipLaunchKernelGGL(cast_params_kernel, dim3(total_tiles), dim3(256), 0, as_stream(stream), table_dev, n);
+    return check_launch();
+}
+
 extern "C" int hsp_gemm_rows_f32(const float* A1, int lda1, const float* B1, int ldb1, int b1_layout, int K1,
                                  const float* A2, int lda2, const float* B2, int ldb2, int b2_layout, int K2, int M, int N,
                                  const float* bias, const float* resid, int ldr, const float* cloud_bias,
-                                 int rows_per_cloud, float alpha, float* C, int ldc, hspStream_t stream) {
+                                 int rows_per_cloud, float alpha, const float* xyz3, const float* w3, float* C, int ldc,
+                                 hspStream_t stream) {
     return gemm_rows_dispatch<float>(A1, lda1, B1, ldb1, b1_layout, K1, A2, lda2, B2, ldb2, b2_layout, K2, M, N, bias, resid,
-                                     ldr, cloud_bias, rows_per_cloud, alpha, C, ldc, stream);
+                                     ldr, cloud_bias, rows_per_cloud, alpha, xyz3, w3, C, ldc, 1, stream);
 }
 
 extern "C" int hsp_gemm_rows_bf16(const hsp_bf16_t* A1, int lda1, const hsp_bf16_t* B1, int ldb1, int K1,
                                   const hsp_bf16_t* A2, int lda2, const hsp_bf16_t* B2, int ldb2, int K2, int M, int N,
                                   const float* bias, const hsp_bf16_t* resid, int ldr, const float* cloud_bias,
-                                  int rows_per_cloud, float alpha, hsp_bf16_t* C, int ldc, hspStream_t stream) {
+                                  int rows_per_cloud, float alpha, const float* xyz3, const float* w3, void* C, int ldc,
+                                  int c_is_f32, hspStream_t stream) {
     return gemm_rows_dispatch<unsigned short>(A1, lda1, B1, ldb1, 0, K1, A2, lda2, B2, ldb2, 0, K2, M, N, bias, resid, ldr,
-                                              cloud_bias, rows_per_cloud, alpha, C, ldc, stream);
+                                              cloud_bias, rows_per_cloud, alpha, xyz3, w3, C, ldc, c_is_f32 ? 1 : 0, stream);
 }

@@ -23,9 +23,11 @@ namespace hsp {
 // partial[blk][0][c] = sum_r v1, partial[blk][1][c] = sum_r v2 over the rows of chunk blk, where
 //   MODE 0 (forward stats):  v1 = x - shift,  v2 = (x - shift)^2            shift = x[0][c]
 //   MODE 1 (backward):       v1 = dz,         v2 = dz * xhat                dz = relu ? dy*[a>0] : dy
-template <int MODE>
-__global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float* __restrict__ x,
-                                                                const float* __restrict__ dy, int R, int C,
+// FT: storage type of the row tensors x / dy / y / dx (statistics, affine parameters and partial sums are fp32)
+// XT: storage type of x (the BatchNorm INPUT) -- fp32 with bf16 y / dy / dx in the "mixed" form
+template <int MODE, typename FT, typename XT>
+__global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const XT* __restrict__ x,
+                                                                const FT* __restrict__ dy, int R, int C,
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma,
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float* __r
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     float4 sh = make_float4(0.f, 0.f, 0.f, 0.f), mu = sh, is = sh, ga = sh, be = sh;
     if (MODE == 0) {
-        sh = *reinterpret_cast<const float4*>(x + (g << 2));
+        sh = Feat<XT>::ld4(x + (g << 2));
     } else {
         mu = *reinterpret_cast<const float4*>(mean + (g << 2));
         is = *reinterpret_cast<const float4*>(invstd + (g << 2));
@@ -49,13 +51,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float* __r
         be = *reinterpret_cast<const float4*>(beta + (g << 2));
     }
     for (int r = r0 + rl; r < r1; r += RL) {
-        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * C + (g << 2));
+        const float4 v = Feat<XT>::ld4(x + (size_t)r * C + (g << 2));
         if (MODE == 0) {
             const float a = v.x - sh.x, b = v.y - sh.y, c = v.z - sh.z, d = v.w - sh.w;
             s1.x += a; s1.y += b; s1.z += c; s1.w += d;
             s2.x += a * a; s2.y += b * b; s2.z += c * c; s2.w += d * d;
         } else {
-            float4 dz = *reinterpret_cast<const float4*>(dy + (size_t)r * C + (g << 2));
+            float4 dz = Feat<FT>::ld4(dy + (size_t)r * C + (g << 2));
             const float4 xh = make_float4((v.x - mu.x) * is.x, (v.y - mu.y) * is.y, (v.z - mu.z) * is.z, (v.w - mu.w) * is.w);
             if (relu) {
                 if (!(xh.x * ga.x + be.x > 0.f)) dz.x = 0.f;
@@ -85,9 +87,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float* __r
 // one thread per channel: fold the partials (ascending block order), then
 //   MODE 0: mean, biased var -> invstd; running stats (momentum, unbiased var); num_batches_tracked += 1
 //   MODE 1: dgamma = sum dz*xhat, dbeta = sum dz; also keep both means for the dx pass
-template <int MODE>
+template <int MODE, typename FT>
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int R, int C,
-                                                           const float* __restrict__ x, float eps, float momentum,
+                                                           const FT* __restrict__ x, float eps, float momentum,
                                                            float* __restrict__ out_a, float* __restrict__ out_b,
                                                            float* __restrict__ run_mean, float* __restrict__ run_var,
                                                            long long* __restrict__ num_batches) {
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
         const float ms = s1 * invR;                              // mean of (x - shift)
         float var = s2 * invR - ms * ms;
         if (var < 0.f) var = 0.f;
-        const float mean = x[c] + ms;
+        const float mean = Feat<FT>::ld(x + c) + ms;
         out_a[c] = mean;
         out_b[c] = 1.0f / sqrtf(var + eps);
         if (run_mean) {
@@ -143,16 +145,17 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
 }
 
 // y = relu?((x - mean) * invstd * gamma + beta)
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, long long total4, int C,
+template <typename FT, typename XT>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const XT* __restrict__ x, long long total4, int C,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int relu,
-                                                       float* __restrict__ y) {
+                                                       FT* __restrict__ y) {
     const int cq = C >> 2;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
         const int g = (int)(e % cq);
-        const float4 v = *reinterpret_cast<const float4*>(x + e * 4);
+        const float4 v = Feat<XT>::ld4(x + e * 4);
         const float4 mu = *reinterpret_cast<const float4*>(mean + (g << 2));
         const float4 is = *reinterpret_cast<const float4*>(invstd + (g << 2));
         const float4 ga = *reinterpret_cast<const float4*>(gamma + (g << 2));
@@ -160,22 +163,23 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         float4 o = make_float4((v.x - mu.x) * is.x * ga.x + be.x, (v.y - mu.y) * is.y * ga.y + be.y,
                                (v.z - mu.z) * is.z * ga.z + be.z, (v.w - mu.w) * is.w * ga.w + be.w);
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-        *reinterpret_cast<float4*>(y + e * 4) = o;
+        Feat<FT>::st4(y + e * 4, o);
     }
 }
 
 // dx = gamma*invstd*(dz - dbeta/R - xhat*dgamma/R)
-__global__ __launch_bounds__(256) void bn_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename FT, typename XT>
+__global__ __launch_bounds__(256) void bn_dx_kernel(const XT* __restrict__ x, const FT* __restrict__ dy,
                                                     long long total4, int R, int C, const float* __restrict__ mean,
                                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, const float* __restrict__ dgamma,
-                                                    const float* __restrict__ dbeta, int relu, float* __restrict__ dx) {
+                                                    const float* __restrict__ dbeta, int relu, FT* __restrict__ dx) {
     const int cq = C >> 2;
     const float invR = 1.0f / (float)R;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
         const int g = (int)(e % cq);
-        const float4 v = *reinterpret_cast<const float4*>(x + e * 4);
-        float4 dz = *reinterpret_cast<const float4*>(dy + e * 4);
+        const float4 v = Feat<XT>::ld4(x + e * 4);
+        float4 dz = Feat<FT>::ld4(dy + e * 4);
         const float4 mu = *reinterpret_cast<const float4*>(mean + (g << 2));
         const float4 is = *reinterpret_cast<const float4*>(invstd + (g << 2));
         const float4 ga = *reinterpret_cast<const float4*>(gamma + (g << 2));
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256) void bn_dx_kernel(const float* __restrict__ x,
         o.y = ga.y * is.y * (dz.y - db.y * invR - xh.y * dg.y * invR);
         o.z = ga.z * is.z * (dz.z - db.z * invR - xh.z * dg.z * invR);
         o.w = ga.w * is.w * (dz.w - db.w * invR - xh.w * dg.w * invR);
-        *reinterpret_cast<float4*>(dx + e * 4) = o;
+        Feat<FT>::st4(dx + e * 4, o);
     }
 }
 
@@ -228,8 +232,9 @@ extern "C" size_t hsp_bn_workspace_bytes(int R, int C) {
     return (size_t)bn_blocks(R) * 2 * C * sizeof(float);
 }
 
-extern "C" int hsp_bn_relu_fwd(const float* x, int R, int C, const float* gamma, const float* beta, float eps,
-                               float momentum, int relu, float* y, float* save_mean, float* save_invstd,
+template <typename FT, typename XT>
+static int bn_relu_fwd_impl(const XT* x, int R, int C, const float* gamma, const float* beta, float eps,
+                               float momentum, int relu, FT* y, float* save_mean, float* save_invstd,
                                float* running_mean, float* running_var, long long* num_batches_tracked, void* ws,
                                size_t ws_bytes, hspStream_t stream) {
     if (!x || !gamma || !beta || !y || !save_mean || !save_invstd) return HSP_ERR_BAD_ARG;
@@ -239,29 +244,31 @@ extern "C" int hsp_bn_relu_fwd(const float* x, int R, int C, const float* gamma,
     hipStream_t st = as_stream(stream);
     float* part = reinterpret_cast<float*>(ws);
     const int nblk = bn_blocks(R);
-    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nblk), dim3(BN_THREADS), 0, st, x, nullptr, R, C, nullptr, nullptr,
+    hipLaunchKernelGGL((bn_partial_kernel<0, FT, XT>), dim3(nblk), dim3(BN_THREADS), 0, st, x, (const FT*)nullptr, R, C, nullptr, nullptr,
                        nullptr, nullptr, 0, part, bn_rows_per_block(R));
-    hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 63) / 64), dim3(1024), 0, st, part, nblk, R, C, x, eps, momentum,
+    hipLaunchKernelGGL((bn_finalize_kernel<0, XT>), dim3((C + 63) / 64), dim3(1024), 0, st, part, nblk, R, C, x, eps, momentum,
                        save_mean, save_invstd, running_mean, running_var, num_batches_tracked);
     const long long total4 = (long long)R * (C >> 2);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid4(total4)), dim3(256), 0, st, x, total4, C, save_mean, save_invstd,
+    hipLaunchKernelGGL((bn_apply_kernel<FT, XT>), dim3(stream_grid4(total4)), dim3(256), 0, st, x, total4, C, save_mean, save_invstd,
                        gamma, beta, relu, y);
     return check_launch();
 }
 
-extern "C" int hsp_bn_relu_apply(const float* x, int R, int C, const float* mean, const float* invstd,
-                                 const float* gamma, const float* beta, int relu, float* y, hspStream_t stream) {
+template <typename FT, typename XT>
+static int bn_relu_apply_impl(const XT* x, int R, int C, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, int relu, FT* y, hspStream_t stream) {
     if (!x || !mean || !invstd || !gamma || !beta || !y) return HSP_ERR_BAD_ARG;
     int rc = bn_check(R, C);
     if (rc) return rc;
     const long long total4 = (long long)R * (C >> 2);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid4(total4)), dim3(256), 0, as_stream(stream), x, total4, C, mean,
+    hipLaunchKernelGGL((bn_apply_kernel<FT, XT>), dim3(stream_grid4(total4)), dim3(256), 0, as_stream(stream), x, total4, C, mean,
                        invstd, gamma, beta, relu, y);
     return check_launch();
 }
 
-extern "C" int hsp_bn_relu_bwd(const float* x, const float* dy, int R, int C, const float* gamma, const float* beta,
-                               const float* save_mean, const float* save_invstd, int relu, float* dx, float* dgamma,
+template <typename FT, typename XT>
+static int bn_relu_bwd_impl(const XT* x, const FT* dy, int R, int C, const float* gamma, const float* beta,
+                               const float* save_mean, const float* save_invstd, int relu, FT* dx, float* dgamma,
                                float* dbeta, void* ws, size_t ws_bytes, hspStream_t stream) {
     if (!x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta) return HSP_ERR_BAD_ARG;
     int rc = bn_check(R, C);
@@ -270,12 +277,67 @@ extern "C" int hsp_bn_relu_bwd(const float* x, const float* dy, int R, int C, co
     hipStream_t st = as_stream(stream);
     float* part = reinterpret_cast<float*>(ws);
     const int nblk = bn_blocks(R);
-    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nblk), dim3(BN_THREADS), 0, st, x, dy, R, C, save_mean, save_invstd, gamma,
+    hipLaunchKernelGGL((bn_partial_kernel<1, FT, XT>), dim3(nblk), dim3(BN_THREADS), 0, st, x, dy, R, C, save_mean, save_invstd, gamma,
                        beta, relu, part, bn_rows_per_block(R));
-    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 63) / 64), dim3(1024), 0, st, part, nblk, R, C, x, 0.f, 0.f, dgamma,
+    hipLaunchKernelGGL((bn_finalize_kernel<1, XT>), dim3((C + 63) / 64), dim3(1024), 0, st, part, nblk, R, C, x, 0.f, 0.f, dgamma,
                        dbeta, nullptr, nullptr, nullptr);
     const long long total4 = (long long)R * (C >> 2);
-    hipLaunchKernelGGL(bn_dx_kernel, dim3(stream_grid4(total4)), dim3(256), 0, st, x, dy, total4, R, C, save_mean,
+    hipLaunchKernelGGL((bn_dx_kernel<FT, XT>), dim3(stream_grid4(total4)), dim3(256), 0, st, x, dy, total4, R, C, save_mean,
                        save_invstd, gamma, beta, dgamma, dbeta, relu, dx);
     return check_launch();
+}
+
+extern "C" int hsp_bn_relu_fwd(const float* x, int R, int C, const float* gamma, const float* beta, float eps,
+                               float momentum, int relu, float* y, float* save_mean, float* save_invstd,
+                               float* running_mean, float* running_var, long long* num_batches_tracked, void* ws,
+                               size_t ws_bytes, hspStream_t stream) {
+    return bn_relu_fwd_impl<float, float>(x, R, C, gamma, beta, eps, momentum, relu, y, save_mean, save_invstd, running_mean,
+                                   running_var, num_batches_tracked, ws, ws_bytes, stream);
+}
+extern "C" int hsp_bn_relu_fwd_bf16(const hsp_bf16_t* x, int R, int C, const float* gamma, const float* beta, float eps,
+                                    float momentum, int relu, hsp_bf16_t* y, float* save_mean, float* save_invstd,
+                                    float* running_mean, float* running_var, long long* num_batches_tracked, void* ws,
+                                    size_t ws_bytes, hspStream_t stream) {
+    return bn_relu_fwd_impl<bf16_t, bf16_t>(x, R, C, gamma, beta, eps, momentum, relu, y, save_mean, save_invstd, running_mean,
+                                    running_var, num_batches_tracked, ws, ws_bytes, stream);
+}
+extern "C" int hsp_bn_relu_apply(const float* x, int R, int C, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, int relu, float* y, hspStream_t stream) {
+    return bn_relu_apply_impl<float, float>(x, R, C, mean, invstd, gamma, beta, relu, y, stream);
+}
+extern "C" int hsp_bn_relu_apply_bf16(const hsp_bf16_t* x, int R, int C, const float* mean, const float* invstd,
+                                      const float* gamma, const float* beta, int relu, hsp_bf16_t* y, hspStream_t stream) {
+    return bn_relu_apply_impl<bf16_t, bf16_t>(x, R, C, mean, invstd, gamma, beta, relu, y, stream);
+}
+extern "C" int hsp_bn_relu_bwd(const float* x, const float* dy, int R, int C, const float* gamma, const float* beta,
+                               const float* save_mean, const float* save_invstd, int relu, float* dx, float* dgamma,
+                               float* dbeta, void* ws, size_t ws_bytes, hspStream_t stream) {
+    return bn_relu_bwd_impl<float, float>(x, dy, R, C, gamma, beta, save_mean, save_invstd, relu, dx, dgamma, dbeta, ws, ws_bytes,
+                                   stream);
+}
+extern "C" int hsp_bn_relu_bwd_bf16(const hsp_bf16_t* x, const hsp_bf16_t* dy, int R, int C, const float* gamma,
+                                    const float* beta, const float* save_mean, const float* save_invstd, int relu,
+                                    hsp_bf16_t* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                                    hspStream_t stream) {
+    return bn_relu_bwd_impl<bf16_t, bf16_t>(x, dy, R, C, gamma, beta, save_mean, save_invstd, relu, dx, dgamma, dbeta, ws, ws_bytes,
+                                    stream);
+}
+
+extern "C" int hsp_bn_relu_fwd_mixed(const float* x, int R, int C, const float* gamma, const float* beta, float eps,
+                                     float momentum, int relu, hsp_bf16_t* y, float* save_mean, float* save_invstd,
+                                     float* running_mean, float* running_var, long long* num_batches_tracked, void* ws,
+                                     size_t ws_bytes, hspStream_t stream) {
+    return bn_relu_fwd_impl<bf16_t, float>(x, R, C, gamma, beta, eps, momentum, relu, y, save_mean, save_invstd, running_mean,
+                                           running_var, num_batches_tracked, ws, ws_bytes, stream);
+}
+extern "C" int hsp_bn_relu_apply_mixed(const float* x, int R, int C, const float* mean, const float* invstd,
+                                       const float* gamma, const float* beta, int relu, hsp_bf16_t* y, hspStream_t stream) {
+    return bn_relu_apply_impl<bf16_t, float>(x, R, C, mean, invstd, gamma, beta, relu, y, stream);
+}
+extern "C" int hsp_bn_relu_bwd_mixed(const float* x, const hsp_bf16_t* dy, int R, int C, const float* gamma,
+                                     const float* beta, const float* save_mean, const float* save_invstd, int relu,
+                                     hsp_bf16_t* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                                     hspStream_t stream) {
+    return bn_relu_bwd_impl<bf16_t, float>(x, dy, R, C, gamma, beta, save_mean, save_invstd, relu, dx, dgamma, dbeta, ws,
+                                           ws_bytes, stream);
 }

@@ -58,14 +58,15 @@ struct PointIter {
 // dynamic LDS: (S*C + 4*k + k) floats
 // ------------------------------------------------------------------------------------------------
 // WF: also record the winners' support values (fwin)
-template <bool SURFACE, int NCH, bool WF>
+// FT: storage type of fm / out / fwin (float, or bf16_t: arithmetic stays fp32, common.h Feat<>)
+template <bool SURFACE, int NCH, bool WF, typename FT>
 __global__ __launch_bounds__(RF_THREADS) void rf_fwd_kernel(const float* __restrict__ xyz,
                                                             const int32_t* __restrict__ idx,
                                                             const float* __restrict__ dirs,
-                                                            const float* __restrict__ fm, int B, int N, int k,
-                                                            int S, int C, float* __restrict__ out,
+                                                            const FT* __restrict__ fm, int B, int N, int k,
+                                                            int S, int C, FT* __restrict__ out,
                                                             uint16_t* __restrict__ argrow,
-                                                            float* __restrict__ fwin) {
+                                                            FT* __restrict__ fwin) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int SC = S * C;
     float* smax = reinterpret_cast<float*>(smem);             // SC
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_kernel(const float* __restr
                     float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
                     int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
                     float4 wf = make_float4(1.f, 1.f, 1.f, 1.f);          // the support value behind each winner
-                    const float* fsup = SURFACE ? nullptr : fm + (size_t)b * N * fstride + C + j;
+                    const FT* fsup = SURFACE ? nullptr : fm + (size_t)b * N * fstride + C + j;
 #pragma unroll 4
                     for (int n = 0; n < k; ++n) {
                         const float4 r = sR[n];
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_kernel(const float* __restr
                         th.z = fmaxf(__fmaf_rn(r.z, d2[u].z, __fmaf_rn(r.y, d1[u].z, mul_rn(r.x, d0[u].z))), 0.f);
                         th.w = fmaxf(__fmaf_rn(r.z, d2[u].w, __fmaf_rn(r.y, d1[u].w, mul_rn(r.x, d0[u].w))), 0.f);
                         if (!SURFACE) {
-                            const float4 f = *reinterpret_cast<const float4*>(fsup + (size_t)sIdx[n] * fstride);
+                            const float4 f = Feat<FT>::ld4(fsup + (size_t)sIdx[n] * fstride);
                             th.x = mul_rn(th.x, f.x); th.y = mul_rn(th.y, f.y);
                             th.z = mul_rn(th.z, f.z); th.w = mul_rn(th.w, f.w);
                             if (WF) {
@@ -132,11 +133,7 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_kernel(const float* __restr
                     // as a stream instead of gathering 4-byte values from N rows (4x the HBM traffic, measured)
                     // fwin / argrow / out are write-once streams read again only by the backward: non-temporal stores keep
                     // them from evicting the cloud's fm rows (the gather's working set) from the XCD's L2
-                    if (WF) {
-                        float* fw = fwin + pt * SC + j;
-                        __builtin_nontemporal_store(wf.x, fw); __builtin_nontemporal_store(wf.y, fw + 1);
-                        __builtin_nontemporal_store(wf.z, fw + 2); __builtin_nontemporal_store(wf.w, fw + 3);
-                    }
+                    if (WF) Feat<FT>::st4_nt(fwin + pt * SC + j, wf);
                     *reinterpret_cast<float4*>(smax + j) = best;
                     // the winning SOURCE ROW m* = idx[b,i,n*] (uint16): the backward needs neither idx nor n
                     {
@@ -152,8 +149,8 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_kernel(const float* __restr
                 float s = smax[c];
                 for (int sp = 1; sp < S; ++sp) s = add_rn(s, smax[sp * C + c]);
                 float v = __fdiv_rn(s, invS_div);
-                if (!SURFACE) v = add_rn(fm[pt * fstride + c], v);
-                __builtin_nontemporal_store(v, out + pt * C + c);
+                if (!SURFACE) v = add_rn(Feat<FT>::ld(fm + pt * fstride + c), v);
+                Feat<FT>::st_nt(out + pt * C + c, v);
             }
         }
     }
@@ -304,11 +301,11 @@ __global__ __launch_bounds__(RF_THREADS) void rf_conv_bwd_csr_kernel(
 
 // FWIN: the support values come from the forward's fwin stream; else they are gathered from fm (fine while a
 // cloud's fm stays L2-resident: small N)
-template <int TC, bool SURFACE, bool FWIN>
+template <int TC, bool SURFACE, bool FWIN, typename FT>
 __global__ __launch_bounds__(RF_TILE_THREADS) void rf_bwd_tile_kernel(
-    const float* __restrict__ xyz, const float* __restrict__ dirs, const float* __restrict__ fwin,
-    const uint16_t* __restrict__ argrow, const float* __restrict__ gout, int B, int N, int S, int C,
-    float* __restrict__ gfm, float* __restrict__ gd_part) {
+    const float* __restrict__ xyz, const float* __restrict__ dirs, const FT* __restrict__ fwin,
+    const uint16_t* __restrict__ argrow, const FT* __restrict__ gout, int B, int N, int S, int C,
+    FT* __restrict__ gfm, float* __restrict__ gd_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* acc = reinterpret_cast<float*>(smem);                       // N*TC   (unused when SURFACE)
     float* sx = acc + (SURFACE ? 0 : (size_t)N * TC);                  // 3*N
@@ -330,7 +327,7 @@ __global__ __launch_bounds__(RF_TILE_THREADS) void rf_bwd_tile_kernel(
     float4 d0, d1, d2;
     load_dirs_normed(dirs, SC, j, d0, d1, d2);
     float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
-    const float* fsup = (SURFACE || FWIN) ? nullptr : fwin + (size_t)b * N * fstride + C + j;   // (fwin is fm then)
+    const FT* fsup = (SURFACE || FWIN) ? nullptr : fwin + (size_t)b * N * fstride + C + j;   // (fwin is fm then)
     __syncthreads();
     // software pipeline: the next point's winning rows / their support values / gradient are in flight while
     // this one is processed; with FWIN every global read of the loop is a coalesced stream
@@ -338,8 +335,8 @@ __global__ __launch_bounds__(RF_TILE_THREADS) void rf_bwd_tile_kernel(
     float4 ga_n = make_float4(0.f, 0.f, 0.f, 0.f), fw_n = make_float4(1.f, 1.f, 1.f, 1.f);
     if (pl < N) {
         am_n = *reinterpret_cast<const ushort4*>(argrow + ((size_t)b * N + pl) * SC + j);
-        ga_n = *reinterpret_cast<const float4*>(gout + ((size_t)b * N + pl) * C + c);
-        if (!SURFACE && FWIN) fw_n = *reinterpret_cast<const float4*>(fwin + ((size_t)b * N + pl) * SC + j);
+        ga_n = Feat<FT>::ld4(gout + ((size_t)b * N + pl) * C + c);
+        if (!SURFACE && FWIN) fw_n = Feat<FT>::ld4(fwin + ((size_t)b * N + pl) * SC + j);
     }
     for (int p = pl; p < N; p += PL) {
         const ushort4 am = am_n;
@@ -347,14 +344,14 @@ __global__ __launch_bounds__(RF_TILE_THREADS) void rf_bwd_tile_kernel(
         const float4 fw = fw_n;
         const int pn = p + PL < N ? p + PL : p;                      // clamped: no branch around the loads
         am_n = *reinterpret_cast<const ushort4*>(argrow + ((size_t)b * N + pn) * SC + j);
-        ga_n = *reinterpret_cast<const float4*>(gout + ((size_t)b * N + pn) * C + c);
-        if (!SURFACE && FWIN) fw_n = *reinterpret_cast<const float4*>(fwin + ((size_t)b * N + pn) * SC + j);
+        ga_n = Feat<FT>::ld4(gout + ((size_t)b * N + pn) * C + c);
+        if (!SURFACE && FWIN) fw_n = Feat<FT>::ld4(fwin + ((size_t)b * N + pn) * SC + j);
         float f0 = fw.x, f1 = fw.y, f2 = fw.z, f3 = fw.w;
         if (!SURFACE && !FWIN) {
-            f0 = fsup[(size_t)am.x * fstride + 0];
-            f1 = fsup[(size_t)am.y * fstride + 1];
-            f2 = fsup[(size_t)am.z * fstride + 2];
-            f3 = fsup[(size_t)am.w * fstride + 3];
+            f0 = Feat<FT>::ld(fsup + (size_t)am.x * fstride + 0);
+            f1 = Feat<FT>::ld(fsup + (size_t)am.y * fstride + 1);
+            f2 = Feat<FT>::ld(fsup + (size_t)am.z * fstride + 2);
+            f3 = Feat<FT>::ld(fsup + (size_t)am.w * fstride + 3);
         }
         ga.x *= invS; ga.y *= invS; ga.z *= invS; ga.w *= invS;
         const float px = sx[p * 3], py = sx[p * 3 + 1], pz = sx[p * 3 + 2];
@@ -377,14 +374,14 @@ __global__ __launch_bounds__(RF_TILE_THREADS) void rf_bwd_tile_kernel(
         // flush the tile: one 16-byte store per (row, group)
         for (int q = tid; q < N * G; q += RF_TILE_THREADS) {
             const int m = q / G, g4 = q - m * G;
-            *reinterpret_cast<float4*>(gfm + ((size_t)b * N + m) * fstride + C + j0 + g4 * 4) =
-                *reinterpret_cast<const float4*>(acc + m * TC + g4 * 4);
+            Feat<FT>::st4(gfm + ((size_t)b * N + m) * fstride + C + j0 + g4 * 4,
+                          *reinterpret_cast<const float4*>(acc + m * TC + g4 * 4));
         }
         if (j0 < C) {   // the first C/TC tiles also copy the centre columns grad_fm[b,m,c] = g[b,m,c]
             for (int q = tid; q < N * G; q += RF_TILE_THREADS) {
                 const int m = q / G, g4 = q - m * G;
-                *reinterpret_cast<float4*>(gfm + ((size_t)b * N + m) * fstride + j0 + g4 * 4) =
-                    *reinterpret_cast<const float4*>(gout + ((size_t)b * N + m) * C + j0 + g4 * 4);
+                Feat<FT>::st4(gfm + ((size_t)b * N + m) * fstride + j0 + g4 * 4,
+                              Feat<FT>::ld4(gout + ((size_t)b * N + m) * C + j0 + g4 * 4));
             }
         }
         __syncthreads();
@@ -475,9 +472,9 @@ static int rf_check(const void* a, const void* b, const void* c, int B, int N, i
     return HSP_OK;
 }
 
-template <bool SURFACE>
-static int rf_fwd(const float* xyz, const int32_t* idx, const float* dirs, const float* fm, int B, int N, int k,
-                  int S, int C, float* out, uint16_t* argrow, float* fwin, hspStream_t stream) {
+template <bool SURFACE, typename FT>
+static int rf_fwd(const float* xyz, const int32_t* idx, const float* dirs, const FT* fm, int B, int N, int k,
+                  int S, int C, FT* out, uint16_t* argrow, FT* fwin, hspStream_t stream) {
     int rc = rf_check(xyz, idx, dirs, B, N, k, S, C);
     if (rc) return rc;
     if (!out || !argrow || (!SURFACE && !fm)) return HSP_ERR_BAD_ARG;
@@ -488,10 +485,10 @@ static int rf_fwd(const float* xyz, const int32_t* idx, const float* dirs, const
     if (nch > 4) return HSP_ERR_UNSUPPORTED;              // S*C <= 4096
 #define RF_FWD_LAUNCH(NCH)                                                                                        \
     if (!SURFACE && fwin)                                                                                          \
-        hipLaunchKernelGGL((rf_fwd_kernel<SURFACE, NCH, !SURFACE>), dim3(grid), dim3(RF_THREADS), lds, as_stream(stream), \
+        hipLaunchKernelGGL((rf_fwd_kernel<SURFACE, NCH, !SURFACE, FT>), dim3(grid), dim3(RF_THREADS), lds, as_stream(stream), \
                            xyz, idx, dirs, fm, B, N, k, S, C, out, argrow, fwin);                                 \
     else                                                                                                           \
-        hipLaunchKernelGGL((rf_fwd_kernel<SURFACE, NCH, false>), dim3(grid), dim3(RF_THREADS), lds, as_stream(stream), \
+        hipLaunchKernelGGL((rf_fwd_kernel<SURFACE, NCH, false, FT>), dim3(grid), dim3(RF_THREADS), lds, as_stream(stream), \
                            xyz, idx, dirs, fm, B, N, k, S, C, out, argrow, fwin)
     switch (nch) {
         case 1: RF_FWD_LAUNCH(1); break;
@@ -505,7 +502,11 @@ static int rf_fwd(const float* xyz, const int32_t* idx, const float* dirs, const
 
 extern "C" int hsp_rf_surface_fwd(const float* xyz, const int32_t* idx, const float* dirs_n, int B, int N, int k,
                                   int S, int K, float* out, uint16_t* argrow, hspStream_t stream) {
-    return rf_fwd<true>(xyz, idx, dirs_n, nullptr, B, N, k, S, K, out, argrow, nullptr, stream);
+    return rf_fwd<true, float>(xyz, idx, dirs_n, nullptr, B, N, k, S, K, out, argrow, nullptr, stream);
+}
+extern "C" int hsp_rf_surface_fwd_bf16(const float* xyz, const int32_t* idx, const float* dirs_n, int B, int N, int k,
+                                       int S, int K, hsp_bf16_t* out, uint16_t* argrow, hspStream_t stream) {
+    return rf_fwd<true, bf16_t>(xyz, idx, dirs_n, nullptr, B, N, k, S, K, out, argrow, nullptr, stream);
 }
 
 // the forward's fwin stream pays off once a cloud's fm no longer stays in its XCD's L2 next to the other streams
@@ -516,7 +517,15 @@ extern "C" int hsp_rf_conv_wants_fwin(int N, int S, int C) {
 extern "C" int hsp_rf_conv_fwd(const float* xyz, const int32_t* idx, const float* dirs_n, const float* fm, int B,
                                int N, int k, int S, int C, float* out, uint16_t* argrow, float* fwin,
                                hspStream_t stream) {
-    return rf_fwd<false>(xyz, idx, dirs_n, fm, B, N, k, S, C, out, argrow, fwin, stream);
+    return rf_fwd<false, float>(xyz, idx, dirs_n, fm, B, N, k, S, C, out, argrow, fwin, stream);
+}
+extern "C" int hsp_rf_conv_fwd_bf16(const float* xyz, const int32_t* idx, const float* dirs_n, const hsp_bf16_t* fm, int B,
+                                    int N, int k, int S, int C, hsp_bf16_t* out, uint16_t* argrow, hsp_bf16_t* fwin,
+                                    hspStream_t stream) {
+    return rf_fwd<false, bf16_t>(xyz, idx, dirs_n, fm, B, N, k, S, C, out, argrow, fwin, stream);
+}
+extern "C" int hsp_rf_conv_wants_fwin_bf16(int N, int S, int C) {
+    return (size_t)N * (S + 1) * C * sizeof(bf16_t) >= ((size_t)3 << 20) ? 1 : 0;
 }
 
 extern "C" size_t hsp_rf_bwd_workspace_bytes(int SC) {
@@ -575,9 +584,9 @@ extern "C" size_t hsp_rf_bwd_scatter_workspace_bytes(int B, int SC) {
     return (size_t)B * 3 * SC * sizeof(float);
 }
 
-template <bool SURFACE, bool FWIN>
-static int rf_bwd_scatter(const float* xyz, const float* dirs, const float* fm, const uint16_t* argrow,
-                          const float* gout, int B, int N, int S, int C, float* gfm, float* gdirs, void* ws,
+template <bool SURFACE, bool FWIN, typename FT>
+static int rf_bwd_scatter(const float* xyz, const float* dirs, const FT* fm, const uint16_t* argrow,
+                          const FT* gout, int B, int N, int S, int C, FT* gfm, float* gdirs, void* ws,
                           size_t ws_bytes, hspStream_t stream) {
     int rc = rf_check(xyz, dirs, argrow, B, N, 1, S, C);
     if (rc) return rc;
@@ -593,7 +602,7 @@ static int rf_bwd_scatter(const float* xyz, const float* dirs, const float* fm, 
     dim3 grid(SC / tc, B);
 #define RF_TILE_LAUNCH(TC)                                                                                          \
     {                                                                                                               \
-        auto kern = rf_bwd_tile_kernel<TC, SURFACE, FWIN>;                                                                \
+        auto kern = rf_bwd_tile_kernel<TC, SURFACE, FWIN, FT>;                                                                \
         if (lds > 64 * 1024) {                                                                                      \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                 \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
@@ -613,8 +622,14 @@ static int rf_bwd_scatter(const float* xyz, const float* dirs, const float* fm, 
 extern "C" int hsp_rf_surface_bwd(const float* xyz, const float* dirs_n, const uint16_t* argrow, const float* grad_out,
                                   int B, int N, int S, int K, float* grad_dirs_n, void* ws, size_t ws_bytes,
                                   hspStream_t stream) {
-    return rf_bwd_scatter<true, false>(xyz, dirs_n, nullptr, argrow, grad_out, B, N, S, K, nullptr, grad_dirs_n, ws, ws_bytes,
-                                stream);
+    return rf_bwd_scatter<true, false, float>(xyz, dirs_n, nullptr, argrow, grad_out, B, N, S, K, nullptr, grad_dirs_n, ws,
+                                              ws_bytes, stream);
+}
+extern "C" int hsp_rf_surface_bwd_bf16(const float* xyz, const float* dirs_n, const uint16_t* argrow,
+                                       const hsp_bf16_t* grad_out, int B, int N, int S, int K, float* grad_dirs_n, void* ws,
+                                       size_t ws_bytes, hspStream_t stream) {
+    return rf_bwd_scatter<true, false, bf16_t>(xyz, dirs_n, nullptr, argrow, grad_out, B, N, S, K, nullptr, grad_dirs_n, ws,
+                                               ws_bytes, stream);
 }
 
 extern "C" int hsp_rf_conv_bwd_scatter(const float* xyz, const float* dirs_n, const float* fm, const float* fwin,
@@ -622,8 +637,18 @@ extern "C" int hsp_rf_conv_bwd_scatter(const float* xyz, const float* dirs_n, co
                                        float* grad_fm, float* grad_dirs_n, void* ws, size_t ws_bytes,
                                        hspStream_t stream) {
     if (fwin)
-        return rf_bwd_scatter<false, true>(xyz, dirs_n, fwin, argrow, grad_out, B, N, S, C, grad_fm, grad_dirs_n, ws,
-                                           ws_bytes, stream);
-    return rf_bwd_scatter<false, false>(xyz, dirs_n, fm, argrow, grad_out, B, N, S, C, grad_fm, grad_dirs_n, ws, ws_bytes,
-                                        stream);
+        return rf_bwd_scatter<false, true, float>(xyz, dirs_n, fwin, argrow, grad_out, B, N, S, C, grad_fm, grad_dirs_n, ws,
+                                                  ws_bytes, stream);
+    return rf_bwd_scatter<false, false, float>(xyz, dirs_n, fm, argrow, grad_out, B, N, S, C, grad_fm, grad_dirs_n, ws,
+                                               ws_bytes, stream);
+}
+extern "C" int hsp_rf_conv_bwd_scatter_bf16(const float* xyz, const float* dirs_n, const hsp_bf16_t* fm,
+                                            const hsp_bf16_t* fwin, const uint16_t* argrow, const hsp_bf16_t* grad_out,
+                                            int B, int N, int S, int C, hsp_bf16_t* grad_fm, float* grad_dirs_n, void* ws,
+                                            size_t ws_bytes, hspStream_t stream) {
+    if (fwin)
+        return rf_bwd_scatter<false, true, bf16_t>(xyz, dirs_n, fwin, argrow, grad_out, B, N, S, C, grad_fm, grad_dirs_n, ws,
+                                                   ws_bytes, stream);
+    return rf_bwd_scatter<false, false, bf16_t>(xyz, dirs_n, fm, argrow, grad_out, B, N, S, C, grad_fm, grad_dirs_n, ws,
+                                                ws_bytes, stream);
 }

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, ops_bf16
 
 # ------------------------------------------------------------------------------------------------
 # per-forward xyz-KNN memo
@@ -135,7 +135,9 @@ def _orl_fused(feature, vertices, neighbor_num, conv2_weight):
 
 class HSlayer_surface(nn.Module):
     """reference gcn3d.py:61-113.  Parameters: directions (3, S*K), STE_layer.weight (K,3,1),
-    conv2.weight (K,2K,1)."""
+    conv2.weight (K,2K,1).  ``out_dtype`` (fp32 default): torch.bfloat16 makes the layer emit bf16 feature rows
+    (FaceRecon.set_feature_dtype; the coordinates and directions it consumes stay fp32)."""
+    out_dtype = torch.float32
 
     def __init__(self, kernel_num, support_num):
         super().__init__()
@@ -157,8 +159,8 @@ class HSlayer_surface(nn.Module):
         idx = _xyz_knn(vertices, neighbor_num)                       # RF-P
         if idx.shape[2] != neighbor_num:
             idx = idx[:, :, :neighbor_num].contiguous()
-        return ops.surface_layer(vertices, idx, neighbor_num, self.support_num, self.directions,
-                                 self.STE_layer.weight, self.conv2.weight)
+        layer = ops_bf16.surface_layer if self.out_dtype == torch.bfloat16 else ops.surface_layer
+        return layer(vertices, idx, neighbor_num, self.support_num, self.directions, self.STE_layer.weight, self.conv2.weight)
 
     def graph_conv(self, neighbor_index, vertices, neighbor_num):
         """fused relu(R @ D^) -> max over neighbours -> mean over supports (reference :92-107).  Takes the
@@ -174,7 +176,10 @@ class HSlayer_surface(nn.Module):
 
 class HS_layer(nn.Module):
     """reference gcn3d.py:116-187.  Parameters: weights (Cin,(S+1)*Cout), bias ((S+1)*Cout),
-    directions (3,S*Cout), STE_layer.weight (Cout,Cin,1), conv2.weight (Cout,2*Cout,1)."""
+    directions (3,S*Cout), STE_layer.weight (Cout,Cin,1), conv2.weight (Cout,2*Cout,1).  With bf16 feature rows
+    (FaceRecon.set_feature_dtype) ``out_fp32`` makes the layer write its output in fp32 -- set for the layers a BatchNorm
+    follows."""
+    out_fp32 = False
 
     def __init__(self, in_channel, out_channel, support_num):
         super().__init__()
@@ -200,9 +205,12 @@ class HS_layer(nn.Module):
                 neighbor_num: int):
         """(bs, vertice_num, out_channel) -- STE + fm GEMM + RF-F graph conv + ORL as one fused autograd node"""
         neighbor_index = ops.knn(feature_map, neighbor_num)          # RF-F: neighbours in feature space
+        if feature_map.dtype == torch.bfloat16:                      # bf16 feature rows in -> out (fp32 out ahead of a BatchNorm)
+            return ops_bf16.hs_layer(vertices, feature_map, neighbor_index, _xyz_knn(vertices, neighbor_num), neighbor_num,
+                                     self.support_num, self.weights, self.bias, self.directions, self.STE_layer.weight,
+                                     self.conv2.weight, out_f32=self.out_fp32)
         return ops.hs_layer(vertices, feature_map, neighbor_index, _xyz_knn(vertices, neighbor_num), neighbor_num,
-                            self.support_num, self.weights, self.bias, self.directions,
-                            self.STE_layer.weight, self.conv2.weight)
+                            self.support_num, self.weights, self.bias, self.directions, self.STE_layer.weight, self.conv2.weight)
 
     def graph_conv(self, neighbor_index, feature_map, vertices, neighbor_num):
         """reference :158-181 with the gather, theta product, max and mean fused into one kernel."""

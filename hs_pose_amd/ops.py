@@ -36,6 +36,29 @@ def _req(t, dtype, name):
     return t if t.is_contiguous() else t.contiguous()
 
 
+_FEAT_DTYPES = (torch.float32, torch.bfloat16)
+
+
+def _reqf(t, name, like=None):
+    """a FEATURE tensor: fp32, or bf16 storage (BASELINE configs[3]; the kernels still compute in fp32).  ``like``: a
+    tensor whose dtype it must share."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise HspError(f"{name}: expected a GPU tensor (hs_pose_amd has no CPU path), got "
+                       f"{getattr(t, 'device', type(t))}")
+    if t.dtype not in _FEAT_DTYPES or (like is not None and t.dtype != like.dtype):
+        raise HspError(f"{name}: expected dtype {like.dtype if like is not None else 'float32 or bfloat16'}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _sfx(t):
+    """entry-point suffix for a feature tensor's storage type"""
+    return "_bf16" if t.dtype == torch.bfloat16 else ""
+
+
+def _es(t):
+    return 2 if t.dtype == torch.bfloat16 else 4
+
+
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
@@ -95,10 +118,18 @@ def _run(name, args, key="", abytes=0, aflops=0):
 
 def knn(x, k, drop_first=True):
     """int32 (B,N,k) nearest rows of x (B,N,C) per row; semantics of gcn3d.get_neighbor_index."""
-    x = _req(x.detach(), torch.float32, "knn.x")
+    x = _reqf(x.detach(), "knn.x")
     B, N, C = x.shape
     idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
     L = lib()
+    if x.dtype == torch.bfloat16:                           # feature rows stored in bf16: bf16 MFMA distance tiles
+        if C == 3:
+            raise HspError("knn: coordinates stay fp32 (gcn3d.py:57,59); bf16 is for feature rows")
+        wsb = B * N * 4
+        ws = _ws(wsb, x.device)
+        _run("hsp_knn_bf16", (_p(x), B, N, C, k, 1 if drop_first else 0, _p(idx), _p(ws), wsb, _stream()),
+             key=f"B{B}N{N}C{C}k{k}", abytes=B * N * (2 * C + 4 * k + 8), aflops=2 * B * N * N * C)
+        return idx
     wsb = L.hsp_knn_workspace_bytes(B, N, C, k)
     ws = _ws(wsb, x.device)
     _run("hsp_knn_f32", (_p(x), B, N, C, k, 1 if drop_first else 0, _p(idx), _p(ws), wsb, _stream()),
@@ -228,18 +259,19 @@ def rf_conv(xyz, idx, directions, fm, S):
 class _GatherMax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, idx, qsel, k):
-        feat = _req(feat, torch.float32, "gather_max.feat")
+        feat = _reqf(feat, "gather_max.feat")
         idx = _req(idx, torch.int32, "gather_max.idx")
         if qsel is not None:
             qsel = _req(qsel, torch.int32, "gather_max.qsel")
         B, Nsrc, C = feat.shape
         Nidx, kstride = idx.shape[1], idx.shape[2]
         Nq = qsel.numel() if qsel is not None else Nidx
-        out = torch.empty(B, Nq, C, dtype=torch.float32, device=feat.device)
+        out = torch.empty(B, Nq, C, dtype=feat.dtype, device=feat.device)
         arg = torch.empty(B, Nq, C, dtype=torch.uint8, device=feat.device)
-        _run("hsp_gather_max_fwd", (_p(feat), _p(idx), _p(qsel), B, Nsrc, Nidx, Nq, k, kstride, C, _p(out), _p(arg),
-                                    _stream()),
-             key=f"B{B}Ns{Nsrc}Nq{Nq}k{k}C{C}", abytes=B * (4 * Nsrc * C + Nq * (4 * k + 5 * C)))
+        es = _es(feat)
+        _run("hsp_gather_max_fwd" + _sfx(feat), (_p(feat), _p(idx), _p(qsel), B, Nsrc, Nidx, Nq, k, kstride, C, _p(out),
+                                                 _p(arg), _stream()),
+             key=f"B{B}Ns{Nsrc}Nq{Nq}k{k}C{C}", abytes=B * (es * Nsrc * C + Nq * (4 * k + (es + 1) * C)))
         ctx.save_for_backward(idx, qsel, arg)
         ctx.dims = (B, Nsrc, Nidx, Nq, kstride, C)
         return out
@@ -248,11 +280,12 @@ class _GatherMax(torch.autograd.Function):
     def backward(ctx, g):
         idx, qsel, arg = ctx.saved_tensors
         B, Nsrc, Nidx, Nq, kstride, C = ctx.dims
-        g = _req(g, torch.float32, "gather_max.grad")
-        gfeat = torch.empty(B, Nsrc, C, dtype=torch.float32, device=g.device)
-        _run("hsp_gather_max_bwd", (_p(g), 0, _p(idx), _p(qsel), _p(arg), B, Nsrc, Nidx, Nq, kstride, C, _p(gfeat), 0,
-                                    _vp(0), _stream()),
-             key=f"B{B}Ns{Nsrc}Nq{Nq}C{C}", abytes=B * (4 * Nsrc * C + Nq * (4 * kstride + 5 * C)))
+        g = _reqf(g, "gather_max.grad")
+        gfeat = torch.empty(B, Nsrc, C, dtype=g.dtype, device=g.device)
+        es = _es(g)
+        _run("hsp_gather_max_bwd" + _sfx(g), (_p(g), 0, _p(idx), _p(qsel), _p(arg), B, Nsrc, Nidx, Nq, kstride, C, _p(gfeat),
+                                              0, _vp(0), _stream()),
+             key=f"B{B}Ns{Nsrc}Nq{Nq}C{C}", abytes=B * (es * Nsrc * C + Nq * (4 * kstride + (es + 1) * C)))
         return gfeat, None, None, None
 
 
@@ -421,18 +454,21 @@ def _ld(t):
 
 
 def gemm_rows(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=None, cloud_bias=None, rows_per_cloud=0,
-              out=None, alpha=1.0):
+              out=None, alpha=1.0, xyz3=None, w3=None):
     """out (M,N) = alpha * (A1 @ op(B1) [+ A2 @ op(B2)]) [+ bias] [+ resid] [+ cloud_bias[row // rows_per_cloud]]   (csrc/gemm_rows.hip)
 
     op(B) = B^T for a (N,K) weight (``nn=False``: a Linear / Conv1d(k=1) weight) or B for a (K,N) matrix (``nn=True``:
     HS_layer.weights).  fp32 or bf16 (all of A, B, resid, out alike; bias / cloud_bias always fp32; bf16 takes (N,K)
-    operands only).  Operands may be row-strided views (column blocks of wider tensors)."""
+    operands only).  Operands may be row-strided views (column blocks of wider tensors).  ``xyz3`` (M,3) / ``w3`` (N,3)
+    fp32: adds xyz3[row] . w3[col] -- the K = 3 STE of HSlayer_surface on raw coordinates."""
     dt = A1.dtype
     if dt not in (torch.float32, torch.bfloat16):
         raise HspError(f"gemm_rows: fp32 or bf16 operands, got {dt}")
-    for t_, nm in ((A1, "A1"), (B1, "B1"), (A2, "A2"), (B2, "B2"), (resid, "resid"), (out, "out")):
+    for t_, nm in ((A1, "A1"), (B1, "B1"), (A2, "A2"), (B2, "B2"), (resid, "resid")):
         if t_ is not None and (not t_.is_cuda or t_.dtype != dt):
             raise HspError(f"gemm_rows.{nm}: expected a {dt} GPU tensor")
+    if out is not None and (not out.is_cuda or out.dtype not in (dt, torch.float32)):
+        raise HspError(f"gemm_rows.out: expected a {dt} (or, for bf16 operands, fp32) GPU tensor")
     M, K1 = A1.shape
     N = B1.shape[1] if nn1 else B1.shape[0]
     if (B1.shape[0] if nn1 else B1.shape[1]) != K1:
@@ -444,9 +480,11 @@ def gemm_rows(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=N
             raise HspError("gemm_rows: second source has the wrong shape")
     if out is None:
         out = torch.empty(M, N, dtype=dt, device=A1.device)
-    for t_ in (bias, cloud_bias):
+    for t_ in (bias, cloud_bias, xyz3, w3):
         if t_ is not None and (t_.dtype != torch.float32 or not t_.is_cuda or not t_.is_contiguous()):
-            raise HspError("gemm_rows: bias / cloud_bias must be contiguous fp32 GPU tensors")
+            raise HspError("gemm_rows: bias / cloud_bias / xyz3 / w3 must be contiguous fp32 GPU tensors")
+    if (xyz3 is None) != (w3 is None) or (xyz3 is not None and (xyz3.shape != (M, 3) or w3.shape != (N, 3))):
+        raise HspError("gemm_rows: xyz3 (M,3) and w3 (N,3) go together")
     flops = 2 * M * N * (K1 + K2)
     es = 4 if dt == torch.float32 else 2
     ab = es * (M * (K1 + K2) + N * (K1 + K2) + M * N * (2 if resid is not None else 1))
@@ -455,7 +493,8 @@ def gemm_rows(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=N
         _run("hsp_gemm_rows_f32", (_p(A1), _ld(A1), _p(B1), _ld(B1), 1 if nn1 else 0, K1,
                                    _p(A2), _ld(A2) if A2 is not None else 0, _p(B2), _ld(B2) if B2 is not None else 0,
                                    1 if nn2 else 0, K2, M, N, _p(bias), _p(resid), _ld(resid) if resid is not None else 0,
-                                   _p(cloud_bias), int(rows_per_cloud), float(alpha), _p(out), _ld(out), _stream()),
+                                   _p(cloud_bias), int(rows_per_cloud), float(alpha), _p(xyz3), _p(w3), _p(out), _ld(out),
+                                   _stream()),
              key=key, abytes=ab, aflops=flops)
     else:
         if nn1 or nn2:
@@ -463,7 +502,8 @@ def gemm_rows(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=N
         _run("hsp_gemm_rows_bf16", (_p(A1), _ld(A1), _p(B1), _ld(B1), K1,
                                     _p(A2), _ld(A2) if A2 is not None else 0, _p(B2), _ld(B2) if B2 is not None else 0, K2,
                                     M, N, _p(bias), _p(resid), _ld(resid) if resid is not None else 0, _p(cloud_bias),
-                                    int(rows_per_cloud), float(alpha), _p(out), _ld(out), _stream()),
+                                    int(rows_per_cloud), float(alpha), _p(xyz3), _p(w3), _p(out), _ld(out),
+                                    1 if out.dtype == torch.float32 else 0, _stream()),
              key=key + "bf16", abytes=ab, aflops=flops)
     return out
 
@@ -825,20 +865,23 @@ def linear_rows(x2, weight, bias=None):
 
 class _BNRelu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, num_batches, eps, momentum, relu):
-        x = _req(x, torch.float32, "bn_relu.x")
+    def forward(ctx, x, weight, bias, running_mean, running_var, num_batches, eps, momentum, relu, out_dtype=None):
+        x = _reqf(x, "bn_relu.x")
         C = x.shape[-1]
         R = x.numel() // C
-        y = torch.empty_like(x)
+        # "mixed": fp32 rows in (a pre-BatchNorm tensor keeps its mantissa: |mean| >> std per channel is common), bf16 out
+        mixed = out_dtype == torch.bfloat16 and x.dtype == torch.float32
+        y = torch.empty_like(x, dtype=torch.bfloat16) if mixed else torch.empty_like(x)
+        ctx.mixed = mixed
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         invstd = torch.empty(C, dtype=torch.float32, device=x.device)
         L = lib()
         wsb = L.hsp_bn_workspace_bytes(R, C)
         ws = _ws(wsb, x.device)
-        _run("hsp_bn_relu_fwd", (_p(x), R, C, _p(weight), _p(bias), float(eps), float(momentum), 1 if relu else 0, _p(y),
-                                 _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(num_batches), _p(ws), wsb,
-                                 _stream()),
-             key=f"R{R}C{C}", abytes=8 * R * C)
+        _run("hsp_bn_relu_fwd" + ("_mixed" if mixed else _sfx(x)), (_p(x), R, C, _p(weight), _p(bias), float(eps), float(momentum), 1 if relu else 0,
+                                           _p(y), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(num_batches),
+                                           _p(ws), wsb, _stream()),
+             key=f"R{R}C{C}", abytes=(_es(x) + _es(y)) * R * C)
         ctx.save_for_backward(x, weight, bias, mean, invstd)
         ctx.relu = relu
         ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, num_batches) if t is not None])
@@ -847,33 +890,44 @@ class _BNRelu(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight, bias, mean, invstd = ctx.saved_tensors
-        dy = _req(dy, torch.float32, "bn_relu.grad")
+        dy = _reqf(dy, "bn_relu.grad", like=None if ctx.mixed else x)
         C = x.shape[-1]
         R = x.numel() // C
-        dx = torch.empty_like(x)
+        dx = torch.empty_like(dy)
         dg = torch.empty_like(weight)
         db = torch.empty_like(bias)
         L = lib()
         wsb = L.hsp_bn_workspace_bytes(R, C)
         ws = _ws(wsb, x.device)
-        _run("hsp_bn_relu_bwd", (_p(x), _p(dy), R, C, _p(weight), _p(bias), _p(mean), _p(invstd), 1 if ctx.relu else 0,
-                                 _p(dx), _p(dg), _p(db), _p(ws), wsb, _stream()),
-             key=f"R{R}C{C}", abytes=12 * R * C)
-        return dx, dg, db, None, None, None, None, None, None
+        _run("hsp_bn_relu_bwd" + ("_mixed" if ctx.mixed else _sfx(x)), (_p(x), _p(dy), R, C, _p(weight), _p(bias), _p(mean), _p(invstd),
+                                           1 if ctx.relu else 0, _p(dx), _p(dg), _p(db), _p(ws), wsb, _stream()),
+             key=f"R{R}C{C}", abytes=(_es(x) + 2 * _es(dy)) * R * C)
+        return dx, dg, db, None, None, None, None, None, None, None
 
 
-def bn_relu(x, bn, relu=True):
+def bn_relu(x, bn, relu=True, out_dtype=None):
     """relu(bn(x)) for point rows x (..., C) with an nn.BatchNorm1d module ``bn`` (its parameters, running
     statistics and train/eval state are honoured exactly like calling the module on the (R,C) view, which
     is what the reference's transpose->BatchNorm1d->transpose computes, FaceRecon.py:90-95)."""
     C = x.shape[-1]
     fused = (bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None and x.is_cuda
-             and x.dtype == torch.float32 and C % 4 == 0 and 256 % (C // 4) == 0)
+             and x.dtype in _FEAT_DTYPES and C % 4 == 0 and 256 % (C // 4) == 0)
+    want_bf16 = x.dtype == torch.bfloat16 or out_dtype == torch.bfloat16
+    if not fused and want_bf16:                      # eval mode, bf16 rows out: running statistics, fused affine + ReLU
+        if bn.training or not bn.affine or C % 4 or 256 % (C // 4):
+            raise HspError("bn_relu: this BatchNorm configuration is not built for bf16 rows")
+        xc = _reqf(x, "bn_relu.x")
+        y = torch.empty_like(xc, dtype=torch.bfloat16)
+        invstd = torch.rsqrt(bn.running_var + bn.eps)
+        _run("hsp_bn_relu_apply" + ("_bf16" if xc.dtype == torch.bfloat16 else "_mixed"),
+             (_p(xc), xc.numel() // C, C, _p(bn.running_mean), _p(invstd), _p(bn.weight), _p(bn.bias), 1 if relu else 0, _p(y),
+              _stream()), key=f"R{xc.numel() // C}C{C}", abytes=(_es(xc) + 2) * xc.numel())
+        return y
     if not fused:                                   # eval mode / exotic configurations: not on the training hot path
         y = bn(x.reshape(-1, C)).view_as(x)
         return torch.relu_(y) if relu else y
     return _BNRelu.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
-                         bn.momentum, relu)
+                         bn.momentum, relu, out_dtype)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -929,24 +983,32 @@ class _AssembleFeat(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, kinds, idxs, *tensors):
-        B, N = None, None
+        B, N, dt = None, None, None
         for t, kd in zip(tensors, kinds):
             if kd == 0:
-                B, N = t.shape[0], t.shape[1]
-        tensors = [_req(t, torch.float32, "assemble_feat.src") for t in tensors]
+                B, N, dt = t.shape[0], t.shape[1], t.dtype
+        # point-row segments share the feature dtype (fp32 or bf16); per-cloud rows (kind 2: the one-hot columns) are fp32
+        tensors = [(_req(t, torch.float32, "assemble_feat.src") if kd == 2 or dt == torch.float32 else
+                    _req(t, dt, "assemble_feat.src")) for t, kd in zip(tensors, kinds)]
         idxs = [(_req(i, torch.int32, "assemble_feat.idx") if i is not None else None) for i in idxs]
         n = len(tensors)
         widths = [t.shape[-1] for t in tensors]
         W = sum(widths)
-        out = torch.empty(B, N, W, dtype=torch.float32, device=tensors[0].device)
+        out = torch.empty(B, N, W, dtype=dt, device=tensors[0].device)
         src = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tensors])
         ix = (ctypes.c_void_p * n)(*[(i.data_ptr() if i is not None else 0) for i in idxs])
         wd = (ctypes.c_int * n)(*widths)
         kd = (ctypes.c_int * n)(*kinds)
         ns = (ctypes.c_int * n)(*[(t.shape[1] if k_ == 1 else 0) for t, k_ in zip(tensors, kinds)])
-        _run("hsp_concat_rows", (n, ctypes.cast(src, _vp), ctypes.cast(ix, _vp), ctypes.cast(wd, _vp), ctypes.cast(kd, _vp),
-                                 ctypes.cast(ns, _vp), B, N, _p(out), _stream()),
-             key=f"B{B}N{N}W{W}", abytes=8 * B * N * W)
+        es = 2 if dt == torch.bfloat16 else 4
+        if dt == torch.bfloat16:
+            _run("hsp_concat_rows_bf16", (n, ctypes.cast(src, _vp), ctypes.cast(ix, _vp), ctypes.cast(wd, _vp),
+                                          ctypes.cast(kd, _vp), ctypes.cast(ns, _vp), B, N, _p(out), W, _stream()),
+                 key=f"B{B}N{N}W{W}", abytes=2 * es * B * N * W)
+        else:
+            _run("hsp_concat_rows", (n, ctypes.cast(src, _vp), ctypes.cast(ix, _vp), ctypes.cast(wd, _vp), ctypes.cast(kd, _vp),
+                                     ctypes.cast(ns, _vp), B, N, _p(out), _stream()),
+                 key=f"B{B}N{N}W{W}", abytes=2 * es * B * N * W)
         ctx.kinds, ctx.widths = kinds, widths
         ctx.nsrc = [t.shape[1] for t in tensors]
         ctx.save_for_backward(*[i for i in idxs if i is not None])
@@ -971,12 +1033,15 @@ class _AssembleFeat(torch.autograd.Function):
             elif kd == 1:
                 idx = saved.pop(0)
                 Ns = ctx.nsrc[s_]
-                gfeat = torch.empty(B, Ns, w, dtype=torch.float32, device=g.device)
-                if w % 2 == 0 and W % 2 == 0 and (w // 2 >= 256 or 256 % (w // 2) == 0) and gs.data_ptr() % 8 == 0:
+                gfeat = torch.empty(B, Ns, w, dtype=g.dtype, device=g.device)
+                es = _es(g)
+                if w % 2 == 0 and W % 2 == 0 and (w // 2 >= 256 or 256 % (w // 2) == 0) and gs.data_ptr() % (2 * es) == 0:
                     # gather form over the reverse map (memoised on idx: fm_2 and fm_3 share one); deterministic
                     off, edge = rev_index(idx, 1, Ns)
-                    _run("hsp_gather_rows_bwd_csr", (_p(gs), W, _p(off), _p(edge), B, Ns, N, w, _p(gfeat), _stream()),
-                         key=f"B{B}Ns{Ns}Nq{N}C{w}", abytes=B * (4 * Ns * w + N * (4 + 4 * w)))
+                    _run("hsp_gather_rows_bwd_csr" + _sfx(g), (_p(gs), W, _p(off), _p(edge), B, Ns, N, w, _p(gfeat), _stream()),
+                         key=f"B{B}Ns{Ns}Nq{N}C{w}", abytes=B * (es * Ns * w + N * (4 + es * w)))
+                elif g.dtype == torch.bfloat16:
+                    raise HspError("assemble_feat backward: bf16 segments must be even-width and 4-byte aligned")
                 else:
                     _run("hsp_gather_rows_bwd", (_p(gs), W, _p(idx), 0, B, Ns, N, w, _p(gfeat), _stream()),
                          key=f"B{B}Ns{Ns}Nq{N}C{w}", abytes=B * (4 * Ns * w + N * (4 + 4 * w)))

@@ -206,19 +206,29 @@ int hsp_gather_rows_bwd_csr(const float *grad_out, int grad_stride, const int32_
  *   their input gradients (g Wa ; g Wste + gfm W^T)                          autograd of the above
  *   Conv1d(Cin, Cout, 1) of the heads                                       PoseR.py:16-39, PoseTs.py:18-45, FaceRecon.py:37-68
  * C (M,N) = alpha * (A1 (M,K1) op(B1) [+ A2 (M,K2) op(B2)]) [+ bias (N)] [+ resid (M,N)] [+ cloud_bias[row / rows_per_cloud] (N)]
+ *           [+ xyz3[row] . w3[col]]     (xyz3 (M,3), w3 (N,3) fp32: the K = 3 STE of HSlayer_surface on raw coordinates,
+ *                                        gcn3d.py:85 -- coordinates never pass through bf16, gcn3d.py:57,59)
  * b?_layout 0 = "nt": B is (N,K), k contiguous (a Linear / Conv1d weight);  1 = "nn": B is (K,N) (HS_layer.weights).
  * A2 == NULL: single source.  Leading dimensions in elements; any K, any alignment (aligned operands stage 16 bytes
  * per load).  fp32: v_mfma_f32_32x32x2_f32 (exact fp32).  bf16: v_mfma_f32_32x32x16_bf16, fp32 accumulate, "nt"
- * operands only, bias / cloud_bias fp32, resid and C bf16 (round to nearest even).
+ * operands only, bias / cloud_bias fp32, resid bf16, C bf16 (round to nearest even) or fp32.
  */
 int hsp_gemm_rows_f32(const float *A1, int lda1, const float *B1, int ldb1, int b1_layout, int K1,
                       const float *A2, int lda2, const float *B2, int ldb2, int b2_layout, int K2, int M, int N,
                       const float *bias, const float *resid, int ldr, const float *cloud_bias, int rows_per_cloud,
-                      float alpha, float *C, int ldc, hspStream_t stream);
+                      float alpha, const float *xyz3, const float *w3, float *C, int ldc, hspStream_t stream);
 int hsp_gemm_rows_bf16(const hsp_bf16_t *A1, int lda1, const hsp_bf16_t *B1, int ldb1, int K1,
                        const hsp_bf16_t *A2, int lda2, const hsp_bf16_t *B2, int ldb2, int K2, int M, int N,
                        const float *bias, const hsp_bf16_t *resid, int ldr, const float *cloud_bias,
-                       int rows_per_cloud, float alpha, hsp_bf16_t *C, int ldc, hspStream_t stream);
+                       int rows_per_cloud, float alpha, const float *xyz3, const float *w3, void *C, int ldc,
+                       int c_is_f32 /* != 0: C is fp32 (an output that feeds BatchNorm keeps its mantissa) */,
+                       hspStream_t stream);
+
+/* fp32 master parameters -> bf16 working copies for the *_bf16 entry points, every tensor of a step in one launch:
+ * entry e copies src (rows, cols; row pitch ld) to dst (rows, cols) and / or dstT (cols, rows) -- either may be NULL --
+ * rounding to nearest even.  tile0 = number of 32 x 32 tiles of the entries before e; table_dev lives in DEVICE memory. */
+typedef struct HspCastDesc { const float *src; void *dst; void *dstT; int rows, cols, ld, tile0; } HspCastDesc;
+int hsp_cast_params_bf16(const HspCastDesc *table_dev, int n, int total_tiles, hspStream_t stream);
 
 /* ---- weight-gradient GEMM ---------------------------------------------------------------------
  * replaces the parameter-gradient matmuls autograd runs for `feature_map @ self.weights + self.bias`
@@ -328,6 +338,67 @@ int hsp_fps_f32(const float *xyz, int B, int N, int n_samples, int32_t *sel, voi
                 hspStream_t stream);
 int hsp_fps_f64(const double *xyz, int B, int N, int n_samples, int32_t *sel, void *ws, size_t ws_bytes,
                 hspStream_t stream);
+
+/* ---- bf16 feature storage (BASELINE configs[3]: dense clouds, bf16 features / weights / fm / gradients) -----------
+ * Twins of the entry points above for feature tensors stored as bfloat16 (hsp_bf16_t = the upper 16 bits of an fp32).
+ * Same argument roles and semantics; every kernel still computes in fp32 (loads widen, stores round to nearest even).
+ * What stays fp32: xyz, support directions and theta (the reference hard-casts them with .float(), gcn3d.py:57,59),
+ * arg-max / index tensors, BatchNorm statistics and affine parameters, every parameter gradient, per-cloud (B,C) rows
+ * (ORL global feature and its gradient).  The fp32 master parameters are rounded once per step by hsp_cast_params_bf16.
+ * hsp_knn_bf16: inner products on v_mfma_f32_32x32x16_bf16 (exact products, fp32 accumulation), |x|^2 in fp32, the fp32
+ * path's distance expression and selection rule; C % 32 == 0.  ws: B*N*4 bytes.
+ */
+int hsp_knn_bf16(const hsp_bf16_t *x, int B, int N, int C, int k, int drop_first, int32_t *idx, void *ws,
+                 size_t ws_bytes, hspStream_t stream);
+int hsp_rf_surface_fwd_bf16(const float *xyz, const int32_t *idx, const float *dirs, int B, int N, int k, int S, int K,
+                            hsp_bf16_t *out, uint16_t *argrow, hspStream_t stream);
+int hsp_rf_surface_bwd_bf16(const float *xyz, const float *dirs, const uint16_t *argrow, const hsp_bf16_t *grad_out, int B,
+                            int N, int S, int K, float *grad_dirs, void *ws, size_t ws_bytes, hspStream_t stream);
+int hsp_rf_conv_wants_fwin_bf16(int N, int S, int C);
+int hsp_rf_conv_fwd_bf16(const float *xyz, const int32_t *idx, const float *dirs, const hsp_bf16_t *fm, int B, int N, int k,
+                         int S, int C, hsp_bf16_t *out, uint16_t *argrow, hsp_bf16_t *fwin, hspStream_t stream);
+int hsp_rf_conv_bwd_scatter_bf16(const float *xyz, const float *dirs, const hsp_bf16_t *fm, const hsp_bf16_t *fwin,
+                                 const uint16_t *argrow, const hsp_bf16_t *grad_out, int B, int N, int S, int C,
+                                 hsp_bf16_t *grad_fm, float *grad_dirs, void *ws, size_t ws_bytes, hspStream_t stream);
+int hsp_gather_max_fwd_bf16(const hsp_bf16_t *feat, const int32_t *idx, const int32_t *qsel, int B, int Nsrc, int Nidx,
+                            int Nq, int k, int kstride, int C, hsp_bf16_t *out, uint8_t *argmax, hspStream_t stream);
+/* grad_out: (B,Nq,C) bf16, or with grad_bcast != 0 the fp32 (B,C) per-cloud row; LDS tile form only */
+int hsp_gather_max_bwd_bf16(const void *grad_out, int grad_bcast, const int32_t *idx, const int32_t *qsel,
+                            const uint8_t *argmax, int B, int Nsrc, int Nidx, int Nq, int kstride, int C,
+                            hsp_bf16_t *grad_feat, int accumulate, const hsp_bf16_t *extra, hspStream_t stream);
+int hsp_orl_global_fwd_bf16(const hsp_bf16_t *feat, const int32_t *idx, int B, int N, int k, int kstride, int C, float *fg,
+                            uint8_t *argmax, void *ws, size_t ws_bytes, hspStream_t stream);
+int hsp_colsum_rows_bf16(const hsp_bf16_t *x, int B, int N, int C, float *out, void *ws, size_t ws_bytes,
+                         hspStream_t stream);
+/* out_pitch: row pitch of out in elements (>= sum of widths; padding columns are left untouched).  bf16 form: kind 0 / 1
+ * sources are bf16, kind 2 (per-cloud rows, the one-hot category columns) fp32 */
+int hsp_concat_rows_pitched(int nseg, const float *const *src, const int32_t *const *idx, const int *width, const int *kind,
+                            const int *nsrc, int B, int N, float *out, int out_pitch, hspStream_t stream);
+int hsp_concat_rows_bf16(int nseg, const void *const *src, const int32_t *const *idx, const int *width, const int *kind,
+                         const int *nsrc, int B, int N, hsp_bf16_t *out, int out_pitch, hspStream_t stream);
+int hsp_gather_rows_bwd_csr_bf16(const hsp_bf16_t *grad_out, int grad_stride, const int32_t *rev_off,
+                                 const int32_t *rev_edge, int B, int Nsrc, int Nq, int C, hsp_bf16_t *grad_feat,
+                                 hspStream_t stream);
+int hsp_wgrad_bf16(const hsp_bf16_t *A, int lda, const hsp_bf16_t *B, int ldb, int M, int N, int K, float *C, int ldc,
+                   float *colsum_B, void *ws, size_t ws_bytes, hspStream_t stream);
+/* "mixed": x fp32 (the pre-BatchNorm layer output is kept in fp32: with |mean| >> std per channel a bf16 x would leave
+ * the normalised value only a few significant bits), y / dy / dx bf16 */
+int hsp_bn_relu_fwd_mixed(const float *x, int R, int C, const float *gamma, const float *beta, float eps, float momentum,
+                          int relu, hsp_bf16_t *y, float *save_mean, float *save_invstd, float *running_mean,
+                          float *running_var, long long *num_batches_tracked, void *ws, size_t ws_bytes, hspStream_t stream);
+int hsp_bn_relu_apply_mixed(const float *x, int R, int C, const float *mean, const float *invstd, const float *gamma,
+                            const float *beta, int relu, hsp_bf16_t *y, hspStream_t stream);
+int hsp_bn_relu_bwd_mixed(const float *x, const hsp_bf16_t *dy, int R, int C, const float *gamma, const float *beta,
+                          const float *save_mean, const float *save_invstd, int relu, hsp_bf16_t *dx, float *dgamma,
+                          float *dbeta, void *ws, size_t ws_bytes, hspStream_t stream);
+int hsp_bn_relu_fwd_bf16(const hsp_bf16_t *x, int R, int C, const float *gamma, const float *beta, float eps, float momentum,
+                         int relu, hsp_bf16_t *y, float *save_mean, float *save_invstd, float *running_mean,
+                         float *running_var, long long *num_batches_tracked, void *ws, size_t ws_bytes, hspStream_t stream);
+int hsp_bn_relu_apply_bf16(const hsp_bf16_t *x, int R, int C, const float *mean, const float *invstd, const float *gamma,
+                           const float *beta, int relu, hsp_bf16_t *y, hspStream_t stream);
+int hsp_bn_relu_bwd_bf16(const hsp_bf16_t *x, const hsp_bf16_t *dy, int R, int C, const float *gamma, const float *beta,
+                         const float *save_mean, const float *save_invstd, int relu, hsp_bf16_t *dx, float *dgamma,
+                         float *dbeta, void *ws, size_t ws_bytes, hspStream_t stream);
 
 #ifdef __cplusplus
 }
