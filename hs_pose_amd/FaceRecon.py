@@ -81,10 +81,13 @@ class FaceRecon(nn.Module):
         if dtype == torch.bfloat16:
             if FLAGS.train:
                 raise NotImplementedError("bf16 feature rows: the HS stack (feat); the train-only heads take fp32 rows")
-            specs = [(self.conv_0.conv2.weight.squeeze(-1), True, True)]
+            # DETACHED views: a view with a grad_fn would create (and keep alive) the parameter's gradient accumulator bound
+            # to whatever stream is current here, and a later backward inside a hipGraph capture would then hop to that
+            # stream (an event on the null stream inside a capture crashes hipStreamEndCapture)
+            specs = [(self.conv_0.conv2.weight.detach().squeeze(-1), True, True)]
             for layer in (self.conv_1, self.conv_2, self.conv_3, self.conv_4):
-                specs += [(layer.weights, True, True), (layer.STE_layer.weight.squeeze(-1), True, True),
-                          (layer.conv2.weight.squeeze(-1), True, True)]
+                specs += [(layer.weights.detach(), True, True), (layer.STE_layer.weight.detach().squeeze(-1), True, True),
+                          (layer.conv2.weight.detach().squeeze(-1), True, True)]
             self._bf16 = ops_bf16.Bf16Params(specs)
         return self
 
