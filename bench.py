@@ -70,6 +70,53 @@ def make_inputs(B, N, device, seed=0):
     return centred.to(device), obj.to(device), dfeat.to(device)
 
 
+def u3_full_step(B, N, device, steps=12, warmup=4):
+    """unit U3 of SURVEY 8(d) = BASELINE configs[1] as worded ("full HSPose forward+backward"): HSPose.forward(do_loss=True)
+    -- on-device augmentation, backbone, the three pose heads + reconstruction / face heads, the 19 loss terms -- backward,
+    clip_grad_norm_(5), fused Ranger step, exactly the body of the reference's engine/train.py:72-110, on B synthetic clouds
+    with a synthetic pose / size ground truth.  The network's forward / backward replay from two hipGraphs
+    (graph.py::GraphedNetwork); losses, augmentation and optimizer are issued eagerly.  Reported next to the headline,
+    never instead of it."""
+    from hs_pose_amd.config import FLAGS
+    from hs_pose_amd.HSPose import HSPose
+    from hs_pose_amd.train import TrainDriver
+    FLAGS.reset(); FLAGS.train = 1
+    torch.manual_seed(0)
+    net = HSPose("PoseNet_only").to(device).train()
+    drv = TrainDriver(net, total_iters=150 * 1500, check_nan=False)
+    g = torch.Generator().manual_seed(7)
+    pc = torch.randn(B, N, 3, generator=g) * 0.05 + torch.tensor([0.0, 0.0, 0.8])
+    obj = torch.randint(0, 6, (B,), generator=g).float()
+    q, r = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))
+    q = q * torch.sign(torch.diagonal(r, dim1=-2, dim2=-1)).unsqueeze(-2)
+    gt_R = q * torch.sign(torch.linalg.det(q)).view(B, 1, 1)
+    sym_table = torch.tensor([[1, 1, 0, 1], [1, 1, 0, 1], [0, 0, 0, 0], [1, 1, 1, 1], [0, 1, 0, 0], [0, 1, 0, 0]], dtype=torch.float32)
+    case = dict(PC=pc, obj_id=obj, gt_R=gt_R, gt_t=pc.mean(dim=1) + 0.01 * torch.randn(B, 3, generator=g),
+                gt_s=0.02 * torch.randn(B, 3, generator=g), mean_shape=0.12 + 0.03 * torch.rand(B, 3, generator=g),
+                sym=sym_table[obj.long()], aug_bb=torch.ones(B, 3), aug_rt_t=torch.zeros(B, 3),
+                aug_rt_r=torch.eye(3).repeat(B, 1, 1), model_point=0.5 * torch.randn(B, 32, 3, generator=g),
+                nocs_scale=torch.full((B,), 0.3))
+    case = {k: v.to(device) for k, v in case.items()}
+    net.enable_graphed_posenet(case["PC"], case["obj_id"])
+
+    def step():
+        _, ld = net(do_loss=True, **case)
+        total = sum(ld['fsnet_loss'].values()) + sum(ld['recon_loss'].values()) + sum(ld['geo_loss'].values()) \
+            + sum(ld['prop_loss'].values())
+        drv.step(total)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    FLAGS.reset()
+    return {"u3_ms_per_step": round(ms, 3), "u3_clouds_per_s": round(B * 1e3 / ms, 1), "u3_steps": steps,
+            "u3_unit": "HSPose.forward(do_loss=True) + backward + clip + Ranger, network graphed, losses / optimizer eager"}
+
+
 def cpu_baseline(n_points, sample_clouds):
     """time the CPU oracle (restatement of the reference, oracle/ref_cpu.py) on the host cores:
     same unit (HS stack fwd + bwd, train-mode BN, reference-shaped params), bounded sample."""
@@ -115,6 +162,7 @@ def main():
                     help="feature storage of the HS stack: f32 = BASELINE configs[1] (the headline); bf16 = configs[3] "
                          "(run it as --dtype bf16 --points 4096 --batch 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-u3", action="store_true", help="skip the full-training-step (unit U3) figure appended to config")
     ap.add_argument("--cpu-sample", type=int, default=16, help="clouds in the CPU-baseline sample (one per-GPU batch)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying a hipGraph")
@@ -311,6 +359,13 @@ def main():
             "roofline": roof,
             "step_roofline": step_roof,
         }
+        if world == 1 and not args.no_u3 and not bf16:
+            try:                                        # BASELINE configs[1] as worded: the FULL training step, same run
+                del graphed
+                torch.cuda.empty_cache()
+                line["config"].update(u3_full_step(B, N, device))
+            except Exception as exc:                    # never lose the headline line to the extra figure
+                line["config"]["u3_error"] = f"{type(exc).__name__}: {exc}"[:200]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_sample)
         print(json.dumps(line), file=result_out, flush=True)

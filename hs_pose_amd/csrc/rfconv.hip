@@ -11,6 +11,7 @@
 // Layout: column j of the S*C axis <-> (s = j / C, c = j % C)  (gcn3d.py:104,177).
 // HBM-bound kernels: algorithmic bytes/point (fwd) = k*S*C*4 (gather, L2) + (S+1)*C*4/own row ... see DESIGN.md.
 #include "common.h"
+#include <stdlib.h>
 
 namespace hsp {
 
@@ -151,6 +152,116 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_kernel(const float* __restr
                 float v = __fdiv_rn(s, invS_div);
                 if (!SURFACE) v = add_rn(Feat<FT>::ld(fm + pt * fstride + c), v);
                 Feat<FT>::st_nt(out + pt * C + c, v);
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// forward, CHANNEL-SPLIT schedule (HS_layer only) for clouds whose fm does not fit an XCD's 4 MiB L2 (N = 1028, C = 128:
+// 4.2 MB fp32; N = 4096 bf16: 8.4 MB).  The neighbour gather re-reads every support row ~k times; when the cloud's fm
+// overflows L2 those re-reads go to MALL / HBM (measured 449 MB per launch against 166 MB algorithmic at N = 1028).
+// Here the C channels are walked in NSPLIT passes of C / NSPLIT channels x all S supports (a channel's S supports stay
+// together, so the mean over supports completes inside a pass): the gather working set of a pass is
+// N * S * (C / NSPLIT) elements (1.8 MB for both shapes above), L2-resident.  A pass has GH = S * C / (4 NSPLIT) float4
+// column groups, so a 256-thread workgroup takes PP = 256 / GH points at a time (2 at C = 128 fp32, 4 at bf16 / 4 passes).
+// Same arithmetic, same results bit for bit as rf_fwd_kernel (tests compare them).
+// dynamic LDS: PP * (S * C / NSPLIT + 5 k) floats
+// ------------------------------------------------------------------------------------------------
+template <bool WF, typename FT>
+__global__ __launch_bounds__(RF_THREADS) void rf_fwd_split_kernel(const float* __restrict__ xyz,
+                                                                  const int32_t* __restrict__ idx,
+                                                                  const float* __restrict__ dirs,
+                                                                  const FT* __restrict__ fm, int B, int N, int k,
+                                                                  int S, int C, int nsplit, FT* __restrict__ out,
+                                                                  uint16_t* __restrict__ argrow,
+                                                                  FT* __restrict__ fwin) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int SC = S * C;
+    const int CH = C / nsplit;                                 // channels per pass
+    const int G4 = CH >> 2;                                    // float4 groups per support in a pass
+    const int GH = S * G4;                                     // float4 groups per point in a pass
+    const int PP = RF_THREADS / GH;                            // points per iteration
+    float* smax = reinterpret_cast<float*>(smem);              // PP x (S*CH)
+    float4* sR = reinterpret_cast<float4*>(smax + PP * S * CH);   // PP x k
+    int* sIdx = reinterpret_cast<int*>(sR + PP * k);           // PP x k
+    const int tid = threadIdx.x;
+    const int slot = tid / GH, g = tid - slot * GH;            // point slot, group inside the pass
+    const bool active = slot < PP;
+    const int sp = g / G4, c4 = g - sp * G4;                   // support, float4 group inside the pass's channels
+    const int fstride = (S + 1) * C;
+    const float invS_div = (float)S;
+    const PointIter it(B);
+    for (int b = it.b0; b < B; b += it.bstep) {
+        const float* xb = xyz + (size_t)b * N * 3;
+        for (int pass = 0; pass < nsplit; ++pass) {
+            const int j = sp * C + pass * CH + c4 * 4;             // column of the S*C axis
+            float4 d0, d1, d2;
+            load_dirs_normed(dirs, SC, active ? j : 0, d0, d1, d2);
+            const FT* fsup = fm + (size_t)b * N * fstride + C + j;
+            for (int i0 = it.i0 * PP; i0 < N; i0 += it.istep * PP) {
+                __syncthreads();                                   // previous iteration's LDS reads are done
+                if (tid < PP * k) {
+                    const int ps = tid / k, n = tid - ps * k;
+                    const int i = min(i0 + ps, N - 1);
+                    const int m = idx[((size_t)b * N + i) * k + n];
+                    sIdx[tid] = m;
+                    const float3 r = unit_dir(xb[i * 3], xb[i * 3 + 1], xb[i * 3 + 2], xb[m * 3], xb[m * 3 + 1], xb[m * 3 + 2]);
+                    sR[tid] = make_float4(r.x, r.y, r.z, 0.f);
+                }
+                __syncthreads();
+                const int i = i0 + slot;
+                if (active && i < N) {
+                    const size_t pt = (size_t)b * N + i;
+                    const float4* rr = sR + slot * k;
+                    const int* ii = sIdx + slot * k;
+                    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                    int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                    float4 wf = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll 4
+                    for (int n = 0; n < k; ++n) {
+                        const float4 r = rr[n];
+                        float4 th;
+                        th.x = fmaxf(__fmaf_rn(r.z, d2.x, __fmaf_rn(r.y, d1.x, mul_rn(r.x, d0.x))), 0.f);
+                        th.y = fmaxf(__fmaf_rn(r.z, d2.y, __fmaf_rn(r.y, d1.y, mul_rn(r.x, d0.y))), 0.f);
+                        th.z = fmaxf(__fmaf_rn(r.z, d2.z, __fmaf_rn(r.y, d1.z, mul_rn(r.x, d0.z))), 0.f);
+                        th.w = fmaxf(__fmaf_rn(r.z, d2.w, __fmaf_rn(r.y, d1.w, mul_rn(r.x, d0.w))), 0.f);
+                        const float4 f = Feat<FT>::ld4(fsup + (size_t)ii[n] * fstride);
+                        th.x = mul_rn(th.x, f.x); th.y = mul_rn(th.y, f.y);
+                        th.z = mul_rn(th.z, f.z); th.w = mul_rn(th.w, f.w);
+                        if (WF) {
+                            if (th.x > best.x) wf.x = f.x;
+                            if (th.y > best.y) wf.y = f.y;
+                            if (th.z > best.z) wf.z = f.z;
+                            if (th.w > best.w) wf.w = f.w;
+                        }
+                        if (th.x > best.x) { best.x = th.x; a0 = n; }
+                        if (th.y > best.y) { best.y = th.y; a1 = n; }
+                        if (th.z > best.z) { best.z = th.z; a2 = n; }
+                        if (th.w > best.w) { best.w = th.w; a3 = n; }
+                    }
+                    if (WF) Feat<FT>::st4_nt(fwin + pt * SC + j, wf);
+                    *reinterpret_cast<float4*>(smax + (slot * S + sp) * CH + c4 * 4) = best;
+                    const unsigned lo = (unsigned)ii[a0] | ((unsigned)ii[a1] << 16);
+                    const unsigned hi = (unsigned)ii[a2] | ((unsigned)ii[a3] << 16);
+                    unsigned* ap = reinterpret_cast<unsigned*>(argrow + pt * SC + j);
+                    __builtin_nontemporal_store(lo, ap); __builtin_nontemporal_store(hi, ap + 1);
+                }
+                __syncthreads();
+                for (int e = tid; e < PP * CH; e += RF_THREADS) {
+                    const int ps = e / CH, c = e - ps * CH;
+                    const int ip = i0 + ps;
+                    if (ip < N) {
+                        const size_t pt = (size_t)b * N + ip;
+                        const float* sm = smax + ps * S * CH + c;
+                        float acc = sm[0];
+                        for (int q = 1; q < S; ++q) acc = add_rn(acc, sm[q * CH]);
+                        float v = __fdiv_rn(acc, invS_div);
+                        v = add_rn(Feat<FT>::ld(fm + pt * fstride + pass * CH + c), v);
+                        Feat<FT>::st_nt(out + pt * C + pass * CH + c, v);
+                    }
+                }
             }
         }
     }
@@ -478,6 +589,31 @@ static int rf_fwd(const float* xyz, const int32_t* idx, const float* dirs, const
     int rc = rf_check(xyz, idx, dirs, B, N, k, S, C);
     if (rc) return rc;
     if (!out || !argrow || (!SURFACE && !fm)) return HSP_ERR_BAD_ARG;
+    if constexpr (!SURFACE) {
+        // channel-split schedule once a cloud's fm outgrows an XCD's L2 (rf_fwd_split_kernel); HSP_RF_SPLIT=0/1 overrides
+        const size_t cloud = (size_t)N * (S + 1) * C * sizeof(FT);
+        int nsplit = 1;
+        while (nsplit < 8 && cloud / nsplit > ((size_t)5 << 19) && C % (8 * nsplit) == 0 && S * (C / (4 * 2 * nsplit)) >= 32)
+            nsplit *= 2;
+        // measured (round 2): the split schedule is bit-identical but SLOWER (121 vs 101 us at B=16 N=1028 fp32, 2.12 vs 1.81 ms
+        // at B=64 N=4096 bf16) -- the forward is bound by VALU work per gathered element (~45 instructions per float4 and
+        // neighbour), not by L2 misses -- so it stays opt-in (HSP_RF_SPLIT=1) and the one-pass kernel is the default.
+        // (Also measured and reverted: the theta chain on v_pk_mul_f32 / v_pk_fma_f32 with the winner's support value fetched
+        // after the loop: 111 vs 101 us -- packed fp32 issues slower than the two scalar ops it replaces here.)
+        { const char* e = getenv("HSP_RF_SPLIT"); if (!e || e[0] != '1') nsplit = 1; }
+        if (nsplit > 1 && B >= HSP_NUM_XCD) {
+            const int GH = S * (C / (4 * nsplit)), PP = RF_THREADS / GH;
+            const size_t lds2 = (size_t)PP * (S * (C / nsplit) + 5 * k) * 4;
+            const int grid2 = persistent_blocks(((long long)B * N + PP - 1) / PP, 8);
+            if (fwin)
+                hipLaunchKernelGGL((rf_fwd_split_kernel<true, FT>), dim3(grid2), dim3(RF_THREADS), lds2, as_stream(stream), xyz,
+                                   idx, dirs, fm, B, N, k, S, C, nsplit, out, argrow, fwin);
+            else
+                hipLaunchKernelGGL((rf_fwd_split_kernel<false, FT>), dim3(grid2), dim3(RF_THREADS), lds2, as_stream(stream), xyz,
+                                   idx, dirs, fm, B, N, k, S, C, nsplit, out, argrow, fwin);
+            return check_launch();
+        }
+    }
     const size_t lds = (size_t)(S * C + 5 * k) * 4;
     if (lds > 64 * 1024) return HSP_ERR_UNSUPPORTED;
     const int grid = persistent_blocks((long long)B * N, 8);

@@ -1,22 +1,49 @@
 #!/bin/bash
-# regenerate the judged artifacts under gpurun_out/refresh (then copied into profiles/<round>/ by hand):
-#   kernel stats of the default bench run (rocprofv3 --kernel-trace --stats), the bench line, per-shape table,
-#   PMC traffic (separate FETCH_SIZE / WRITE_SIZE passes), eager per-kernel event breakdown.
+# regenerate the judged artifacts of a round under gpurun_out/refresh (then copied into profiles/<round>/ by hand).
+#   tools/refresh_profiles.sh <round dir, e.g. r02>      -- run on the GPU box via gpurun
+# Order matters: the PMC traffic passes first (bench.py reads profiles/<round>/traffic.json for roofline.traffic), then the
+# bench line of the same build, then rocprofv3 kernel stats / per-shape table / per-call event breakdown of that command.
+# Second half: the bf16 dense-cloud configuration (BASELINE configs[3]).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+RD=${1:-r02}
 O=$R/gpurun_out/refresh
-rm -rf $O; mkdir -p $O
-python $R/bench.py > $O/bench.json 2> $O/bench.err
-tail -1 $O/bench.json | cut -c1-200
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline > $O/stats_bench.log 2>&1
-cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/graph_kernel_stats.csv
-T=$(find $O/stats -name '*kernel_trace.csv' | head -1)
-python $R/tools/trace_by_shape.py $T auto > $O/per_shape_kernel_us.txt
-python $R/bench.py --steps 20 --warmup 5 --breakdown --no-cpu-baseline > $O/breakdown_eager_events.txt 2>&1
+rm -rf $O; mkdir -p $O $R/profiles/$RD
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 4 --warmup 2 --no-graph --no-cpu-baseline > $O/pmc_$c.log 2>&1
-  cp $(find $O/pmc_$c -name '*counter_collection.csv' | head -1) $O/pmc_$c.csv
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 4 --warmup 2 --no-graph --no-cpu-baseline --no-u3 > $O/pmc_$c.log 2>&1
+  cp $(find $O/pmc_$c -name '*counter_collection.csv' | head -1) $O/k_pmc_$c.csv
 done
-python $R/tools/pmc_traffic.py $O/pmc_FETCH_SIZE.csv $O/pmc_WRITE_SIZE.csv $O/traffic.json > /dev/null
-rm -rf $O/stats $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+python $R/tools/pmc_traffic.py $O/k_pmc_FETCH_SIZE.csv $O/k_pmc_WRITE_SIZE.csv $O/traffic.json > /dev/null
+cp $O/traffic.json $R/profiles/$RD/traffic.json
+python $R/bench.py > $O/k_bench.json 2> $O/bench.err
+tail -1 $O/k_bench.json | cut -c1-300
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline --no-u3 > $O/stats_bench.log 2>&1
+cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/k_graph_kernel_stats.csv
+T=$(find $O/stats -name '*kernel_trace.csv' | head -1)
+python $R/tools/trace_by_shape.py $T auto > $O/k_per_shape_kernel_us.txt
+python $R/bench.py --steps 20 --warmup 5 --breakdown --no-cpu-baseline --no-u3 > $O/k_breakdown_eager_events.txt 2>&1
+# own GEMMs only (no BLAS library on the layer path)
+HSP_GEMM=own python $R/bench.py --no-cpu-baseline --no-u3 > $O/k_bench_gemm_own.json 2>/dev/null
+HSP_GEMM=library python $R/bench.py --no-cpu-baseline --no-u3 > $O/k_bench_gemm_library.json 2>/dev/null
+# ---- bf16, B=64, N=4096
+BF="--dtype bf16 --points 4096 --batch 64 --no-cpu-baseline"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/bpmc_$c -- python $R/bench.py $BF --steps 2 --warmup 1 --no-graph > $O/bpmc_$c.log 2>&1
+  cp $(find $O/bpmc_$c -name '*counter_collection.csv' | head -1) $O/b_pmc_$c.csv
+done
+python $R/tools/pmc_traffic.py $O/b_pmc_FETCH_SIZE.csv $O/b_pmc_WRITE_SIZE.csv $O/b_traffic.json > /dev/null
+python - $O/traffic.json $O/b_traffic.json $R/profiles/$RD/traffic.json <<'PY'
+import json, sys
+a = json.load(open(sys.argv[1])); a.update(json.load(open(sys.argv[2]))); json.dump(a, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+PY
+cp $R/profiles/$RD/traffic.json $O/traffic.json
+python $R/bench.py $BF --steps 10 --warmup 3 > $O/b_bench_bf16.json 2>> $O/bench.err
+tail -1 $O/b_bench_bf16.json | cut -c1-300
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bstats -- python $R/bench.py $BF --steps 10 --warmup 3 > $O/bstats_bench.log 2>&1
+cp $(find $O/bstats -name '*kernel_stats.csv' | head -1) $O/b_graph_kernel_stats_bf16.csv
+T=$(find $O/bstats -name '*kernel_trace.csv' | head -1)
+python $R/tools/trace_by_shape.py $T auto > $O/b_per_shape_kernel_us_bf16.txt
+python $R/bench.py $BF --steps 5 --warmup 2 --breakdown > $O/b_breakdown_eager_events_bf16.txt 2>&1
+python $R/bench.py --points 4096 --batch 64 --steps 10 --warmup 3 --no-cpu-baseline --no-u3 > $O/b_bench_f32_same_shape.json 2>/dev/null
+rm -rf $O/stats $O/bstats $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/bpmc_FETCH_SIZE $O/bpmc_WRITE_SIZE $O/b_pmc_*.csv
 ls -la $O
