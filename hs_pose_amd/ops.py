@@ -543,11 +543,10 @@ def _pick(key, own_fn, lib_fn):
 def _fm_rows(X2, weights, bias, out=None):
     """fm = X W + b   (gcn3d.py:171)"""
     R, Cin = X2.shape
-    if out is None:
-        out = torch.empty(R, weights.shape[1], dtype=X2.dtype, device=X2.device)
+    # (the library form allocates its own result: addmm with out= and a broadcast bias takes a slower path in ATen)
     return _pick(f"fm[R{R}K{Cin}N{weights.shape[1]}]",
                  lambda: gemm_rows(X2, weights, True, bias=bias, out=out),
-                 lambda: torch.addmm(bias, X2, weights, out=out))
+                 lambda: torch.addmm(bias, X2, weights) if out is None else torch.addmm(bias, X2, weights, out=out))
 
 
 def _layer_out_rows(x2, w_ste, F2, Wa, t2, out3):
@@ -569,10 +568,10 @@ def _layer_out_rows(x2, w_ste, F2, Wa, t2, out3):
 def _mm_nn(g2, W, out=None, alpha=1.0):
     """alpha * (g @ W) for a row-strided (K,N) matrix W"""
     R, K = g2.shape
-    if out is None:
-        out = torch.empty(R, W.shape[1], dtype=g2.dtype, device=g2.device)
 
     def lib():
+        if out is None:
+            return torch.mm(g2, W) if alpha == 1.0 else _scaled_mm(g2, W, alpha)
         if alpha == 1.0:
             return torch.mm(g2, W, out=out)
         return torch.addmm(out, g2, W, beta=0.0, alpha=alpha, out=out)
@@ -582,10 +581,10 @@ def _mm_nn(g2, W, out=None, alpha=1.0):
 def _mm_nt(x2, W, bias=None, out=None):
     """x @ W^T (+ bias) for a (N,K) weight"""
     R, K = x2.shape
-    if out is None:
-        out = torch.empty(R, W.shape[0], dtype=x2.dtype, device=x2.device)
 
     def lib():
+        if out is None:
+            return torch.addmm(bias, x2, W.t()) if bias is not None else torch.mm(x2, W.t())
         if bias is not None:
             return torch.addmm(bias, x2, W.t(), out=out)
         return torch.mm(x2, W.t(), out=out)
