@@ -53,6 +53,8 @@ struct GemmRowsArgs {
     float alpha;                           // scales the accumulated products (before bias / resid / cloud bias)
     const float* xyz3; const float* w3;    // rank-3 fp32 update + xyz3[row] . w3[col] ((M,3), (N,3)) or null
     int c_f32;                             // bf16 operands: write C as fp32 (a tensor that feeds BatchNorm keeps its mantissa)
+    int nsplit; float* ws;                 // split-K: nsplit > 1 -> raw fp32 partial tiles to ws[split][M][N], folded (with the
+                                           // whole epilogue) by gemm_rows_reduce_kernel
     int tiles_m, tiles_n;
 };
 
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
     // ---- tiles of this workgroup.  Workgroups b = x (mod 8) run on XCD x: it takes a contiguous range of the ordered
     // tile list, and its workgroups take every (gridDim/8)-th tile of that range, so the tiles in flight on an XCD are
     // consecutive in the order below.
-    const int ntiles = g.tiles_m * g.tiles_n;
+    const int ntiles = g.tiles_m * g.tiles_n * g.nsplit;     // work items: (tile, K split), the splits of a tile adjacent
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per = gridDim.x >> 3;      // gridDim.x is a multiple of 8
     const int q8 = ntiles >> 3, r8 = ntiles & 7;
     const int x_first = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
@@ -109,9 +111,17 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
     const int my_count = idx < x_count ? (x_count - idx + per - 1) / per : 0;
     if (my_count == 0) return;
 
-    auto tile_origin = [&](int i, int& m0, int& n0) {
+    const int T1 = (g.K1 + BKE - 1) / BKE;
+    const int T2 = LB2 ? (g.K2 + BKE - 1) / BKE : 0;
+    const int TT = T1 + T2;
+    const int Tper = (TT + g.nsplit - 1) / g.nsplit;           // k-blocks per split (the host keeps every split non-empty)
+
+    auto tile_origin = [&](int i, int& m0, int& n0, int& ks, int& kb0, int& kb1) {
         // ordered tile id -> (tm, tn): groups of GR_TM_GROUP row panels; inside a group tm fastest, then tn
-        const int o = x_first + idx + i * per;
+        const int w = x_first + idx + i * per;
+        const int o = w / g.nsplit;
+        ks = w - o * g.nsplit;
+        kb0 = ks * Tper; kb1 = min(TT, kb0 + Tper);
         const int gsz = GR_TM_GROUP * g.tiles_n;
         const int grp = o / gsz, rem = o - grp * gsz;
         const int gh = min(GR_TM_GROUP, g.tiles_m - grp * GR_TM_GROUP);          // panels in this (maybe last, shorter) group
@@ -126,10 +136,6 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
         for (int b = 0; b < WN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const int T1 = (g.K1 + BKE - 1) / BKE;
-    const int T2 = LB2 ? (g.K2 + BKE - 1) / BKE : 0;
-    const int TT = T1 + T2;
 
     // ---- staging ---------------------------------------------------------------------------------------------------
     // thread -> 16-byte chunk p = tid & 7 (physical position) of tile rows (tid >> 3) + 32 j; logical chunk = p ^ rowkey.
@@ -289,7 +295,23 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
     };
 
     // ---- write a finished tile: accumulator r of (x,y) <-> row wm0 + 32x + (r&3) + 8(r>>2) + 4 lh, column wn0 + 32y + li
-    auto epilogue = [&](int m0, int n0) {
+    auto epilogue = [&](int m0, int n0, int ks) {
+        if (g.nsplit > 1) {                                   // raw partial tile; the reduce kernel applies the epilogue
+            float* wsp = g.ws + (size_t)ks * g.M * g.N;
+#pragma unroll
+            for (int y = 0; y < WN; ++y) {
+                const int col = n0 + wn0 + 32 * y + li;
+#pragma unroll
+                for (int x = 0; x < WM; ++x)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wm0 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (col < g.N && row < g.M) wsp[(size_t)row * g.N + col] = acc[x][y][r];
+                        acc[x][y][r] = 0.f;
+                    }
+            }
+            return;
+        }
         const int rpc = g.rows_per_cloud;
         int c0 = 0, nb = 0x7fffffff;                      // per-cloud bias: cloud boundaries by comparison, no per-row division
         if (g.cbias) { c0 = m0 / rpc; nb = (c0 + 1) * rpc; }
@@ -328,27 +350,57 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
         }
     };
 
-    // ---- the flattened (tile, k-block) walk: stage it+1 while block `it` is multiplied
-    int m0, n0, nm0, nn0;
-    tile_origin(0, m0, n0);
-    issue(0, m0, n0, 0);
-    stash(0, 0);
+    // ---- the flattened (work item, k-block) walk: stage the next block while this one is multiplied
+    int m0, n0, ks, k0, k1, nm0, nn0, nks, nk0, nk1;
+    tile_origin(0, m0, n0, ks, k0, k1);
+    issue(k0, m0, n0, 0);
+    stash(k0, 0);
     __syncthreads();
-    int ti = 0, t = 0;
-    const int total = my_count * TT;
-    for (int it = 0; it < total; ++it) {
+    int ti = 0, t = k0;
+    for (int it = 0;; ++it) {
         int nt = t + 1, nti = ti;
-        nm0 = m0; nn0 = n0;
-        if (nt == TT) { nt = 0; nti = ti + 1; if (nti < my_count) tile_origin(nti, nm0, nn0); }
-        const bool more = it + 1 < total;
+        nm0 = m0; nn0 = n0; nks = ks; nk0 = k0; nk1 = k1;
+        bool more = true;
+        if (nt == k1) {
+            nti = ti + 1;
+            more = nti < my_count;
+            if (more) { tile_origin(nti, nm0, nn0, nks, nk0, nk1); nt = nk0; }
+        }
         if (more) issue(nt, nm0, nn0, (it + 1) & 1);          // in flight under this block's MFMAs
         __builtin_amdgcn_sched_barrier(0);                   // (hipcc would sink register-mode loads next to their use)
         compute(t, it & 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (t == TT - 1) epilogue(m0, n0);
-        if (more) stash(nt, (it + 1) & 1);                   // the other stage: last read in iteration it-1, before the barrier below
+        if (t == k1 - 1) epilogue(m0, n0, ks);
+        if (!more) break;
+        stash(nt, (it + 1) & 1);                             // the other stage: last read in iteration it-1, before the barrier below
         __syncthreads();                                     // (waits for the LDS-DMA / ds_write of stage it+1 as well)
-        t = nt; ti = nti; m0 = nm0; n0 = nn0;
+        t = nt; ti = nti; m0 = nm0; n0 = nn0; ks = nks; k0 = nk0; k1 = nk1;
+    }
+}
+
+// split-K second stage: C = alpha * sum_s ws[s] (+ the whole epilogue), one thread per output element
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_rows_reduce_kernel(const GemmRowsArgs g) {
+    const long long total = (long long)g.M * g.N;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int row = (int)(e / g.N), col = (int)(e - (long long)row * g.N);
+        float s0 = 0.f, s1 = 0.f;
+        int sp = 0;
+        for (; sp + 1 < g.nsplit; sp += 2) { s0 += g.ws[(size_t)sp * total + e]; s1 += g.ws[(size_t)(sp + 1) * total + e]; }
+        if (sp < g.nsplit) s0 += g.ws[(size_t)sp * total + e];
+        float v = g.alpha * (s0 + s1);
+        if (g.bias) v += g.bias[col];
+        if (g.resid) {
+            if (sizeof(T) == 4) v += reinterpret_cast<const float*>(g.resid)[(size_t)row * g.ldr + col];
+            else v += bf16_to_f32(reinterpret_cast<const unsigned short*>(g.resid)[(size_t)row * g.ldr + col]);
+        }
+        if (g.xyz3) {
+            const float* p3 = g.xyz3 + (size_t)row * 3;
+            v += __fmaf_rn(p3[2], g.w3[col * 3 + 2], __fmaf_rn(p3[1], g.w3[col * 3 + 1], p3[0] * g.w3[col * 3]));
+        }
+        if (g.cbias) v += g.cbias[(size_t)(row / g.rows_per_cloud) * g.N + col];
+        if (sizeof(T) == 4 || g.c_f32) reinterpret_cast<float*>(g.C)[(size_t)row * g.ldc + col] = v;
+        else reinterpret_cast<unsigned short*>(g.C)[(size_t)row * g.ldc + col] = f32_to_bf16(v);
     }
 }
 
@@ -357,18 +409,37 @@ static bool aligned16(const void* p, int ld_elems, int es) {
     return reinterpret_cast<size_t>(p) % 16 == 0 && ((size_t)ld_elems * es) % 16 == 0;
 }
 
+// splits of K for `tiles` output tiles and TT k-blocks: enough work items for ~2 per CU, >= 4 k-blocks per split, <= 16
+static int gemm_rows_pick_split(long long tiles, int TT) {
+    if (tiles >= 2 * HSP_NUM_CU || TT < 8) return 1;
+    int ns = (int)((2 * HSP_NUM_CU + tiles - 1) / tiles);
+    if (ns > TT / 4) ns = TT / 4;
+    if (ns > 16) ns = 16;
+    if (ns < 2) return 1;
+    const int per = (TT + ns - 1) / ns;
+    return (TT + per - 1) / per;                   // every split non-empty
+}
+
 template <typename T, int WM, int WN, int MODE>
-static int launch_cfg(const GemmRowsArgs& a, int lb1, int lb2, hipStream_t st) {
+static int launch_cfg(const GemmRowsArgs& a, int lb1, int lb2, float* a_ws, size_t a_ws_bytes, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int ES = sizeof(T);
     GemmRowsArgs g = a;
     g.tiles_m = (a.M + BM - 1) / BM;
     g.tiles_n = (a.N + BN - 1) / BN;
+    {   // split-K when the tiles alone cannot fill the chip and K is deep (the input-gradient products: 64 tiles x K = 4608)
+        constexpr int BKE = 128 / ES;
+        const int TT = (a.K1 + BKE - 1) / BKE + (lb2 ? (a.K2 + BKE - 1) / BKE : 0);
+        int ns = gemm_rows_pick_split((long long)g.tiles_m * g.tiles_n, TT);
+        if ((size_t)ns * a.M * a.N * sizeof(float) > a_ws_bytes) ns = 1;          // no (or too small a) workspace: unsplit
+        g.nsplit = ns;
+        g.ws = ns > 1 ? a_ws : nullptr;
+    }
     const size_t lds = 2 * (size_t)(BM + BN) * 128;
     // persistent grid: as many workgroups as stay resident (LDS: 160 KiB per CU), a multiple of 8 (XCDs), no more than tiles
     const int per_cu = (int)((160 * 1024) / lds) > 4 ? 4 : (int)((160 * 1024) / lds);
     long long nb = (long long)HSP_NUM_CU * per_cu;
-    const long long tiles = (long long)g.tiles_m * g.tiles_n;
+    const long long tiles = (long long)g.tiles_m * g.tiles_n * g.nsplit;
     if (const char* e = getenv("HSP_GEMM_PERSIST")) { if (e[0] == '0') nb = tiles; }        // profiling override: one tile per workgroup
     if (nb > tiles) nb = tiles;
     nb = (nb + 7) / 8 * 8;
@@ -384,6 +455,12 @@ static int launch_cfg(const GemmRowsArgs& a, int lb1, int lb2, hipStream_t st) {
             attr_set = true;                                                                                           \
         }                                                                                                              \
         hipLaunchKernelGGL(kern, grid, block, lds, st, g);                                                             \
+        int rc_ = check_launch();                                                                                      \
+        if (rc_ || g.nsplit == 1) return rc_;                                                                          \
+        const long long tot_ = (long long)g.M * g.N;                                                                   \
+        long long rg_ = (tot_ + 255) / 256;                                                                            \
+        if (rg_ > HSP_NUM_CU * 8) rg_ = HSP_NUM_CU * 8;                                                                \
+        hipLaunchKernelGGL(gemm_rows_reduce_kernel<T>, dim3((unsigned)rg_), dim3(256), 0, st, g);                      \
         return check_launch();                                                                                         \
     } while (0)
     // layouts on this path: X W ("nn"), x W^T ("nt"), X Wste^T + F Wa^T ("nt" + "nt"), g Wste + gfm W^T ("nn" + "nt")
@@ -401,10 +478,10 @@ static int launch_cfg(const GemmRowsArgs& a, int lb1, int lb2, hipStream_t st) {
 }
 
 template <typename T, int WM, int WN>
-static int launch_mode(const GemmRowsArgs& a, int lb1, int lb2, int mode, hipStream_t st) {
-    if (mode == 2) return launch_cfg<T, WM, WN, 2>(a, lb1, lb2, st);
-    if (mode == 1) return launch_cfg<T, WM, WN, 1>(a, lb1, lb2, st);
-    if constexpr (sizeof(T) == 4) return launch_cfg<T, WM, WN, 0>(a, lb1, lb2, st);
+static int launch_mode(const GemmRowsArgs& a, int lb1, int lb2, int mode, float* ws, size_t wsb, hipStream_t st) {
+    if (mode == 2) return launch_cfg<T, WM, WN, 2>(a, lb1, lb2, ws, wsb, st);
+    if (mode == 1) return launch_cfg<T, WM, WN, 1>(a, lb1, lb2, ws, wsb, st);
+    if constexpr (sizeof(T) == 4) return launch_cfg<T, WM, WN, 0>(a, lb1, lb2, ws, wsb, st);
     return HSP_ERR_UNSUPPORTED;                    // bf16 operands: 16-byte aligned rows
 }
 
@@ -422,7 +499,7 @@ template <typename T>
 static int gemm_rows_dispatch(const void* A1, int lda1, const void* B1, int ldb1, int l1, int K1, const void* A2, int lda2,
                               const void* B2, int ldb2, int l2, int K2, int M, int N, const float* bias, const void* resid,
                               int ldr, const float* cbias, int rpc, float alpha, const float* xyz3, const float* w3, void* C, int ldc,
-                              int c_f32, hspStream_t stream) {
+                              int c_f32, void* ws, size_t ws_bytes, hspStream_t stream) {
     constexpr int ES = sizeof(T);
     if (!A1 || !B1 || !C || M <= 0 || N <= 0 || K1 <= 0 || lda1 < K1 || ldc < N) return HSP_ERR_BAD_ARG;
     if (l1 != 0 && l1 != 1) return HSP_ERR_BAD_ARG;
@@ -465,8 +542,9 @@ static int gemm_rows_dispatch(const void* A1, int lda1, const void* B1, int ldb1
     if (const char* e = getenv("HSP_GEMM_TILE")) small = e[0] == 's' ? true : e[0] == 'l' ? false : small;   // profiling override
     int mode = glds ? 1 : 0;                                   // aligned: 16-byte register staging (LDS-DMA measured slower here)
     if (const char* e = getenv("HSP_GEMM_GLDS")) { if (glds && e[0] == '1') mode = 2; }                        // profiling override
-    if (small) return launch_mode<T, 1, 1>(g, lb1, lb2, mode, st);
-    return launch_mode<T, 2, 2>(g, lb1, lb2, mode, st);
+    g.nsplit = 1;
+    if (small) return launch_mode<T, 1, 1>(g, lb1, lb2, mode, reinterpret_cast<float*>(ws), ws ? ws_bytes : 0, st);
+    return launch_mode<T, 2, 2>(g, lb1, lb2, mode, reinterpret_cast<float*>(ws), ws ? ws_bytes : 0, st);
 }
 
 // ---- fp32 master parameters -> bf16 working copies, all tensors of a step in ONE launch --------------------------------
@@ -512,20 +590,32 @@ extern "C" int hsp_cast_params_bf16(const HspCastDesc* table_dev, int n, int tot
     return check_launch();
 }
 
+/* split-K workspace: 16 fp32 partial copies of C at most (0 = the shape never splits) */
+extern "C" size_t hsp_gemm_rows_workspace_bytes(int M, int N, int K1, int K2, int elem_bytes) {
+    if (M <= 0 || N <= 0 || K1 <= 0 || (elem_bytes != 2 && elem_bytes != 4)) return 0;
+    const int bke = 128 / elem_bytes;
+    const int TT = (K1 + bke - 1) / bke + (K2 > 0 ? (K2 + bke - 1) / bke : 0);
+    const bool small = prefer_small_tile(M, N);
+    const int bm = small ? 64 : 128;
+    const int ns = gemm_rows_pick_split((long long)((M + bm - 1) / bm) * ((N + bm - 1) / bm), TT);
+    return ns > 1 ? (size_t)ns * M * N * sizeof(float) : 0;
+}
+
 extern "C" int hsp_gemm_rows_f32(const float* A1, int lda1, const float* B1, int ldb1, int b1_layout, int K1,
                                  const float* A2, int lda2, const float* B2, int ldb2, int b2_layout, int K2, int M, int N,
                                  const float* bias, const float* resid, int ldr, const float* cloud_bias,
                                  int rows_per_cloud, float alpha, const float* xyz3, const float* w3, float* C, int ldc,
-                                 hspStream_t stream) {
+                                 void* ws, size_t ws_bytes, hspStream_t stream) {
     return gemm_rows_dispatch<float>(A1, lda1, B1, ldb1, b1_layout, K1, A2, lda2, B2, ldb2, b2_layout, K2, M, N, bias, resid,
-                                     ldr, cloud_bias, rows_per_cloud, alpha, xyz3, w3, C, ldc, 1, stream);
+                                     ldr, cloud_bias, rows_per_cloud, alpha, xyz3, w3, C, ldc, 1, ws, ws_bytes, stream);
 }
 
 extern "C" int hsp_gemm_rows_bf16(const hsp_bf16_t* A1, int lda1, const hsp_bf16_t* B1, int ldb1, int K1,
                                   const hsp_bf16_t* A2, int lda2, const hsp_bf16_t* B2, int ldb2, int K2, int M, int N,
                                   const float* bias, const hsp_bf16_t* resid, int ldr, const float* cloud_bias,
                                   int rows_per_cloud, float alpha, const float* xyz3, const float* w3, void* C, int ldc,
-                                  int c_is_f32, hspStream_t stream) {
+                                  int c_is_f32, void* ws, size_t ws_bytes, hspStream_t stream) {
     return gemm_rows_dispatch<unsigned short>(A1, lda1, B1, ldb1, 0, K1, A2, lda2, B2, ldb2, 0, K2, M, N, bias, resid, ldr,
-                                              cloud_bias, rows_per_cloud, alpha, xyz3, w3, C, ldc, c_is_f32 ? 1 : 0, stream);
+                                              cloud_bias, rows_per_cloud, alpha, xyz3, w3, C, ldc, c_is_f32 ? 1 : 0, ws, ws_bytes,
+                                              stream);
 }

@@ -875,11 +875,14 @@ static int launch_knn3_wave(const float* x, int B, int N, int k, int drop, int32
 template <int K1>
 static int launch_knn3_t(const float* x, int B, int N, int k, int drop, int32_t* idx, hipStream_t st) {
     const long long nq = (long long)B * N;
-    // one wave per query while the per-lane distances fit in registers and the grid is not already huge
-    if (N >= 64 && nq < 131072) {
+    // one wave per query while the per-lane distances fit in registers (<= 65 per lane: N <= 4160, the dense clouds of
+    // BASELINE configs[3]; 1.8 ms with the per-lane-list kernel below at B=64 N=4096)
+    if (N >= 64 && (nq < 131072 || N > 64 * 17)) {
         if (N <= 64 * 5) return launch_knn3_wave<5>(x, B, N, k, drop, idx, st);
         if (N <= 64 * 9) return launch_knn3_wave<9>(x, B, N, k, drop, idx, st);
         if (N <= 64 * 17) return launch_knn3_wave<17>(x, B, N, k, drop, idx, st);
+        if (N <= 64 * 33) return launch_knn3_wave<33>(x, B, N, k, drop, idx, st);
+        if (N <= 64 * 65) return launch_knn3_wave<65>(x, B, N, k, drop, idx, st);
     }
     if (nq >= 131072) return launch_knn3<K1, 1>(x, B, N, k, drop, idx, st);
     if (nq >= 32768) return launch_knn3<K1, 4>(x, B, N, k, drop, idx, st);
@@ -979,7 +982,7 @@ __global__ __launch_bounds__(256) void quad_bf16_kernel(const bf16_t* __restrict
 }
 
 template <int K1>
-__global__ __launch_bounds__(256, 2) void knn_feat_bf16_kernel(const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(256, 3) void knn_feat_bf16_kernel(const bf16_t* __restrict__ x,
                                                                const float* __restrict__ quad, int N, int C, int k,
                                                                int drop, int32_t* __restrict__ idx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

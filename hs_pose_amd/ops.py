@@ -489,12 +489,14 @@ def gemm_rows(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=N
     es = 4 if dt == torch.float32 else 2
     ab = es * (M * (K1 + K2) + N * (K1 + K2) + M * N * (2 if resid is not None else 1))
     key = f"M{M}N{N}K{K1}" + (f"+{K2}" if K2 else "")
+    wsb = lib().hsp_gemm_rows_workspace_bytes(M, N, K1, K2, es)       # split-K partial tiles (0 for most shapes)
+    ws = _ws(wsb, A1.device) if wsb else None
     if dt == torch.float32:
         _run("hsp_gemm_rows_f32", (_p(A1), _ld(A1), _p(B1), _ld(B1), 1 if nn1 else 0, K1,
                                    _p(A2), _ld(A2) if A2 is not None else 0, _p(B2), _ld(B2) if B2 is not None else 0,
                                    1 if nn2 else 0, K2, M, N, _p(bias), _p(resid), _ld(resid) if resid is not None else 0,
                                    _p(cloud_bias), int(rows_per_cloud), float(alpha), _p(xyz3), _p(w3), _p(out), _ld(out),
-                                   _stream()),
+                                   _p(ws), wsb, _stream()),
              key=key, abytes=ab, aflops=flops)
     else:
         if nn1 or nn2:
@@ -503,18 +505,21 @@ def gemm_rows(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=N
                                     _p(A2), _ld(A2) if A2 is not None else 0, _p(B2), _ld(B2) if B2 is not None else 0, K2,
                                     M, N, _p(bias), _p(resid), _ld(resid) if resid is not None else 0, _p(cloud_bias),
                                     int(rows_per_cloud), float(alpha), _p(xyz3), _p(w3), _p(out), _ld(out),
-                                    1 if out.dtype == torch.float32 else 0, _stream()),
+                                    1 if out.dtype == torch.float32 else 0, _p(ws), wsb, _stream()),
              key=key + "bf16", abytes=ab, aflops=flops)
     return out
 
 
 # ------------------------------------------------------------------------------------------------
 # dense per-point products of a layer: the hand-written fused kernel (csrc/gemm_rows.hip) or the BLAS library through
-# torch.  HSP_GEMM = own | library | auto (default): "auto" times both forms of a composite once per shape (outside any
-# graph capture, on the real buffers -- both forms write the same result) and keeps the faster; "own" runs no library
-# GEMM at all on the layer path.  ``gemm_choices()`` reports what was picked.
+# torch.  HSP_GEMM = library (default for fp32 rows) | own | auto: "own" runs no library GEMM at all on the layer path
+# (measured, round 2, B=16 N=1028: 2.30 ms / step against 2.06 ms with the tuned library -- the hand-written kernel reaches
+# 60-78 TFLOP/s on the layer's shapes, the TunableOp-selected Tensile kernels 90-120); "auto" times both forms of a composite
+# once per shape (outside any graph capture, on the real buffers -- both forms write the same result) and keeps the faster
+# (isolated timings are host-launch-bound for the small shapes and flatter the fused form: 2.10 ms).  bf16 rows always run on
+# the hand-written kernel (ops_bf16.py).  ``gemm_choices()`` reports what "auto" picked.
 # ------------------------------------------------------------------------------------------------
-GEMM_MODE = os.environ.get("HSP_GEMM", "auto")
+GEMM_MODE = os.environ.get("HSP_GEMM", "library")
 _gemm_choice = {}
 
 
@@ -601,6 +606,14 @@ def _grad_in_rows(g2, w_ste, gfm2, weights, out):
         return out.addmm_(gfm2, weights.t())
     return _pick(f"gx[R{R}K{g2.shape[1]}+{gfm2.shape[1]}N{out.shape[1]}]",
                  lambda: gemm_rows(g2, w_ste, True, gfm2, weights, False, out=out), lib)
+
+
+def _tiny_tn(a, b, out):
+    """out = a^T b for per-cloud rows a (B,M), b (B,N) (B = 16: one library launch; the split-K weight-gradient kernel needs
+    two launches for it and is used only when no library GEMM may run, HSP_GEMM=own)"""
+    if GEMM_MODE == "own":
+        return wgrad(a, b, out=out)
+    return torch.mm(a.t(), b, out=out)
 
 
 def _orl_fwd_raw(F3, idx_x, k):
@@ -745,7 +758,7 @@ class _HSLayer(torch.autograd.Function):
         gt = colsum_rows(g)                                                    # (B,C) = sum_i g
         g_conv2 = torch.empty_like(w_conv2)
         wgrad(g2, F2, out=g_conv2[:, :C])                                      # gWa, written in place (ldc = 2C)
-        wgrad(gt, fg, out=g_conv2[:, C:])                                      # gWb = gt^T fg (tiny), straight into its column block
+        _tiny_tn(gt, fg, g_conv2[:, C:])                                       # gWb = gt^T fg (tiny), straight into its column block
         gF3 = torch.empty(B, N, C, dtype=torch.float32, device=g.device)
         _mm_nn(g2, Wa, out=gF3.view(B * N, C))                                 # g Wa ...
         _orl_bwd_accumulate_raw(_mm_nn(gt, Wb, alpha=1.0 / N), idx_x, arg_o, k, gF3, extra=g)  # ... + g + ORL scatter, one pass
@@ -798,7 +811,7 @@ class _SurfaceLayer(torch.autograd.Function):
         gt = colsum_rows(g)
         g_conv2 = torch.empty_like(w_conv2)
         wgrad(g2, F2, out=g_conv2[:, :C])
-        wgrad(gt, fg, out=g_conv2[:, C:])
+        _tiny_tn(gt, fg, g_conv2[:, C:])
         gF3 = torch.empty(B, N, C, dtype=torch.float32, device=g.device)
         _mm_nn(g2, Wa, out=gF3.view(B * N, C))
         _orl_bwd_accumulate_raw(_mm_nn(gt, Wb, alpha=1.0 / N), idx_x, arg_o, k, gF3, extra=g)

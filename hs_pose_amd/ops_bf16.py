@@ -207,7 +207,7 @@ class _HSLayerBf16(torch.autograd.Function):
         gt = _colsum(g)                                           # fp32 (B,C)
         g_conv2 = torch.empty_like(w_conv2)
         _wgrad(g2, F2, out=g_conv2[:, :C])                        # gWa
-        ops.wgrad(gt, fg, out=g_conv2[:, C:])                     # gWb (fp32, tiny)
+        ops._tiny_tn(gt, fg, g_conv2[:, C:])                      # gWb (fp32, tiny)
         gF3 = torch.empty(B, N, C, dtype=BF16, device=g.device)
         ops.gemm_rows(g2, c2T_b[:C], out=gF3.view(B * N, C))      # g Wa ...
         _orl_bwd_accumulate(ops._mm_nn(gt, Wb, alpha=1.0 / N), idx_x, arg_o, gF3, g)      # ... + g + ORL scatter
@@ -264,7 +264,7 @@ class _SurfaceLayerBf16(torch.autograd.Function):
         gt = _colsum(g)
         g_conv2 = torch.empty_like(w_conv2)
         _wgrad(g2, F2, out=g_conv2[:, :C])
-        ops.wgrad(gt, fg, out=g_conv2[:, C:])
+        ops._tiny_tn(gt, fg, g_conv2[:, C:])
         gF3 = torch.empty(B, N, C, dtype=BF16, device=g.device)
         ops.gemm_rows(g2, c2T_b[:C], out=gF3.view(B * N, C))
         _orl_bwd_accumulate(ops._mm_nn(gt, Wb, alpha=1.0 / N), idx_x, arg_o, gF3, g)

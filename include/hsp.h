@@ -216,13 +216,18 @@ int hsp_gather_rows_bwd_csr(const float *grad_out, int grad_stride, const int32_
 int hsp_gemm_rows_f32(const float *A1, int lda1, const float *B1, int ldb1, int b1_layout, int K1,
                       const float *A2, int lda2, const float *B2, int ldb2, int b2_layout, int K2, int M, int N,
                       const float *bias, const float *resid, int ldr, const float *cloud_bias, int rows_per_cloud,
-                      float alpha, const float *xyz3, const float *w3, float *C, int ldc, hspStream_t stream);
+                      float alpha, const float *xyz3, const float *w3, float *C, int ldc, void *ws, size_t ws_bytes,
+                      hspStream_t stream);
+/* ws: hsp_gemm_rows_workspace_bytes(M,N,K1,K2, 4 | 2) -- 0 unless few output tiles meet a deep K (the input-gradient
+ * products), which then split K over up to 16 workgroups per tile and fold the partial tiles in a second launch; with
+ * ws == NULL (or too small) the product runs unsplit */
+size_t hsp_gemm_rows_workspace_bytes(int M, int N, int K1, int K2, int elem_bytes);
 int hsp_gemm_rows_bf16(const hsp_bf16_t *A1, int lda1, const hsp_bf16_t *B1, int ldb1, int K1,
                        const hsp_bf16_t *A2, int lda2, const hsp_bf16_t *B2, int ldb2, int K2, int M, int N,
                        const float *bias, const hsp_bf16_t *resid, int ldr, const float *cloud_bias,
                        int rows_per_cloud, float alpha, const float *xyz3, const float *w3, void *C, int ldc,
                        int c_is_f32 /* != 0: C is fp32 (an output that feeds BatchNorm keeps its mantissa) */,
-                       hspStream_t stream);
+                       void *ws, size_t ws_bytes, hspStream_t stream);
 
 /* fp32 master parameters -> bf16 working copies for the *_bf16 entry points, every tensor of a step in one launch:
  * entry e copies src (rows, cols; row pitch ld) to dst (rows, cols) and / or dstT (cols, rows) -- either may be NULL --

@@ -40,6 +40,9 @@ CASES = [
     (2056, 1286, 1024, True, 0, False, False, False, 0),       # its input gradient: N = 1286
     (2056, 30, 128, False, 0, False, True, False, 0),          # face_head's last layer: N = 30
     (64, 64, 32, False, 0, False, False, False, 0),            # one small tile, one k block
+    (1024, 256, 512, True, 4096, False, False, False, 0),      # conv_4's input gradient: 64 tiles x K = 4608 -> split-K
+    (1024, 128, 2000, False, 0, False, True, True, 100),       # split-K with the whole epilogue (bias, resid, cloud bias)
+    (16, 128, 128, False, 0, False, False, False, 0),          # the per-cloud products (16 rows)
 ]
 
 
