@@ -944,19 +944,14 @@ static int launch_knn_feat(const float* x, const float* quad, float* dtail, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// feature path, bf16 rows (BASELINE configs[3]): the same decomposition -- a workgroup = 32 queries of one cloud,
-// wave w sweeps candidate tiles w, w+4, ... -- with the inner products on v_mfma_f32_32x32x16_bf16 (bf16 x bf16
-// products are exact in fp32, accumulation fp32) and |x|^2 in fp32 (quad_bf16_kernel).  A candidate tile is staged
-// in 128-element (256-byte) row chunks through wave-private LDS: coalesced 16-byte global loads, row pitch 272 bytes
-// (17 sixteen-byte slots: the 16 lanes of a ds_read_b128 group land on 16 different slots), one ds_read_b128 per
-// operand per MFMA.  d = ((inner * -2) + |c|^2) + |q|^2 as in the fp32 path; selection (shared pruning bound, drain
-// loop, tournament merge, lowest index on ties) is the fp32 kernel's.  Not bit-identical with an fp32 evaluation of
-// the same bf16 rows (the MFMA adds 16 products per step in its own order): tests/test_gpu_bf16.py reports the
-// neighbour-set agreement.  C % 32 == 0.
-// LDS: 32 query rows x (2C + 16) bytes + 4 waves x 32 x 272 bytes + bounds; lists alias it at the end.
+// feature path, bf16 rows (BASELINE configs[3]): inner products on v_mfma_f32_32x32x16_bf16 (bf16 x bf16 products are
+// exact in fp32, accumulation fp32), |x|^2 in fp32 (quad_bf16_kernel), d = ((inner * -2) + |c|^2) + |q|^2 as in the fp32
+// path; selection (shared pruning bound, drain loop, tournament merge, lowest index on ties) is the fp32 kernel's.  Rows
+// are staged whole (C <= 256) with a pitch of 2C + 16 bytes: an odd number of 16-byte slots, so the 16 lanes of a
+// ds_read_b128 group land on 16 different slots; one ds_read_b128 per operand per MFMA.  Not bit-identical with an fp32
+// evaluation of the same bf16 rows in principle (the MFMA adds 16 products per step in its own order):
+// tests/test_gpu_bf16.py reports the neighbour-set agreement (measured: identical sets on every tested shape).  C % 32 == 0.
 // ------------------------------------------------------------------------------------------------
-#define KB_CH 128                 // k elements per staged chunk
-#define KB_PITCH 272              // bytes per staged candidate row (256 + 16)
 
 __global__ __launch_bounds__(256) void quad_bf16_kernel(const bf16_t* __restrict__ x, long long rows, int C,
                                                         float* __restrict__ quad) {
@@ -981,152 +976,136 @@ __global__ __launch_bounds__(256) void quad_bf16_kernel(const bf16_t* __restrict
     if (row < rows && l8 == 0) quad[row] = s;
 }
 
+// 128 queries per workgroup: wave w owns queries 32w .. 32w+31 against EVERY candidate tile; the 32-row candidate tiles
+// are staged once per workgroup (double-buffered LDS, one barrier per tile) and shared by the four waves.  Against one
+// 32-query workgroup per candidate sweep this reads the cloud from L2 a quarter as often (measured round 2: that kernel
+// waited on memory 62 % of its wave-cycles, 8.6 GB of L2 requests per launch at B=64 N=4096) and keeps TWO lists per
+// query (the two row halves of a tile) instead of eight, so ~3x fewer list insertions in total.
+// LDS: 128 x (2C+16) query rows + 2 x 32 x (2C+16) candidate rows + 4 x 4 KB selection scratch + bounds.
 template <int K1>
-__global__ __launch_bounds__(256, 3) void knn_feat_bf16_kernel(const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(256, 2) void knn_feat_bf16_kernel(const bf16_t* __restrict__ x,
                                                                const float* __restrict__ quad, int N, int C, int k,
                                                                int drop, int32_t* __restrict__ idx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-    const int QP = C * 2 + 16;                                  // query row pitch (bytes): (C/8 + 1) slots, odd
-    char* qtile = smem;
+    const int RP = C * 2 + 16;                                  // row pitch (bytes): (C/8 + 1) sixteen-byte slots, odd
+    char* qtile = smem;                                         // 128 rows
+    char* ctile = qtile + 128 * RP;                             // 2 x 32 rows
+    float* stash_all = reinterpret_cast<float*>(ctile + 2 * 32 * RP);      // 4 waves x 16 x 64
+    float* qsm = stash_all + 4 * 16 * 64;                       // 2 x 32: |c|^2 of the staged tiles (+inf past N)
+    float* pub = qsm + 2 * 32;                                  // [128 queries][2 lists]
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int col = lane & 31, h = lane >> 5;
-    char* ctile = qtile + 32 * QP + wave * 32 * KB_PITCH;
-    float* qsm = reinterpret_cast<float*>(qtile + 32 * QP + 4 * 32 * KB_PITCH) + wave * 32;
-    float* pub = reinterpret_cast<float*>(qtile + 32 * QP + 4 * 32 * KB_PITCH) + 4 * 32;     // [32 queries][8 lists]
-    constexpr bool SHARE_OK = K1 >= 8;
-    constexpr int A_HI = SHARE_OK ? K1 / 8 : 0, A_LO = SHARE_OK ? K1 / 8 - 1 : 0;
-    const bool SHARE = SHARE_OK && ((N + 31) >> 5) >= 4;
+    float* stash = stash_all + wave * 16 * 64;
+    constexpr bool SHARE = K1 >= 2;
+    constexpr int A0 = (K1 + 1) / 2, A1 = K1 / 2;               // entries the two lists of a query vouch for: A0 + A1 = K1
     pub[tid] = INFINITY;
     const int b = blockIdx.y;
-    const int q0 = (int)blockIdx.x * 32;
+    const int q0 = (int)blockIdx.x * 128;
     const bf16_t* xb = x + (size_t)b * N * C;
     const float* quadb = quad + (size_t)b * N;
-
-    // ---- the 32 query rows (rows past N: clamped, never written out)
-    const int cpr = C >> 3;                                     // 16-byte chunks per row
-    for (int e = tid; e < 32 * cpr; e += 256) {
+    const int cpr = C >> 3;                                     // 16-byte pieces per row
+    for (int e = tid; e < 128 * cpr; e += 256) {
         const int row = e / cpr, ch = e - row * cpr;
-        const uint4 v = *reinterpret_cast<const uint4*>(xb + (size_t)min(q0 + row, N - 1) * C + ch * 8);
-        *reinterpret_cast<uint4*>(qtile + row * QP + ch * 16) = v;
+        *reinterpret_cast<uint4*>(qtile + row * RP + ch * 16) =
+            *reinterpret_cast<const uint4*>(xb + (size_t)min(q0 + row, N - 1) * C + ch * 8);
     }
-    __syncthreads();
-
-    const int q = q0 + col;
-    const bool qvalid = q < N;
+    const int q = q0 + wave * 32 + col;
     const float qq = quadb[min(q, N - 1)];
     TopList<K1> top;
     top.init();
-
     const int ntiles = (N + 31) >> 5;
-    const int nchunks = (C + KB_CH - 1) / KB_CH;
-    // register prefetch of one candidate chunk: 32 rows x (<=) 256 bytes = 8 x 16 bytes per lane; lane (r4 = lane >> 4,
-    // c16 = lane & 15) takes 16-byte piece c16 of rows r4, r4 + 4, ...: a quarter wave reads 256 contiguous bytes
-    uint4 pre[8];
-    const int r4 = lane >> 4, c16 = lane & 15;
-    auto prefetch = [&](int tile, int chunk) {
-        const int kc = chunk * KB_CH + c16 * 8;
-        const int kcc = kc < C ? kc : 0;                        // (C % 128 == 32/64/96: pieces past C re-read piece 0, unused)
+    const int npc = (32 * cpr + 255) / 256;                     // staging pieces per thread and tile (<= 4: C <= 256)
+    uint4 pre[4];
+    float preq = 0.f;
+    auto fetch = [&](int tile) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = min(tile * 32 + r4 + 4 * it, N - 1);
-            pre[it] = *reinterpret_cast<const uint4*>(xb + (size_t)row * C + kcc);
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + 256 * j;
+            const int row = e / cpr, ch = e - row * cpr;
+            if (j < npc) pre[j] = *reinterpret_cast<const uint4*>(xb + (size_t)min(tile * 32 + min(row, 31), N - 1) * C + ch * 8);
         }
+        if (tid < 32) preq = tile * 32 + tid < N ? quadb[tile * 32 + tid] : INFINITY;
     };
-
-    int tile = wave, chunk = 0;
-    if (tile < ntiles) prefetch(tile, 0);
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + 256 * j;
+            const int row = e / cpr, ch = e - row * cpr;
+            if (j < npc && row < 32) *reinterpret_cast<uint4*>(ctile + (buf * 32 + row) * RP + ch * 16) = pre[j];
+        }
+        if (tid < 32) qsm[buf * 32 + tid] = preq;
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float qraw = 0.f;
-
-    while (tile < ntiles) {
-#pragma unroll
-        for (int it = 0; it < 8; ++it)
-            *reinterpret_cast<uint4*>(ctile + (r4 + 4 * it) * KB_PITCH + c16 * 16) = pre[it];
-        if (chunk == 0) qraw = tile * 32 + col < N ? quadb[tile * 32 + col] : INFINITY;
-        int ntile = tile, nchunk = chunk + 1;
-        if (nchunk == nchunks) { nchunk = 0; ntile = tile + 4; }
-        if (ntile < ntiles) prefetch(ntile, nchunk);
-        __builtin_amdgcn_wave_barrier();
-
-        const int ksteps = min(KB_CH, C - chunk * KB_CH) >> 4;  // MFMA steps (16 k each) in this chunk
-        const char* arow = ctile + col * KB_PITCH + h * 16;
-        const char* brow = qtile + col * QP + chunk * (KB_CH * 2) + h * 16;
+    const int ksteps = C >> 4;
+    const char* brow = qtile + (wave * 32 + col) * RP + h * 16;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int buf = tile & 1;
+        if (tile + 1 < ntiles) fetch(tile + 1);                  // in flight under this tile's MFMAs and selection
+        const char* arow = ctile + (buf * 32 + col) * RP + h * 16;
         for (int s_ = 0; s_ < ksteps; ++s_) {
             const uint4 a = *reinterpret_cast<const uint4*>(arow + s_ * 32);
             const uint4 bq = *reinterpret_cast<const uint4*>(brow + s_ * 32);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq), acc, 0, 0, 0);
         }
-        __builtin_amdgcn_wave_barrier();
-
-        if (chunk == nchunks - 1) {
-            qsm[col] = qraw;                                      // both halves write the same value
-            __builtin_amdgcn_wave_barrier();
-            float thr = top.d[K1 - 1];
-            if (SHARE) {
-                const float4 t0 = *reinterpret_cast<const float4*>(pub + col * 8);
-                const float4 t1 = *reinterpret_cast<const float4*>(pub + col * 8 + 4);
-                const float tau = fmaxf(fmaxf(fmaxf(t0.x, t0.y), fmaxf(t0.z, t0.w)),
-                                        fmaxf(fmaxf(t1.x, t1.y), fmaxf(t1.z, t1.w)));
-                thr = fminf(thr, tau);
-            }
-            float* stash = reinterpret_cast<float*>(ctile);    // the chunk is consumed: 16 x 64 floats fit (4 KB of 8.5)
-            unsigned m = 0;
+        float thr = top.d[K1 - 1];
+        if (SHARE) thr = fminf(thr, fmaxf(pub[(wave * 32 + col) * 2], pub[(wave * 32 + col) * 2 + 1]));
+        unsigned m = 0;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 qc = *reinterpret_cast<const float4*>(qsm + 8 * g + 4 * h);
-                const float qcv[4] = {qc.x, qc.y, qc.z, qc.w};
+        for (int g = 0; g < 4; ++g) {
+            const float4 qc = *reinterpret_cast<const float4*>(qsm + buf * 32 + 8 * g + 4 * h);
+            const float qcv[4] = {qc.x, qc.y, qc.z, qc.w};
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int r = 4 * g + u;
-                    const float d = add_rn(add_rn(mul_rn(acc[r], -2.0f), qcv[u]), qq);   // +inf past N
-                    stash[r * 64 + lane] = d;
-                    m |= d <= thr ? (1u << r) : 0u;
-                    acc[r] = 0.f;
-                }
+            for (int u = 0; u < 4; ++u) {
+                const int r = 4 * g + u;
+                const float d = add_rn(add_rn(mul_rn(acc[r], -2.0f), qcv[u]), qq);   // +inf past N
+                stash[r * 64 + lane] = d;
+                m |= d <= thr ? (1u << r) : 0u;
+                acc[r] = 0.f;
             }
-            __builtin_amdgcn_wave_barrier();
-            const int c0 = tile * 32 + 4 * h;
-            bool has = m != 0;
-            int r = has ? __builtin_ctz(m) : 0;
-            m &= m - 1;
-            float v = stash[r * 64 + lane];
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                if (!__any(has)) break;
-                const bool has_n = m != 0;
-                const int r_n = has_n ? __builtin_ctz(m) : 0;
-                m &= m - 1;
-                const float v_n = stash[r_n * 64 + lane];
-                top.insert_always(has ? v : INFINITY, c0 + (r & 3) + 8 * (r >> 2));
-                has = has_n; r = r_n; v = v_n;
-            }
-            if (SHARE) pub[col * 8 + wave * 2 + h] = (wave * 2 + h < (K1 & 7)) ? top.d[A_HI] : top.d[A_LO];
-            __builtin_amdgcn_wave_barrier();
         }
-        tile = ntile;
-        chunk = nchunk;
+        __builtin_amdgcn_wave_barrier();
+        const int c0 = tile * 32 + 4 * h;
+        bool has = m != 0;
+        int r = has ? __builtin_ctz(m) : 0;
+        m &= m - 1;
+        float v = stash[r * 64 + lane];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            if (!__any(has)) break;
+            const bool has_n = m != 0;
+            const int r_n = has_n ? __builtin_ctz(m) : 0;
+            m &= m - 1;
+            const float v_n = stash[r_n * 64 + lane];
+            top.insert_always(has ? v : INFINITY, c0 + (r & 3) + 8 * (r >> 2));
+            has = has_n; r = r_n; v = v_n;
+        }
+        if (SHARE) pub[(wave * 32 + col) * 2 + h] = h == 0 ? top.d[A0 - 1] : top.d[A1 > 0 ? A1 - 1 : 0];
+        if (tile + 1 < ntiles) stage(buf ^ 1);                   // the other buffer: last read in the previous iteration
+        __syncthreads();
     }
-
-    __syncthreads();
+    // merge the two lists of every query
     int2* lists = reinterpret_cast<int2*>(smem);
     top.store(lists + (size_t)tid * K1);
     __syncthreads();
-    const int mq = tid >> 3, ml = tid & 7;
-    const int src = (ml >> 1) * 64 + (ml & 1) * 32 + mq;
+    const int mq = tid >> 1, ml = tid & 1;
+    const int src = (mq >> 5) * 64 + ml * 32 + (mq & 31);
     const int oq = q0 + mq;
     const bool ovalid = oq < N;
-    (void)qvalid;
-    merge_write<K1, 8>(lists, src, ml, k, drop, ovalid, idx + ((size_t)b * N + (ovalid ? oq : 0)) * k, N, ovalid ? oq : 0);
+    merge_write<K1, 2>(lists, src, ml, k, drop, ovalid, idx + ((size_t)b * N + (ovalid ? oq : 0)) * k, N, ovalid ? oq : 0);
 }
 
 template <int K1>
 static int launch_knn_feat_bf16(const bf16_t* x, const float* quad, int B, int N, int C, int k, int drop, int32_t* idx,
                                 hipStream_t st) {
-    size_t lds = (size_t)32 * (C * 2 + 16) + (size_t)4 * 32 * KB_PITCH + (size_t)(4 * 32 + 32 * 8) * 4;
+    if (C > 256) return HSP_ERR_UNSUPPORTED;                   // staging registers: 4 pieces per thread and tile
+    size_t lds = (size_t)(128 + 64) * (C * 2 + 16) + (size_t)(4 * 16 * 64 + 2 * 32 + 128 * 2) * 4;
     const size_t lds_lists = (size_t)256 * K1 * 8;
     if (lds_lists > lds) lds = lds_lists;
     if (lds > 160 * 1024) return HSP_ERR_UNSUPPORTED;
@@ -1135,7 +1114,7 @@ static int launch_knn_feat_bf16(const bf16_t* x, const float* quad, int B, int N
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
     }
-    hipLaunchKernelGGL(kern, dim3((N + 31) / 32, B), dim3(256), lds, st, x, quad, N, C, k, drop, idx);
+    hipLaunchKernelGGL(kern, dim3((N + 127) / 128, B), dim3(256), lds, st, x, quad, N, C, k, drop, idx);
     return check_launch();
 }
 
