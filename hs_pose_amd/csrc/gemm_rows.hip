@@ -40,6 +40,7 @@ namespace hsp {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 struct GemmRowsArgs {
     const void* A1; const void* B1; const void* A2; const void* B2;
@@ -68,19 +69,12 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {              //
     return (unsigned short)(u >> 16);
 }
 
-// 16 bytes, global -> LDS, no registers: every lane supplies its own source address, the destination is
-// lds_wave_base + lane * 16 (lds_wave_base must be wave-uniform)
-__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
 // T: float or unsigned short (bf16 bits).  WM, WN: 32x32 MFMA tiles per wave along M / N (block tile = 64*WM x 64*WN).
 // LB1 / LB2: layout of B1 / B2 -- 1 "nt" (N,K) k contiguous, 2 "nn" (K,N) n contiguous (fp32 only), 0 (LB2) = no 2nd source.
-// GLDS: every operand 16-byte aligned (base and row pitch) -> LDS-DMA staging; else 4-byte pieces through registers.
+// MODE 1: every operand 16-byte aligned (base and row pitch): 16-byte staging loads; MODE 2: 8-byte aligned (an even fp32
+// pitch such as 1286): 8-byte pieces; MODE 0: 4-byte pieces (any alignment).
 template <typename T, int WM, int WN, int LB1, int LB2, int MODE>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
-    constexpr bool GLDS = MODE == 2;             // MODE 2: LDS-DMA, 1: registers, 16-byte loads, 0: registers, 4-byte pieces
     constexpr int ES = sizeof(T);
     constexpr int EPC = 16 / ES;                 // elements per 16-byte chunk
     constexpr int BKE = 128 / ES;                // k elements per block
@@ -91,7 +85,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
     constexpr int NA = BM / 32, NB = BN / 32;    // staging pieces per thread (16-byte chunks)
     static_assert(LB1 == 1 || (LB1 == 2 && ES == 4), "nn operands are fp32 only");
     static_assert(LB2 == 0 || LB2 == 1 || (LB2 == 2 && ES == 4), "nn operands are fp32 only");
-    static_assert(MODE != 0 || ES == 4, "bf16 operands must be 16-byte aligned");
+    static_assert(MODE == 1 || ES == 4, "bf16 operands must be 16-byte aligned");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -100,12 +94,12 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
     const int li = lane & 31, lh = lane >> 5;
     const int key = (li >> 1) & 7;               // swizzle key of the rows this lane reads (tile row offsets are multiples of 32)
 
-    // ---- tiles of this workgroup.  Workgroups b = x (mod 8) run on XCD x: it takes a contiguous range of the ordered
-    // tile list, and its workgroups take every (gridDim/8)-th tile of that range, so the tiles in flight on an XCD are
-    // consecutive in the order below.
-    const int ntiles = g.tiles_m * g.tiles_n * g.nsplit;     // work items: (tile, K split), the splits of a tile adjacent
+    // ---- work items of this workgroup: (tile, K split) pairs.  Workgroups b = x (mod 8) run on XCD x: it takes a
+    // contiguous range of the ordered item list, and its workgroups take every (gridDim/8)-th item of that range, so the
+    // items in flight on an XCD are consecutive in the order below.
+    const int nitems = g.tiles_m * g.tiles_n * g.nsplit;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per = gridDim.x >> 3;      // gridDim.x is a multiple of 8
-    const int q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int q8 = nitems >> 3, r8 = nitems & 7;
     const int x_first = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
     const int x_count = q8 + (xcd < r8 ? 1 : 0);
     const int my_count = idx < x_count ? (x_count - idx + per - 1) / per : 0;
@@ -116,17 +110,29 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
     const int TT = T1 + T2;
     const int Tper = (TT + g.nsplit - 1) / g.nsplit;           // k-blocks per split (the host keeps every split non-empty)
 
-    auto tile_origin = [&](int i, int& m0, int& n0, int& ks, int& kb0, int& kb1) {
+    // position in the flattened (item, k-block) walk
+    struct Pos { int ti, t, m0, n0, ks, k1; bool ok; };
+    auto item = [&](int i, Pos& p) {
         // ordered tile id -> (tm, tn): groups of GR_TM_GROUP row panels; inside a group tm fastest, then tn
         const int w = x_first + idx + i * per;
         const int o = w / g.nsplit;
-        ks = w - o * g.nsplit;
-        kb0 = ks * Tper; kb1 = min(TT, kb0 + Tper);
+        p.ks = w - o * g.nsplit;
+        p.t = p.ks * Tper; p.k1 = min(TT, p.t + Tper);
         const int gsz = GR_TM_GROUP * g.tiles_n;
         const int grp = o / gsz, rem = o - grp * gsz;
         const int gh = min(GR_TM_GROUP, g.tiles_m - grp * GR_TM_GROUP);          // panels in this (maybe last, shorter) group
         const int tn = rem / gh, tm = grp * GR_TM_GROUP + (rem - tn * gh);
-        m0 = tm * BM; n0 = tn * BN;
+        p.m0 = tm * BM; p.n0 = tn * BN; p.ti = i; p.ok = true;
+    };
+    auto next = [&](const Pos& p) {
+        Pos q = p;
+        if (!p.ok) return q;
+        q.t = p.t + 1;
+        if (q.t == p.k1) {
+            if (p.ti + 1 < my_count) item(p.ti + 1, q);
+            else q.ok = false;
+        }
+        return q;
     };
 
     f32x16 acc[WM][WN];
@@ -137,26 +143,20 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // ---- staging ---------------------------------------------------------------------------------------------------
-    // thread -> 16-byte chunk p = tid & 7 (physical position) of tile rows (tid >> 3) + 32 j; logical chunk = p ^ rowkey.
-    // In LDS-DMA mode wave w's 64 lanes are exactly rows 8w .. 8w+7 (+ 32 j) x 8 chunks = 1024 contiguous LDS bytes.
+    // ---- staging: thread -> 16-byte chunk p = tid & 7 (physical position) of tile rows (tid >> 3) + 32 j; the logical chunk
+    // is p ^ rowkey (rows s_row + 32 j share the key)
     const int s_row = tid >> 3, s_p = tid & 7;
-    const int s_c = s_p ^ ((s_row >> 1) & 7);                 // (rows s_row + 32 j share the key)
-    uint4 ra[GLDS ? 1 : NA], rb[GLDS ? 1 : NB];
+    const int s_c = s_p ^ ((s_row >> 1) & 7);
 
-    auto src_of = [&](int t, const char*& A, const char*& B, int& lda, int& ldb, int& K, int& kb, int& lb) {
-        const bool second = LB2 && t >= T1;
-        A = reinterpret_cast<const char*>(second ? g.A2 : g.A1);
-        B = reinterpret_cast<const char*>(second ? g.B2 : g.B1);
-        lda = second ? g.lda2 : g.lda1; ldb = second ? g.ldb2 : g.ldb1; K = second ? g.K2 : g.K1;
-        kb = (second ? t - T1 : t) * BKE;
-        lb = (LB2 == 0 || LB1 == LB2) ? LB1 : (second ? LB2 : LB1);
-    };
-    // 16 bytes as four 4-byte pieces, no branches (a piece at or past `lim` is redirected to element 0: garbage, zeroed
-    // when it is read from LDS)
-    auto load4 = [&](const char* row, int e0, int lim) {
+    auto layout_of = [&](int t) { return (LB2 == 0 || LB1 == LB2) ? LB1 : ((LB2 && t >= T1) ? LB2 : LB1); };
+    // 16 bytes, no branches: a piece at or past `lim` is redirected to element 0 (garbage, zeroed on the LDS read path)
+    auto load16 = [&](const char* row, int e0, int lim) {
         if constexpr (MODE == 1) {
             return *reinterpret_cast<const uint4*>(row + (size_t)(e0 < lim ? e0 : 0) * ES);
+        } else if constexpr (MODE == 2) {
+            const uint2 lo = *reinterpret_cast<const uint2*>(row + (size_t)(e0 < lim ? e0 : 0) * 4);
+            const uint2 hi = *reinterpret_cast<const uint2*>(row + (size_t)(e0 + 2 < lim ? e0 + 2 : 0) * 4);
+            return make_uint4(lo.x, lo.y, hi.x, hi.y);
         } else {
             unsigned w[4];
 #pragma unroll
@@ -164,27 +164,23 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
             return make_uint4(w[0], w[1], w[2], w[3]);
         }
     };
-    auto issue = [&](int t, int m0, int n0, int buf) {       // loads of k-block t of tile (m0, n0) -> stage `buf`
-        const char *A, *B; int lda, ldb, K, kb, lb;
-        src_of(t, A, B, lda, ldb, K, kb, lb);
-        char* sa = smem + buf * STAGE;
-        char* sb = sa + A_BYTES;
+    auto fetch = [&](const Pos& p, uint4 (&ra)[NA], uint4 (&rb)[NB]) {        // global loads of k-block p.t of tile p
+        const bool second = LB2 && p.t >= T1;
+        const char* A = reinterpret_cast<const char*>(second ? g.A2 : g.A1);
+        const char* B = reinterpret_cast<const char*>(second ? g.B2 : g.B1);
+        const int lda = second ? g.lda2 : g.lda1, ldb = second ? g.ldb2 : g.ldb1, K = second ? g.K2 : g.K1;
+        const int kb = (second ? p.t - T1 : p.t) * BKE;
         const int k0 = kb + s_c * EPC;
-        const int k0c = k0 < K ? k0 : 0;                     // (a chunk that starts before K lies inside the 16-byte-multiple pitch)
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            const int row = min(m0 + s_row + 32 * j, g.M - 1);
-            const char* src = A + (size_t)row * lda * ES;
-            if constexpr (GLDS) glds16(src + (size_t)k0c * ES, sa + (wave * 8 + 32 * j) * 128);
-            else ra[j] = load4(src, k0, K);
+            const int row = min(p.m0 + s_row + 32 * j, g.M - 1);
+            ra[j] = load16(A + (size_t)row * lda * ES, k0, K);
         }
-        if (lb == 1) {
+        if (layout_of(p.t) == 1) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const int col = min(n0 + s_row + 32 * j, g.N - 1);
-                const char* src = B + (size_t)col * ldb * ES;
-                if constexpr (GLDS) glds16(src + (size_t)k0c * ES, sb + (wave * 8 + 32 * j) * 128);
-                else rb[j] = load4(src, k0, K);
+                const int col = min(p.n0 + s_row + 32 * j, g.N - 1);
+                rb[j] = load16(B + (size_t)col * ldb * ES, k0, K);
             }
         } else {
             // "nn": the tile is 32 k-rows of BN fp32, linear; thread -> 16 bytes at byte (tid + 256 j) * 16
@@ -193,108 +189,103 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
                 const int off = (tid + 256 * j) * 16;
                 const int kr = off / NN_PITCH, nc = (off - kr * NN_PITCH) >> 2;
                 const int k = kb + kr < K ? kb + kr : 0;
-                const char* src = B + (size_t)k * ldb * 4;
-                if constexpr (GLDS) glds16(src + (size_t)(n0 + nc < g.N ? n0 + nc : 0) * 4, sb + (wave * 64 + 256 * j) * 16);
-                else rb[j] = load4(src, n0 + nc, g.N);
+                rb[j] = load16(B + (size_t)k * ldb * 4, p.n0 + nc, g.N);
             }
         }
     };
-    auto stash = [&](int t, int buf) {                       // register mode: staged registers -> LDS
-        if constexpr (!GLDS) {
-            char* sa = smem + buf * STAGE;
-            char* sb = sa + A_BYTES;
-            const bool second = LB2 && t >= T1;
-            const int lb = (LB2 == 0 || LB1 == LB2) ? LB1 : (second ? LB2 : LB1);
+    // zero the elements of a 16-byte piece at k >= lim (k0 = k of its first element)
+    auto keep_k = [&](uint4 v, int k0, int lim) {
+        unsigned w[4] = {v.x, v.y, v.z, v.w};
+        if constexpr (ES == 4) {
 #pragma unroll
-            for (int j = 0; j < NA; ++j) *reinterpret_cast<uint4*>(sa + (s_row + 32 * j) * 128 + s_p * 16) = ra[j];
-            if (lb == 1) {
+            for (int e = 0; e < 4; ++e) w[e] = k0 + e < lim ? w[e] : 0u;
+        } else {
 #pragma unroll
-                for (int j = 0; j < NB; ++j) *reinterpret_cast<uint4*>(sb + (s_row + 32 * j) * 128 + s_p * 16) = rb[j];
-            } else {
+            for (int e = 0; e < 4; ++e)
+                w[e] &= (k0 + 2 * e < lim ? 0x0000ffffu : 0u) | (k0 + 2 * e + 1 < lim ? 0xffff0000u : 0u);
+        }
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    };
+    // staged registers -> LDS.  The ragged last block of a source is zero-filled past K here (a uniform branch, rare), so the
+    // MFMA loop has one shape
+    auto stash = [&](const Pos& p, int buf, uint4 (&ra)[NA], uint4 (&rb)[NB]) {
+        char* sa = smem + buf * STAGE;
+        char* sb = sa + A_BYTES;
+        const bool second = LB2 && p.t >= T1;
+        const int K = second ? g.K2 : g.K1;
+        const int kb = (second ? p.t - T1 : p.t) * BKE;
+        const bool nt = layout_of(p.t) == 1;
+        if (K - kb < BKE) {
+            const int k0 = kb + s_c * EPC;
 #pragma unroll
-                for (int j = 0; j < NB; ++j) *reinterpret_cast<uint4*>(sb + (tid + 256 * j) * 16) = rb[j];
+            for (int j = 0; j < NA; ++j) ra[j] = keep_k(ra[j], k0, K);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (nt) rb[j] = keep_k(rb[j], k0, K);
+                else if (kb + (tid + 256 * j) * 16 / NN_PITCH >= K) rb[j] = make_uint4(0u, 0u, 0u, 0u);
             }
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j) *reinterpret_cast<uint4*>(sa + (s_row + 32 * j) * 128 + s_p * 16) = ra[j];
+        if (nt) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) *reinterpret_cast<uint4*>(sb + (s_row + 32 * j) * 128 + s_p * 16) = rb[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) *reinterpret_cast<uint4*>(sb + (tid + 256 * j) * 16) = rb[j];
         }
     };
 
-    // ---- MFMAs of one k-block.  MASK: the ragged last block of a source -- operands at k >= kvalid are zeroed
-    auto mma_block = [&](int buf, int lb, int kvalid, auto mask_tag) {
-        constexpr bool MASK = decltype(mask_tag)::value;
+    // ---- operand fragments of one k-block: step s = 32 bytes of k per row (8 fp32 / 16 bf16); this lane holds the half lh
+    uint4 fa[4][WM], fb[4][WN];
+    auto read_frags = [&](int buf, int lb, int s) {
         const char* sa = smem + buf * STAGE;
         const char* sb = sa + A_BYTES;
-        const char* pa = sa + (wm0 + li) * 128;
+        const int coff = ((2 * s + lh) ^ key) << 4;
+        const char* pa = sa + (wm0 + li) * 128 + coff;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int coff = ((2 * s + lh) ^ key) << 4;
-            uint4 a[WM];
+        for (int x = 0; x < WM; ++x) fa[s][x] = *reinterpret_cast<const uint4*>(pa + x * 32 * 128);
+        if (lb == 1) {
+            const char* pb = sb + (wn0 + li) * 128 + coff;
 #pragma unroll
-            for (int x = 0; x < WM; ++x) a[x] = *reinterpret_cast<const uint4*>(pa + x * 32 * 128 + coff);
-            if (ES == 4) {
-                float b[WN][4];
-                if (lb == 1) {
-                    const char* pb = sb + (wn0 + li) * 128 + coff;
+            for (int y = 0; y < WN; ++y) fb[s][y] = *reinterpret_cast<const uint4*>(pb + y * 32 * 128);
+        } else {
+            const char* pb = sb + (8 * s + 4 * lh) * NN_PITCH + (wn0 + li) * 4;
 #pragma unroll
-                    for (int y = 0; y < WN; ++y) {
-                        const uint4 v = *reinterpret_cast<const uint4*>(pb + y * 32 * 128);
-                        b[y][0] = __uint_as_float(v.x); b[y][1] = __uint_as_float(v.y);
-                        b[y][2] = __uint_as_float(v.z); b[y][3] = __uint_as_float(v.w);
-                    }
-                } else {
-                    const char* pb = sb + (8 * s + 4 * lh) * NN_PITCH + (wn0 + li) * 4;
+            for (int y = 0; y < WN; ++y) {
+                unsigned w[4];
 #pragma unroll
-                    for (int y = 0; y < WN; ++y)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) b[y][j] = *reinterpret_cast<const float*>(pb + j * NN_PITCH + y * 128);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool live = !MASK || 8 * s + 4 * lh + j < kvalid;
-#pragma unroll
-                    for (int x = 0; x < WM; ++x) {
-                        const unsigned au = j == 0 ? a[x].x : j == 1 ? a[x].y : j == 2 ? a[x].z : a[x].w;
-                        const float av = live ? __uint_as_float(au) : 0.f;
-#pragma unroll
-                        for (int y = 0; y < WN; ++y)
-                            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, live ? b[y][j] : 0.f, acc[x][y], 0, 0, 0);
-                    }
-                }
-            } else {
-                const char* pb = sb + (wn0 + li) * 128 + coff;
-                uint4 b[WN];
-#pragma unroll
-                for (int y = 0; y < WN; ++y) b[y] = *reinterpret_cast<const uint4*>(pb + y * 32 * 128);
-                if (MASK) {
-                    const int keep = kvalid - (16 * s + 8 * lh);              // of this lane's 8 elements
-                    auto m = [&](uint4 v) {
-                        unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) w[e] &= (2 * e < keep ? 0x0000ffffu : 0u) | (2 * e + 1 < keep ? 0xffff0000u : 0u);
-                        return make_uint4(w[0], w[1], w[2], w[3]);
-                    };
-#pragma unroll
-                    for (int x = 0; x < WM; ++x) a[x] = m(a[x]);
-#pragma unroll
-                    for (int y = 0; y < WN; ++y) b[y] = m(b[y]);
-                }
-#pragma unroll
-                for (int x = 0; x < WM; ++x)
-#pragma unroll
-                    for (int y = 0; y < WN; ++y)
-                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[x]),
-                                                                            __builtin_bit_cast(bf16x8, b[y]), acc[x][y], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const unsigned*>(pb + j * NN_PITCH + y * 128);
+                fb[s][y] = make_uint4(w[0], w[1], w[2], w[3]);
             }
         }
     };
-    auto compute = [&](int t, int buf) {
-        const bool second = LB2 && t >= T1;
-        const int lb = (LB2 == 0 || LB1 == LB2) ? LB1 : (second ? LB2 : LB1);
-        const int K = second ? g.K2 : g.K1;
-        const int kvalid = K - (second ? t - T1 : t) * BKE;
-        if (kvalid >= BKE) mma_block(buf, lb, BKE, std::false_type{});
-        else mma_block(buf, lb, kvalid, std::true_type{});
+    auto mma = [&](int s) {
+        if constexpr (ES == 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int x = 0; x < WM; ++x) {
+                    const uint4 a = fa[s][x];
+                    const float av = __uint_as_float(j == 0 ? a.x : j == 1 ? a.y : j == 2 ? a.z : a.w);
+#pragma unroll
+                    for (int y = 0; y < WN; ++y) {
+                        const uint4 b = fb[s][y];
+                        const float bv = __uint_as_float(j == 0 ? b.x : j == 1 ? b.y : j == 2 ? b.z : b.w);
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[x][y], 0, 0, 0);
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int x = 0; x < WM; ++x)
+#pragma unroll
+                for (int y = 0; y < WN; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s][x]),
+                                                                        __builtin_bit_cast(bf16x8, fb[s][y]), acc[x][y], 0, 0, 0);
+        }
     };
 
-    // ---- write a finished tile: accumulator r of (x,y) <-> row wm0 + 32x + (r&3) + 8(r>>2) + 4 lh, column wn0 + 32y + li
+    // ---- write a finished item: accumulator r of (x,y) <-> row wm0 + 32x + (r&3) + 8(r>>2) + 4 lh, column wn0 + 32y + li
     auto epilogue = [&](int m0, int n0, int ks) {
         if (g.nsplit > 1) {                                   // raw partial tile; the reduce kernel applies the epilogue
             float* wsp = g.ws + (size_t)ks * g.M * g.N;
@@ -350,31 +341,48 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
         }
     };
 
-    // ---- the flattened (work item, k-block) walk: stage the next block while this one is multiplied
-    int m0, n0, ks, k0, k1, nm0, nn0, nks, nk0, nk1;
-    tile_origin(0, m0, n0, ks, k0, k1);
-    issue(k0, m0, n0, 0);
-    stash(k0, 0);
+    // ---- the walk over (item, k-block).  The staging pipeline runs ahead of the MFMAs and across item boundaries:
+    //   at the top of a step  stage[cur] holds the step's own block (visible) and the staging registers hold the next block
+    //   of the walk (`pn`; loads issued in the middle of the previous step, a whole step of MFMAs ago).  The step reads its
+    //   first two fragment groups, runs a quarter of the MFMAs, reads the other two groups, runs the second quarter, writes
+    //   the staging registers into stage[cur ^ 1] (last read before the previous barrier) and at once re-issues them for the
+    //   block after, then runs the second half of the MFMAs over those ds_writes / loads and meets the other waves at ONE
+    //   barrier.
+    uint4 ra[NA], rb[NB];
+    Pos pn;
+    item(0, pn);
+    fetch(pn, ra, rb);
+    stash(pn, 0, ra, rb);
+    pn = next(pn);
+    if (pn.ok) fetch(pn, ra, rb);
     __syncthreads();
-    int ti = 0, t = k0;
-    for (int it = 0;; ++it) {
-        int nt = t + 1, nti = ti;
-        nm0 = m0; nn0 = n0; nks = ks; nk0 = k0; nk1 = k1;
-        bool more = true;
-        if (nt == k1) {
-            nti = ti + 1;
-            more = nti < my_count;
-            if (more) { tile_origin(nti, nm0, nn0, nks, nk0, nk1); nt = nk0; }
+    int cur = 0;
+    for (int i = 0; i < my_count; ++i) {
+        Pos it;
+        item(i, it);
+        for (int t = it.t; t < it.k1; ++t) {
+            const int lb = layout_of(t);
+            read_frags(cur, lb, 0);
+            read_frags(cur, lb, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(0);
+            read_frags(cur, lb, 2);
+            read_frags(cur, lb, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1);
+            if (pn.ok) {
+                stash(pn, cur ^ 1, ra, rb);
+                pn = next(pn);
+                if (pn.ok) fetch(pn, ra, rb);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma(2);
+            mma(3);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            cur ^= 1;
         }
-        if (more) issue(nt, nm0, nn0, (it + 1) & 1);          // in flight under this block's MFMAs
-        __builtin_amdgcn_sched_barrier(0);                   // (hipcc would sink register-mode loads next to their use)
-        compute(t, it & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t == k1 - 1) epilogue(m0, n0, ks);
-        if (!more) break;
-        stash(nt, (it + 1) & 1);                             // the other stage: last read in iteration it-1, before the barrier below
-        __syncthreads();                                     // (waits for the LDS-DMA / ds_write of stage it+1 as well)
-        t = nt; ti = nti; m0 = nm0; n0 = nn0; ks = nks; k0 = nk0; k1 = nk1;
+        epilogue(it.m0, it.n0, it.ks);
     }
 }
 
@@ -404,9 +412,10 @@ __global__ __launch_bounds__(256) void gemm_rows_reduce_kernel(const GemmRowsArg
     }
 }
 
-// 16-byte alignment of an operand (base pointer and row pitch)
-static bool aligned16(const void* p, int ld_elems, int es) {
-    return reinterpret_cast<size_t>(p) % 16 == 0 && ((size_t)ld_elems * es) % 16 == 0;
+// alignment of an operand (base pointer and row pitch): 16, 8 or 4 bytes
+static int align_of(const void* p, int ld_elems, int es) {
+    const size_t v = reinterpret_cast<size_t>(p) | ((size_t)ld_elems * es);
+    return v % 16 == 0 ? 16 : v % 8 == 0 ? 8 : 4;
 }
 
 // splits of K for `tiles` output tiles and TT k-blocks: enough work items for ~2 per CU, >= 4 k-blocks per split, <= 16
@@ -479,9 +488,11 @@ static int launch_cfg(const GemmRowsArgs& a, int lb1, int lb2, float* a_ws, size
 
 template <typename T, int WM, int WN>
 static int launch_mode(const GemmRowsArgs& a, int lb1, int lb2, int mode, float* ws, size_t wsb, hipStream_t st) {
-    if (mode == 2) return launch_cfg<T, WM, WN, 2>(a, lb1, lb2, ws, wsb, st);
     if (mode == 1) return launch_cfg<T, WM, WN, 1>(a, lb1, lb2, ws, wsb, st);
-    if constexpr (sizeof(T) == 4) return launch_cfg<T, WM, WN, 0>(a, lb1, lb2, ws, wsb, st);
+    if constexpr (sizeof(T) == 4) {
+        if (mode == 2) return launch_cfg<T, WM, WN, 2>(a, lb1, lb2, ws, wsb, st);
+        return launch_cfg<T, WM, WN, 0>(a, lb1, lb2, ws, wsb, st);
+    }
     return HSP_ERR_UNSUPPORTED;                    // bf16 operands: 16-byte aligned rows
 }
 
@@ -511,12 +522,12 @@ static int gemm_rows_dispatch(const void* A1, int lda1, const void* B1, int ldb1
     if (ES == 2 && (l1 == 1 || (two && l2 == 1))) return HSP_ERR_UNSUPPORTED;     // bf16: "nt" operands only
     GemmRowsArgs g{};
     g.A1 = A1; g.B1 = B1; g.lda1 = lda1; g.ldb1 = ldb1; g.K1 = K1;
-    bool glds = aligned16(A1, lda1, ES) && aligned16(B1, ldb1, ES);
+    int al = std::min(align_of(A1, lda1, ES), align_of(B1, ldb1, ES));
     if (two) {
         g.A2 = A2; g.B2 = B2; g.lda2 = lda2; g.ldb2 = ldb2; g.K2 = K2;
-        glds = glds && aligned16(A2, lda2, ES) && aligned16(B2, ldb2, ES);
+        al = std::min(al, std::min(align_of(A2, lda2, ES), align_of(B2, ldb2, ES)));
     }
-    if (!glds && ES == 4) {                                    // register mode reads 4-byte pieces
+    if (al < 16 && ES == 4) {                                  // 8- or 4-byte pieces
         const void* ps[4] = {A1, B1, A2, B2};
         for (const void* q : ps)
             if (reinterpret_cast<size_t>(q) % 4) return HSP_ERR_UNSUPPORTED;
@@ -540,8 +551,7 @@ static int gemm_rows_dispatch(const void* A1, int lda1, const void* B1, int ldb1
     hipStream_t st = as_stream(stream);
     bool small = prefer_small_tile(M, N);
     if (const char* e = getenv("HSP_GEMM_TILE")) small = e[0] == 's' ? true : e[0] == 'l' ? false : small;   // profiling override
-    int mode = glds ? 1 : 0;                                   // aligned: 16-byte register staging (LDS-DMA measured slower here)
-    if (const char* e = getenv("HSP_GEMM_GLDS")) { if (glds && e[0] == '1') mode = 2; }                        // profiling override
+    const int mode = al == 16 ? 1 : al == 8 ? 2 : 0;           // staging load width
     g.nsplit = 1;
     if (small) return launch_mode<T, 1, 1>(g, lb1, lb2, mode, reinterpret_cast<float*>(ws), ws ? ws_bytes : 0, st);
     return launch_mode<T, 2, 2>(g, lb1, lb2, mode, reinterpret_cast<float*>(ws), ws ? ws_bytes : 0, st);
