@@ -70,20 +70,8 @@ def make_inputs(B, N, device, seed=0):
     return centred.to(device), obj.to(device), dfeat.to(device)
 
 
-def u3_full_step(B, N, device, steps=12, warmup=4):
-    """unit U3 of SURVEY 8(d) = BASELINE configs[1] as worded ("full HSPose forward+backward"): HSPose.forward(do_loss=True)
-    -- on-device augmentation, backbone, the three pose heads + reconstruction / face heads, the 19 loss terms -- backward,
-    clip_grad_norm_(5), fused Ranger step, exactly the body of the reference's engine/train.py:72-110, on B synthetic clouds
-    with a synthetic pose / size ground truth.  The network's forward / backward replay from two hipGraphs
-    (graph.py::GraphedNetwork); losses, augmentation and optimizer are issued eagerly.  Reported next to the headline,
-    never instead of it."""
-    from hs_pose_amd.config import FLAGS
-    from hs_pose_amd.HSPose import HSPose
-    from hs_pose_amd.train import TrainDriver
-    FLAGS.reset(); FLAGS.train = 1
-    torch.manual_seed(0)
-    net = HSPose("PoseNet_only").to(device).train()
-    drv = TrainDriver(net, total_iters=150 * 1500, check_nan=False)
+def u3_case(B, N, device):
+    """synthetic training batch of B clouds x N points with a pose / size ground truth (HSPose.forward's keyword set)"""
     g = torch.Generator().manual_seed(7)
     pc = torch.randn(B, N, 3, generator=g) * 0.05 + torch.tensor([0.0, 0.0, 0.8])
     obj = torch.randint(0, 6, (B,), generator=g).float()
@@ -96,7 +84,25 @@ def u3_full_step(B, N, device, steps=12, warmup=4):
                 sym=sym_table[obj.long()], aug_bb=torch.ones(B, 3), aug_rt_t=torch.zeros(B, 3),
                 aug_rt_r=torch.eye(3).repeat(B, 1, 1), model_point=0.5 * torch.randn(B, 32, 3, generator=g),
                 nocs_scale=torch.full((B,), 0.3))
-    case = {k: v.to(device) for k, v in case.items()}
+    return {k: v.to(device) for k, v in case.items()}
+
+
+def u3_full_step(B, N, device, steps=12, warmup=4):
+    """unit U3 of SURVEY 8(d) = BASELINE configs[1] as worded ("full HSPose forward+backward"): HSPose.forward(do_loss=True)
+    -- on-device augmentation, backbone, the three pose heads + reconstruction / face heads, the 19 loss terms -- backward,
+    clip_grad_norm_(5), fused Ranger step, exactly the body of the reference's engine/train.py:72-110, on B synthetic clouds
+    with a synthetic pose / size ground truth.  The network's forward / backward replay from two hipGraphs
+    (graph.py::GraphedNetwork); the 19 loss terms and their gradients are libhsp's five loss kernels
+    (hs_pose_amd/fused_losses.py); augmentation and optimizer are issued eagerly.  Reported next to the headline, never
+    instead of it."""
+    from hs_pose_amd.config import FLAGS
+    from hs_pose_amd.HSPose import HSPose
+    from hs_pose_amd.train import TrainDriver
+    FLAGS.reset(); FLAGS.train = 1
+    torch.manual_seed(0)
+    net = HSPose("PoseNet_only").to(device).train()
+    drv = TrainDriver(net, total_iters=150 * 1500, check_nan=False)
+    case = u3_case(B, N, device)
     net.enable_graphed_posenet(case["PC"], case["obj_id"])
 
     def step():
@@ -114,7 +120,8 @@ def u3_full_step(B, N, device, steps=12, warmup=4):
     ms = 1e3 * (time.perf_counter() - t0) / steps
     FLAGS.reset()
     return {"u3_ms_per_step": round(ms, 3), "u3_clouds_per_s": round(B * 1e3 / ms, 1), "u3_steps": steps,
-            "u3_unit": "HSPose.forward(do_loss=True) + backward + clip + Ranger, network graphed, losses / optimizer eager"}
+            "u3_unit": "HSPose.forward(do_loss=True) + backward + clip + Ranger; network graphed, fused loss kernels, "
+                       "augmentation / optimizer eager"}
 
 
 def cpu_baseline(n_points, sample_clouds):

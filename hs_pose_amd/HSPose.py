@@ -6,6 +6,8 @@ HSPose.py:39-48), the on-device augmentation (``FLAGS.train``, HSPose.py:53-61, 
 training losses (``do_loss=True``, HSPose.py:84-181, hs_pose_amd/losses.py): ``forward`` returns ``output_dict``
 or ``(output_dict, loss_dict)`` with the four sub-dictionaries ``engine/train.py:84-90`` sums.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -73,6 +75,11 @@ class HSPose(nn.Module):
         if not do_loss:
             return output_dict
 
+        if self.fused_losses and PC.is_cuda and self.train_stage == 'PoseNet_only' and FLAGS.prop_sym_w > 0:
+            # the same 19 terms from libhsp's five loss kernels (fused_losses.py; csrc/losses.hip)
+            from .fused_losses import pose_losses
+            return output_dict, pose_losses(out, PC, gt_R, gt_t, gt_s, mean_shape, sym, obj_id)
+
         # the four loss modules read their inputs from dictionaries keyed as in the reference (HSPose.py:84-160); the axis
         # confidences enter every loss except fs_net's own confidence terms as constants (detached)
         axes = {'Rot1': out['p_green_R'], 'Rot2': out['p_red_R']}
@@ -97,6 +104,8 @@ class HSPose(nn.Module):
         return output_dict, loss_dict
 
     graphed_posenet = None
+    # device batches take the fused loss kernels; HSP_FUSED_LOSSES=0 keeps the torch-op composition of losses.py (A/B runs)
+    fused_losses = os.environ.get("HSP_FUSED_LOSSES", "1") != "0"
 
     def enable_graphed_posenet(self, PC, obj_id):
         """capture ``posenet`` forward / backward for training batches of this shape (hs_pose_amd.graph.GraphedNetwork);

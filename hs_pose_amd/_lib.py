@@ -84,7 +84,18 @@ SIGNATURES = {
     "hsp_fps_workspace_bytes": (_sz, [_i, _i]),
     "hsp_fps_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "hsp_fps_f64": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "hsp_pose_losses_workspace_bytes": (_sz, [_i]),
+    "hsp_pose_losses_fwd": (_i, [_vp] * 17 + [_i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "hsp_pose_losses_bwd": (_i, [_vp] * 17 + [_i, _i, _vp, _vp, _vp, _sz] + [_vp] * 11 + [_vp]),
 }
+
+
+class HspLossCfg(ctypes.Structure):
+    """include/hsp.h: HspLossCfg (a HOST struct)"""
+    _fields_ = [(n, ctypes.c_float) for n in (
+        "rot_1_w", "rot_2_w", "rot_regular", "tran_w", "size_w", "r_con_w", "recon_n_w", "recon_d_w", "recon_f_w",
+        "recon_v_w", "recon_bb_r_w", "recon_bb_t_w", "recon_bb_s_w", "recon_bb_self_w", "geo_p_w", "prop_pm_w",
+        "prop_sym_w")] + [("smooth_l1", ctypes.c_int)]
 
 
 class HspError(RuntimeError):

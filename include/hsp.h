@@ -405,6 +405,41 @@ int hsp_bn_relu_bwd_bf16(const hsp_bf16_t *x, const hsp_bf16_t *dy, int R, int C
                          const float *save_mean, const float *save_invstd, int relu, hsp_bf16_t *dx, float *dgamma,
                          float *dbeta, void *ws, size_t ws_bytes, hspStream_t stream);
 
+/* ---- training losses of the PoseNet_only stage -----------------------------------------------------------
+ * replaces, for one batch, the four loss modules as network/HSPose.py:84-160 wires them:
+ *   fs_net_loss          losses/fs_net_loss.py:95-235      Rot1 Rot1_cos Rot2 Rot2_cos Rot_r_a Tran Size R_con
+ *   recon_6face_loss     losses/recon_loss.py:464-649      recon_per_p recon_p_f recon_point_{vote,r,t,s,self}
+ *   geo_transform_loss   losses/geometry_loss.py:123-150   geo_point
+ *   prop_rot_loss        losses/prop_loss.py:156-276       Prop_pm Prop_sym_recon Prop_sym_rt
+ * terms (19) in that order, each already multiplied by its FLAGS weight.  PC (B,N,3), gt_R (B,3,3), gt_t / gt_s /
+ * mean_shape (B,3), sym (B,4), obj_id (B) fp32; network outputs recon (B,N,3), face_normal (B,N,6,3), face_dis / face_f
+ * (B,N,6) in the network's face order (y+ x+ z+ x- z- y-), p_green / p_red / pred_T / pred_s (B,3), f_green / f_red (B).
+ * The axis confidences are variables only in R_con and the face confidences only in recon_p_f (HSPose.py detaches them
+ * elsewhere).  `cfg` is a HOST struct.  The workspace written by _fwd is read by _bwd (keep it until then).
+ * _bwd: grad_terms (19) = d(objective)/d(term); every d_* buffer is OVERWRITTEN with the gradient w.r.t. that network output;
+ * d_mom_scratch: B*54 floats.  Five launches in all; sums in a fixed order (bit-reproducible). */
+#define HSP_LOSS_TERMS 19
+typedef struct HspLossCfg {       /* config/config.py:64-93 */
+    float rot_1_w, rot_2_w, rot_regular, tran_w, size_w, r_con_w;
+    float recon_n_w, recon_d_w, recon_f_w, recon_v_w, recon_bb_r_w, recon_bb_t_w, recon_bb_s_w, recon_bb_self_w;
+    float geo_p_w, prop_pm_w, prop_sym_w;
+    int smooth_l1;                /* fsnet_loss_type: 0 = 'l1', 1 = 'smoothl1' (beta 0.5) */
+} HspLossCfg;
+size_t hsp_pose_losses_workspace_bytes(int B);
+int hsp_pose_losses_fwd(const float *PC, const float *gt_R, const float *gt_t, const float *gt_s, const float *mean_shape,
+                        const float *sym, const float *obj_id, const float *recon, const float *face_normal,
+                        const float *face_dis, const float *face_f, const float *p_green, const float *p_red,
+                        const float *f_green, const float *f_red, const float *pred_T, const float *pred_s, int B, int N,
+                        const HspLossCfg *cfg, float *terms, void *ws, size_t ws_bytes, hspStream_t stream);
+int hsp_pose_losses_bwd(const float *PC, const float *gt_R, const float *gt_t, const float *gt_s, const float *mean_shape,
+                        const float *sym, const float *obj_id, const float *recon, const float *face_normal,
+                        const float *face_dis, const float *face_f, const float *p_green, const float *p_red,
+                        const float *f_green, const float *f_red, const float *pred_T, const float *pred_s, int B, int N,
+                        const HspLossCfg *cfg, const float *grad_terms, const void *ws, size_t ws_bytes,
+                        float *d_mom_scratch, float *d_recon, float *d_face_normal, float *d_face_dis, float *d_face_f,
+                        float *d_green, float *d_red, float *d_f_green, float *d_f_red, float *d_T, float *d_s,
+                        hspStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
