@@ -224,21 +224,22 @@ class GraphedTrainStep:
     static device tensors with HSPose.forward's keyword names (``load_batch`` copies new data in); gradients land in
     the fused optimizer's flat buffer.  Eagerly the step is CPU-bound (~2500 tiny launches in the losses alone).
 
-    The process must start with ``DEBUG_CLR_GRAPH_PACKET_CAPTURE=0`` in the environment (the constructor refuses to run
-    otherwise).  With ROCm 7.2's default AQL-packet capture of graph kernel nodes, ATen's multi-block reductions (the
-    semaphore-ordered global-reduce path: bias-gradient column sums over 16448 rows, ``max`` over the points) replay with
-    wrong results at B=16, N=1028 -- measured: a head's ``conv2.bias`` gradient of 17 instead of 2e-7, every other
-    parameter equal to the eager step to rounding; with the flag off all 19 losses and all gradients match eager.  The
-    kernel-only graph of ``GraphedStep`` is not affected and keeps the default.
+    Runtime note.  In round 1 the step still held ATen multi-block reductions (bias-gradient column sums over 16448 rows,
+    ``max`` over the points, the ~2 200 small kernels of the losses) and two of them replayed with wrong results under ROCm
+    7.2's default AQL-packet capture of graph kernel nodes, so the constructor demanded ``DEBUG_CLR_GRAPH_PACKET_CAPTURE=0``.
+    With the heads on ``ops.linear_rows`` / ``ops.points_max`` and the losses in libhsp's five kernels the captured step
+    replays equal to the eager step under the DEFAULT runtime (tests/test_gpu_train_graph.py, B=4 N=256 and B=16 N=1028:
+    every loss term, gradient and updated parameter), and the flag is no longer needed.  The replay of this one large
+    graph is still slower (30 ms at B=16 N=1028) than the eager step with ``GraphedNetwork`` (10 ms), which stays the
+    default training path; under rocprofv3 (which dispatches the nodes one by one) the same replay spans 11.4 ms for
+    10.2 ms of kernel time, so the cost is in the runtime's execution of the mixed kernel / copy node graph, not in the
+    kernels.
 
     Build it BEFORE the network's first eager backward: autograd binds each parameter's gradient accumulator to the
     stream of its first use, and an accumulator bound to another stream than the capture stream is executed outside
     the capture (the replayed graph then reads freed memory).  The warm-up iterations here run on the capture stream."""
 
     def __init__(self, network, optimizer, batch, scheduler=None, max_norm=5, warmup=3):
-        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0" and os.environ.get("HSP_TRAIN_GRAPH_UNCHECKED") != "1":
-            raise RuntimeError("GraphedTrainStep: start the process with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (before the "
-                               "first HIP call) -- ATen reductions replay incorrectly under the packet-capture graph path")
         self.net, self.opt, self.sched, self.max_norm = network, optimizer, scheduler, max_norm
         self.batch = batch
         PC = batch["PC"]
@@ -261,7 +262,8 @@ class GraphedTrainStep:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, **_CAPTURE):
+            # capture ON THE WARM-UP STREAM: the parameters' gradient accumulators were bound to it by the warm-up backward
+            with torch.cuda.graph(self.graph, stream=side, **_CAPTURE):
                 self._body()
         finally:
             keep.__exit__()

@@ -1,5 +1,5 @@
-"""Run by test_gpu_train_graph.py in a fresh process (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 has to be in the environment
-before the HIP runtime starts): one GraphedTrainStep replay against the same step issued eagerly on a twin network --
+"""Run by test_gpu_train_graph.py in a fresh process (the HIP runtime reads DEBUG_CLR_GRAPH_PACKET_CAPTURE when it
+starts): one GraphedTrainStep replay against the same step issued eagerly on a twin network --
 all loss terms, every parameter gradient and the parameters after the Ranger step.
 usage: python tests/_train_graph_check.py B N
 """

@@ -9,9 +9,6 @@ import os
 import sys
 import time
 
-# read by the HIP runtime when it starts: GraphedTrainStep needs it (see hs_pose_amd/graph.py)
-if "--no-graph" not in sys.argv and "--graph-net" not in sys.argv:
-    os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
 import torch
