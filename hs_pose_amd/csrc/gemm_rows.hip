@@ -237,18 +237,19 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
     };
 
     // ---- operand fragments of one k-block: step s = 32 bytes of k per row (8 fp32 / 16 bf16); this lane holds the half lh
-    uint4 fa[4][WM], fb[4][WN];
+    // (two fragment sets alive at a time: step s lives in set s & 1)
+    uint4 fa[2][WM], fb[2][WN];
     auto read_frags = [&](int buf, int lb, int s) {
         const char* sa = smem + buf * STAGE;
         const char* sb = sa + A_BYTES;
         const int coff = ((2 * s + lh) ^ key) << 4;
         const char* pa = sa + (wm0 + li) * 128 + coff;
 #pragma unroll
-        for (int x = 0; x < WM; ++x) fa[s][x] = *reinterpret_cast<const uint4*>(pa + x * 32 * 128);
+        for (int x = 0; x < WM; ++x) fa[s & 1][x] = *reinterpret_cast<const uint4*>(pa + x * 32 * 128);
         if (lb == 1) {
             const char* pb = sb + (wn0 + li) * 128 + coff;
 #pragma unroll
-            for (int y = 0; y < WN; ++y) fb[s][y] = *reinterpret_cast<const uint4*>(pb + y * 32 * 128);
+            for (int y = 0; y < WN; ++y) fb[s & 1][y] = *reinterpret_cast<const uint4*>(pb + y * 32 * 128);
         } else {
             const char* pb = sb + (8 * s + 4 * lh) * NN_PITCH + (wn0 + li) * 4;
 #pragma unroll
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
                 unsigned w[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const unsigned*>(pb + j * NN_PITCH + y * 128);
-                fb[s][y] = make_uint4(w[0], w[1], w[2], w[3]);
+                fb[s & 1][y] = make_uint4(w[0], w[1], w[2], w[3]);
             }
         }
     };
@@ -266,11 +267,11 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int x = 0; x < WM; ++x) {
-                    const uint4 a = fa[s][x];
+                    const uint4 a = fa[s & 1][x];
                     const float av = __uint_as_float(j == 0 ? a.x : j == 1 ? a.y : j == 2 ? a.z : a.w);
 #pragma unroll
                     for (int y = 0; y < WN; ++y) {
-                        const uint4 b = fb[s][y];
+                        const uint4 b = fb[s & 1][y];
                         const float bv = __uint_as_float(j == 0 ? b.x : j == 1 ? b.y : j == 2 ? b.z : b.w);
                         acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[x][y], 0, 0, 0);
                     }
@@ -280,12 +281,14 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
             for (int x = 0; x < WM; ++x)
 #pragma unroll
                 for (int y = 0; y < WN; ++y)
-                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s][x]),
-                                                                        __builtin_bit_cast(bf16x8, fb[s][y]), acc[x][y], 0, 0, 0);
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][x]),
+                                                                        __builtin_bit_cast(bf16x8, fb[s & 1][y]), acc[x][y], 0, 0, 0);
         }
     };
 
     // ---- write a finished item: accumulator r of (x,y) <-> row wm0 + 32x + (r&3) + 8(r>>2) + 4 lh, column wn0 + 32y + li
+    // (a row-per-lane form -- MFMA operands swapped, 8-byte stores of 4 consecutive columns -- was measured slower: a store
+    // instruction then touches 32 rows instead of 2)
     auto epilogue = [&](int m0, int n0, int ks) {
         if (g.nsplit > 1) {                                   // raw partial tile; the reduce kernel applies the epilogue
             float* wsp = g.ws + (size_t)ks * g.M * g.N;
@@ -300,10 +303,13 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
                         if (col < g.N && row < g.M) wsp[(size_t)row * g.N + col] = acc[x][y][r];
                         acc[x][y][r] = 0.f;
                     }
+                __builtin_amdgcn_sched_barrier(0);
             }
             return;
         }
         const int rpc = g.rows_per_cloud;
+        // bf16 output in column pairs: needs dword-aligned pairs (even N and pitch, 4-byte aligned base)
+        const bool pack2 = ES == 2 && !g.c_f32 && ((g.N | g.ldc) & 1) == 0 && (reinterpret_cast<size_t>(g.C) & 3) == 0;
         int c0 = 0, nb = 0x7fffffff;                      // per-cloud bias: cloud boundaries by comparison, no per-row division
         if (g.cbias) { c0 = m0 / rpc; nb = (c0 + 1) * rpc; }
 #pragma unroll
@@ -315,11 +321,13 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
             if (g.xyz3 && cok) { w30 = g.w3[col * 3]; w31 = g.w3[col * 3 + 1]; w32 = g.w3[col * 3 + 2]; }
 #pragma unroll
             for (int x = 0; x < WM; ++x) {
+                float keep[16];                               // (bf16 output) finished values, packed in pairs below
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm0 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     float v = g.alpha * acc[x][y][r] + bv;
                     acc[x][y][r] = 0.f;
+                    keep[r] = 0.f;
                     if (!cok || row >= g.M) continue;
                     if (g.resid) {
                         if (ES == 4) v += reinterpret_cast<const float*>(g.resid)[(size_t)row * g.ldr + col];
@@ -335,8 +343,28 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
                         v += g.cbias[(size_t)c * g.N + col];
                     }
                     if (ES == 4 || g.c_f32) reinterpret_cast<float*>(g.C)[(size_t)row * g.ldc + col] = v;
-                    else reinterpret_cast<unsigned short*>(g.C)[(size_t)row * g.ldc + col] = f32_to_bf16(v);
+                    else if (!pack2) reinterpret_cast<unsigned short*>(g.C)[(size_t)row * g.ldc + col] = f32_to_bf16(v);
+                    else keep[r] = v;
                 }
+                if (ES == 2 && !g.c_f32 && pack2) {
+                    // 2-byte stores run at half the rate of 4-byte ones (measured: the fp32-output form of the same product is
+                    // faster): neighbouring lanes trade values so that the even lane of a pair owns both columns of the
+                    // even register rows and the odd lane those of the odd rows -- 8 dword stores instead of 16 short ones
+                    const bool odd = li & 1;
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) {
+                        const float mine = odd ? keep[2 * p + 1] : keep[2 * p];
+                        const float give = odd ? keep[2 * p] : keep[2 * p + 1];
+                        const float got = __shfl_xor(give, 1);
+                        const int r = 2 * p + (odd ? 1 : 0);
+                        const int row = m0 + wm0 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const unsigned lo = f32_to_bf16(odd ? got : mine), hi = f32_to_bf16(odd ? mine : got);
+                        if (row < g.M && (col | 1) < g.N)      // (pack2: N is even, so the pair is inside or outside together)
+                            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(g.C) + (size_t)row * g.ldc + (col & ~1)) =
+                                lo | (hi << 16);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);        // one 32 x 32 block at a time: keeps the live set of the unrolled body small
             }
         }
     };
@@ -344,8 +372,8 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
     // ---- the walk over (item, k-block).  The staging pipeline runs ahead of the MFMAs and across item boundaries:
     //   at the top of a step  stage[cur] holds the step's own block (visible) and the staging registers hold the next block
     //   of the walk (`pn`; loads issued in the middle of the previous step, a whole step of MFMAs ago).  The step reads its
-    //   first two fragment groups, runs a quarter of the MFMAs, reads the other two groups, runs the second quarter, writes
-    //   the staging registers into stage[cur ^ 1] (last read before the previous barrier) and at once re-issues them for the
+    //   first two fragment groups, runs a quarter of the MFMAs, reads the third group into the freed set, runs the second
+    //   quarter, reads the fourth, writes the staging registers into stage[cur ^ 1] (last read before the previous barrier) and at once re-issues them for the
     //   block after, then runs the second half of the MFMAs over those ds_writes / loads and meets the other waves at ONE
     //   barrier.
     uint4 ra[NA], rb[NB];
@@ -367,9 +395,9 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsArgs g) {
             __builtin_amdgcn_sched_barrier(0);
             mma(0);
             read_frags(cur, lb, 2);
-            read_frags(cur, lb, 3);
             __builtin_amdgcn_sched_barrier(0);
             mma(1);
+            read_frags(cur, lb, 3);
             if (pn.ok) {
                 stash(pn, cur ^ 1, ra, rb);
                 pn = next(pn);
@@ -498,7 +526,10 @@ static int launch_mode(const GemmRowsArgs& a, int lb1, int lb2, int mode, float*
 
 // tile shape: the one whose tiles fill the 256 CUs most evenly (cost = tiles per CU, rounded up, x tile area; the small
 // tile pays ~6 % for its extra operand traffic)
-static bool prefer_small_tile(int M, int N) {
+static bool prefer_small_tile(int M, int N, int TT = 1 << 30) {
+    // short K (<= 4 k-blocks): the epilogue is a large share of a tile's life; the small tile keeps several workgroups per CU
+    // to overlap it with the others' MFMAs (measured 66 vs 83 us fp32, 420 vs 538 us bf16 on the K = 128 layer products)
+    if (TT <= 4 && (long long)((M + 63) / 64) * ((N + 63) / 64) >= HSP_NUM_CU) return true;
     auto cost = [&](int bm, int bn, double pen) {
         const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
         return (double)((tiles + HSP_NUM_CU - 1) / HSP_NUM_CU) * bm * bn * pen;
@@ -549,7 +580,8 @@ static int gemm_rows_dispatch(const void* A1, int lda1, const void* B1, int ldb1
     }
     if (two && lb1 == 2 && lb2 == 2) return HSP_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);
-    bool small = prefer_small_tile(M, N);
+    const int TTall = (K1 + 128 / ES - 1) / (128 / ES) + (two ? (K2 + 128 / ES - 1) / (128 / ES) : 0);
+    bool small = prefer_small_tile(M, N, TTall);
     if (const char* e = getenv("HSP_GEMM_TILE")) small = e[0] == 's' ? true : e[0] == 'l' ? false : small;   // profiling override
     const int mode = al == 16 ? 1 : al == 8 ? 2 : 0;           // staging load width
     g.nsplit = 1;
@@ -605,7 +637,7 @@ extern "C" size_t hsp_gemm_rows_workspace_bytes(int M, int N, int K1, int K2, in
     if (M <= 0 || N <= 0 || K1 <= 0 || (elem_bytes != 2 && elem_bytes != 4)) return 0;
     const int bke = 128 / elem_bytes;
     const int TT = (K1 + bke - 1) / bke + (K2 > 0 ? (K2 + bke - 1) / bke : 0);
-    const bool small = prefer_small_tile(M, N);
+    const bool small = prefer_small_tile(M, N, TT);
     const int bm = small ? 64 : 128;
     const int ns = gemm_rows_pick_split((long long)((M + bm - 1) / bm) * ((N + bm - 1) / bm), TT);
     return ns > 1 ? (size_t)ns * M * N * sizeof(float) : 0;

@@ -80,7 +80,9 @@ def test_gemm_rows_f32_strided_views(dev, ref):
 
 @pytest.mark.parametrize("M,N,K1,K2,use_bias,use_resid,rpc", [
     (8192, 1024, 128, 0, True, False, 0), (8192, 128, 128, 128, False, True, 4096), (4096, 2048, 256, 0, True, False, 0),
-    (1000, 136, 72, 40, True, True, 300), (2048, 1024, 1288, 0, True, False, 0), (64, 64, 64, 0, False, False, 0)])
+    (1000, 136, 72, 40, True, True, 300), (2048, 1024, 1288, 0, True, False, 0), (64, 64, 64, 0, False, False, 0),
+    # enough tiles for the 256 x 128 workgroup tile (128 x 64 per wave): plain, ragged rows, dual source + every epilogue
+    (65536, 512, 128, 0, True, False, 0), (65500, 520, 200, 0, False, False, 0), (65536, 512, 128, 128, True, True, 4096)])
 def test_gemm_rows_bf16(dev, ref, M, N, K1, K2, use_bias, use_resid, rpc):
     from hs_pose_amd import ops
     h = lambda shape, seed: ref.hash_tensor(shape, seed, 1.0).to(dev)

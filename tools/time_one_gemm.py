@@ -12,7 +12,7 @@ A = torch.randn(M, pad(K), device=dev).to(dt)[:, :K]
 B = (torch.randn(K, N, device=dev) if nn else torch.randn(N, pad(K), device=dev)[:, :K]).to(dt)
 if not nn and "pitch" in sys.argv:
     B = torch.randn(N, pad(K), device=dev).to(dt)[:, :K]
-out = torch.empty(M, N, device=dev, dtype=dt)
+out = torch.empty(M, N, device=dev, dtype=torch.float32 if "f32out" in sys.argv else dt)
 fn = lambda: ops.gemm_rows(A, B, nn, out=out)
 fn(); torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()

@@ -4,6 +4,13 @@
 import csv, collections, sys
 f = sys.argv[1]
 rows = list(csv.DictReader(open(f)))
+if sys.argv[2].startswith("last"):
+    # "last<k>": only the final k steps (after warm-up / library tuning), split at the concat_rows_kernel dispatches
+    k = int(sys.argv[2][4:] or 3)
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    marks = [i for i, r in enumerate(rows) if "concat_rows_kernel" in r["Kernel_Name"]]
+    rows = rows[marks[-k - 1]:marks[-1]]
+    sys.argv[2] = str(k)
 steps = float(sum("concat_rows_kernel" in r["Kernel_Name"] for r in rows)) if sys.argv[2] == "auto" else float(sys.argv[2])
 flt = sys.argv[3].split(",") if len(sys.argv) > 3 else None
 acc = collections.defaultdict(list)
