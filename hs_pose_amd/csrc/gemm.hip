@@ -216,6 +216,177 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// ---- bf16 point rows on the bf16 matrix cores ---------------------------------------------------------------------------
+// Same product, partial-sum layout and reduce kernel as above, for A (K x M) / B (K x N) stored in bf16 with M, N multiples
+// of 128.  v_mfma_f32_32x32x16_bf16 wants 8 consecutive k per lane, the rows are k-major: each staging thread loads an
+// 8 (k) x 8 (m) block (eight 16-byte row pieces), transposes it in registers (16-bit interleaves: v_perm_b32; the 32-bit
+// steps of the transpose are register renaming) and writes eight 16-byte (m, 8 k) chunks into an LDS image [m][64 k] with the
+// chunk position XOR-swizzled by the row -- the image gemm_rows.hip's MFMA loop reads conflict-free with ds_read_b128.
+// Workgroup: 128 x 128 output tile x one K slice, waves 2 x 2 (64 x 64 each), 64 k per block, two stages (64 KB LDS).
+// The kernel is HBM-bound (one pass over A and B): 8 loads of 16 bytes per thread in flight, 2 workgroups per CU.
+using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
+
+template <bool COLSUM>
+__global__ __launch_bounds__(256) void wgrad_bf16_mfma_kernel(const unsigned short* __restrict__ A, int lda,
+                                                              const unsigned short* __restrict__ B, int ldb, int M, int N,
+                                                              int K, int kslice, float* __restrict__ part,
+                                                              float* __restrict__ cs_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int OP_BYTES = 128 * 128;          // one operand image: 128 rows (m or n) x 64 k x 2 B
+    constexpr int STAGE = 2 * OP_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_m = M >> 7, tiles = tiles_m * (N >> 7);
+    const int slice = blockIdx.x / tiles, t = blockIdx.x - slice * tiles;
+    const int tn = t / tiles_m, tm = t - tn * tiles_m;
+    const int m0 = tm << 7, n0 = tn << 7;
+    const int k0 = slice * kslice, k1 = min(K, k0 + kslice);
+    const int nblk = (k1 - k0 + 63) >> 6;
+
+    // staging role: waves 0,1 transpose A blocks, waves 2,3 B blocks; block = (k octet kb8, 8-column chunk mc)
+    const int half = tid >> 7, id = tid & 127;
+    const int kb8 = id >> 4, mc = id & 15;
+    const unsigned short* src = half ? B + n0 + mc * 8 : A + m0 + mc * 8;
+    const int ld = half ? ldb : lda;
+    char* const img = smem + half * OP_BYTES;
+
+    uint4 r[8];
+    float cs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+    auto fetch = [&](int b) {
+        const int kr = k0 + (b << 6) + (kb8 << 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = kr + j < k1 ? kr + j : k1 - 1;                  // clamped (branch-free); zeroed in stash
+            r[j] = *reinterpret_cast<const uint4*>(src + (size_t)row * ld);
+        }
+    };
+    auto stash = [&](int b, int buf) {
+        const int kr = k0 + (b << 6) + (kb8 << 3);
+        if (kr + 8 > k1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (kr + j >= k1) r[j] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (COLSUM && half == 1 && tm == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned w[4] = {r[j].x, r[j].y, r[j].z, r[j].w};
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    cs[2 * d] += __uint_as_float(w[d] << 16);
+                    cs[2 * d + 1] += __uint_as_float(w[d] & 0xffff0000u);
+                }
+            }
+        }
+        // out[e][i]: row e of the block (m = 8 mc + e), k pair i (k = 2i, 2i + 1)
+        unsigned o[8][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned x[4] = {r[2 * i].x, r[2 * i].y, r[2 * i].z, r[2 * i].w};
+            const unsigned y[4] = {r[2 * i + 1].x, r[2 * i + 1].y, r[2 * i + 1].z, r[2 * i + 1].w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                o[2 * d][i] = __builtin_amdgcn_perm(y[d], x[d], 0x05040100u);       // (x.lo16, y.lo16)
+                o[2 * d + 1][i] = __builtin_amdgcn_perm(y[d], x[d], 0x07060302u);   // (x.hi16, y.hi16)
+            }
+        }
+        char* base = img + buf * STAGE;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int row = (mc << 3) + e;
+            *reinterpret_cast<uint4*>(base + row * 128 + ((kb8 ^ ((row >> 1) & 7)) << 4)) = make_uint4(o[e][0], o[e][1], o[e][2], o[e][3]);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int li = lane & 31, lh = lane >> 5;
+    const int key = (li >> 1) & 7;
+    auto compute = [&](int buf) {
+        const char* sa = smem + buf * STAGE + (wm0 + li) * 128;
+        const char* sb = smem + buf * STAGE + OP_BYTES + (wn0 + li) * 128;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int coff = ((2 * s + lh) ^ key) << 4;
+            uint4 fa[2], fb[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) fa[x] = *reinterpret_cast<const uint4*>(sa + x * 32 * 128 + coff);
+#pragma unroll
+            for (int y = 0; y < 2; ++y) fb[y] = *reinterpret_cast<const uint4*>(sb + y * 32 * 128 + coff);
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[x]),
+                                                                        __builtin_bit_cast(bf16x8_t, fb[y]), acc[x][y], 0, 0, 0);
+        }
+    };
+
+    if (nblk > 0) {
+        fetch(0);
+        stash(0, 0);
+    }
+    __syncthreads();
+    for (int b = 0; b < nblk; ++b) {
+        if (b + 1 < nblk) fetch(b + 1);
+        compute(b & 1);
+        if (b + 1 < nblk) stash(b + 1, (b + 1) & 1);
+        __syncthreads();
+    }
+    // partial tile: accumulator q of (x,y) <-> row wm0 + 32x + (q&3) + 8(q>>2) + 4 lh, column wn0 + 32y + li
+    float* pc = part + (size_t)slice * M * N;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = m0 + wm0 + 32 * x + (q & 3) + 8 * (q >> 2) + 4 * lh;
+                pc[(size_t)row * N + n0 + wn0 + 32 * y + li] = acc[x][y][q];
+            }
+    if (COLSUM && tm == 0) {
+        float* red = reinterpret_cast<float*>(smem);          // [8 k octets][128 columns]  (all stages are dead here)
+        if (half == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[kb8 * 128 + mc * 8 + e] = cs[e];
+        }
+        __syncthreads();
+        if (tid < 128) {
+            float v = red[tid];
+#pragma unroll
+            for (int o8 = 1; o8 < 8; ++o8) v += red[o8 * 128 + tid];
+            cs_part[(size_t)slice * N + n0 + tid] = v;
+        }
+    }
+}
+
+// slices for the bf16-MFMA form: ~512 workgroups, >= 4 blocks of 64 rows per slice, <= 128 partial copies
+static int wgrad_bf16_pick(int M, int N, int K, int* kslice) {
+    const int tiles = (M >> 7) * (N >> 7);
+    int sk = tiles > 0 ? (512 + tiles - 1) / tiles : 1;
+    const int max_sk = (K + 255) / 256;
+    if (sk > max_sk) sk = max_sk;
+    if (sk > 128) sk = 128;
+    if (sk < 1) sk = 1;
+    int ks = (K + sk - 1) / sk;
+    ks = (ks + 63) / 64 * 64;
+    *kslice = ks;
+    return (K + ks - 1) / ks;
+}
+static bool wgrad_bf16_mfma_ok(const void* A, int lda, const void* B, int ldb, int M, int N) {
+    static const bool off = [] { const char* e = getenv("HSP_WGRAD_BF16"); return e && e[0] == 'f'; }();   // "fp32": the widening form
+    return !off && (M & 127) == 0 && (N & 127) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 &&
+           ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(B)) & 15) == 0;
+}
+
 // (slices, rows per slice, waves of a workgroup along K)
 static int wgrad_pick_sk(int M, int N, int K, int* kslice, int* kblock) {
     const int tiles = (M >> 6) * (N >> 6);
@@ -256,7 +427,13 @@ extern "C" size_t hsp_wgrad_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     int ks, kb;
     const int sk = wgrad_pick_sk(M, N, K, &ks, &kb);
-    return (size_t)(sk / kb) * ((size_t)M * N + N) * sizeof(float);
+    size_t parts = (size_t)(sk / kb);
+    if ((M & 127) == 0 && (N & 127) == 0) {                    // the bf16-MFMA form may cut K finer
+        int ks2;
+        const size_t p2 = (size_t)wgrad_bf16_pick(M, N, K, &ks2);
+        if (p2 > parts) parts = p2;
+    }
+    return parts * ((size_t)M * N + N) * sizeof(float);
 }
 
 template <bool COLSUM, typename FT>
@@ -283,11 +460,41 @@ static int wgrad_impl(const FT* A, int lda, const FT* B, int ldb, int M, int N, 
     if ((M & 63) || (N & 63) || (lda & 1) || (ldb & 1)) return HSP_ERR_UNSUPPORTED;   // 64x64 wave tiles, float2 loads
     if (!ws || ws_bytes < hsp_wgrad_workspace_bytes(M, N, K)) return HSP_ERR_WORKSPACE;
     int ks, kb;
+    hipStream_t st = as_stream(stream);
+    if constexpr (sizeof(FT) == 2) {
+        if (wgrad_bf16_mfma_ok(A, lda, B, ldb, M, N)) {
+            const int sk2 = wgrad_bf16_pick(M, N, K, &ks);
+            float* part = reinterpret_cast<float*>(ws);
+            float* cs_part = part + (size_t)sk2 * M * N;
+            const int grid = (M >> 7) * (N >> 7) * sk2;
+            const int lds = 4 * 128 * 128;
+            const unsigned short* a = reinterpret_cast<const unsigned short*>(A);
+            const unsigned short* b = reinterpret_cast<const unsigned short*>(B);
+#define WG_BF16_LAUNCH(CS)                                                                                                      \
+    do {                                                                                                                       \
+        auto kern = wgrad_bf16_mfma_kernel<CS>;                                                                                \
+        static bool attr_set = false;                                                                                          \
+        if (!attr_set) {                                                                                                       \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }                                             \
+            attr_set = true;                                                                                                   \
+        }                                                                                                                      \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, lda, b, ldb, M, N, K, ks, part, cs_part);                   \
+    } while (0)
+            if (colsum_B) WG_BF16_LAUNCH(true); else WG_BF16_LAUNCH(false);
+#undef WG_BF16_LAUNCH
+            int rc = check_launch();
+            if (rc) return rc;
+            const long long total = (long long)M * (N >> 2) + (colsum_B ? (N >> 2) : 0);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, part, sk2, M, N, C, ldc,
+                               cs_part, colsum_B);
+            return check_launch();
+        }
+    }
     const int sk = wgrad_pick_sk(M, N, K, &ks, &kb);
     const int nparts = sk / kb;
     float* part = reinterpret_cast<float*>(ws);
     float* cs_part = part + (size_t)nparts * M * N;
-    hipStream_t st = as_stream(stream);
     int rc = colsum_B ? wgrad_launch<true, FT>(A, lda, B, ldb, M, N, K, sk, ks, kb, part, cs_part, st)
                       : wgrad_launch<false, FT>(A, lda, B, ldb, M, N, K, sk, ks, kb, part, cs_part, st);
     if (rc) return rc;

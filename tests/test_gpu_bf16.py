@@ -154,13 +154,25 @@ def test_assemble_feat_and_upsample_backward_bf16(dev, ref):
     assert ((c.grad.float() - ref_c).abs() <= ref_c.abs() * 2.0 ** -8 + 1e-5).all()
 
 
-def test_wgrad_bf16_equals_fp32_twin(dev, ref):
-    from hs_pose_amd import ops, ops_bf16
-    A = _h(ref, (16448, 128), 51, 1.0).to(dev).bfloat16()
-    Bm = _h(ref, (16448, 1024), 52, 1.0).to(dev).bfloat16()
-    gw_b, cs_b = ops_bf16._wgrad(A, Bm, colsum=True)
-    gw_f, cs_f = ops._wgrad_custom(A.float(), Bm.float(), torch.empty(128, 1024, device=dev), True)
-    assert torch.equal(gw_b, gw_f) and torch.equal(cs_b, cs_f)
+@pytest.mark.parametrize("K,M,N,colsum,pitch", [(16448, 128, 1024, True, 0), (4112, 256, 2048, False, 0), (1000, 128, 128, True, 0),
+                                                 (65536, 128, 1024, True, 0), (5000, 128, 256, True, 8), (300, 64, 192, True, 0)])
+def test_wgrad_bf16(dev, ref, K, M, N, colsum, pitch):
+    """A^T B (+ column sums of B) of bf16 point rows: exact bf16 x bf16 products accumulated in fp32 -- on the bf16 matrix cores
+    when M, N are multiples of 128 (8 x 8 register transposes into the LDS operand image), else by widening onto the fp32
+    ones.  Against float64, within fp32 accumulation error of the summed magnitudes; `pitch`: rows are slices of wider tensors."""
+    from hs_pose_amd import ops_bf16
+    A = _h(ref, (K, M + pitch), 51, 1.0).to(dev).bfloat16()[:, :M]
+    Bm = _h(ref, (K, N + pitch), 52, 1.0).to(dev).bfloat16()[:, pitch:]
+    out = ops_bf16._wgrad(A, Bm, colsum=colsum)
+    gw, cs = out if colsum else (out, None)
+    want = A.double().t() @ Bm.double()
+    mag = A.double().abs().t() @ Bm.double().abs()
+    assert ((gw.double() - want).abs() <= 1e-6 * mag + 1e-6).all()
+    if colsum:
+        wc, mc = Bm.double().sum(0), Bm.double().abs().sum(0)
+        assert ((cs.double() - wc).abs() <= 1e-6 * mc + 1e-6).all()
+    again = ops_bf16._wgrad(A, Bm, colsum=colsum)
+    assert torch.equal(gw, again[0] if colsum else again)          # fixed summation order
 
 
 def _twin_nets(ref, flags, dev, seed=0):

@@ -8,8 +8,15 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 shapes = [(128, 1024, 16448), (128, 2048, 4112), (256, 2048, 4112), (256, 4096, 1024), (256, 256, 4112), (512, 512, 1024),
           (256, 128, 4112), (128, 128, 16448)]
+bf16 = "bf16" in sys.argv
+if bf16:
+    from hs_pose_amd import ops_bf16
+    shapes = [(128, 1024, 262144), (128, 128, 262144), (128, 2048, 65536), (256, 2048, 65536), (256, 4096, 16384), (256, 256, 65536)]
 for M, N, K in shapes:
     A = torch.randn(K, M, device=dev); Bm = torch.randn(K, N, device=dev)
+    if bf16:
+        A, Bm = A.bfloat16(), Bm.bfloat16()
+        ops._wgrad_custom = lambda a, b, o, c: ops_bf16._wgrad(a, b, out=o, colsum=c)
     out = torch.empty(M, N, device=dev)
     for colsum in (False,):
         for _ in range(5):
