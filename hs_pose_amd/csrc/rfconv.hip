@@ -412,14 +412,21 @@ __global__ __launch_bounds__(RF_THREADS) void rf_conv_bwd_csr_kernel(
 
 // FWIN: the support values come from the forward's fwin stream; else they are gathered from fm (fine while a
 // cloud's fm stays L2-resident: small N)
-template <int TC, bool SURFACE, bool FWIN, typename FT>
+// RS > 1 (dense clouds: N = 4096): the tile holds only the source rows [r0, r0 + N/RS) of the cloud -- RS workgroups (grid z)
+// sweep the same points and each keeps the elements whose winning row falls in its range.  What LDS buys is bytes of
+// accumulator: lines touched per launch = N * SC * RS / TC, and acc = (N / RS) * TC * 4 bytes, so two 128 KB half-cloud
+// tiles of 16 columns touch half the lines of one 64 KB whole-cloud tile of 4 (the only whole-cloud width that fits).
+template <int TC, bool SURFACE, bool FWIN, typename FT, int RS = 1>
 __global__ __launch_bounds__(RF_TILE_THREADS) void rf_bwd_tile_kernel(
     const float* __restrict__ xyz, const float* __restrict__ dirs, const FT* __restrict__ fwin,
     const uint16_t* __restrict__ argrow, const FT* __restrict__ gout, int B, int N, int S, int C,
     FT* __restrict__ gfm, float* __restrict__ gd_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* acc = reinterpret_cast<float*>(smem);                       // N*TC   (unused when SURFACE)
-    float* sx = acc + (SURFACE ? 0 : (size_t)N * TC);                  // 3*N
+    const int NR = RS > 1 ? (N + RS - 1) / RS : N;                     // source rows of this tile
+    const int r0 = RS > 1 ? (int)blockIdx.z * NR : 0;
+    const int r1 = min(N, r0 + NR);
+    float* acc = reinterpret_cast<float*>(smem);                       // NR*TC   (unused when SURFACE)
+    float* sx = acc + (SURFACE ? 0 : (size_t)NR * TC);                 // 3*NR: xyz of the source rows (RS == 1: of all points)
     constexpr int G = TC / 4;                 // float4 groups per tile
     constexpr int PL = RF_TILE_THREADS / G;        // point lanes
     const int SC = S * C;
@@ -433,8 +440,8 @@ __global__ __launch_bounds__(RF_TILE_THREADS) void rf_bwd_tile_kernel(
     const float invS = 1.0f / (float)S;
     const float* xb = xyz + (size_t)b * N * 3;
     if (!SURFACE)
-        for (int q = tid; q < N * G; q += RF_TILE_THREADS) *reinterpret_cast<float4*>(acc + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int q = tid; q < 3 * N; q += RF_TILE_THREADS) sx[q] = xb[q];
+        for (int q = tid; q < NR * G; q += RF_TILE_THREADS) *reinterpret_cast<float4*>(acc + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = tid; q < 3 * (r1 - r0); q += RF_TILE_THREADS) sx[q] = xb[r0 * 3 + q];
     float4 d0, d1, d2;
     load_dirs_normed(dirs, SC, j, d0, d1, d2);
     float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
@@ -465,16 +472,20 @@ __global__ __launch_bounds__(RF_TILE_THREADS) void rf_bwd_tile_kernel(
             f3 = Feat<FT>::ld(fsup + (size_t)am.w * fstride + 3);
         }
         ga.x *= invS; ga.y *= invS; ga.z *= invS; ga.w *= invS;
-        const float px = sx[p * 3], py = sx[p * 3 + 1], pz = sx[p * 3 + 2];
+        float px, py, pz;
+        if (RS > 1) { px = xb[p * 3]; py = xb[p * 3 + 1]; pz = xb[p * 3 + 2]; }      // the point itself: a coalesced stream
+        else { px = sx[p * 3]; py = sx[p * 3 + 1]; pz = sx[p * 3 + 2]; }
 #define RF_T1(X, E, FV)                                                                              \
         {                                                                                            \
-            const int m = am.X;                                                                      \
-            const float3 r = unit_dir_fast(px, py, pz, sx[m * 3], sx[m * 3 + 1], sx[m * 3 + 2]);     \
-            const float z = __fmaf_rn(r.z, d2.X, __fmaf_rn(r.y, d1.X, mul_rn(r.x, d0.X)));           \
-            if (z > 0.f) {                                                                           \
-                if (!SURFACE) atomicAdd(acc + m * TC + cg * 4 + E, ga.X * z);                        \
-                const float w = ga.X * FV;                                                           \
-                g0.X += w * r.x; g1.X += w * r.y; g2.X += w * r.z;                                   \
+            const int m = (int)am.X - r0;                                                            \
+            if (RS == 1 || (unsigned)m < (unsigned)(r1 - r0)) {                                      \
+                const float3 r = unit_dir_fast(px, py, pz, sx[m * 3], sx[m * 3 + 1], sx[m * 3 + 2]); \
+                const float z = __fmaf_rn(r.z, d2.X, __fmaf_rn(r.y, d1.X, mul_rn(r.x, d0.X)));       \
+                if (z > 0.f) {                                                                       \
+                    if (!SURFACE) atomicAdd(acc + m * TC + cg * 4 + E, ga.X * z);                    \
+                    const float w = ga.X * FV;                                                       \
+                    g0.X += w * r.x; g1.X += w * r.y; g2.X += w * r.z;                               \
+                }                                                                                    \
             }                                                                                        \
         }
         RF_T1(x, 0, f0) RF_T1(y, 1, f1) RF_T1(z, 2, f2) RF_T1(w, 3, f3)
@@ -483,16 +494,16 @@ __global__ __launch_bounds__(RF_TILE_THREADS) void rf_bwd_tile_kernel(
     __syncthreads();
     if (!SURFACE) {
         // flush the tile: one 16-byte store per (row, group)
-        for (int q = tid; q < N * G; q += RF_TILE_THREADS) {
+        for (int q = tid; q < (r1 - r0) * G; q += RF_TILE_THREADS) {
             const int m = q / G, g4 = q - m * G;
-            Feat<FT>::st4(gfm + ((size_t)b * N + m) * fstride + C + j0 + g4 * 4,
+            Feat<FT>::st4(gfm + ((size_t)b * N + r0 + m) * fstride + C + j0 + g4 * 4,
                           *reinterpret_cast<const float4*>(acc + m * TC + g4 * 4));
         }
         if (j0 < C) {   // the first C/TC tiles also copy the centre columns grad_fm[b,m,c] = g[b,m,c]
-            for (int q = tid; q < N * G; q += RF_TILE_THREADS) {
+            for (int q = tid; q < (r1 - r0) * G; q += RF_TILE_THREADS) {
                 const int m = q / G, g4 = q - m * G;
-                Feat<FT>::st4(gfm + ((size_t)b * N + m) * fstride + j0 + g4 * 4,
-                              Feat<FT>::ld4(gout + ((size_t)b * N + m) * C + j0 + g4 * 4));
+                Feat<FT>::st4(gfm + ((size_t)b * N + r0 + m) * fstride + j0 + g4 * 4,
+                              Feat<FT>::ld4(gout + ((size_t)b * N + r0 + m) * C + j0 + g4 * 4));
             }
         }
         __syncthreads();
@@ -509,7 +520,7 @@ __global__ __launch_bounds__(RF_TILE_THREADS) void rf_bwd_tile_kernel(
         float sacc = 0.f;
         for (int l = 0; l < PL; ++l) sacc += red[(l * G + gg) * 12 + w];
         const int d = w >> 2, e = w & 3;
-        gd_part[((size_t)b * 3 + d) * SC + j0 + gg * 4 + e] = sacc;
+        gd_part[((size_t)(b * RS + (RS > 1 ? (int)blockIdx.z : 0)) * 3 + d) * SC + j0 + gg * 4 + e] = sacc;
     }
 }
 
@@ -717,7 +728,15 @@ static int pick_tile_cols(int N, int C, bool surface, int B = 0, int SC = 0) {
 
 extern "C" size_t hsp_rf_bwd_scatter_workspace_bytes(int B, int SC) {
     if (B <= 0 || SC <= 0) return 0;
-    return (size_t)B * 3 * SC * sizeof(float);
+    return (size_t)B * 2 * 3 * SC * sizeof(float);             // (x2: the two half-cloud tiles of the dense-cloud form)
+}
+
+// dense clouds: two half-cloud tiles of 16 columns instead of one whole-cloud tile of <= 8 (see rf_bwd_tile_kernel)
+static bool rf_use_row_split(int N, int C, bool surface, int tc_whole) {
+    static const bool off = [] { const char* e = getenv("HSP_RF_ROWSPLIT"); return e && e[0] == '0'; }();
+    if (off || surface || tc_whole >= 16 || C % 16) return false;
+    const int nr = (N + 1) / 2;
+    return ((size_t)nr * 16 + 3 * (size_t)nr) * 4 <= 156u * 1024;
 }
 
 template <bool SURFACE, bool FWIN, typename FT>
@@ -730,11 +749,23 @@ static int rf_bwd_scatter(const float* xyz, const float* dirs, const FT* fm, con
     const int SC = S * C;
     if (!ws || ws_bytes < hsp_rf_bwd_scatter_workspace_bytes(B, SC)) return HSP_ERR_WORKSPACE;
     const int tc = pick_tile_cols(N, C, SURFACE, B, S * C);
+    hipStream_t st = as_stream(stream);
+    float* part = reinterpret_cast<float*>(ws);
+    if (rf_use_row_split(N, C, SURFACE, tc)) {
+        const int nr = (N + 1) / 2;
+        const size_t lds2 = ((size_t)nr * 16 + 3 * (size_t)nr) * 4;
+        auto kern = rf_bwd_tile_kernel<16, SURFACE, FWIN, FT, 2>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
+        hipLaunchKernelGGL(kern, dim3(SC / 16, B, 2), dim3(RF_TILE_THREADS), lds2, st, xyz, dirs, fm, argrow, gout, B, N, S, C, gfm, part);
+        rc = check_launch();
+        if (rc) return rc;
+        hipLaunchKernelGGL(rf_dirs_reduce_kernel, dim3((SC + 63) / 64), dim3(1024), 0, st, part, 2 * B, SC, dirs, gdirs);
+        return check_launch();
+    }
     if (!tc) return HSP_ERR_UNSUPPORTED;
     size_t lds = ((SURFACE ? 0 : (size_t)N * tc) + 3 * (size_t)N) * 4;
     if (lds < RF_TILE_THREADS * 12 * 4) lds = RF_TILE_THREADS * 12 * 4;
-    hipStream_t st = as_stream(stream);
-    float* part = reinterpret_cast<float*>(ws);
     dim3 grid(SC / tc, B);
 #define RF_TILE_LAUNCH(TC)                                                                                          \
     {                                                                                                               \
