@@ -159,6 +159,128 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_kernel(const float* __restr
 
 
 // ------------------------------------------------------------------------------------------------
+// forward, PIPELINED over the points of a workgroup (the default schedule).  rf_fwd_kernel spends a point in three phases
+// separated by barriers: k threads fetch the neighbour list and build the unit directions (two dependent global round
+// trips while 236 threads wait), everybody gathers, C threads average the S maxima.  Here the three phases of three
+// consecutive points share ONE barrier interval: the threads that have no column group in the last of the NCH slots
+// (S*C/4 = 224 groups on 256 threads at C = 128) build the directions of point i+1 into the other half of a double
+// buffer while the gather of point i runs, and the average of point i-1 is taken from the other maxima buffer at the
+// start of the interval.  Same arithmetic, same results bit for bit (tests/test_gpu_layers.py compares the schedules).
+// dynamic LDS: 2 * (S*C + 5 k) floats.  Needs S*C/4 - (NCH-1)*256 + k <= 256.
+// ------------------------------------------------------------------------------------------------
+template <bool SURFACE, int NCH, bool WF, typename FT>
+__global__ __launch_bounds__(RF_THREADS) void rf_fwd_pipe_kernel(const float* __restrict__ xyz,
+                                                                 const int32_t* __restrict__ idx,
+                                                                 const float* __restrict__ dirs,
+                                                                 const FT* __restrict__ fm, int B, int N, int k,
+                                                                 int S, int C, FT* __restrict__ out,
+                                                                 uint16_t* __restrict__ argrow,
+                                                                 FT* __restrict__ fwin) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int SC = S * C;
+    float* smax2 = reinterpret_cast<float*>(smem);            // 2 x SC
+    float4* sR2 = reinterpret_cast<float4*>(smax2 + 2 * SC);  // 2 x k
+    int* sIdx2 = reinterpret_cast<int*>(sR2 + 2 * k);         // 2 x k
+    const int tid = threadIdx.x;
+    const int nq = SC >> 2;
+    const int fstride = (S + 1) * C;
+    const float invS_div = (float)S;
+    const int spare0 = nq - (NCH - 1) * RF_THREADS;           // first thread without a group in the last slot
+    float4 d0[NCH], d1[NCH], d2[NCH];
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+        const int cq = tid + u * RF_THREADS;
+        load_dirs_normed(dirs, SC, (cq < nq ? cq : 0) << 2, d0[u], d1[u], d2[u]);
+    }
+    const PointIter it(B);
+    auto dirs_phase = [&](int b, int i, int buf) {
+        const int t = tid - spare0;
+        if (t >= 0 && t < k) {
+            const float* xb = xyz + (size_t)b * N * 3;
+            const int m = idx[((size_t)b * N + i) * k + t];
+            sIdx2[buf * k + t] = m;
+            const float3 r = unit_dir(xb[i * 3], xb[i * 3 + 1], xb[i * 3 + 2], xb[m * 3], xb[m * 3 + 1], xb[m * 3 + 2]);
+            sR2[buf * k + t] = make_float4(r.x, r.y, r.z, 0.f);
+        }
+    };
+    auto mean_phase = [&](size_t pt, const float* smax) {
+        for (int c = tid; c < C; c += RF_THREADS) {
+            float s = smax[c];
+            for (int sp = 1; sp < S; ++sp) s = add_rn(s, smax[sp * C + c]);
+            float v = __fdiv_rn(s, invS_div);
+            if (!SURFACE) v = add_rn(Feat<FT>::ld(fm + pt * fstride + c), v);
+            Feat<FT>::st_nt(out + pt * C + c, v);
+        }
+    };
+    int b = it.b0, i = it.i0;
+    bool have = b < B && i < N;
+    if (have) dirs_phase(b, i, 0);
+    int cur = 0;
+    bool have_prev = false;
+    size_t prev_pt = 0;
+    while (have) {
+        int nb = b, ni = i + it.istep;
+        if (ni >= N) { nb = b + it.bstep; ni = it.i0; }
+        const bool have_next = nb < B;
+        const size_t pt = (size_t)b * N + i;
+        __syncthreads();        // directions of this point are in place; the previous point's maxima are complete
+        if (have_prev) mean_phase(prev_pt, smax2 + (cur ^ 1) * SC);
+        if (have_next) dirs_phase(nb, ni, cur ^ 1);
+        float* smax = smax2 + cur * SC;
+        const float4* sR = sR2 + cur * k;
+        const int* sIdx = sIdx2 + cur * k;
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            const int cq = tid + u * RF_THREADS;
+            if (cq < nq) {
+                const int j = cq << 2;
+                float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                float4 wf = make_float4(1.f, 1.f, 1.f, 1.f);
+                const FT* fsup = SURFACE ? nullptr : fm + (size_t)b * N * fstride + C + j;
+#pragma unroll 4
+                for (int n = 0; n < k; ++n) {
+                    const float4 r = sR[n];
+                    float4 th;
+                    th.x = fmaxf(__fmaf_rn(r.z, d2[u].x, __fmaf_rn(r.y, d1[u].x, mul_rn(r.x, d0[u].x))), 0.f);
+                    th.y = fmaxf(__fmaf_rn(r.z, d2[u].y, __fmaf_rn(r.y, d1[u].y, mul_rn(r.x, d0[u].y))), 0.f);
+                    th.z = fmaxf(__fmaf_rn(r.z, d2[u].z, __fmaf_rn(r.y, d1[u].z, mul_rn(r.x, d0[u].z))), 0.f);
+                    th.w = fmaxf(__fmaf_rn(r.z, d2[u].w, __fmaf_rn(r.y, d1[u].w, mul_rn(r.x, d0[u].w))), 0.f);
+                    if (!SURFACE) {
+                        const float4 f = Feat<FT>::ld4(fsup + (size_t)sIdx[n] * fstride);
+                        th.x = mul_rn(th.x, f.x); th.y = mul_rn(th.y, f.y);
+                        th.z = mul_rn(th.z, f.z); th.w = mul_rn(th.w, f.w);
+                        if (WF) {
+                            if (th.x > best.x) wf.x = f.x;
+                            if (th.y > best.y) wf.y = f.y;
+                            if (th.z > best.z) wf.z = f.z;
+                            if (th.w > best.w) wf.w = f.w;
+                        }
+                    }
+                    if (th.x > best.x) { best.x = th.x; a0 = n; }
+                    if (th.y > best.y) { best.y = th.y; a1 = n; }
+                    if (th.z > best.z) { best.z = th.z; a2 = n; }
+                    if (th.w > best.w) { best.w = th.w; a3 = n; }
+                }
+                if (WF) Feat<FT>::st4_nt(fwin + pt * SC + j, wf);
+                *reinterpret_cast<float4*>(smax + j) = best;
+                {
+                    const unsigned lo = (unsigned)sIdx[a0] | ((unsigned)sIdx[a1] << 16);
+                    const unsigned hi = (unsigned)sIdx[a2] | ((unsigned)sIdx[a3] << 16);
+                    unsigned* ap = reinterpret_cast<unsigned*>(argrow + pt * SC + j);
+                    __builtin_nontemporal_store(lo, ap); __builtin_nontemporal_store(hi, ap + 1);
+                }
+            }
+        }
+        have_prev = true; prev_pt = pt;
+        cur ^= 1;
+        b = nb; i = ni; have = have_next;
+    }
+    __syncthreads();
+    if (have_prev) mean_phase(prev_pt, smax2 + (cur ^ 1) * SC);
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward, CHANNEL-SPLIT schedule (HS_layer only) for clouds whose fm does not fit an XCD's 4 MiB L2 (N = 1028, C = 128:
 // 4.2 MB fp32; N = 4096 bf16: 8.4 MB).  The neighbour gather re-reads every support row ~k times; when the cloud's fm
 // overflows L2 those re-reads go to MALL / HBM (measured 449 MB per launch against 166 MB algorithmic at N = 1028).
@@ -630,6 +752,28 @@ static int rf_fwd(const float* xyz, const int32_t* idx, const float* dirs, const
     const int grid = persistent_blocks((long long)B * N, 8);
     const int nch = ((S * C >> 2) + RF_THREADS - 1) / RF_THREADS;
     if (nch > 4) return HSP_ERR_UNSUPPORTED;              // S*C <= 4096
+    {
+        // the pipelined schedule (three points' phases per barrier interval) wherever the last slot leaves k threads free
+        static const bool pipe_off = [] { const char* e = getenv("HSP_RF_PIPE"); return e && e[0] == '0'; }();
+        const int spare0 = (S * C >> 2) - (nch - 1) * RF_THREADS;
+        if (!pipe_off && spare0 + k <= RF_THREADS && 2 * lds <= 64 * 1024) {
+#define RF_PIPE_LAUNCH(NCH)                                                                                        \
+    if (!SURFACE && fwin)                                                                                          \
+        hipLaunchKernelGGL((rf_fwd_pipe_kernel<SURFACE, NCH, !SURFACE, FT>), dim3(grid), dim3(RF_THREADS), 2 * lds,  \
+                           as_stream(stream), xyz, idx, dirs, fm, B, N, k, S, C, out, argrow, fwin);               \
+    else                                                                                                           \
+        hipLaunchKernelGGL((rf_fwd_pipe_kernel<SURFACE, NCH, false, FT>), dim3(grid), dim3(RF_THREADS), 2 * lds,    \
+                           as_stream(stream), xyz, idx, dirs, fm, B, N, k, S, C, out, argrow, fwin)
+            switch (nch) {
+                case 1: RF_PIPE_LAUNCH(1); break;
+                case 2: RF_PIPE_LAUNCH(2); break;
+                case 3: RF_PIPE_LAUNCH(3); break;
+                default: RF_PIPE_LAUNCH(4); break;
+            }
+#undef RF_PIPE_LAUNCH
+            return check_launch();
+        }
+    }
 #define RF_FWD_LAUNCH(NCH)                                                                                        \
     if (!SURFACE && fwin)                                                                                          \
         hipLaunchKernelGGL((rf_fwd_kernel<SURFACE, NCH, !SURFACE, FT>), dim3(grid), dim3(RF_THREADS), lds, as_stream(stream), \
