@@ -43,6 +43,10 @@ CASES = [
     (1024, 256, 512, True, 4096, False, False, False, 0),      # conv_4's input gradient: 64 tiles x K = 4608 -> split-K
     (1024, 128, 2000, False, 0, False, True, True, 100),       # split-K with the whole epilogue (bias, resid, cloud bias)
     (16, 128, 128, False, 0, False, False, False, 0),          # the per-cloud products (16 rows)
+    # full-size rows (16448 = 257 x 64: whole tiles fill 256 CUs unevenly)
+    (16448, 1024, 1286, False, 0, False, True, False, 0),      # a head's first layer at full size
+    (16448, 128, 128, True, 1024, False, False, True, 1028),   # gX = g Wste + gfm W^T: 514 tiles of 64 x 64, residual + cloud bias
+    (16448, 256, 1024, False, 0, False, True, True, 0),        # 16448 x 1024 -> 256
 ]
 
 
@@ -82,7 +86,8 @@ def test_gemm_rows_f32_strided_views(dev, ref):
     (8192, 1024, 128, 0, True, False, 0), (8192, 128, 128, 128, False, True, 4096), (4096, 2048, 256, 0, True, False, 0),
     (1000, 136, 72, 40, True, True, 300), (2048, 1024, 1288, 0, True, False, 0), (64, 64, 64, 0, False, False, 0),
     # enough tiles for the 256 x 128 workgroup tile (128 x 64 per wave): plain, ragged rows, dual source + every epilogue
-    (65536, 512, 128, 0, True, False, 0), (65500, 520, 200, 0, False, False, 0), (65536, 512, 128, 128, True, True, 4096)])
+    (65536, 512, 128, 0, True, False, 0), (65500, 520, 200, 0, False, False, 0), (65536, 512, 128, 128, True, True, 4096),
+    (16448, 1024, 1288, 0, True, False, 0), (16448, 128, 1024, 128, False, True, 1028)])
 def test_gemm_rows_bf16(dev, ref, M, N, K1, K2, use_bias, use_resid, rpc):
     from hs_pose_amd import ops
     h = lambda shape, seed: ref.hash_tensor(shape, seed, 1.0).to(dev)
