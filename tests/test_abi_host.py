@@ -54,7 +54,7 @@ def test_argument_validation_without_gpu():
     assert L.hsp_bn_relu_fwd(one, 100, 128, one, one, 1e-5, 0.1, 1, one, one, one, null, null, null, null, 0, null) == -3
     assert L.hsp_bn_workspace_bytes(16448, 128) == 499 * 2 * 128 * 4         # 499 row chunks of 33 rows
     assert L.hsp_rf_bwd_workspace_bytes(896) > 0
-    assert L.hsp_rf_bwd_scatter_workspace_bytes(16, 896) == 16 * 3 * 896 * 4
+    assert L.hsp_rf_bwd_scatter_workspace_bytes(16, 896) == 2 * 16 * 3 * 896 * 4   # (two half-cloud tiles on dense clouds)
     assert L.hsp_rf_conv_bwd_scatter(one, one, one, null, one, one, 1, 8, 7, 128, one, one, null, 0, null) == -3
 
 
