@@ -87,6 +87,7 @@ SIGNATURES = {
     "hsp_pose_losses_workspace_bytes": (_sz, [_i]),
     "hsp_pose_losses_fwd": (_i, [_vp] * 17 + [_i, _i, _vp, _vp, _vp, _sz, _vp]),
     "hsp_pose_losses_bwd": (_i, [_vp] * 17 + [_i, _i, _vp, _vp, _vp, _sz] + [_vp] * 11 + [_vp]),
+    "hsp_pose_augment": (_i, [_vp] * 14 + [_i, _i, _i] + [ctypes.c_float] * 4 + [_vp] * 5),
 }
 
 

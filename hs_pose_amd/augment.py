@@ -8,6 +8,7 @@ made in the reference's order on the tensors' device (``torch.rand``), so a seed
 identically.
 """
 import contextlib
+import os
 
 import torch
 
@@ -88,9 +89,39 @@ def defor_3D_pc(pc, gt_t, r=0.2, points_defor=None, return_defor=False):
     return (new_pc, points_defor) if return_defor else new_pc
 
 
+FUSED = os.environ.get("HSP_FUSED_AUGMENT", "1") != "0"      # device batches: one libhsp launch (hsp_pose_augment)
+
+
+def _data_augment_fused(PC, gt_R, gt_t, gt_s, mean_shape, sym, aug_bb, aug_rt_t, aug_rt_r, model_point, nocs_scale, obj_ids):
+    """the same augmentation through ``hsp_pose_augment`` (csrc/losses.hip): the six uniform draws are made here, on the
+    device generator and in the composition's order (flag, flag, flag, ey_up, ey_down, flag; then the jitter noise on the
+    CPU generator), so a seeded run consumes both generators exactly as the torch composition below does."""
+    from . import ops
+    bs, N, _ = PC.shape
+    dev = PC.device
+    draws = torch.cat([torch.rand((bs, 1), device=dev) for _ in range(6)], dim=1).t().contiguous()      # (6, bs)
+    noise = _noise_feed if _noise_feed is not None else _host_rand(PC) * FLAGS.aug_pc_r
+    f = lambda t, shape: ops._req(t.detach().float().reshape(shape), torch.float32, "data_augment")
+    M = model_point.shape[1]
+    out_pc = torch.empty(bs, N, 3, dtype=torch.float32, device=dev)
+    out_R = torch.empty(bs, 3, 3, dtype=torch.float32, device=dev)
+    out_t = torch.empty(bs, 3, dtype=torch.float32, device=dev)
+    out_s = torch.empty(bs, 3, dtype=torch.float32, device=dev)
+    args = [f(PC, (bs, N, 3)), f(gt_R, (bs, 3, 3)), f(gt_t, (bs, 3)), f(gt_s, (bs, 3)), f(mean_shape, (bs, 3)), f(sym, (bs, 4)),
+            f(aug_bb, (bs, 3)), f(aug_rt_t, (bs, 3)), f(aug_rt_r, (bs, 3, 3)), f(model_point, (bs, M, 3)), f(nocs_scale, (bs,)),
+            f(obj_ids, (bs,)), draws, f(noise, (bs, N, 3))]
+    ops._run("hsp_pose_augment", [ops._p(a) for a in args] + [bs, N, M, float(FLAGS.aug_bb_pro), float(FLAGS.aug_rt_pro),
+                                                            float(FLAGS.aug_bc_pro), float(FLAGS.aug_pc_pro), ops._p(out_pc),
+                                                            ops._p(out_R), ops._p(out_t), ops._p(out_s), ops._stream()])
+    return out_pc, out_R, out_t, out_s
+
+
 def data_augment(PC, gt_R, gt_t, gt_s, mean_shape, sym, aug_bb, aug_rt_t, aug_rt_r, model_point, nocs_scale, obj_ids):
     """HSPose.data_augment (HSPose.py:185-256): -> (PC, gt_R, gt_t, gt_s) with each augmentation applied where its
     draw says so.  gt_s is the size RESIDUAL to mean_shape, as everywhere in the network."""
+    if FUSED and PC.is_cuda:
+        return _data_augment_fused(PC, gt_R, gt_t, gt_s, mean_shape, sym, aug_bb, aug_rt_t, aug_rt_r, model_point, nocs_scale,
+                                   obj_ids)
     bs = PC.shape[0]
 
     flag = torch.rand((bs, 1), device=PC.device) < FLAGS.aug_bb_pro

@@ -669,6 +669,105 @@ __global__ __launch_bounds__(256) void loss_points_bwd_kernel(
     }
 }
 
+// ---- on-device augmentation of a training batch (HSPose.data_augment, network/HSPose.py:185-256 over
+// datasets/data_augmentation.py:70-190) in one launch: box scaling in the object frame, rigid perturbation, box-cage taper
+// (bowls / mugs), per-point radial jitter, each applied to the clouds whose uniform draw falls under its probability.
+// One workgroup per cloud; a thread carries a point through the four stages (no cross-point dependency), the tapered
+// model's extent (the new size) is a min / max over the model points through LDS.  draws (6,B): u_bb, u_rt, u_bc,
+// ey_up, ey_down (raw uniforms, mapped to [0.8, 1.2)), u_pc -- drawn by the caller in the reference's order.
+__global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ PC, const float* gt_R, const float* gt_t,
+                                                      const float* gt_s, const float* mean_shape, const float* sym,
+                                                      const float* aug_bb, const float* aug_rt_t, const float* aug_rt_r,
+                                                      const float* __restrict__ model_point, const float* nocs_scale,
+                                                      const float* obj_id, const float* draws, const float* __restrict__ noise,
+                                                      int B, int N, int M, float p_bb, float p_rt, float p_bc, float p_pc,
+                                                      float* __restrict__ PC_out, float* R_out, float* t_out, float* s_out) {
+    __shared__ float red[6][256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float R[9], t[3], s[3], ms[3], ar[9], at[3], k[3];
+    for (int i = 0; i < 9; ++i) { R[i] = gt_R[b * 9 + i]; ar[i] = aug_rt_r[b * 9 + i]; }
+    for (int i = 0; i < 3; ++i) { t[i] = gt_t[b * 3 + i]; s[i] = gt_s[b * 3 + i]; ms[i] = mean_shape[b * 3 + i]; at[i] = aug_rt_t[b * 3 + i]; }
+    const bool f_bb = draws[0 * B + b] < p_bb, f_rt = draws[1 * B + b] < p_rt;
+    const float obj = obj_id[b];
+    const bool f_bc = draws[2 * B + b] < p_bc && (obj == 5.f || obj == 1.f);
+    const float ey_up = draws[3 * B + b] * (1.2f - 0.8f) + 0.8f, ey_down = draws[4 * B + b] * (1.2f - 0.8f) + 0.8f;
+    const bool f_pc = draws[5 * B + b] < p_pc;
+    // 1. box scaling (data_augmentation.py:70-79): x and z share the mean factor under rotational symmetry
+    {
+        const float a0 = aug_bb[b * 3], a1 = aug_bb[b * 3 + 1], a2 = aug_bb[b * 3 + 2];
+        const bool rs = sym[b * 4] == 1.f;
+        k[0] = rs ? (a0 + a2) / 2.0f : a0; k[1] = rs ? (a1 + a1) / 2.0f : a1; k[2] = rs ? (a2 + a0) / 2.0f : a2;
+    }
+    const float R0[9] = {R[0], R[1], R[2], R[3], R[4], R[5], R[6], R[7], R[8]};
+    const float t0[3] = {t[0], t[1], t[2]};
+    if (f_bb) for (int i = 0; i < 3; ++i) s[i] = (s[i] + ms[i]) * k[i] - ms[i];
+    // 2. rigid perturbation (data_augmentation.py:183-190)
+    if (f_rt) {
+        float Rn[9], tn[3];
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) Rn[3 * i + j] = ar[3 * i] * R[j] + ar[3 * i + 1] * R[3 + j] + ar[3 * i + 2] * R[6 + j];
+            tn[i] = ar[3 * i] * (t[0] + at[0]) + ar[3 * i + 1] * (t[1] + at[1]) + ar[3 * i + 2] * (t[2] + at[2]);
+        }
+        for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+        for (int i = 0; i < 3; ++i) t[i] = tn[i];
+    }
+    // 3. box-cage taper (data_augmentation.py:108-129): the new size is the extent of the tapered (scaled) model
+    const float s_y = s[1] + ms[1];
+    auto taper_f = [&](float y) { return (y + s_y / 2.0f) / s_y * (ey_up - ey_down) + ey_down; };
+    if (f_bc) {
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int m = tid; m < M; m += 256) {
+            const float* mp = model_point + ((size_t)b * M + m) * 3;
+            float v[3] = {mp[0], mp[1], mp[2]};
+            if (f_bb) for (int i = 0; i < 3; ++i) v[i] *= k[i];
+            const float f = taper_f(v[1]);
+            v[0] *= f; v[2] *= f;
+            for (int i = 0; i < 3; ++i) { mn[i] = fminf(mn[i], v[i]); mx[i] = fmaxf(mx[i], v[i]); }
+        }
+        for (int i = 0; i < 3; ++i) { red[i][tid] = mn[i]; red[3 + i][tid] = mx[i]; }
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o)
+                for (int i = 0; i < 3; ++i) {
+                    red[i][tid] = fminf(red[i][tid], red[i][tid + o]);
+                    red[3 + i][tid] = fmaxf(red[3 + i][tid], red[3 + i][tid + o]);
+                }
+            __syncthreads();
+        }
+        const float ns = nocs_scale[b];
+        for (int i = 0; i < 3; ++i) s[i] = (red[3 + i][0] - red[i][0]) * ns - ms[i];
+    }
+    if (tid == 0) {
+        for (int i = 0; i < 9; ++i) R_out[b * 9 + i] = R[i];
+        for (int i = 0; i < 3; ++i) { t_out[b * 3 + i] = t[i]; s_out[b * 3 + i] = s[i]; }
+    }
+    for (int n = tid; n < N; n += 256) {
+        const size_t pn = (size_t)b * N + n;
+        float p[3] = {PC[pn * 3], PC[pn * 3 + 1], PC[pn * 3 + 2]};
+        if (f_bb) {
+            const float d0 = p[0] - t0[0], d1 = p[1] - t0[1], d2 = p[2] - t0[2];
+            float o[3];
+            for (int j = 0; j < 3; ++j) o[j] = (d0 * R0[j] + d1 * R0[3 + j] + d2 * R0[6 + j]) * k[j];
+            for (int i = 0; i < 3; ++i) p[i] = (o[0] * R0[3 * i] + o[1] * R0[3 * i + 1] + o[2] * R0[3 * i + 2]) + t0[i];
+        }
+        if (f_rt) {
+            const float q0 = p[0] + at[0], q1 = p[1] + at[1], q2 = p[2] + at[2];
+            for (int i = 0; i < 3; ++i) p[i] = q0 * ar[3 * i] + q1 * ar[3 * i + 1] + q2 * ar[3 * i + 2];
+        }
+        if (f_bc) {
+            const float d0 = p[0] - t[0], d1 = p[1] - t[1], d2 = p[2] - t[2];
+            float o[3];
+            for (int j = 0; j < 3; ++j) o[j] = d0 * R[j] + d1 * R[3 + j] + d2 * R[6 + j];
+            const float f = taper_f(o[1]);
+            o[0] *= f; o[2] *= f;
+            for (int i = 0; i < 3; ++i) p[i] = (o[0] * R[3 * i] + o[1] * R[3 * i + 1] + o[2] * R[3 * i + 2]) + t[i];
+        }
+        if (f_pc)
+            for (int i = 0; i < 3; ++i) p[i] = p[i] + noise[pn * 3 + i] * (p[i] - t[i]);
+        for (int i = 0; i < 3; ++i) PC_out[pn * 3 + i] = p[i];
+    }
+}
+
 struct LossWs {
     float *prm, *red, *per_cloud;
     double* mom;
@@ -737,5 +836,19 @@ extern "C" int hsp_pose_losses_bwd(const float* PC, const float* gt_R, const flo
     hipLaunchKernelGGL(loss_points_bwd_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, PC, gt_R, gt_t, gt_s, mean_shape, sym,
                        obj_id, recon, face_normal, face_dis, face_f, p_green, pred_T, w.prm, d_mom_scratch, grad_terms, *cfg, B, N,
                        d_recon, d_face_normal, d_face_dis, d_face_f);
+    return check_launch();
+}
+
+extern "C" int hsp_pose_augment(const float* PC, const float* gt_R, const float* gt_t, const float* gt_s, const float* mean_shape,
+                                const float* sym, const float* aug_bb, const float* aug_rt_t, const float* aug_rt_r,
+                                const float* model_point, const float* nocs_scale, const float* obj_id, const float* draws,
+                                const float* noise, int B, int N, int M, float p_bb, float p_rt, float p_bc, float p_pc,
+                                float* PC_out, float* R_out, float* t_out, float* s_out, hspStream_t stream) {
+    if (!PC || !gt_R || !gt_t || !gt_s || !mean_shape || !sym || !aug_bb || !aug_rt_t || !aug_rt_r || !model_point ||
+        !nocs_scale || !obj_id || !draws || !noise || !PC_out || !R_out || !t_out || !s_out || B <= 0 || N <= 0 || M <= 0)
+        return HSP_ERR_BAD_ARG;
+    hipLaunchKernelGGL(augment_kernel, dim3(B), dim3(256), 0, as_stream(stream), PC, gt_R, gt_t, gt_s, mean_shape, sym, aug_bb,
+                       aug_rt_t, aug_rt_r, model_point, nocs_scale, obj_id, draws, noise, B, N, M, p_bb, p_rt, p_bc, p_pc, PC_out,
+                       R_out, t_out, s_out);
     return check_launch();
 }

@@ -440,6 +440,20 @@ int hsp_pose_losses_bwd(const float *PC, const float *gt_R, const float *gt_t, c
                         float *d_green, float *d_red, float *d_f_green, float *d_f_red, float *d_T, float *d_s,
                         hspStream_t stream);
 
+/* replaces HSPose.data_augment                          network/HSPose.py:185-256 over
+ *          defor_3D_bb_in_batch / _rt_in_batch / _bc_in_batch / defor_3D_pc   datasets/data_augmentation.py:70-190
+ * one launch for a training batch: box scaling in the object frame (aug_bb; x and z share the mean factor under rotational
+ * symmetry), rigid perturbation (aug_rt_t, aug_rt_r), box-cage taper for bowls (1) / mugs (5) with the size taken from the
+ * tapered model's extent * nocs_scale, per-point radial jitter noise * (p - t).  Each applies to the clouds whose draw is
+ * below its probability.  draws (6,B): u_bb, u_rt, u_bc, ey_up, ey_down (uniforms in [0,1), mapped to [0.8,1.2)), u_pc -- the
+ * caller draws them in the reference's order; noise (B,N,3) = rand * FLAGS.aug_pc_r (the reference's CPU draw, uploaded).
+ * PC (B,N,3), model_point (B,M,3); gt_s / s_out are size residuals to mean_shape.  Outputs may not alias the inputs. */
+int hsp_pose_augment(const float *PC, const float *gt_R, const float *gt_t, const float *gt_s, const float *mean_shape,
+                     const float *sym, const float *aug_bb, const float *aug_rt_t, const float *aug_rt_r,
+                     const float *model_point, const float *nocs_scale, const float *obj_id, const float *draws,
+                     const float *noise, int B, int N, int M, float p_bb, float p_rt, float p_bc, float p_pc, float *PC_out,
+                     float *R_out, float *t_out, float *s_out, hspStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

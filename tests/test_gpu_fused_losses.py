@@ -135,3 +135,29 @@ def test_hspose_forward_uses_fused_losses(dev, flags):
     assert torch.isfinite(total).all()
     total.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.posenet.parameters() if p.requires_grad)
+
+
+@pytest.mark.parametrize("pro,n_points,repeat", [(0.6, 64, 1), (1.1, 1028, 3), (0.35, 257, 4), (-1.0, 64, 1)])
+def test_fused_augmentation_matches_torch_composition(dev, ref, flags, pro, n_points, repeat):
+    """hsp_pose_augment (one launch) against the torch-op composition of hs_pose_amd/augment.py -- itself pinned on the CPU
+    by the reference-written fixture losses_augment.npz -- under the same seed: both consume the device generator (six
+    draws) and the CPU generator (jitter noise) in the same order, so every cloud takes the same branches and factors."""
+    from hs_pose_amd import augment
+    flags.aug_bb_pro = flags.aug_rt_pro = flags.aug_bc_pro = flags.aug_pc_pro = pro
+    gts = [ref.augment_case(n_points, 4100 + 50 * i) for i in range(repeat)]
+    gt = {k: torch.cat([g[k] for g in gts]).to(dev) for k in gts[0]}
+    args = (gt["PC"], gt["gt_R"], gt["gt_t"], gt["gt_s"], gt["mean_shape"], gt["sym"], gt["aug_bb"], gt["aug_rt_t"],
+            gt["aug_rt_r"], gt["model_point"], gt["nocs_scale"], gt["obj_id"])
+    outs = []
+    for fused in (True, False):
+        torch.manual_seed(11)
+        old, augment.FUSED = augment.FUSED, fused
+        try:
+            outs.append(augment.data_augment(*[a.clone() for a in args]))
+        finally:
+            augment.FUSED = old
+    for name, a, b in zip(("PC", "R", "t", "s"), *outs):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 5e-6, (name, float((a - b).abs().max()))
+    if pro > 1.0:                                   # every augmentation fired: the clouds did move
+        assert float((outs[0][0] - gt["PC"]).abs().max()) > 1e-3

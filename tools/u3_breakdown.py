@@ -49,3 +49,13 @@ for i in range(n):
 for k, v in acc.items():
     print(f"{k:45s} {1e3 * v / n:8.3f} ms")
 print("total", 1e3 * sum(acc.values()) / n)
+
+# augmentation alone (eager torch composition), host-synchronised
+from hs_pose_amd.augment import data_augment
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(20):
+    with torch.no_grad():
+        data_augment(case["PC"], case["gt_R"], case["gt_t"], case["gt_s"], case["mean_shape"], case["sym"], case["aug_bb"],
+                     case["aug_rt_t"], case["aug_rt_r"], case["model_point"], case["nocs_scale"], case["obj_id"])
+torch.cuda.synchronize()
+print(f"data_augment alone                            {1e3 * (time.perf_counter() - t0) / 20:8.3f} ms")
