@@ -458,6 +458,9 @@ class GraphedNetwork:
             self.graph_bwd = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_bwd, pool=self.graph_fwd.pool(), **_CAPTURE):
                 self.pgrads = list(torch.autograd.grad(self.outs, self.params, self.gouts, allow_unused=True))
+                # contiguous static gradients (copies inside the graph where autograd hands back a transposed view): the
+                # multi-tensor add below then takes its fused path instead of one small kernel per parameter
+                self.pgrads = [g if g is None or g.is_contiguous() else g.contiguous() for g in self.pgrads]
         finally:
             keep.__exit__()
             ops.set_timer(prev_timer)
