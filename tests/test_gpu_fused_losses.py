@@ -161,3 +161,66 @@ def test_fused_augmentation_matches_torch_composition(dev, ref, flags, pro, n_po
         assert float((a - b).abs().max()) <= 5e-6, (name, float((a - b).abs().max()))
     if pro > 1.0:                                   # every augmentation fired: the clouds did move
         assert float((outs[0][0] - gt["PC"]).abs().max()) > 1e-3
+
+
+def _subset(gt, pred, rows):
+    sel = lambda d: {k: v.detach()[rows].clone() for k, v in d.items()}
+    g, p = sel(gt), sel(pred)
+    return g, {k: v.requires_grad_(True) for k, v in p.items()}
+
+
+@pytest.mark.parametrize("rows,n_points", [([2], 96), ([0, 5], 5), ([1, 1, 1, 6, 6], 33)])
+def test_fused_losses_small_and_odd_batches(dev, ref, flags, rows, n_points):
+    """one cloud, five points, repeated symmetry classes (all clouds rotationally symmetric / none): the batch-level
+    rescaling B / #kept and the per-class masks, against the torch composition"""
+    from hs_pose_amd import HSPose as H
+    gt, pred = case(ref, dev, n_points, 4500)
+    gt, pred = _subset(gt, pred, rows)
+    pred2 = {k: v.detach().clone().requires_grad_(True) for k, v in pred.items()}
+    ld_f = fused(gt, pred)
+    net = H.HSPose.__new__(H.HSPose)                     # only the loss wiring of HSPose.forward is needed
+    torch.nn.Module.__init__(net)
+    names = H.control_loss('PoseNet_only')
+    g_green, g_red = H.get_gt_v(gt["gt_R"])
+    p, sym, PC = pred2, gt["sym"], gt["PC"]
+    axes = {'Rot1': p['p_green_R'], 'Rot2': p['p_red_R']}
+    conf = {'Rot1_f': p['f_green_R'], 'Rot2_f': p['f_red_R']}
+    conf_c = {k: v.detach() for k, v in conf.items()}
+    pose = {'Tran': p['Pred_T'], 'Size': p['Pred_s']}
+    gt_pose = {'Points': PC, 'R': gt["gt_R"], 'T': gt["gt_t"], 'Mean_shape': gt["mean_shape"]}
+    ld_t = {
+        'fsnet_loss': H.fs_net_loss()(names[0], {**axes, **conf, **pose, 'Recon': p['recon']},
+                                      {'Rot1': g_green, 'Rot2': g_red, 'Recon': PC, 'Tran': gt["gt_t"], 'Size': gt["gt_s"]}, sym),
+        'recon_loss': H.recon_6face_loss()(names[1], {**axes, **conf_c, **pose, 'F_n': p['face_normal'], 'F_d': p['face_dis'],
+                                                      'F_c': p['face_f']}, {**gt_pose, 'Size': gt["gt_s"]}, sym, gt["obj_id"]),
+        'geo_loss': H.geo_transform_loss()(names[2], {**axes, **conf_c, **pose}, gt_pose, sym),
+        'prop_loss': H.prop_rot_loss()(names[3], {**axes, **conf_c, 'Recon': p['recon'], 'Tran': p['Pred_T'], 'Scale': p['Pred_s']},
+                                       gt_pose, sym),
+    }
+    tf = tt = 0.0
+    for grp, keys in LOSS_KEYS.items():
+        for k in keys:
+            a, b = float(ld_f[grp][k].detach().sum()), float(ld_t[grp][k].detach().sum())
+            if np.isnan(b):
+                assert np.isnan(a), (grp, k)
+                continue
+            assert abs(a - b) <= 2e-3 * max(abs(b), 1e-2), (grp, k, a, b)
+            tf = tf + ld_f[grp][k].sum(); tt = tt + ld_t[grp][k].sum()
+    tf.backward(); tt.backward()
+    for k in NET:
+        ga, gb = pred[k].grad, pred2[k].grad
+        ok = torch.isfinite(gb)
+        tol = 1e-2 if k in ("face_normal", "face_dis") else 5e-4
+        assert float((ga - gb)[ok].abs().max()) <= tol * max(1.0, float(gb[ok].abs().max())), k
+
+
+def test_fused_losses_nan_plane_poisons_box_terms(dev, ref, flags):
+    """a NaN in any fitted plane turns the five box terms into NaN (recon_loss.py:632-639); the other terms stay finite"""
+    gt, pred = case(ref, dev)
+    with torch.no_grad():
+        pred["face_dis"][0, :, 1] = float("nan")
+    ld = fused(gt, pred)
+    for k in ("recon_point_vote", "recon_point_r", "recon_point_t", "recon_point_s", "recon_point_self"):
+        assert torch.isnan(ld["recon_loss"][k]).all(), k
+    for grp, k in (("fsnet_loss", "Rot1"), ("fsnet_loss", "R_con"), ("geo_loss", "geo_point"), ("prop_loss", "Prop_pm")):
+        assert torch.isfinite(ld[grp][k]).all(), (grp, k)
