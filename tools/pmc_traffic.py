@@ -18,10 +18,10 @@ MAP = {
     ("knn_feat_kernel<21, true", "131072"): "hsp_knn_f32[B16N1028C128k20]",
     ("knn_feat_kernel<9, true", "8192"): "hsp_knn_f32[B16N64C256k8]",
     ("knn3_wave_kernel<17", "266240"): "hsp_knn_f32[B16N1028C3k20]",
-    ("rf_fwd_kernel<true, 1, false, float", "524288"): "hsp_rf_surface_fwd[B16N1028k20S7C128]",
-    ("rf_fwd_kernel<false, 1, true, float", "524288"): "hsp_rf_conv_fwd[B16N1028k20S7C128]",
-    ("rf_fwd_kernel<false, 2, false, float", "524288"): "hsp_rf_conv_fwd[B16N257k20S7C256]",
-    ("rf_fwd_kernel<false, 4, false, float", "262144"): "hsp_rf_conv_fwd[B16N64k8S7C512]",
+    ("rf_fwd_pipe_kernel<true, 1, false, float", "524288"): "hsp_rf_surface_fwd[B16N1028k20S7C128]",
+    ("rf_fwd_pipe_kernel<false, 1, true, float", "524288"): "hsp_rf_conv_fwd[B16N1028k20S7C128]",
+    ("rf_fwd_pipe_kernel<false, 2, false, float", "524288"): "hsp_rf_conv_fwd[B16N257k20S7C256]",
+    ("rf_fwd_pipe_kernel<false, 4, false, float", "262144"): "hsp_rf_conv_fwd[B16N64k8S7C512]",
     ("rf_bwd_tile_kernel<16, true, false, float", "458752"): "hsp_rf_surface_bwd[B16N1028S7C128]",
     ("rf_bwd_tile_kernel<16, false, true, float", "458752"): "hsp_rf_conv_bwd_scatter[B16N1028S7C128]",
     ("rf_bwd_tile_kernel<32, false, false, float", "458752"): "hsp_rf_conv_bwd_scatter[B16N257S7C256]",
@@ -29,9 +29,9 @@ MAP = {
     ("concat_rows_kernel<float", "2097152"): "hsp_concat_rows[B16N1028W1286]",
     # bf16 feature storage, B=64, N=4096 (BASELINE configs[3])
     ("knn_feat_bf16_kernel<21", "2097152"): "hsp_knn_bf16[B64N4096C128k20]",
-    ("rf_fwd_kernel<false, 1, true, unsigned short", "524288"): "hsp_rf_conv_fwd_bf16[B64N4096k20S7C128]",
-    ("rf_fwd_kernel<true, 1, false, unsigned short", "524288"): "hsp_rf_surface_fwd_bf16[B64N4096k20S7C128]",
-    ("rf_bwd_tile_kernel<4, false, true, unsigned short", "7340032"): "hsp_rf_conv_bwd_scatter_bf16[B64N4096S7C128]",
+    ("rf_fwd_pipe_kernel<false, 1, true, unsigned short", "524288"): "hsp_rf_conv_fwd_bf16[B64N4096k20S7C128]",
+    ("rf_fwd_pipe_kernel<true, 1, false, unsigned short", "524288"): "hsp_rf_surface_fwd_bf16[B64N4096k20S7C128]",
+    ("rf_bwd_tile_kernel<16, false, true, unsigned short, 2>", "3670016"): "hsp_rf_conv_bwd_scatter_bf16[B64N4096S7C128]",
 }       # (the weight-gradient and N=257 feature-KNN launches share one grid size between shapes: not separable here)
 
 
