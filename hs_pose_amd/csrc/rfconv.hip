@@ -166,7 +166,7 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_kernel(const float* __restr
 // (S*C/4 = 224 groups on 256 threads at C = 128) build the directions of point i+1 into the other half of a double
 // buffer while the gather of point i runs, and the average of point i-1 is taken from the other maxima buffer at the
 // start of the interval.  Same arithmetic, same results bit for bit (tests/test_gpu_layers.py compares the schedules).
-// dynamic LDS: 2 * (S*C + 5 k) floats.  Needs S*C/4 - (NCH-1)*256 + k <= 256.
+// dynamic LDS: 2 * (S*C + 6 k) floats.  Needs S*C/4 - (NCH-1)*256 + k <= 256.
 // ------------------------------------------------------------------------------------------------
 template <bool SURFACE, int NCH, bool WF, typename FT>
 __global__ __launch_bounds__(RF_THREADS) void rf_fwd_pipe_kernel(const float* __restrict__ xyz,
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_pipe_kernel(const float* __
     float* smax2 = reinterpret_cast<float*>(smem);            // 2 x SC
     float4* sR2 = reinterpret_cast<float4*>(smax2 + 2 * SC);  // 2 x k
     int* sIdx2 = reinterpret_cast<int*>(sR2 + 2 * k);         // 2 x k
+    unsigned* sOff2 = reinterpret_cast<unsigned*>(sIdx2 + 2 * k);   // 2 x k: the neighbour row's byte offset in the cloud's fm
     const int tid = threadIdx.x;
     const int nq = SC >> 2;
     const int fstride = (S + 1) * C;
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_pipe_kernel(const float* __
             const float* xb = xyz + (size_t)b * N * 3;
             const int m = idx[((size_t)b * N + i) * k + t];
             sIdx2[buf * k + t] = m;
+            sOff2[buf * k + t] = (unsigned)m * (unsigned)fstride * (unsigned)sizeof(FT);
             const float3 r = unit_dir(xb[i * 3], xb[i * 3 + 1], xb[i * 3 + 2], xb[m * 3], xb[m * 3 + 1], xb[m * 3 + 2]);
             sR2[buf * k + t] = make_float4(r.x, r.y, r.z, 0.f);
         }
@@ -229,6 +231,7 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_pipe_kernel(const float* __
         float* smax = smax2 + cur * SC;
         const float4* sR = sR2 + cur * k;
         const int* sIdx = sIdx2 + cur * k;
+        const unsigned* sOff = sOff2 + cur * k;
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
             const int cq = tid + u * RF_THREADS;
@@ -237,7 +240,16 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_pipe_kernel(const float* __
                 float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
                 int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
                 float4 wf = make_float4(1.f, 1.f, 1.f, 1.f);
-                const FT* fsup = SURFACE ? nullptr : fm + (size_t)b * N * fstride + C + j;
+                // gathers through a buffer descriptor over the cloud's fm: address = base + 32-bit (column + row) byte offset, one
+                // v_add per gather instead of a 64-bit multiply-add
+                // (the base goes through v_readfirstlane: hipcc does not see that the cloud index is wave-uniform and would wrap
+                // every load in a waterfall loop over the descriptor)
+                const unsigned long long fbase = reinterpret_cast<unsigned long long>(SURFACE ? out : fm + (size_t)b * N * fstride);
+                FT* ubase = reinterpret_cast<FT*>(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(fbase >> 32)) << 32) |
+                                                  (unsigned)__builtin_amdgcn_readfirstlane((unsigned)fbase));
+                const __amdgpu_buffer_rsrc_t frs =
+                    __builtin_amdgcn_make_buffer_rsrc(ubase, 0, (int)((size_t)N * fstride * sizeof(FT)), 0x00020000);
+                const unsigned voff = (unsigned)(C + j) * (unsigned)sizeof(FT);
 #pragma unroll 4
                 for (int n = 0; n < k; ++n) {
                     const float4 r = sR[n];
@@ -247,7 +259,15 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_pipe_kernel(const float* __
                     th.z = fmaxf(__fmaf_rn(r.z, d2[u].z, __fmaf_rn(r.y, d1[u].z, mul_rn(r.x, d0[u].z))), 0.f);
                     th.w = fmaxf(__fmaf_rn(r.z, d2[u].w, __fmaf_rn(r.y, d1[u].w, mul_rn(r.x, d0[u].w))), 0.f);
                     if (!SURFACE) {
-                        const float4 f = Feat<FT>::ld4(fsup + (size_t)sIdx[n] * fstride);
+                        float4 f;
+                        if constexpr (sizeof(FT) == 4) {
+                            const auto v = __builtin_amdgcn_raw_buffer_load_b128(frs, (int)(voff + sOff[n]), 0, 0);
+                            f = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+                        } else {
+                            const auto v = __builtin_amdgcn_raw_buffer_load_b64(frs, (int)(voff + sOff[n]), 0, 0);
+                            f = make_float4(__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u),
+                                            __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u));
+                        }
                         th.x = mul_rn(th.x, f.x); th.y = mul_rn(th.y, f.y);
                         th.z = mul_rn(th.z, f.z); th.w = mul_rn(th.w, f.w);
                         if (WF) {
@@ -756,13 +776,14 @@ static int rf_fwd(const float* xyz, const int32_t* idx, const float* dirs, const
         // the pipelined schedule (three points' phases per barrier interval) wherever the last slot leaves k threads free
         static const bool pipe_off = [] { const char* e = getenv("HSP_RF_PIPE"); return e && e[0] == '0'; }();
         const int spare0 = (S * C >> 2) - (nch - 1) * RF_THREADS;
-        if (!pipe_off && spare0 + k <= RF_THREADS && 2 * lds <= 64 * 1024) {
+        const size_t lds_pipe = 2 * (size_t)(S * C + 6 * k) * 4;
+        if (!pipe_off && spare0 + k <= RF_THREADS && lds_pipe <= 64 * 1024) {
 #define RF_PIPE_LAUNCH(NCH)                                                                                        \
     if (!SURFACE && fwin)                                                                                          \
-        hipLaunchKernelGGL((rf_fwd_pipe_kernel<SURFACE, NCH, !SURFACE, FT>), dim3(grid), dim3(RF_THREADS), 2 * lds,  \
+        hipLaunchKernelGGL((rf_fwd_pipe_kernel<SURFACE, NCH, !SURFACE, FT>), dim3(grid), dim3(RF_THREADS), lds_pipe, \
                            as_stream(stream), xyz, idx, dirs, fm, B, N, k, S, C, out, argrow, fwin);               \
     else                                                                                                           \
-        hipLaunchKernelGGL((rf_fwd_pipe_kernel<SURFACE, NCH, false, FT>), dim3(grid), dim3(RF_THREADS), 2 * lds,    \
+        hipLaunchKernelGGL((rf_fwd_pipe_kernel<SURFACE, NCH, false, FT>), dim3(grid), dim3(RF_THREADS), lds_pipe,   \
                            as_stream(stream), xyz, idx, dirs, fm, B, N, k, S, C, out, argrow, fwin)
             switch (nch) {
                 case 1: RF_PIPE_LAUNCH(1); break;
