@@ -87,6 +87,9 @@ SIGNATURES = {
     "hsp_pose_losses_workspace_bytes": (_sz, [_i]),
     "hsp_pose_losses_fwd": (_i, [_vp] * 17 + [_i, _i, _vp, _vp, _vp, _sz, _vp]),
     "hsp_pose_losses_bwd": (_i, [_vp] * 17 + [_i, _i, _vp, _vp, _vp, _sz] + [_vp] * 11 + [_vp]),
+    "hsp_wgrad_partial_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _sz, _vp, _vp]),
+    "hsp_wgrad_partial_bf16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _sz, _vp, _vp]),
+    "hsp_wgrad_fold": (_i, [_vp, _i, _vp]),
     "hsp_pose_augment": (_i, [_vp] * 14 + [_i, _i, _i] + [ctypes.c_float] * 4 + [_vp] * 5),
 }
 
@@ -127,3 +130,9 @@ def check(rc, what):
         msg = L.hsp_error_string(rc).decode()
         hip = L.hsp_last_hip_error().decode()
         raise HspError(f"{what} failed: {msg} (code {rc})" + (f" [hip: {hip}]" if hip and rc == -4 else ""))
+
+
+class HspWgradPending(ctypes.Structure):
+    """include/hsp.h: HspWgradPending (a HOST struct)"""
+    _fields_ = [("part", ctypes.c_void_p), ("cs_part", ctypes.c_void_p), ("C", ctypes.c_void_p), ("colsum", ctypes.c_void_p),
+                ("nparts", ctypes.c_int), ("M", ctypes.c_int), ("N", ctypes.c_int), ("ldc", ctypes.c_int)]

@@ -216,6 +216,62 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// the same fold for up to 4 weight-gradient problems in ONE launch (the three parameter gradients of an HS layer's backward
+// are folded together: two kernel boundaries fewer per layer).  Block ranges: problem p owns blocks [first[p], first[p+1]).
+struct WgradFoldTab {
+    int n;
+    int first[5];
+    HspWgradPending p[4];
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WgradFoldTab tab) {
+    __shared__ float4 red[4][64];
+    int q = 0;
+    while (q + 1 < tab.n && (int)blockIdx.x >= tab.first[q + 1]) ++q;
+    const HspWgradPending pr = tab.p[q];
+    const float* part = reinterpret_cast<const float*>(pr.part);
+    const float* cs_part = reinterpret_cast<const float*>(pr.cs_part);
+    const int SK = pr.nparts, M = pr.M, N = pr.N;
+    const int le = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int nq = N >> 2;
+    const long long total = (long long)M * nq;
+    const long long ncs = pr.colsum ? (N >> 2) : 0;
+    const long long e = (long long)((int)blockIdx.x - tab.first[q]) * 64 + le;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* src = nullptr;
+    size_t stride = 0;
+    if (e < total) { src = part + (size_t)e * 4; stride = (size_t)M * N; }
+    else if (e < total + ncs) { src = cs_part + (size_t)(e - total) * 4; stride = (size_t)N; }
+    if (src) {
+        float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        int sl = sg;
+        for (; sl + 4 < SK; sl += 8) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)sl * stride);
+            const float4 u = *reinterpret_cast<const float4*>(src + (size_t)(sl + 4) * stride);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            s2.x += u.x; s2.y += u.y; s2.z += u.z; s2.w += u.w;
+        }
+        if (sl < SK) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)sl * stride);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        s.x += s2.x; s.y += s2.y; s.z += s2.z; s.w += s2.w;
+    }
+    red[sg][le] = s;
+    __syncthreads();
+    if (sg == 0 && src) {
+        float4 r = red[0][le];
+#pragma unroll
+        for (int g = 1; g < 4; ++g) { const float4 v = red[g][le]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+        if (e < total) {
+            const int m = (int)(e / nq), qq = (int)(e - (long long)m * nq);
+            float* c = reinterpret_cast<float*>(pr.C) + (size_t)m * pr.ldc + (qq << 2);
+            c[0] = r.x; c[1] = r.y; c[2] = r.z; c[3] = r.w;
+        } else {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(pr.colsum) + (size_t)(e - total) * 4) = r;
+        }
+    }
+}
+
 // ---- bf16 point rows on the bf16 matrix cores ---------------------------------------------------------------------------
 // Same product, partial-sum layout and reduce kernel as above, for A (K x M) / B (K x N) stored in bf16 with M, N multiples
 // of 128.  v_mfma_f32_32x32x16_bf16 wants 8 consecutive k per lane, the rows are k-major: each staging thread loads an
@@ -455,7 +511,7 @@ static int wgrad_launch(const FT* A, int lda, const FT* B, int ldb, int M, int N
 
 template <typename FT>
 static int wgrad_impl(const FT* A, int lda, const FT* B, int ldb, int M, int N, int K, float* C, int ldc,
-                      float* colsum_B, void* ws, size_t ws_bytes, hspStream_t stream) {
+                      float* colsum_B, void* ws, size_t ws_bytes, hspStream_t stream, HspWgradPending* pending = nullptr) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda < M || ldb < N || ldc < N) return HSP_ERR_BAD_ARG;
     if ((M & 63) || (N & 63) || (lda & 1) || (ldb & 1)) return HSP_ERR_UNSUPPORTED;   // 64x64 wave tiles, float2 loads
     if (!ws || ws_bytes < hsp_wgrad_workspace_bytes(M, N, K)) return HSP_ERR_WORKSPACE;
@@ -485,6 +541,7 @@ static int wgrad_impl(const FT* A, int lda, const FT* B, int ldb, int M, int N, 
 #undef WG_BF16_LAUNCH
             int rc = check_launch();
             if (rc) return rc;
+            if (pending) { *pending = HspWgradPending{part, cs_part, C, colsum_B, sk2, M, N, ldc}; return HSP_OK; }
             const long long total = (long long)M * (N >> 2) + (colsum_B ? (N >> 2) : 0);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, part, sk2, M, N, C, ldc,
                                cs_part, colsum_B);
@@ -498,6 +555,7 @@ static int wgrad_impl(const FT* A, int lda, const FT* B, int ldb, int M, int N, 
     int rc = colsum_B ? wgrad_launch<true, FT>(A, lda, B, ldb, M, N, K, sk, ks, kb, part, cs_part, st)
                       : wgrad_launch<false, FT>(A, lda, B, ldb, M, N, K, sk, ks, kb, part, cs_part, st);
     if (rc) return rc;
+    if (pending) { *pending = HspWgradPending{part, cs_part, C, colsum_B, nparts, M, N, ldc}; return HSP_OK; }
     const long long total = (long long)M * (N >> 2) + (colsum_B ? (N >> 2) : 0);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, part, nparts, M, N, C,
                        ldc, cs_part, colsum_B);
@@ -512,4 +570,35 @@ extern "C" int hsp_wgrad_f32(const float* A, int lda, const float* B, int ldb, i
 extern "C" int hsp_wgrad_bf16(const hsp_bf16_t* A, int lda, const hsp_bf16_t* B, int ldb, int M, int N, int K, float* C,
                               int ldc, float* colsum_B, void* ws, size_t ws_bytes, hspStream_t stream) {
     return wgrad_impl<bf16_t>(A, lda, B, ldb, M, N, K, C, ldc, colsum_B, ws, ws_bytes, stream);
+}
+
+/* split forms: the partial-sum launch only (the fold is left pending), and one fold launch for up to 4 pending problems */
+extern "C" int hsp_wgrad_partial_f32(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc,
+                                     float* colsum_B, void* ws, size_t ws_bytes, HspWgradPending* pending, hspStream_t stream) {
+    if (!pending) return HSP_ERR_BAD_ARG;
+    return wgrad_impl<float>(A, lda, B, ldb, M, N, K, C, ldc, colsum_B, ws, ws_bytes, stream, pending);
+}
+extern "C" int hsp_wgrad_partial_bf16(const hsp_bf16_t* A, int lda, const hsp_bf16_t* B, int ldb, int M, int N, int K, float* C,
+                                      int ldc, float* colsum_B, void* ws, size_t ws_bytes, HspWgradPending* pending,
+                                      hspStream_t stream) {
+    if (!pending) return HSP_ERR_BAD_ARG;
+    return wgrad_impl<bf16_t>(A, lda, B, ldb, M, N, K, C, ldc, colsum_B, ws, ws_bytes, stream, pending);
+}
+extern "C" int hsp_wgrad_fold(const HspWgradPending* pending, int n, hspStream_t stream) {
+    if (!pending || n <= 0 || n > 4) return HSP_ERR_BAD_ARG;
+    WgradFoldTab tab;
+    tab.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const HspWgradPending& p = pending[i];
+        if (!p.part || !p.C || p.nparts <= 0 || p.M <= 0 || p.N <= 0 || (p.N & 3) || p.ldc < p.N || (p.colsum && !p.cs_part))
+            return HSP_ERR_BAD_ARG;
+        tab.first[i] = blocks;
+        const long long total = (long long)p.M * (p.N >> 2) + (p.colsum ? (p.N >> 2) : 0);
+        blocks += (int)((total + 63) / 64);
+        tab.p[i] = p;
+    }
+    tab.first[n] = blocks;
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), tab);
+    return check_launch();
 }

@@ -392,6 +392,34 @@ def _wgrad_library(A2, B2, out, colsum):
     return out, B2.sum(dim=0)
 
 
+class WgradBatch:
+    """Folds of several weight gradients in one launch: inside ``with WgradBatch():`` the custom ``wgrad`` runs only its split-K
+    launch and leaves the fold pending (the outputs are NOT valid until the block exits); the exit folds up to four pending
+    problems per ``hsp_wgrad_fold`` launch.  An HS layer's backward computes three parameter gradients: two kernel boundaries
+    fewer per layer, same fixed summation order, same bits."""
+    current = None
+
+    def __init__(self):
+        self.items = []                   # (HspWgradPending, workspace tensor kept alive)
+
+    def __enter__(self):
+        self.prev, WgradBatch.current = WgradBatch.current, self
+        return self
+
+    def __exit__(self, *exc):
+        WgradBatch.current = self.prev
+        if exc[0] is None:
+            self.flush()
+        return False
+
+    def flush(self):
+        from ._lib import HspWgradPending
+        while self.items:
+            chunk, self.items = self.items[:4], self.items[4:]
+            arr = (HspWgradPending * len(chunk))(*[c[0] for c in chunk])
+            _run("hsp_wgrad_fold", (arr, len(chunk), _stream()), key=f"n{len(chunk)}")
+
+
 def _wgrad_custom(A2, B2, out, colsum):
     K, M = A2.shape
     N = B2.shape[1]
@@ -399,9 +427,20 @@ def _wgrad_custom(A2, B2, out, colsum):
     L = lib()
     wsb = L.hsp_wgrad_workspace_bytes(M, N, K)
     ws = _ws(wsb, A2.device)
-    _run("hsp_wgrad_f32", (_p(A2), A2.stride(0), _p(B2), B2.stride(0), M, N, K, _p(out), out.stride(0), _p(cs),
-                           _p(ws), wsb, _stream()),
-         key=f"M{M}N{N}K{K}", abytes=4 * (K * (M + N) + M * N), aflops=2 * M * N * K)
+    sfx = "bf16" if A2.dtype == torch.bfloat16 else "f32"
+    es = 2 if A2.dtype == torch.bfloat16 else 4
+    batch = WgradBatch.current
+    if batch is not None:
+        from ._lib import HspWgradPending
+        pend = HspWgradPending()
+        _run("hsp_wgrad_partial_" + sfx, (_p(A2), A2.stride(0), _p(B2), B2.stride(0), M, N, K, _p(out), out.stride(0), _p(cs),
+                                          _p(ws), wsb, ctypes.byref(pend), _stream()),
+             key=f"M{M}N{N}K{K}", abytes=es * K * (M + N) + 4 * M * N, aflops=2 * M * N * K)
+        batch.items.append((pend, ws))
+    else:
+        _run("hsp_wgrad_" + sfx, (_p(A2), A2.stride(0), _p(B2), B2.stride(0), M, N, K, _p(out), out.stride(0), _p(cs),
+                                  _p(ws), wsb, _stream()),
+             key=f"M{M}N{N}K{K}", abytes=es * K * (M + N) + 4 * M * N, aflops=2 * M * N * K)
     return (out, cs) if colsum else out
 
 
@@ -440,8 +479,12 @@ def wgrad(A2, B2, out=None, colsum=False):
         if torch.cuda.is_current_stream_capturing() or _timer is not None:
             choice = "custom"                       # cannot time here; decided on a later eager call
         else:
-            t_c = _time_us(lambda: _wgrad_custom(A2, B2, out, colsum))
-            t_l = _time_us(lambda: _wgrad_library(A2, B2, out, colsum))
+            held, WgradBatch.current = WgradBatch.current, None      # time the complete op, not the batched half
+            try:
+                t_c = _time_us(lambda: _wgrad_custom(A2, B2, out, colsum))
+                t_l = _time_us(lambda: _wgrad_library(A2, B2, out, colsum))
+            finally:
+                WgradBatch.current = held
             choice = _wgrad_choice[key] = "custom" if t_c <= t_l else "library"
     return _wgrad_custom(A2, B2, out, colsum) if choice == "custom" else _wgrad_library(A2, B2, out, colsum)
 
@@ -757,17 +800,18 @@ class _HSLayer(torch.autograd.Function):
         Wa, Wb = w_conv2[:, :C], w_conv2[:, C:]
         gt = colsum_rows(g)                                                    # (B,C) = sum_i g
         g_conv2 = torch.empty_like(w_conv2)
-        wgrad(g2, F2, out=g_conv2[:, :C])                                      # gWa, written in place (ldc = 2C)
-        _tiny_tn(gt, fg, g_conv2[:, C:])                                       # gWb = gt^T fg (tiny), straight into its column block
-        gF3 = torch.empty(B, N, C, dtype=torch.float32, device=g.device)
-        _mm_nn(g2, Wa, out=gF3.view(B * N, C))                                 # g Wa ...
-        _orl_bwd_accumulate_raw(_mm_nn(gt, Wb, alpha=1.0 / N), idx_x, arg_o, k, gF3, extra=g)  # ... + g + ORL scatter, one pass
-        gfm, gD = _rf_conv_bwd_raw(xyz, idx_f, directions, fm.view(B, N, -1), arg, gF3, S)
-        gfm2 = gfm.view(B * N, -1)
-        gW, gb = wgrad(X2, gfm2, colsum=True)                                  # X^T gfm and the bias gradient
-        g_ste = wgrad(g2, X2)
-        gX3 = torch.empty(B, N, Cin, dtype=torch.float32, device=g.device)
-        _grad_in_rows(g2, w_ste, gfm2, weights, gX3.view(B * N, Cin))          # g Wste + gfm W^T
+        with WgradBatch():                                                     # the three parameter gradients: one fold launch
+            wgrad(g2, F2, out=g_conv2[:, :C])                                  # gWa, written in place (ldc = 2C)
+            _tiny_tn(gt, fg, g_conv2[:, C:])                                   # gWb = gt^T fg (tiny), straight into its column block
+            gF3 = torch.empty(B, N, C, dtype=torch.float32, device=g.device)
+            _mm_nn(g2, Wa, out=gF3.view(B * N, C))                             # g Wa ...
+            _orl_bwd_accumulate_raw(_mm_nn(gt, Wb, alpha=1.0 / N), idx_x, arg_o, k, gF3, extra=g)  # ... + g + ORL scatter, one pass
+            gfm, gD = _rf_conv_bwd_raw(xyz, idx_f, directions, fm.view(B, N, -1), arg, gF3, S)
+            gfm2 = gfm.view(B * N, -1)
+            gW, gb = wgrad(X2, gfm2, colsum=True)                              # X^T gfm and the bias gradient
+            g_ste = wgrad(g2, X2)
+            gX3 = torch.empty(B, N, Cin, dtype=torch.float32, device=g.device)
+            _grad_in_rows(g2, w_ste, gfm2, weights, gX3.view(B * N, Cin))      # g Wste + gfm W^T
         return None, gX3, None, None, None, None, gW, gb, gD, g_ste.unsqueeze_(-1), g_conv2.unsqueeze_(-1)
 
 

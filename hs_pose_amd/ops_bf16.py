@@ -108,13 +108,7 @@ def _wgrad(A2, B2, out=None, colsum=False):
         out = torch.empty(M, N, dtype=torch.float32, device=A2.device)
     if M % 64 or N % 64 or A2.stride(1) != 1 or B2.stride(1) != 1 or A2.stride(0) % 2 or B2.stride(0) % 2:
         raise HspError("bf16 weight gradient: channel counts must be multiples of 64")
-    cs = torch.empty(N, dtype=torch.float32, device=A2.device) if colsum else None
-    wsb = lib().hsp_wgrad_workspace_bytes(M, N, K)
-    ws = _ws(wsb, A2.device)
-    _run("hsp_wgrad_bf16", (_p(A2), A2.stride(0), _p(B2), B2.stride(0), M, N, K, _p(out), out.stride(0), _p(cs), _p(ws), wsb,
-                            _stream()),
-         key=f"M{M}N{N}K{K}", abytes=2 * K * (M + N) + 4 * M * N, aflops=2 * M * N * K)
-    return (out, cs) if colsum else out
+    return ops._wgrad_custom(A2, B2, out, colsum)          # (hsp_wgrad_bf16, or its partial form inside an ops.WgradBatch)
 
 
 def _orl_bwd_accumulate(gfg_over_n, idx_x, arg, gF3, extra):
@@ -206,17 +200,18 @@ class _HSLayerBf16(torch.autograd.Function):
         Wb = w_conv2[:, C:]
         gt = _colsum(g)                                           # fp32 (B,C)
         g_conv2 = torch.empty_like(w_conv2)
-        _wgrad(g2, F2, out=g_conv2[:, :C])                        # gWa
-        ops._tiny_tn(gt, fg, g_conv2[:, C:])                      # gWb (fp32, tiny)
-        gF3 = torch.empty(B, N, C, dtype=BF16, device=g.device)
-        ops.gemm_rows(g2, c2T_b[:C], out=gF3.view(B * N, C))      # g Wa ...
-        _orl_bwd_accumulate(ops._mm_nn(gt, Wb, alpha=1.0 / N), idx_x, arg_o, gF3, g)      # ... + g + ORL scatter
-        gfm, gD = _rf_conv_bwd(xyz, directions, fm.view(B, N, -1), arg, gF3, S)
-        gfm2 = gfm.view(B * N, -1)
-        gW, gb = _wgrad(X2, gfm2, colsum=True)
-        g_ste = _wgrad(g2, X2)
-        gX3 = torch.empty(B, N, Cin, dtype=BF16, device=g.device)
-        ops.gemm_rows(g2, steT_b, False, gfm2, W_b, False, out=gX3.view(B * N, Cin))      # g Wste + gfm W^T
+        with ops.WgradBatch():                                        # the three parameter gradients: one fold launch
+            _wgrad(g2, F2, out=g_conv2[:, :C])                        # gWa
+            ops._tiny_tn(gt, fg, g_conv2[:, C:])                      # gWb (fp32, tiny)
+            gF3 = torch.empty(B, N, C, dtype=BF16, device=g.device)
+            ops.gemm_rows(g2, c2T_b[:C], out=gF3.view(B * N, C))      # g Wa ...
+            _orl_bwd_accumulate(ops._mm_nn(gt, Wb, alpha=1.0 / N), idx_x, arg_o, gF3, g)      # ... + g + ORL scatter
+            gfm, gD = _rf_conv_bwd(xyz, directions, fm.view(B, N, -1), arg, gF3, S)
+            gfm2 = gfm.view(B * N, -1)
+            gW, gb = _wgrad(X2, gfm2, colsum=True)
+            g_ste = _wgrad(g2, X2)
+            gX3 = torch.empty(B, N, Cin, dtype=BF16, device=g.device)
+            ops.gemm_rows(g2, steT_b, False, gfm2, W_b, False, out=gX3.view(B * N, Cin))      # g Wste + gfm W^T
         return None, gX3, None, None, None, None, gW, gb, gD, g_ste.unsqueeze_(-1), g_conv2.unsqueeze_(-1), None
 
 

@@ -244,8 +244,19 @@ int hsp_cast_params_bf16(const HspCastDesc *table_dev, int n, int total_tiles, h
  * a fixed order (deterministic).  ws: hsp_wgrad_workspace_bytes(M,N,K).
  */
 size_t hsp_wgrad_workspace_bytes(int M, int N, int K);
+/* split forms for a backward that computes several parameter gradients (an HS layer has three): hsp_wgrad_partial_* runs the
+ * split-K launch only and describes the pending fold in *pending (a HOST struct; the workspace must stay alive and untouched
+ * until the fold); hsp_wgrad_fold folds up to 4 pending problems in ONE launch (same fixed order, same results). */
+typedef struct HspWgradPending {
+    const void *part, *cs_part;   /* split-K partials in the problem's workspace */
+    void *C, *colsum;             /* outputs (colsum may be NULL) */
+    int nparts, M, N, ldc;
+} HspWgradPending;
+int hsp_wgrad_fold(const HspWgradPending *pending, int n, hspStream_t stream);
 int hsp_wgrad_f32(const float *A, int lda, const float *B, int ldb, int M, int N, int K, float *C, int ldc,
                   float *colsum_B, void *ws, size_t ws_bytes, hspStream_t stream);
+int hsp_wgrad_partial_f32(const float *A, int lda, const float *B, int ldb, int M, int N, int K, float *C, int ldc,
+                          float *colsum_B, void *ws, size_t ws_bytes, HspWgradPending *pending, hspStream_t stream);
 
 /* ---- BatchNorm1d (train mode) + ReLU over point rows -------------------------------------------
  * replaces F.relu(bn(x.transpose(1,2)).transpose(1,2))          FaceRecon.py:27-29, :90-95
@@ -386,6 +397,8 @@ int hsp_gather_rows_bwd_csr_bf16(const hsp_bf16_t *grad_out, int grad_stride, co
                                  hspStream_t stream);
 int hsp_wgrad_bf16(const hsp_bf16_t *A, int lda, const hsp_bf16_t *B, int ldb, int M, int N, int K, float *C, int ldc,
                    float *colsum_B, void *ws, size_t ws_bytes, hspStream_t stream);
+int hsp_wgrad_partial_bf16(const hsp_bf16_t *A, int lda, const hsp_bf16_t *B, int ldb, int M, int N, int K, float *C, int ldc,
+                           float *colsum_B, void *ws, size_t ws_bytes, HspWgradPending *pending, hspStream_t stream);
 /* "mixed": x fp32 (the pre-BatchNorm layer output is kept in fp32: with |mean| >> std per channel a bf16 x would leave
  * the normalised value only a few significant bits), y / dy / dx bf16 */
 int hsp_bn_relu_fwd_mixed(const float *x, int R, int C, const float *gamma, const float *beta, float eps, float momentum,
