@@ -93,24 +93,25 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float* __restrict__ out_a, float* __restrict__ out_b,
                                                            float* __restrict__ run_mean, float* __restrict__ run_var,
                                                            long long* __restrict__ num_batches) {
-    // workgroup = 64 channels x 16 slices of the partials: every thread sums its <= BN_MAX_PARTIALS/16 partials with
-    // all loads in flight (a single thread walking 64 partials is a 10 us chain of L2 round trips), then the 16
-    // slices are folded through LDS in a fixed order (deterministic)
-    __shared__ float red[16][2][64];
-    const int lc = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lc;
+    // workgroup = 16 channels x 64 slices of the partials: every thread sums its <= BN_MAX_PARTIALS/64 = 8 partials with all
+    // loads in flight (one L2 round trip; a single thread walking 64 partials is a 10 us chain), then the 64 slices are
+    // folded through LDS in a fixed order (deterministic).  (16 x 64 rather than 64 x 16: four times the workgroups --
+    // C = 128 gave two -- and a quarter of the dependent rounds: 8.2 -> 4 us at 16448 rows.)
+    __shared__ float red[64][2][16];
+    const int lc = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + lc;
     float a1 = 0.f, a2 = 0.f;
     if (c < C) {
         float u1[4] = {0.f, 0.f, 0.f, 0.f}, u2[4] = {0.f, 0.f, 0.f, 0.f};
         int b = sl;
-        for (; b + 48 < nblk; b += 64) {                    // 8 loads in flight
+        for (; b + 192 < nblk; b += 256) {                  // 8 loads in flight
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                u1[u] += partial[(size_t)(b + 16 * u) * 2 * C + c];
-                u2[u] += partial[(size_t)(b + 16 * u) * 2 * C + C + c];
+                u1[u] += partial[(size_t)(b + 64 * u) * 2 * C + c];
+                u2[u] += partial[(size_t)(b + 64 * u) * 2 * C + C + c];
             }
         }
-        for (; b < nblk; b += 16) {
+        for (; b < nblk; b += 64) {
             u1[0] += partial[(size_t)b * 2 * C + c];
             u2[0] += partial[(size_t)b * 2 * C + C + c];
         }
@@ -122,8 +123,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     __syncthreads();
     if (sl != 0 || c >= C) return;
     float s1 = red[0][0][lc], s2 = red[0][1][lc];
-#pragma unroll
-    for (int t = 1; t < 16; ++t) { s1 += red[t][0][lc]; s2 += red[t][1][lc]; }
+#pragma unroll 8
+    for (int t = 1; t < 64; ++t) { s1 += red[t][0][lc]; s2 += red[t][1][lc]; }
     if (MODE == 0) {
         const float invR = 1.0f / (float)R;
         const float ms = s1 * invR;                              // mean of (x - shift)
@@ -246,7 +247,7 @@ static int bn_relu_fwd_impl(const XT* x, int R, int C, const float* gamma, const
     const int nblk = bn_blocks(R);
     hipLaunchKernelGGL((bn_partial_kernel<0, FT, XT>), dim3(nblk), dim3(BN_THREADS), 0, st, x, (const FT*)nullptr, R, C, nullptr, nullptr,
                        nullptr, nullptr, 0, part, bn_rows_per_block(R));
-    hipLaunchKernelGGL((bn_finalize_kernel<0, XT>), dim3((C + 63) / 64), dim3(1024), 0, st, part, nblk, R, C, x, eps, momentum,
+    hipLaunchKernelGGL((bn_finalize_kernel<0, XT>), dim3((C + 15) / 16), dim3(1024), 0, st, part, nblk, R, C, x, eps, momentum,
                        save_mean, save_invstd, running_mean, running_var, num_batches_tracked);
     const long long total4 = (long long)R * (C >> 2);
     hipLaunchKernelGGL((bn_apply_kernel<FT, XT>), dim3(stream_grid4(total4)), dim3(256), 0, st, x, total4, C, save_mean, save_invstd,
@@ -279,7 +280,7 @@ static int bn_relu_bwd_impl(const XT* x, const FT* dy, int R, int C, const float
     const int nblk = bn_blocks(R);
     hipLaunchKernelGGL((bn_partial_kernel<1, FT, XT>), dim3(nblk), dim3(BN_THREADS), 0, st, x, dy, R, C, save_mean, save_invstd, gamma,
                        beta, relu, part, bn_rows_per_block(R));
-    hipLaunchKernelGGL((bn_finalize_kernel<1, XT>), dim3((C + 63) / 64), dim3(1024), 0, st, part, nblk, R, C, x, 0.f, 0.f, dgamma,
+    hipLaunchKernelGGL((bn_finalize_kernel<1, XT>), dim3((C + 15) / 16), dim3(1024), 0, st, part, nblk, R, C, x, 0.f, 0.f, dgamma,
                        dbeta, nullptr, nullptr, nullptr);
     const long long total4 = (long long)R * (C >> 2);
     hipLaunchKernelGGL((bn_dx_kernel<FT, XT>), dim3(stream_grid4(total4)), dim3(256), 0, st, x, dy, total4, R, C, save_mean,
