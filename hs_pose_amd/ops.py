@@ -571,11 +571,15 @@ def gemm_choices():
     return dict(_gemm_choice)
 
 
+# composite families ("fm", "out", "gx", "nn", "nt": the key prefixes below) that take the own kernel even in library mode
+GEMM_OWN_FAMILIES = set(f for f in os.environ.get("HSP_GEMM_OWN", "").split(",") if f)
+
+
 def _pick(key, own_fn, lib_fn):
     if GEMM_MODE == "own":
         return own_fn()
     if GEMM_MODE == "library":
-        return lib_fn()
+        return own_fn() if key.split("[")[0] in GEMM_OWN_FAMILIES else lib_fn()
     choice = _gemm_choice.get(key)
     if choice is None:
         if torch.cuda.is_current_stream_capturing() or _timer is not None:
