@@ -118,3 +118,39 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "ref_cpu" not in txt and "hsp_oracle" not in txt.replace("oracle/hsp_oracle.c", ""), f
+
+def test_round2_entry_points_validate_arguments_without_gpu():
+    """the round-2 entry points (dense products, losses, augmentation, split weight-gradient fold) reject bad arguments
+    before any launch -- checked here on the CPU"""
+    from hs_pose_amd._lib import HspLossCfg, HspWgradPending, lib
+    L = lib()
+    null, one = ctypes.c_void_p(0), ctypes.c_void_p(64)
+    f = ctypes.c_float
+    # hsp_gemm_rows_f32(A1, lda1, B1, ldb1, layout1, K1, A2, lda2, B2, ldb2, layout2, K2, M, N, bias, resid, ldr, cbias, rpc, alpha,
+    #                   xyz3, w3, C, ldc, ws, ws_bytes, stream)
+    g = lambda *a: L.hsp_gemm_rows_f32(*a)
+    assert g(null, 8, one, 8, 0, 8, null, 0, null, 0, 0, 0, 4, 4, null, null, 0, null, 0, f(1), null, null, one, 4, null, 0, null) == -1
+    assert g(one, 4, one, 8, 0, 8, null, 0, null, 0, 0, 0, 4, 4, null, null, 0, null, 0, f(1), null, null, one, 4, null, 0, null) == -1  # lda < K
+    assert g(one, 8, one, 8, 0, 8, null, 0, null, 0, 0, 0, 4, 4, null, null, 0, null, 0, f(1), null, null, one, 2, null, 0, null) == -1  # ldc < N
+    assert g(one, 8, one, 8, 0, 8, null, 0, null, 0, 0, 0, 4, 4, null, null, 0, null, 0, f(1), one, null, one, 4, null, 0, null) == -1  # xyz3 w/o w3
+    assert L.hsp_gemm_rows_workspace_bytes(0, 4, 4, 0, 4) == 0 and L.hsp_gemm_rows_workspace_bytes(1024, 256, 4608, 0, 4) > 0
+    # bf16 form: "nn + nn" does not exist, elem size checked by the query
+    assert L.hsp_gemm_rows_workspace_bytes(64, 64, 64, 0, 3) == 0
+    # losses
+    cfg = HspLossCfg()
+    args17 = [one] * 17
+    assert L.hsp_pose_losses_workspace_bytes(0) == 0 and L.hsp_pose_losses_workspace_bytes(16) > 0
+    assert L.hsp_pose_losses_fwd(*([null] + [one] * 16), 2, 8, ctypes.byref(cfg), one, one, 1 << 20, null) == -1     # null input
+    assert L.hsp_pose_losses_fwd(*args17, 2, 0, ctypes.byref(cfg), one, one, 1 << 20, null) == -1                    # N = 0
+    assert L.hsp_pose_losses_fwd(*args17, 2, 8, ctypes.byref(cfg), one, null, 0, null) == -3                         # no workspace
+    assert L.hsp_pose_losses_bwd(*args17, 2, 8, ctypes.byref(cfg), one, one, 16, one, *([one] * 10), null) == -3      # workspace too small
+    assert L.hsp_pose_losses_bwd(*args17, 2, 8, ctypes.byref(cfg), null, one, 1 << 20, one, *([one] * 10), null) == -1  # no grad_terms
+    # augmentation
+    fl = [f(0.3)] * 4
+    assert L.hsp_pose_augment(*([one] * 14), 2, 8, 0, *fl, one, one, one, one, null) == -1                            # M = 0
+    assert L.hsp_pose_augment(*([one] * 13 + [null]), 2, 8, 4, *fl, one, one, one, one, null) == -1                   # no noise
+    # split weight gradient: the fold checks its table
+    pend = (HspWgradPending * 2)()
+    assert L.hsp_wgrad_fold(pend, 0, null) == -1 and L.hsp_wgrad_fold(pend, 5, null) == -1
+    assert L.hsp_wgrad_fold(pend, 1, null) == -1                                                                      # empty entry
+    assert L.hsp_wgrad_partial_f32(one, 128, one, 1024, 128, 1024, 4000, one, 1024, null, one, 1 << 30, null, null) == -1   # no pending
