@@ -176,12 +176,36 @@ __global__ __launch_bounds__(256) void colsum_partial_scalar_kernel(const float*
 // (bf16 build: kind 0 / 1 sources are bf16 like the output, kind 2 -- the per-cloud one-hot row -- stays fp32 and is
 // rounded on the way in; W is the output ROW PITCH, which may exceed the sum of the widths: padding columns stay untouched)
 struct ConcatSeg { const void* src; const int32_t* idx; int width; int kind; int nsrc; int col0; };
-struct ConcatDesc { ConcatSeg seg[8]; int nseg; int even; };
+struct ConcatDesc { ConcatSeg seg[8]; int nseg; int even; int q0[9]; };      // q0: first 16-byte chunk of each segment (even == 2)
 
 template <typename FT>
 __global__ __launch_bounds__(256) void concat_rows_kernel(ConcatDesc d, int B, int N, int W, FT* __restrict__ out) {
     using Pair = typename std::conditional<sizeof(FT) == 4, float2, unsigned>::type;       // two elements
     const long long rows = (long long)B * N;
+    if (d.even == 2) {
+        // 16-byte form: four rows per workgroup pass, a wave per row; a lane walks the row's 16-byte chunks (all segments
+        // flattened) with stride 64, so every lane has 2-5 independent loads in flight
+        const int lane = threadIdx.x & 63;
+        const int total = d.q0[d.nseg];
+        for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
+            const int b = (int)(row / N);
+            FT* o = out + (size_t)row * W;
+            for (int q = lane; q < total; q += 64) {
+                int sgi = 0;
+                while (q >= d.q0[sgi + 1]) ++sgi;
+                const ConcatSeg sg = d.seg[sgi];
+                const int c = q - d.q0[sgi];
+                if (sg.kind == 2) {                               // per-cloud fp32 row: element c (chunk = one element here)
+                    Feat<FT>::st(o + sg.col0 + c, reinterpret_cast<const float*>(sg.src)[(size_t)b * sg.width + c]);
+                    continue;
+                }
+                const FT* src = reinterpret_cast<const FT*>(sg.src);
+                src += sg.kind == 0 ? (size_t)row * sg.width : ((size_t)b * sg.nsrc + sg.idx[row]) * sg.width;
+                reinterpret_cast<uint4*>(o + sg.col0)[c] = reinterpret_cast<const uint4*>(src)[c];
+            }
+        }
+        return;
+    }
     for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
         const int b = (int)(row / N);
         FT* o = out + (size_t)row * W;
@@ -874,8 +898,21 @@ static int concat_rows_impl(int nseg, const void* const* src, const int32_t* con
         if (kind[s] != 2 && ((width[s] & 1) || (d.seg[s].col0 & 1) || (reinterpret_cast<uintptr_t>(src[s]) & (2 * sizeof(FT) - 1))))
             d.even = 0;
     if (reinterpret_cast<uintptr_t>(out) & (2 * sizeof(FT) - 1)) d.even = 0;
+    if (d.even) {               // 16-byte form: pitch, column offsets, widths and bases all multiples of 16 bytes
+        constexpr int EP = 16 / (int)sizeof(FT);
+        bool q = (out_pitch % EP) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+        for (int s = 0; s < nseg && q; ++s)
+            if (kind[s] != 2 && ((width[s] % EP) || (d.seg[s].col0 % EP) || (reinterpret_cast<uintptr_t>(src[s]) & 15))) q = false;
+        if (q) {
+            d.even = 2;
+            int acc = 0;
+            for (int s = 0; s < nseg; ++s) { d.q0[s] = acc; acc += kind[s] == 2 ? width[s] : width[s] / EP; }
+            d.q0[nseg] = acc;
+        }
+    }
     const long long rows = (long long)B * N;
-    const int grid = (int)(rows < 8192 ? rows : 8192);
+    int grid = (int)(rows < 8192 ? rows : 8192);
+    if (d.even == 2) grid = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
     hipLaunchKernelGGL(concat_rows_kernel<FT>, dim3(grid), dim3(256), 0, as_stream(stream), d, B, N, out_pitch, out);
     return check_launch();
 }

@@ -892,7 +892,10 @@ class _LinearRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x2, weight, bias):
-        x2 = _req(x2, torch.float32, "linear_rows.x")
+        if x2.dim() == 2 and x2.stride(1) == 1 and x2.stride(0) >= x2.shape[1] and x2.dtype == torch.float32 and x2.is_cuda:
+            pass                                    # rows of a wider buffer (feat's padded pitch): every consumer takes a row stride
+        else:
+            x2 = _req(x2, torch.float32, "linear_rows.x")
         ctx.save_for_backward(x2, weight)
         ctx.has_bias = bias is not None
         return _mm_nt(x2, weight, bias)
@@ -1036,6 +1039,10 @@ def gather_rows(feat, idx):
 # feat assembly: nearest up-sampling + one-hot + concat in one kernel (FaceRecon.py:100-107)
 # ------------------------------------------------------------------------------------------------
 
+# feat row pitch: columns padded to a multiple of this many elements (8 = 16 bytes of bf16, 32 of fp32); 1 = no padding
+FEAT_PITCH_ALIGN = int(os.environ.get("HSP_FEAT_PITCH_ALIGN", "8"))
+
+
 class _AssembleFeat(torch.autograd.Function):
     """feat (B,N,W) = cat[ direct..., gathered(src, nearest idx)..., per-cloud... ] along channels.
     segs: list of (tensor, idx or None, kind) with kind 0 direct (B,N,w), 1 gathered rows of (B,Ns,w) by an
@@ -1054,7 +1061,11 @@ class _AssembleFeat(torch.autograd.Function):
         n = len(tensors)
         widths = [t.shape[-1] for t in tensors]
         W = sum(widths)
-        out = torch.empty(B, N, W, dtype=dt, device=tensors[0].device)
+        # rows padded to a multiple of 16 bytes (1286 -> 1288 columns): the kernel then moves 16 bytes per access and the
+        # heads' K = 1286 products read aligned rows; the result is the (B,N,W) view of the padded buffer
+        P = (W + FEAT_PITCH_ALIGN - 1) // FEAT_PITCH_ALIGN * FEAT_PITCH_ALIGN if FEAT_PITCH_ALIGN > 1 else W
+        full = torch.empty(B, N, P, dtype=dt, device=tensors[0].device)
+        out = full[:, :, :W] if P != W else full
         src = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tensors])
         ix = (ctypes.c_void_p * n)(*[(i.data_ptr() if i is not None else 0) for i in idxs])
         wd = (ctypes.c_int * n)(*widths)
@@ -1063,11 +1074,11 @@ class _AssembleFeat(torch.autograd.Function):
         es = 2 if dt == torch.bfloat16 else 4
         if dt == torch.bfloat16:
             _run("hsp_concat_rows_bf16", (n, ctypes.cast(src, _vp), ctypes.cast(ix, _vp), ctypes.cast(wd, _vp),
-                                          ctypes.cast(kd, _vp), ctypes.cast(ns, _vp), B, N, _p(out), W, _stream()),
+                                          ctypes.cast(kd, _vp), ctypes.cast(ns, _vp), B, N, _p(full), P, _stream()),
                  key=f"B{B}N{N}W{W}", abytes=2 * es * B * N * W)
         else:
-            _run("hsp_concat_rows", (n, ctypes.cast(src, _vp), ctypes.cast(ix, _vp), ctypes.cast(wd, _vp), ctypes.cast(kd, _vp),
-                                     ctypes.cast(ns, _vp), B, N, _p(out), _stream()),
+            _run("hsp_concat_rows_pitched", (n, ctypes.cast(src, _vp), ctypes.cast(ix, _vp), ctypes.cast(wd, _vp),
+                                             ctypes.cast(kd, _vp), ctypes.cast(ns, _vp), B, N, _p(full), P, _stream()),
                  key=f"B{B}N{N}W{W}", abytes=2 * es * B * N * W)
         ctx.kinds, ctx.widths = kinds, widths
         ctx.nsrc = [t.shape[1] for t in tensors]
