@@ -444,3 +444,38 @@ def test_rf_conv_fwd_channel_split_schedule_is_bit_identical(dev, ref, monkeypat
         assert (a is None) == (b is None)
         if a is not None:
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("align", [8, 1])
+def test_assemble_feat_pitched_rows(dev, ref, monkeypatch, dtype, align):
+    """feat assembly (FaceRecon.py:108-114: direct levels, nearest-up-sampled coarse levels, one-hot category columns) into
+    rows padded to a 16-byte pitch (align 8: a (B,N,W) view of a wider buffer, 16-byte kernel path) and dense (align 1):
+    both equal the torch cat / gather composition exactly (a copy kernel), and the backward returns the column blocks."""
+    from hs_pose_amd import ops
+    monkeypatch.setattr(ops, "FEAT_PITCH_ALIGN", align)
+    dt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    B, N, N1, N2 = 3, 1028, 257, 64
+    h = lambda shape, seed: ref.hash_tensor(shape, seed, 1.0).to(dev)
+    a0, a1 = h((B, N, 128), 1).to(dt).requires_grad_(True), h((B, N, 128), 2).to(dt).requires_grad_(True)
+    c2, c3 = h((B, N1, 256), 3).to(dt).requires_grad_(True), h((B, N1, 256), 4).to(dt).requires_grad_(True)
+    c4 = h((B, N2, 512), 5).to(dt).requires_grad_(True)
+    g = torch.Generator().manual_seed(3)
+    near1 = torch.randint(0, N1, (B, N), generator=g).int().to(dev)
+    near2 = torch.randint(0, N2, (B, N), generator=g).int().to(dev)
+    one_hot = torch.zeros(B, 6, device=dev).scatter_(1, torch.tensor([[1], [4], [0]], device=dev), 1.0)
+    feat = ops.assemble_feat([(a0, None, 0), (a1, None, 0), (c2, near1, 1), (c3, near1, 1), (c4, near2, 1), (one_hot, None, 2)])
+    assert feat.shape == (B, N, 1286) and feat.dtype == dt
+    assert feat.stride(1) == (1288 if align == 8 else 1286) and feat.stride(2) == 1
+    gat = lambda c, near: torch.gather(c, 1, near.long().unsqueeze(-1).expand(-1, -1, c.shape[2]))
+    want = torch.cat([a0, a1, gat(c2, near1), gat(c3, near1), gat(c4, near2), one_hot.to(dt).unsqueeze(1).expand(-1, N, -1)], dim=2)
+    assert torch.equal(feat, want)
+    rows = feat.reshape(B * N, 1286)
+    assert rows.data_ptr() == feat.data_ptr()                   # the heads take the strided rows: no copy
+    up = h((B, N, 1286), 9).to(dt)
+    feat.backward(up)
+    assert torch.equal(a1.grad, up[:, :, 128:256])
+    ref_c4 = torch.zeros(B, N2, 512, device=dev, dtype=torch.float32)
+    ref_c4.scatter_add_(1, near2.long().unsqueeze(-1).expand(-1, -1, 512), up[:, :, 768:1280].float())
+    tol = 1e-5 if dtype == "f32" else 2.0 ** -7
+    assert float((c4.grad.float() - ref_c4).abs().max()) <= tol * max(1.0, float(ref_c4.abs().max()))
