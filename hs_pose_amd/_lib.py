@@ -43,6 +43,9 @@ SIGNATURES = {
     "hsp_gemm_rows_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "hsp_gemm_rows_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, ctypes.c_float, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "hsp_gemm_rows_bf16": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, ctypes.c_float, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "hsp_gemm_wave_supported": (_i, [_i, _i, _i, _i, _i]),
+    "hsp_gemm_wave_plan_info": (_i, [_i, _i, _i, _i, _i, _vp]),
+    "hsp_gemm_wave_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, ctypes.c_float, _vp, _vp, _vp, _i, _i, _vp]),
     "hsp_bn_relu_fwd_mixed": (_i, [_vp, _i, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "hsp_bn_relu_apply_mixed": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "hsp_bn_relu_bwd_mixed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

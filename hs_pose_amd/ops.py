@@ -553,6 +553,30 @@ def gemm_rows(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=N
     return out
 
 
+def gemm_wave_supported(M, N, K1, K2=0, cfg=0):
+    return bool(lib().hsp_gemm_wave_supported(int(M), int(N), int(K1), int(K2), int(cfg)))
+
+
+def gemm_wave(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=None, cloud_bias=None, rows_per_cloud=0,
+              out=None, alpha=1.0, xyz3=None, w3=None, cfg=0):
+    """the contract of ``gemm_rows`` (fp32 only) on the LDS-free wave-level kernel (csrc/gemm_wave.hip): K1, K2 multiples of
+    32, N of 32, 16-byte aligned rows.  ``cfg`` != 0 forces a tile / cut (include/hsp.h), for tuning."""
+    M, K1 = A1.shape
+    N = B1.shape[1] if nn1 else B1.shape[0]
+    K2 = A2.shape[1] if A2 is not None else 0
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A1.device)
+    flops = 2 * M * N * (K1 + K2)
+    ab = 4 * (M * (K1 + K2) + N * (K1 + K2) + M * N * (2 if resid is not None else 1))
+    _run("hsp_gemm_wave_f32", (_p(A1), _ld(A1), _p(B1), _ld(B1), 1 if nn1 else 0, K1,
+                               _p(A2), _ld(A2) if A2 is not None else 0, _p(B2), _ld(B2) if B2 is not None else 0,
+                               1 if nn2 else 0, K2, M, N, _p(bias), _p(resid), _ld(resid) if resid is not None else 0,
+                               _p(cloud_bias), int(rows_per_cloud), float(alpha), _p(xyz3), _p(w3), _p(out), _ld(out),
+                               int(cfg), _stream()),
+         key=f"M{M}N{N}K{K1}" + (f"+{K2}" if K2 else ""), abytes=ab, aflops=flops)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # dense per-point products of a layer: the hand-written fused kernel (csrc/gemm_rows.hip) or the BLAS library through
 # torch.  HSP_GEMM = library (default for fp32 rows) | own | auto: "own" runs no library GEMM at all on the layer path
@@ -592,12 +616,42 @@ def _pick(key, own_fn, lib_fn):
     return own_fn() if choice == "own" else lib_fn()
 
 
+def _al16(t):
+    return t is None or (t.data_ptr() % 16 == 0 and (t.stride(0) * 4) % 16 == 0)
+
+
+def gemm_own(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=None, cloud_bias=None, rows_per_cloud=0, out=None,
+             alpha=1.0, xyz3=None, w3=None):
+    """the fp32 product of ``gemm_rows`` on whichever hand-written kernel suits the shape: the LDS-free wave-level kernel
+    (csrc/gemm_wave.hip) when the output is large against a short K -- many tiles that each live for a few k-blocks: fm = X W + b
+    and the g Wa products; measured 13-14 us against 15-19 us, 24-48 us against 36-67 us -- and the LDS-staged tile kernel
+    (csrc/gemm_rows.hip: any K / alignment, split-K) otherwise."""
+    M, K1 = A1.shape
+    N = B1.shape[1] if nn1 else B1.shape[0]
+    K2 = A2.shape[1] if A2 is not None else 0
+    two, rc = A2 is not None, resid is not None and cloud_bias is not None
+    plain = bias is None and resid is None and cloud_bias is None and xyz3 is None
+    # the forms gemm_wave.hip instantiates: fm (nn + bias), g W (nn), x W^T (nt [+ bias]), out (nt + nt, residual + cloud bias),
+    # surface out (nt, residual + cloud bias + xyz3), gX (nn + nt)
+    form = ((not two and nn1 and (plain or (bias is not None and resid is None and cloud_bias is None and xyz3 is None)))
+            or (not two and not nn1 and (plain or (bias is not None and resid is None and cloud_bias is None and xyz3 is None)))
+            or (two and not nn1 and not nn2 and bias is None and rc and xyz3 is None)
+            or (not two and not nn1 and bias is None and rc and xyz3 is not None)
+            or (two and nn1 and not nn2 and plain))
+    if (form and A1.dtype == torch.float32 and K1 + K2 <= 512 and M * N >= 512 * 1024 and K1 % 32 == 0 and K2 % 32 == 0
+            and N % 32 == 0 and (not rc or rows_per_cloud >= 64) and all(_al16(t) for t in (A1, B1, A2, B2, resid, out))):
+        return gemm_wave(A1, B1, nn1, A2, B2, nn2, bias=bias, resid=resid, cloud_bias=cloud_bias, rows_per_cloud=rows_per_cloud,
+                         out=out, alpha=alpha, xyz3=xyz3, w3=w3)
+    return gemm_rows(A1, B1, nn1, A2, B2, nn2, bias=bias, resid=resid, cloud_bias=cloud_bias, rows_per_cloud=rows_per_cloud,
+                     out=out, alpha=alpha, xyz3=xyz3, w3=w3)
+
+
 def _fm_rows(X2, weights, bias, out=None):
     """fm = X W + b   (gcn3d.py:171)"""
     R, Cin = X2.shape
     # (the library form allocates its own result: addmm with out= and a broadcast bias takes a slower path in ATen)
     return _pick(f"fm[R{R}K{Cin}N{weights.shape[1]}]",
-                 lambda: gemm_rows(X2, weights, True, bias=bias, out=out),
+                 lambda: gemm_own(X2, weights, True, bias=bias, out=out),
                  lambda: torch.addmm(bias, X2, weights) if out is None else torch.addmm(bias, X2, weights, out=out))
 
 
@@ -612,7 +666,11 @@ def _layer_out_rows(x2, w_ste, F2, Wa, t2, out3):
         _residual_bias(out3, F2.view(B, N, C), t2)
         return out3
     def own():
-        gemm_rows(x2, w_ste, False, F2, Wa, False, resid=F2, cloud_bias=t2.contiguous(), rows_per_cloud=N, out=out)
+        if x2.shape[1] == 3:                                  # HSlayer_surface: the K = 3 STE on raw coordinates rides in the epilogue
+            gemm_own(F2, Wa, False, resid=F2, cloud_bias=t2.contiguous(), rows_per_cloud=N, out=out, xyz3=x2,
+                     w3=w_ste.contiguous())
+        else:
+            gemm_own(x2, w_ste, False, F2, Wa, False, resid=F2, cloud_bias=t2.contiguous(), rows_per_cloud=N, out=out)
         return out3
     return _pick(f"out[R{B * N}K{x2.shape[1]}+{C}N{C}]", own, lib)
 
@@ -627,7 +685,7 @@ def _mm_nn(g2, W, out=None, alpha=1.0):
         if alpha == 1.0:
             return torch.mm(g2, W, out=out)
         return torch.addmm(out, g2, W, beta=0.0, alpha=alpha, out=out)
-    return _pick(f"nn[R{R}K{K}N{W.shape[1]}]", lambda: gemm_rows(g2, W, True, out=out, alpha=alpha), lib)
+    return _pick(f"nn[R{R}K{K}N{W.shape[1]}]", lambda: gemm_own(g2, W, True, out=out, alpha=alpha), lib)
 
 
 def _mm_nt(x2, W, bias=None, out=None):
@@ -641,7 +699,7 @@ def _mm_nt(x2, W, bias=None, out=None):
             return torch.addmm(bias, x2, W.t(), out=out)
         return torch.mm(x2, W.t(), out=out)
     return _pick(f"nt[R{R}K{K}N{W.shape[0]}{'b' if bias is not None else ''}]",
-                 lambda: gemm_rows(x2, W, False, bias=bias, out=out), lib)
+                 lambda: gemm_own(x2, W, False, bias=bias, out=out), lib)
 
 
 def _grad_in_rows(g2, w_ste, gfm2, weights, out):
@@ -652,7 +710,7 @@ def _grad_in_rows(g2, w_ste, gfm2, weights, out):
         torch.mm(g2, w_ste, out=out)
         return out.addmm_(gfm2, weights.t())
     return _pick(f"gx[R{R}K{g2.shape[1]}+{gfm2.shape[1]}N{out.shape[1]}]",
-                 lambda: gemm_rows(g2, w_ste, True, gfm2, weights, False, out=out), lib)
+                 lambda: gemm_own(g2, w_ste, True, gfm2, weights, False, out=out), lib)
 
 
 def _tiny_tn(a, b, out):

@@ -229,6 +229,24 @@ int hsp_gemm_rows_bf16(const hsp_bf16_t *A1, int lda1, const hsp_bf16_t *B1, int
                        int c_is_f32 /* != 0: C is fp32 (an output that feeds BatchNorm keeps its mantissa) */,
                        void *ws, size_t ws_bytes, hspStream_t stream);
 
+/* The same product (same arguments, same result contract; reference gcn3d.py:149,171,186 and their input gradients) by the
+ * LDS-free wave-level kernel of csrc/gemm_wave.hip: every wave is an independent worker that streams both operands from
+ * L2 / L1 straight into MFMA operand layout (16-byte buffer loads, a ring of 4 steps of 8 k in flight that does not drain
+ * between the sources of a product nor between the tiles of a wave), no LDS, no barriers; the work is cut per WAVE -- a
+ * contiguous run of (32|64) x (32|64|128) tiles each, the tiles that do not divide by the wave count dealt out as 32 x 32
+ * blocks -- so there are no partial sums and the result does not depend on the cut.  Covers K1, K2 multiples of 32, N a
+ * multiple of 32, 16-byte aligned rows (hsp_gemm_wave_supported; anything else: hsp_gemm_rows_f32); fp32 on
+ * v_mfma_f32_32x32x2_f32.  cfg: 0 = automatic tile / cut; otherwise RB | NCB << 4 | waves_per_simd << 16 | order << 28
+ * (tuning: rows / 32 and columns / 32 of the wave tile, occupancy, 1 = row panels fastest in the tile order). */
+int hsp_gemm_wave_supported(int M, int N, int K1, int K2, int cfg);
+/* host-only: out[10] = rows / 32 and columns / 32 of the wave tile, waves per SIMD, tiles along M and N, whole tiles per wave,
+ * waves, first leftover tile, 32 x 32 blocks of the leftover tiles, 0; returns 0 when the shape is not covered */
+int hsp_gemm_wave_plan_info(int M, int N, int K1, int K2, int cfg, int *out);
+int hsp_gemm_wave_f32(const float *A1, int lda1, const float *B1, int ldb1, int b1_layout, int K1,
+                      const float *A2, int lda2, const float *B2, int ldb2, int b2_layout, int K2, int M, int N,
+                      const float *bias, const float *resid, int ldr, const float *cloud_bias, int rows_per_cloud,
+                      float alpha, const float *xyz3, const float *w3, float *C, int ldc, int cfg, hspStream_t stream);
+
 /* fp32 master parameters -> bf16 working copies for the *_bf16 entry points, every tensor of a step in one launch:
  * entry e copies src (rows, cols; row pitch ld) to dst (rows, cols) and / or dstT (cols, rows) -- either may be NULL --
  * rounding to nearest even.  tile0 = number of 32 x 32 tiles of the entries before e; table_dev lives in DEVICE memory. */
