@@ -158,6 +158,37 @@ def cpu_baseline(n_points, sample_clouds):
                       f"(oracle/ref_cpu.py, torch CPU, {cores} threads), {dt:.1f} s"}
 
 
+def side_run(extra_args, env_extra=None, timeout=600):
+    """this script again, in a child process, for a secondary figure of the same run (another dtype / GEMM mode: module
+    state, the captured graph and the tuned-library tables of the parent stay untouched); returns the child's JSON line"""
+    import subprocess
+    env = dict(os.environ)
+    for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k_, None)
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-u3", "--no-cpu-baseline", "--no-side"]
+                         + extra_args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    if out.returncode != 0 or not lines:
+        raise RuntimeError(f"side run {extra_args} failed (rc {out.returncode}): {out.stderr[-300:]}")
+    return json.loads(lines[-1])
+
+
+def relaunch_multi_gpu(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) under torch.distributed.run and hand over;
+    refuses when fewer than N devices are visible (a silent 1-rank run would print n_gpus: 1 for an N-GPU request)"""
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.exit(f"bench.py: --gpus {n} but only {have} GPU(s) visible")
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,7 +205,11 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="leave hipBLASLt/rocBLAS on their default heuristics")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the secondary figures appended to config (bf16 dense clouds, the no-BLAS-library step)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_multi_gpu(args.gpus)                   # does not return
 
     # stdout carries exactly ONE line, the JSON result: libraries that write to fd 1 themselves (RCCL prints a version
     # banner there, flushed at exit) are sent to stderr
@@ -192,7 +227,7 @@ def main():
     if not args.no_gemm_tuning:
         from hs_pose_amd import gemm_tuning
         gemm_tuning.enable()                            # library-GEMM solution selection (warm-up only)
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}: launch one rank per GPU (or plain `python bench.py --gpus N`)"
     B, N = args.batch, args.points
 
     FLAGS.reset(); FLAGS.train = 0                      # U1: backbone only (feat), no train-only heads
@@ -373,6 +408,22 @@ def main():
                 line["config"].update(u3_full_step(B, N, device))
             except Exception as exc:                    # never lose the headline line to the extra figure
                 line["config"]["u3_error"] = f"{type(exc).__name__}: {exc}"[:200]
+        if world == 1 and not args.no_side and not bf16 and B == 16 and N == 1028:
+            # secondary figures of the same run, each from a child process: BASELINE configs[3] (bf16 feature storage, dense
+            # clouds) and the fp32 step with NO BLAS-library GEMM (HSP_GEMM=own: gemm_wave / gemm_rows / wgrad everywhere)
+            try:
+                torch.cuda.empty_cache()
+                d = side_run(["--dtype", "bf16", "--points", "4096", "--batch", "64", "--steps", "10", "--warmup", "3"])
+                line["config"].update({"bf16_b64_n4096_ms_per_step": d["ms_per_step"], "bf16_b64_n4096_clouds_per_s": d["value"],
+                                       "bf16_b64_n4096_step_hbm_frac": d["step_roofline"]["step_hbm_frac"]})
+            except Exception as exc:
+                line["config"]["bf16_b64_n4096_error"] = f"{type(exc).__name__}: {exc}"[:200]
+            try:
+                other = "library" if ops.GEMM_MODE == "own" else "own"
+                d = side_run(["--steps", "20", "--warmup", "5"], {"HSP_GEMM": other})
+                line["config"].update({f"{other}_gemm_ms_per_step": d["ms_per_step"], f"{other}_gemm_clouds_per_s": d["value"]})
+            except Exception as exc:
+                line["config"]["other_gemm_error"] = f"{type(exc).__name__}: {exc}"[:200]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_sample)
         print(json.dumps(line), file=result_out, flush=True)

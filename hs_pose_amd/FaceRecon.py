@@ -73,14 +73,14 @@ class FaceRecon(nn.Module):
         module, building the fused optimizer).  torch.float32 restores the default path."""
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("feature dtype: torch.float32 or torch.bfloat16")
+        if dtype == torch.bfloat16 and FLAGS.train:             # (checked before anything is changed: the module stays fp32)
+            raise NotImplementedError("bf16 feature rows: the HS stack (feat); the train-only heads take fp32 rows")
         self.feature_dtype = dtype
         self.conv_0.out_dtype = dtype
         for layer in (self.conv_1, self.conv_2, self.conv_3):          # BatchNorm follows: fp32 rows out of the bf16 layer
             layer.out_fp32 = dtype == torch.bfloat16
         self._bf16 = None
         if dtype == torch.bfloat16:
-            if FLAGS.train:
-                raise NotImplementedError("bf16 feature rows: the HS stack (feat); the train-only heads take fp32 rows")
             # DETACHED views: a view with a grad_fn would create (and keep alive) the parameter's gradient accumulator bound
             # to whatever stream is current here, and a later backward inside a hipGraph capture would then hop to that
             # stream (an event on the null stream inside a capture crashes hipStreamEndCapture)

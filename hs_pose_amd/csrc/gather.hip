@@ -203,6 +203,9 @@ __global__ __launch_bounds__(256) void concat_rows_kernel(ConcatDesc d, int B, i
                 src += sg.kind == 0 ? (size_t)row * sg.width : ((size_t)b * sg.nsrc + sg.idx[row]) * sg.width;
                 reinterpret_cast<uint4*>(o + sg.col0)[c] = reinterpret_cast<const uint4*>(src)[c];
             }
+            // padding columns of a pitched row (1286 -> 1288): zeroed, so a consumer that reads whole 16-byte chunks sees no garbage
+            const int used = d.seg[d.nseg - 1].col0 + d.seg[d.nseg - 1].width;
+            if (lane < W - used) Feat<FT>::st(o + used + lane, 0.f);
         }
         return;
     }
@@ -922,7 +925,8 @@ extern "C" int hsp_concat_rows(int nseg, const float* const* src, const int32_t*
     for (int s = 0; s < nseg && s < 8 && width; ++s) col += width[s];
     return concat_rows_impl<float>(nseg, reinterpret_cast<const void* const*>(src), idx, width, kind, nsrc, B, N, out, col, stream);
 }
-/* the same with an explicit output row pitch (>= sum of widths: padding columns are left untouched) and, in the bf16
+/* the same with an explicit output row pitch (>= sum of widths: padding columns are zeroed when every segment is 16-byte
+ * aligned -- the form the feat assembly takes -- and left untouched otherwise) and, in the bf16
  * form, bf16 kind-0 / kind-1 sources with fp32 kind-2 (per-cloud) sources */
 extern "C" int hsp_concat_rows_pitched(int nseg, const float* const* src, const int32_t* const* idx, const int* width,
                                        const int* kind, const int* nsrc, int B, int N, float* out, int out_pitch,

@@ -1124,6 +1124,7 @@ class _AssembleFeat(torch.autograd.Function):
         P = (W + FEAT_PITCH_ALIGN - 1) // FEAT_PITCH_ALIGN * FEAT_PITCH_ALIGN if FEAT_PITCH_ALIGN > 1 else W
         full = torch.empty(B, N, P, dtype=dt, device=tensors[0].device)
         out = full[:, :, :W] if P != W else full
+        # (the kernel zeroes the pad columns: never read as data, but a consumer that loads whole 16-byte chunks touches them)
         src = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tensors])
         ix = (ctypes.c_void_p * n)(*[(i.data_ptr() if i is not None else 0) for i in idxs])
         wd = (ctypes.c_int * n)(*widths)
@@ -1182,7 +1183,10 @@ class _AssembleFeat(torch.autograd.Function):
 
 
 def assemble_feat(segments):
-    """segments: list of (tensor, idx_or_None, kind) -> (B,N,sum widths); see _AssembleFeat."""
+    """segments: list of (tensor, idx_or_None, kind) -> (B,N,sum widths); see _AssembleFeat.  NOTE the result is the (B,N,W)
+    column slice of a buffer whose rows are padded to a multiple of 16 bytes (``FEAT_PITCH_ALIGN``; 1286 -> 1288 columns, pad
+    columns zeroed): row-strided, not contiguous.  The heads' ``linear_rows`` / ``gemm_rows`` take the row stride as is; a
+    consumer that calls ``.contiguous()`` pays a copy of the whole tensor."""
     tensors = [s_[0] for s_ in segments]
     idxs = [s_[1] for s_ in segments]
     kinds = [s_[2] for s_ in segments]

@@ -16,6 +16,7 @@ The two layer nodes below mirror ``ops._HSLayer`` / ``ops._SurfaceLayer`` kernel
     backward  the same kernels in their *_bf16 forms; parameter gradients from hsp_wgrad_bf16 in fp32.
 """
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -27,15 +28,20 @@ from .ops import _p, _req, _run, _stream, _ws
 _vp = ctypes.c_void_p
 BF16 = torch.bfloat16
 
-# parameter (by storage pointer) -> (bf16 copy, bf16 transposed copy); filled by Bf16Params
+# parameter (by storage pointer) -> (bf16 copy, bf16 transposed copy, weak reference to the owning Bf16Params)
 _copies = {}
 
 
 def copies_of(param):
     hit = _copies.get(param.data_ptr())
+    if hit is not None:                       # the address may have been re-used by another tensor since: the shape must match
+        c, ct = hit[0], hit[1]
+        shape = tuple(param.shape)
+        if (c is not None and tuple(c.shape) != shape) or (ct is not None and tuple(ct.shape) != shape[::-1]):
+            hit = None
     if hit is None:
         raise HspError("bf16 path: no bf16 working copy registered for this parameter (FaceRecon.set_feature_dtype)")
-    return hit
+    return hit[0], hit[1]
 
 
 class Bf16Params:
@@ -45,6 +51,8 @@ class Bf16Params:
 
     def __init__(self, specs):
         dev = specs[0][0].device
+        for key in [k_ for k_, v_ in _copies.items() if v_[2] is not None and v_[2]() is None]:
+            del _copies[key]                  # entries whose Bf16Params is gone
         self.entries = []
         tab = np.zeros(len(specs), dtype=np.dtype([("src", np.uint64), ("dst", np.uint64), ("dstT", np.uint64),
                                                    ("rows", np.int32), ("cols", np.int32), ("ld", np.int32),
@@ -57,7 +65,7 @@ class Bf16Params:
             c = torch.empty(rows, cols, dtype=BF16, device=dev) if want else None
             ct = torch.empty(cols, rows, dtype=BF16, device=dev) if want_t else None
             self.entries.append((w2, c, ct))
-            _copies[w2.data_ptr()] = (c, ct)
+            _copies[w2.data_ptr()] = (c, ct, weakref.ref(self))
             tab[i] = (w2.data_ptr(), c.data_ptr() if c is not None else 0, ct.data_ptr() if ct is not None else 0, rows, cols,
                       w2.stride(0), tiles)
             tiles += ((rows + 31) // 32) * ((cols + 31) // 32)

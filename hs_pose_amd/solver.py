@@ -222,8 +222,9 @@ class Ranger(Optimizer):
         """accepts checkpoints of the reference Ranger (per-parameter tensors): values are copied into the flat state."""
         super().load_state_dict(state_dict)
         for fg in self._flat:
-            # a checkpoint written after >= 1 step carries every slow_buffer; one without them leaves the lazy fill armed
-            fg.slow_ready = all("slow_buffer" in self.state[p] for p in fg.params)
+            # a checkpoint written after >= 1 step carries every slow_buffer; one without them -- or one this optimizer wrote BEFORE
+            # its first step, whose slow_buffer views exist but still hold zeros -- leaves the lazy fill armed
+            fg.slow_ready = all("slow_buffer" in self.state[p] and int(self.state[p].get("step", 0)) > 0 for p in fg.params)
             for p, o in zip(fg.params, fg.offsets):
                 st = self.state[p]
                 for name, flat in (("exp_avg", fg.flat_m), ("exp_avg_sq", fg.flat_v), ("slow_buffer", fg.flat_s)):

@@ -404,7 +404,8 @@ int hsp_orl_global_fwd_bf16(const hsp_bf16_t *feat, const int32_t *idx, int B, i
                             uint8_t *argmax, void *ws, size_t ws_bytes, hspStream_t stream);
 int hsp_colsum_rows_bf16(const hsp_bf16_t *x, int B, int N, int C, float *out, void *ws, size_t ws_bytes,
                          hspStream_t stream);
-/* out_pitch: row pitch of out in elements (>= sum of widths; padding columns are left untouched).  bf16 form: kind 0 / 1
+/* out_pitch: row pitch of out in elements (>= sum of widths; padding columns are zeroed when every segment is 16-byte
+ * aligned -- the feat assembly -- and left untouched otherwise).  bf16 form: kind 0 / 1
  * sources are bf16, kind 2 (per-cloud rows, the one-hot category columns) fp32 */
 int hsp_concat_rows_pitched(int nseg, const float *const *src, const int32_t *const *idx, const int *width, const int *kind,
                             const int *nsrc, int B, int N, float *out, int out_pitch, hspStream_t stream);
