@@ -104,3 +104,72 @@ def test_gemm_rows_bf16(dev, ref, M, N, K1, K2, use_bias, use_resid, rpc):
     tol = want.abs() * 2.0 ** -8 + 4e-6 * (mag + 1.0)
     bad = ((got.double() - want).abs() > tol).sum().item()
     assert bad == 0, f"{bad} entries beyond one bf16 rounding"
+
+
+# ---- the LDS-free wave-level kernel (csrc/gemm_wave.hip): every instantiated form x tile shape, the leftover-block path, strided
+# operands; same truth and tolerance as gemm_rows
+WAVE_CASES = [
+    # M, N, K1, nn1, K2, nn2, bias, resid+cloud rows (0 = none), xyz3
+    (16448, 1024, 128, True, 0, False, True, 0, False),        # fm = X W + b (conv_1): 32 x 128 tiles, leftover blocks
+    (4112, 2048, 256, True, 0, False, True, 0, False),         # conv_3 fm: 32 x 64 tiles
+    (1024, 4096, 256, True, 0, False, True, 0, False),         # conv_4 fm
+    (16448, 128, 128, True, 0, False, False, 0, False),        # g Wa
+    (1024, 512, 512, True, 0, False, False, 0, False),         # g Wa at the coarsest level: 32 x 32 tiles
+    (16448, 128, 128, False, 128, False, False, 1028, False),  # out = X Wste^T + F Wa^T + F + t[b]
+    (4112, 256, 256, False, 256, False, False, 257, False),    # conv_3 out
+    (16448, 128, 128, False, 0, False, False, 1028, True),     # conv_0 out: the K = 3 STE rides in the epilogue
+    (16448, 128, 128, True, 1024, False, False, 0, False),     # gX = g Wste + gfm W^T ("nn" + "nt")
+    (4112, 256, 128, False, 0, False, False, 0, False),        # x W^T
+    (4112, 256, 128, False, 0, False, True, 0, False),         # x W^T + b
+    (1000, 96, 64, False, 0, False, True, 0, False),           # ragged rows, N = 3 x 32
+    (33, 32, 32, True, 0, False, False, 0, False),             # two row blocks, one of them a single row
+]
+
+
+@pytest.mark.parametrize("cfg", [0, 0x10042, 0x20041, 0x20021, 0x20011, 0x10020041])
+@pytest.mark.parametrize("M,N,K1,nn1,K2,nn2,use_bias,rpc,use_xyz", WAVE_CASES)
+def test_gemm_wave_f32(dev, ref, M, N, K1, nn1, K2, nn2, use_bias, rpc, use_xyz, cfg):
+    from hs_pose_amd import ops
+    if not ops.gemm_wave_supported(M, N, K1, K2, cfg):
+        pytest.skip("tile shape does not divide N")
+    h = lambda shape, seed: ref.hash_tensor(shape, seed, 1.0).to(dev)
+    A1 = h((M, K1), 1)
+    B1 = h((K1, N) if nn1 else (N, K1), 2)
+    A2 = h((M, K2), 3) if K2 else None
+    B2 = (h((K2, N) if nn2 else (N, K2), 4)) if K2 else None
+    bias = h((N,), 5) if use_bias else None
+    resid = h((M, N), 6) if rpc else None
+    cb = h(((M + rpc - 1) // rpc, N), 7) if rpc else None
+    xyz3, w3 = (h((M, 3), 8), h((N, 3), 9)) if use_xyz else (None, None)
+    out = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm_wave(A1, B1, nn1, A2, B2, nn2, bias, resid, cb, rpc, out=out, xyz3=xyz3, w3=w3, cfg=cfg)
+    want, mag = _ref(A1, B1, nn1, A2, B2, nn2, bias, resid, cb, rpc)
+    if use_xyz:
+        want = want + xyz3.double() @ w3.double().t()
+        mag = mag + xyz3.double().abs() @ w3.double().abs().t()
+    err = ((out.double() - want).abs() / (mag + 1.0)).max().item()
+    assert err <= 2e-6, f"max error {err:.3e} of the |a||b| scale"
+
+
+def test_gemm_wave_strided_and_unsupported(dev, ref):
+    """column blocks of wider tensors as operands / output; shapes and forms outside the kernel's cover are refused (the host
+    routes them to gemm_rows)"""
+    from hs_pose_amd import ops
+    from hs_pose_amd._lib import HspError
+    h = lambda shape, seed: ref.hash_tensor(shape, seed, 1.0).to(dev)
+    g, conv2 = h((4112, 256), 11), h((256, 512), 12)
+    Wa = conv2[:, :256]
+    got = ops.gemm_wave(g, Wa, nn1=True)                     # gF = g Wa : "nn" with ldb = 2C
+    assert torch.allclose(got, g @ Wa, atol=3e-4, rtol=1e-5)
+    wide = torch.zeros(4112, 768, device=dev)
+    ops.gemm_wave(g, Wa, out=wide[:, 256:512])               # g Wa^T into a column block
+    assert torch.allclose(wide[:, 256:512], g @ Wa.t(), atol=3e-4, rtol=1e-5)
+    assert float(wide[:, :256].abs().max()) == 0.0 and float(wide[:, 512:].abs().max()) == 0.0
+    assert not ops.gemm_wave_supported(1000, 100, 64, 0)     # N not a multiple of 32
+    assert not ops.gemm_wave_supported(1000, 128, 48, 0)     # K not a multiple of 32
+    with pytest.raises(HspError):                            # bias + residual: not an instantiated form
+        ops.gemm_wave(g, Wa, nn1=True, bias=h((256,), 13), resid=h((4112, 256), 14), cloud_bias=h((16, 256), 15), rows_per_cloud=257)
+    # gemm_own picks a kernel that covers the call either way
+    y = ops.gemm_own(g, Wa, True, bias=h((256,), 13), resid=h((4112, 256), 14), cloud_bias=h((16, 256), 15), rows_per_cloud=257)
+    want = g @ Wa + h((256,), 13) + h((4112, 256), 14) + h((16, 256), 15).repeat_interleave(257, 0)
+    assert torch.allclose(y, want, atol=3e-4, rtol=1e-5)

@@ -64,7 +64,8 @@ class ForcedFeatKnn:
         self.real = ops.knn
         self.lists = [torch.from_numpy(g[f"featknn{i}"].astype(np.int32)).to(dev) for i in (1, 2, 3, 4)]
         self.calls = 0
-        self.agree = []
+        self.agree = []                    # rows whose ordered neighbour list equals the reference's
+        self.agree_set = []                # rows whose neighbour SET does
         monkeypatch.setattr(ops, "knn", self)
 
     def __call__(self, x, k, drop_first=True):
@@ -75,6 +76,7 @@ class ForcedFeatKnn:
         self.calls += 1
         assert want.shape == own.shape
         self.agree.append((own == want).all(dim=2).float().mean().item())
+        self.agree_set.append((torch.sort(own, dim=2)[0] == torch.sort(want, dim=2)[0]).all(dim=2).float().mean().item())
         return want if self.force else own
 
 
@@ -258,3 +260,59 @@ def test_posenet9d_free_running_1028(dev, ref, flags, monkeypatch, name):
     bound = 1e-4 if exact else FREE_RUNNING_BOUND[name]
     for n_, e in errs.items():
         assert e <= bound, f"{name} {n_}: {e:.3e} > {bound}"
+
+
+# Reference-INITIALISED weights (the parameters the reference itself starts from, torch.manual_seed(0)) instead of the closed-form
+# fills: oracle/gen_golden_refinit.py.  The fixture carries the reference's own behaviour under a 1-ulp move of the cloud
+# (`self_agree`, `self_drift`): rows with an identical neighbour set per HS layer 0.98 / 0.89-0.91 / 0.80-0.83 / 0.78-0.81 and
+# pose / size drift 5e-4 ... 1.8e-3 in eval mode; 0.98 / 0.93-0.97 / 0.85-0.95 / 0.93-0.98 and 4e-2 ... 1.1e-1 under train-mode
+# BatchNorm.  So the north star's 1e-4 does not hold free-running for the reference against itself either; the product is held to
+# ~2x the reference's worst self-drift and to agreement floors below its self-agreement.
+# Measured on the GPU (round 3): ordered lists identical on 0.90 / 0.74 / 0.58 / 0.62 of the rows and 2.8e-4 on p_green_R
+# (Pred_T 1.1e-5, Pred_s 1.6e-5) in eval mode; 0.91 / 0.84 / 0.69 / 0.84 and 4.9e-2 under train-mode BatchNorm -- both INSIDE the
+# reference's own 1-ulp drift, neither at 1e-4.
+REFINIT_BOUND = {"stack_refinit_eval_1028": 2e-3, "stack_refinit_trainbn_1028": 1.5e-1}
+REFINIT_AGREE = {"stack_refinit_eval_1028": (0.85, 0.65, 0.5, 0.5), "stack_refinit_trainbn_1028": (0.85, 0.75, 0.6, 0.75)}
+
+
+@pytest.mark.parametrize("name", ["stack_refinit_eval_1028", "stack_refinit_trainbn_1028"])
+def test_posenet9d_free_running_refinit(dev, ref, flags, monkeypatch, name):
+    """free-running PoseNet9D on reference-initialised weights at N = 1028: (1) the mirrored modules constructed under the
+    reference's seed hold IDENTICAL parameters (samples + sums of every state tensor); (2) the network's own feature-space
+    neighbour sets against the reference's, and the six pose / size outputs, inside the bounds above."""
+    from hs_pose_amd.PoseNet9D import PoseNet9D
+    g = golden(name)
+    _, B, N, seed, bn_training, wseed = (int(v) for v in g["meta"])
+    flags.train = 0
+    torch.manual_seed(wseed)
+    net = PoseNet9D()
+    for k_, v in net.state_dict().items():
+        if v.is_floating_point():
+            flat = v.reshape(-1)
+            assert np.array_equal(flat[::997].numpy(), g["wsample." + k_]), f"parameter {k_} differs from the reference's draw"
+            assert abs(flat.double().sum().item() - g["wsum." + k_][0]) <= 1e-9 * max(1.0, g["wsum." + k_][1]), k_
+    net = net.to(dev)
+    net.train(bool(bn_training))
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    pts, obj = _inputs(ref, B, N, seed, dev)
+    watch = ForcedFeatKnn(monkeypatch, g, dev, force=False)
+    torch.manual_seed(1)
+    with torch.no_grad():
+        outs = dict(zip(OUT_NAMES, net(pts, obj)))
+    errs = {n_: _maxerr(outs[n_], g["out." + n_]) for n_ in OUT_NAMES[4:]}
+    print(f"FREE-RUNNING {name}: rows with the reference's ordered neighbour list per HS layer {[round(a, 4) for a in watch.agree]}, "
+          f"with its neighbour set {[round(a, 4) for a in watch.agree_set]} "
+          f"(sets, reference vs itself + 1 ulp: {np.round(g['self_agree'].min(axis=0), 3).tolist()}); max abs error "
+          f"{({k_: float(f'{v:.2e}') for k_, v in errs.items()})} (reference self-drift {np.round(g['self_drift'], 5).tolist()})")
+    report = os.environ.get("HSP_REPORT_DIR")
+    if report:
+        import json
+        with open(os.path.join(report, f"free_running_{name}.json"), "w") as f:
+            json.dump({"agree_rows_per_layer": watch.agree, "agree_sets_per_layer": watch.agree_set, "max_abs_err": errs,
+                       "reference_self_agree": g["self_agree"].tolist(),
+                       "reference_self_drift": g["self_drift"].tolist()}, f, indent=1)
+    assert all(a >= f for a, f in zip(watch.agree, REFINIT_AGREE[name])), watch.agree
+    for n_, e in errs.items():
+        assert e <= REFINIT_BOUND[name], f"{name} {n_}: {e:.3e} > {REFINIT_BOUND[name]}"
