@@ -353,6 +353,10 @@ def main():
             roof["traffic_source"] = "profiles/r02/traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE passes of this command)"
         except Exception:
             pass
+        sb = ops.design_stream_bytes.get((kname, kkey))
+        if sb:                             # the bytes the kernel streams by design (uint16 winning-row slots, winners' support values)
+            roof["kernel_stream_bytes_per_launch"] = sb
+            roof["kernel_stream_frac"] = round(sb / (kd["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
         roof["avg_us_source"] = ("HIP events around the call, in the timed region" if graphed is None else
                                  "HIP events around the call, the same K steps re-issued eagerly right after the timed "
                                  "graph replays (events cannot be recorded inside a replay)")

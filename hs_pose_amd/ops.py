@@ -86,6 +86,10 @@ class KernelTimer:
 
 
 _timer = None
+# (entry point, key) -> bytes the kernel streams BY DESIGN where that differs from the algorithmic count of DESIGN.md section 4
+# (the receptive-field kernels keep a uint16 winning-row slot instead of a uint8 neighbour slot and, for large clouds, a private
+# stream of the winners' support values): bench.py reports both
+design_stream_bytes = {}
 
 
 def set_timer(t):
@@ -190,7 +194,7 @@ class _RFSurface(torch.autograd.Function):
         out = torch.empty(B, N, K, dtype=torch.float32, device=xyz.device)
         arg = torch.empty(B, N, SC, dtype=torch.uint16, device=xyz.device)
         _run("hsp_rf_surface_fwd", (_p(xyz), _p(idx), _p(dirs_n), B, N, k, S, K, _p(out), _p(arg), _stream()),
-             key=f"B{B}N{N}k{k}S{S}C{K}", abytes=B * N * (12 + 4 * k + 4 * K + 2 * SC) + 12 * SC)
+             key=f"B{B}N{N}k{k}S{S}C{K}", abytes=B * N * (12 + 4 * k + 4 * K + SC) + 12 * SC)
         ctx.save_for_backward(xyz, idx, dirs_n, arg)
         ctx.S = S
         return out
@@ -207,7 +211,7 @@ class _RFSurface(torch.autograd.Function):
         ws = _ws(wsb, g.device)
         _run("hsp_rf_surface_bwd", (_p(xyz), _p(dirs_n), _p(arg), _p(g), B, N, ctx.S, SC // ctx.S, _p(gd), _p(ws), wsb,
                                     _stream()),
-             key=f"B{B}N{N}S{ctx.S}C{SC // ctx.S}", abytes=B * N * (12 + 4 * (SC // ctx.S) + 2 * SC) + 24 * SC)
+             key=f"B{B}N{N}S{ctx.S}C{SC // ctx.S}", abytes=B * N * (12 + 4 * (SC // ctx.S) + SC) + 24 * SC)
         return None, None, gd, None
 
 
@@ -782,10 +786,15 @@ def _rf_conv_fwd_raw(xyz, idx, directions, fm, S, need_bwd=True):
     arg = torch.empty(B, N, SC, dtype=torch.uint16, device=xyz.device)
     want = need_bwd and not DETERMINISTIC and lib().hsp_rf_conv_wants_fwin(N, S, C)
     fwin = torch.empty(B, N, SC, dtype=torch.float32, device=xyz.device) if want else None
+    key = f"B{B}N{N}k{k}S{S}C{C}"
+    # algorithmic bytes per point: (S+1) C 4 + 4 k + 12 in, 4 C + S C out (a one-byte arg-max slot).  The
+    # kernel itself writes a uint16 winning ROW per slot (the backward then needs neither idx nor the slot -> one gather fewer) and,
+    # when a cloud's fm outgrows L2, the winners' support values: its designed stream is recorded next to the algorithmic count
+    design_stream_bytes[("hsp_rf_conv_fwd", key)] = B * N * (12 + 4 * k + 4 * (S + 1) * C + 4 * C + 2 * SC
+                                                             + (4 * SC if fwin is not None else 0)) + 12 * SC
     _run("hsp_rf_conv_fwd", (_p(xyz), _p(idx), _p(directions), _p(fm), B, N, k, S, C, _p(out), _p(arg), _p(fwin),
                              _stream()),
-         key=f"B{B}N{N}k{k}S{S}C{C}",
-         abytes=B * N * (12 + 4 * k + 4 * (S + 1) * C + 4 * C + 2 * SC + (4 * SC if fwin is not None else 0)) + 12 * SC)
+         key=key, abytes=B * N * (12 + 4 * k + 4 * (S + 1) * C + 4 * C + SC) + 12 * SC)
     return out, arg, fwin
 
 
@@ -801,16 +810,19 @@ def _rf_conv_bwd_raw(xyz, idx, directions, fm, arg, gF3, S):
         wsb = L.hsp_rf_bwd_workspace_bytes(SC)
         ws = _ws(wsb, gF3.device)
         off, edge = rev_index(idx, k, N)
+        # (section 4: S C + 4 S C + 4 C in -- arg slot, the winners' support values, grad_out -- and 4 (S+1) C out per point)
+        design_stream_bytes[("hsp_rf_conv_bwd", f"B{B}N{N}k{k}S{S}C{C}")] = B * N * (12 + 8 * k + 6 * SC + 4 * C + 4 * (S + 1) * C) + 24 * SC
         _run("hsp_rf_conv_bwd", (_p(xyz), _p(directions), _p(fm), _p(arg), _p(gF3), _p(off), _p(edge), B, N, k, S, C,
                                  _p(gfm), _p(gd), _p(ws), wsb, _stream()),
-             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 8 * k + 4 * SC + 2 * SC + 4 * C + 4 * (S + 1) * C) + 24 * SC)
+             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 8 * k + 5 * SC + 4 * C + 4 * (S + 1) * C) + 24 * SC)
     else:
         wsb = L.hsp_rf_bwd_scatter_workspace_bytes(B, SC)
         ws = _ws(wsb, gF3.device)
         is_fwin = fm.shape[-1] == SC
+        design_stream_bytes[("hsp_rf_conv_bwd_scatter", f"B{B}N{N}S{S}C{C}")] = B * N * (12 + 6 * SC + 4 * C + 4 * (S + 1) * C) + 24 * SC
         _run("hsp_rf_conv_bwd_scatter", (_p(xyz), _p(directions), _p(None if is_fwin else fm), _p(fm if is_fwin else None),
                                          _p(arg), _p(gF3), B, N, S, C, _p(gfm), _p(gd), _p(ws), wsb, _stream()),
-             key=f"B{B}N{N}S{S}C{C}", abytes=B * N * (12 + 4 * SC + 2 * SC + 4 * C + 4 * (S + 1) * C) + 24 * SC)
+             key=f"B{B}N{N}S{S}C{C}", abytes=B * N * (12 + 5 * SC + 4 * C + 4 * (S + 1) * C) + 24 * SC)
     return gfm, gd
 
 
@@ -894,7 +906,7 @@ class _SurfaceLayer(torch.autograd.Function):
         F3 = torch.empty(B, N, C, dtype=torch.float32, device=xyz.device)
         arg = torch.empty(B, N, SC, dtype=torch.uint16, device=xyz.device)
         _run("hsp_rf_surface_fwd", (_p(xyz), _p(idx_x), _p(directions), B, N, k, S, C, _p(F3), _p(arg), _stream()),
-             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 4 * k + 4 * C + 2 * SC) + 12 * SC)
+             key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 4 * k + 4 * C + SC) + 12 * SC)
         fg, arg_o = _orl_fwd_raw(F3, idx_x, k)
         F2, x2 = F3.view(B * N, C), xyz.view(B * N, 3)
         out3 = torch.empty(B, N, C, dtype=torch.float32, device=xyz.device)
@@ -926,7 +938,7 @@ class _SurfaceLayer(torch.autograd.Function):
         wsb = L.hsp_rf_bwd_scatter_workspace_bytes(B, SC)
         ws = _ws(wsb, g.device)
         _run("hsp_rf_surface_bwd", (_p(xyz), _p(directions), _p(arg), _p(gF3), B, N, S, C, _p(gD), _p(ws), wsb, _stream()),
-             key=f"B{B}N{N}S{S}C{C}", abytes=B * N * (12 + 4 * C + 2 * SC) + 24 * SC)
+             key=f"B{B}N{N}S{S}C{C}", abytes=B * N * (12 + 4 * C + SC) + 24 * SC)
         g_ste = g2.t() @ x2
         return None, None, None, None, gD, g_ste.unsqueeze_(-1), g_conv2.unsqueeze_(-1)
 
