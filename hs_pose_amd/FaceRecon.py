@@ -94,7 +94,6 @@ class FaceRecon(nn.Module):
     def forward(self, vertices: "tensor (bs, vetice_num, 3)", cat_id: "tensor (bs, 1)"):
         """-> (recon (bs,N,3) | None, face (bs,N,face_recon_c) | None, feat (bs,N,1286))"""
         bs, vertice_num, _ = vertices.size()
-        one_hot = torch.zeros(bs, FLAGS.obj_c, device=vertices.device).scatter_(1, cat_id.view(-1, 1).long(), 1)
         k = self.neighbor_num
         if self._bf16 is not None:
             self._bf16.refresh()                      # fp32 master weights -> this step's bf16 working copies (one launch)
@@ -118,8 +117,10 @@ class FaceRecon(nn.Module):
         nearest_pool_1 = ops.nn1(vertices, v_pool_1)
         nearest_pool_2 = ops.nn1(vertices, v_pool_2)
         # nearest up-sampling of the coarse levels, the one-hot category columns and the concat in one kernel
+        # (the reference's one_hot = zeros(bs, obj_c).scatter_(1, cat_id.long(), 1), FaceRecon.py:80-85, is built inside the kernel)
+        ops.ONE_HOT_WIDTH = FLAGS.obj_c
         feat = ops.assemble_feat([(a_0, None, 0), (a_1, None, 0), (a_2, nearest_pool_1, 1), (fm_3, nearest_pool_1, 1),
-                                  (fm_4, nearest_pool_2, 1), (one_hot, None, 2)])
+                                  (fm_4, nearest_pool_2, 1), (cat_id.detach().reshape(-1).float(), None, 3)])
 
         if FLAGS.train:
             f_global = ops.points_max(fm_4)          # (FaceRecon.py:98 computes it unconditionally; only this branch reads it)

@@ -29,6 +29,7 @@ SIGNATURES = {
     "hsp_rev_build": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "hsp_gather_max_bwd_csr": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "hsp_gather_max_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "hsp_pool_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "hsp_gather_max_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "hsp_points_max_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "hsp_points_max_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -93,6 +94,7 @@ SIGNATURES = {
     "hsp_wgrad_partial_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _sz, _vp, _vp]),
     "hsp_wgrad_partial_bf16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _sz, _vp, _vp]),
     "hsp_wgrad_fold": (_i, [_vp, _i, _vp]),
+    "hsp_wgrad_partial_pair_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _sz] * 2 + [_vp, _vp]),
     "hsp_pose_augment": (_i, [_vp] * 14 + [_i, _i, _i] + [ctypes.c_float] * 4 + [_vp] * 5),
 }
 

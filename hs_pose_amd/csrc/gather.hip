@@ -51,7 +51,9 @@ __global__ __launch_bounds__(256) void gather_max_fwd_kernel(const FT* __restric
                                                              const int32_t* __restrict__ qsel, int B, int Nsrc,
                                                              int Nidx, int Nq, int k, int kstride, int C,
                                                              FT* __restrict__ out,
-                                                             uint8_t* __restrict__ argmax) {
+                                                             uint8_t* __restrict__ argmax,
+                                                             const float* __restrict__ xyz = nullptr,
+                                                             float* __restrict__ xyz_sel = nullptr) {
     const int cq = C >> 2;
     const long long total = (long long)B * Nq * cq;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
@@ -60,6 +62,8 @@ __global__ __launch_bounds__(256) void gather_max_fwd_kernel(const FT* __restric
         const int q = (int)(row % Nq);
         const int b = (int)(row / Nq);
         const int qi = qsel ? qsel[q] : q;
+        if (xyz_sel && g < 3)                    // Pool_layer: the kept points' coordinates ride along (vertices[:, sample_idx], gcn3d.py:244)
+            xyz_sel[row * 3 + g] = xyz[((size_t)b * Nidx + qi) * 3 + g];
         const int32_t* nb = idx + ((size_t)b * Nidx + qi) * kstride;
         const FT* fb = feat + (size_t)b * Nsrc * C + (g << 2);
         float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
@@ -173,6 +177,8 @@ __global__ __launch_bounds__(256) void colsum_partial_scalar_kernel(const float*
 // feat rows assembled from column segments (reference FaceRecon.py:100-107: nearest up-sampling gathers,
 // one-hot category columns and torch.cat) in ONE pass: segment s of row (b,i) comes from
 //   kind 0: src[(b*N + i)*w + c]      kind 1: src[(b*Ns + idx[b*N+i])*w + c]      kind 2: src[b*w + c]
+//   kind 3: (long) src[b] == c ? 1 : 0   -- the one-hot category columns built in place from the (B) float ids
+//           (FaceRecon.py:80-85: zeros + scatter_ were three launches)
 // (bf16 build: kind 0 / 1 sources are bf16 like the output, kind 2 -- the per-cloud one-hot row -- stays fp32 and is
 // rounded on the way in; W is the output ROW PITCH, which may exceed the sum of the widths: padding columns stay untouched)
 struct ConcatSeg { const void* src; const int32_t* idx; int width; int kind; int nsrc; int col0; };
@@ -195,8 +201,9 @@ __global__ __launch_bounds__(256) void concat_rows_kernel(ConcatDesc d, int B, i
                 while (q >= d.q0[sgi + 1]) ++sgi;
                 const ConcatSeg sg = d.seg[sgi];
                 const int c = q - d.q0[sgi];
-                if (sg.kind == 2) {                               // per-cloud fp32 row: element c (chunk = one element here)
-                    Feat<FT>::st(o + sg.col0 + c, reinterpret_cast<const float*>(sg.src)[(size_t)b * sg.width + c]);
+                if (sg.kind >= 2) {                               // per-cloud fp32 row: element c (chunk = one element here)
+                    const float* ps = reinterpret_cast<const float*>(sg.src);
+                    Feat<FT>::st(o + sg.col0 + c, sg.kind == 2 ? ps[(size_t)b * sg.width + c] : ((long long)ps[b] == c ? 1.f : 0.f));
                     continue;
                 }
                 const FT* src = reinterpret_cast<const FT*>(sg.src);
@@ -214,9 +221,10 @@ __global__ __launch_bounds__(256) void concat_rows_kernel(ConcatDesc d, int B, i
         FT* o = out + (size_t)row * W;
         for (int s = 0; s < d.nseg; ++s) {
             const ConcatSeg sg = d.seg[s];
-            if (sg.kind == 2) {
-                const float* src = reinterpret_cast<const float*>(sg.src) + (size_t)b * sg.width;
-                for (int c = threadIdx.x; c < sg.width; c += 256) Feat<FT>::st(o + sg.col0 + c, src[c]);
+            if (sg.kind >= 2) {
+                const float* src = reinterpret_cast<const float*>(sg.src);
+                for (int c = threadIdx.x; c < sg.width; c += 256)
+                    Feat<FT>::st(o + sg.col0 + c, sg.kind == 2 ? src[(size_t)b * sg.width + c] : ((long long)src[b] == c ? 1.f : 0.f));
                 continue;
             }
             const FT* src = reinterpret_cast<const FT*>(sg.src);
@@ -644,6 +652,18 @@ extern "C" int hsp_gather_max_fwd_bf16(const hsp_bf16_t* feat, const int32_t* id
     return gather_max_fwd_impl<bf16_t>(feat, idx, qsel, B, Nsrc, Nidx, Nq, k, kstride, C, out, argmax, stream);
 }
 
+/* Pool_layer in one launch (gcn3d.py:236-245): max over the k listed neighbours of the kept rows qsel + the kept rows' coordinates */
+extern "C" int hsp_pool_fwd(const float* feat, const float* xyz, const int32_t* idx, const int32_t* qsel, int B, int N, int Nq,
+                            int k, int kstride, int C, float* out, uint8_t* argmax, float* xyz_sel, hspStream_t stream) {
+    if (!feat || !xyz || !idx || !qsel || !out || !argmax || !xyz_sel || B <= 0 || N <= 0 || Nq <= 0 || k <= 0 || kstride < k || C < 12)
+        return HSP_ERR_BAD_ARG;
+    if ((C & 3) || k > 255) return HSP_ERR_UNSUPPORTED;
+    const long long total = (long long)B * Nq * (C >> 2);
+    hipLaunchKernelGGL(gather_max_fwd_kernel<float>, dim3(stream_grid(total)), dim3(256), 0, as_stream(stream), feat, idx, qsel, B,
+                       N, N, Nq, k, kstride, C, out, argmax, xyz, xyz_sel);
+    return check_launch();
+}
+
 template <typename FT>
 static int gather_max_bwd_impl(const void* grad_out, int grad_bcast, const int32_t* idx, const int32_t* qsel,
                                const uint8_t* argmax, int B, int Nsrc, int Nidx, int Nq, int kstride, int C,
@@ -886,7 +906,7 @@ static int concat_rows_impl(int nseg, const void* const* src, const int32_t* con
     d.nseg = nseg;
     int col = 0;
     for (int s = 0; s < nseg; ++s) {
-        if (!src[s] || width[s] <= 0 || kind[s] < 0 || kind[s] > 2 || (kind[s] == 1 && (!idx || !idx[s]))) return HSP_ERR_BAD_ARG;
+        if (!src[s] || width[s] <= 0 || kind[s] < 0 || kind[s] > 3 || (kind[s] == 1 && (!idx || !idx[s]))) return HSP_ERR_BAD_ARG;
         d.seg[s].src = src[s];
         d.seg[s].idx = idx ? idx[s] : nullptr;
         d.seg[s].width = width[s];
@@ -898,18 +918,18 @@ static int concat_rows_impl(int nseg, const void* const* src, const int32_t* con
     if (out_pitch < col) return HSP_ERR_BAD_ARG;
     d.even = (out_pitch & 1) ? 0 : 1;
     for (int s = 0; s < nseg; ++s)
-        if (kind[s] != 2 && ((width[s] & 1) || (d.seg[s].col0 & 1) || (reinterpret_cast<uintptr_t>(src[s]) & (2 * sizeof(FT) - 1))))
+        if (kind[s] < 2 && ((width[s] & 1) || (d.seg[s].col0 & 1) || (reinterpret_cast<uintptr_t>(src[s]) & (2 * sizeof(FT) - 1))))
             d.even = 0;
     if (reinterpret_cast<uintptr_t>(out) & (2 * sizeof(FT) - 1)) d.even = 0;
     if (d.even) {               // 16-byte form: pitch, column offsets, widths and bases all multiples of 16 bytes
         constexpr int EP = 16 / (int)sizeof(FT);
         bool q = (out_pitch % EP) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
         for (int s = 0; s < nseg && q; ++s)
-            if (kind[s] != 2 && ((width[s] % EP) || (d.seg[s].col0 % EP) || (reinterpret_cast<uintptr_t>(src[s]) & 15))) q = false;
+            if (kind[s] < 2 && ((width[s] % EP) || (d.seg[s].col0 % EP) || (reinterpret_cast<uintptr_t>(src[s]) & 15))) q = false;
         if (q) {
             d.even = 2;
             int acc = 0;
-            for (int s = 0; s < nseg; ++s) { d.q0[s] = acc; acc += kind[s] == 2 ? width[s] : width[s] / EP; }
+            for (int s = 0; s < nseg; ++s) { d.q0[s] = acc; acc += kind[s] >= 2 ? width[s] : width[s] / EP; }
             d.q0[nseg] = acc;
         }
     }

@@ -32,22 +32,22 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // FT: storage type of A and B (float, or bf16_t: the pair of columns a lane owns is one 4-byte load, widened to fp32 --
 // the products still run on the fp32 MFMA, exact and in the same order as for fp32 operands)
 template <bool COLSUM, int KB, typename FT>
-__global__ __launch_bounds__(256) void wgrad_kernel(const FT* __restrict__ A, int lda,
-                                                    const FT* __restrict__ B, int ldb, int M, int N, int K,
-                                                    int SK, int kslice, float* __restrict__ part,
-                                                    float* __restrict__ cs_part) {
+__device__ __forceinline__ void wgrad_body(const int bid, const FT* __restrict__ A, int lda,
+                                           const FT* __restrict__ B, int ldb, int M, int N, int K,
+                                           int SK, int kslice, float* __restrict__ part,
+                                           float* __restrict__ cs_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, and provably so
     const int tiles = (M >> 6) * (N >> 6);
     int slice, t;
     if (KB == 1) {
-        const int w = blockIdx.x * 4 + wv;
+        const int w = bid * 4 + wv;
         if (w >= tiles * SK) return;
         slice = w / tiles; t = w - slice * tiles;
     } else {
-        const int grp = blockIdx.x / tiles;
-        t = blockIdx.x - grp * tiles;
+        const int grp = bid / tiles;
+        t = bid - grp * tiles;
         slice = grp * 4 + wv;                               // slices past K read zeros
     }
     const int tiles_m = M >> 6;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const FT* __restrict__ A, in
     }
     if (COLSUM) csb[wv * 64 + lane] = cs;
     __syncthreads();
-    const int grp = blockIdx.x / tiles;
+    const int grp = bid / tiles;
     float* pc = part + (size_t)grp * M * N;
     const int ta = wv >> 1, tb = wv & 1;
 #pragma unroll
@@ -165,6 +165,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const FT* __restrict__ A, in
         c.y += __shfl_xor(c.y, 32);
         if (h == 0) *reinterpret_cast<float2*>(cs_part + (size_t)grp * N + n0 + 2 * i) = c;
     }
+}
+
+template <bool COLSUM, int KB, typename FT>
+__global__ __launch_bounds__(256) void wgrad_kernel(const FT* __restrict__ A, int lda,
+                                                    const FT* __restrict__ B, int ldb, int M, int N, int K,
+                                                    int SK, int kslice, float* __restrict__ part,
+                                                    float* __restrict__ cs_part) {
+    wgrad_body<COLSUM, KB, FT>((int)blockIdx.x, A, lda, B, ldb, M, N, K, SK, kslice, part, cs_part);
+}
+
+// two problems of the K-sliced form (KB = 4, no column sum) in ONE launch: workgroups [0, blocks0) work on problem 0, the
+// rest on problem 1.  An HS layer's backward has two such products that depend only on the incoming gradient -- g^T F (conv2's
+// first half) and g^T X (the STE weight) --, each too small to fill the chip on its own.
+struct WgradProb { const float* A; const float* B; float* part; int lda, ldb, M, N, K, SK, kslice; };
+__global__ __launch_bounds__(256) void wgrad_pair_kernel(const WgradProb p0, const WgradProb p1, int blocks0) {
+    const bool second = (int)blockIdx.x >= blocks0;
+    const WgradProb& p = second ? p1 : p0;
+    wgrad_body<false, 4, float>((int)blockIdx.x - (second ? blocks0 : 0), p.A, p.lda, p.B, p.ldb, p.M, p.N, p.K, p.SK, p.kslice,
+                                p.part, nullptr);
 }
 
 // C[m][n] = sum_s part[s][m][n]; likewise colsum.  Workgroup = 64 float4 elements x 4 slice groups:
@@ -584,6 +603,45 @@ extern "C" int hsp_wgrad_partial_bf16(const hsp_bf16_t* A, int lda, const hsp_bf
     if (!pending) return HSP_ERR_BAD_ARG;
     return wgrad_impl<bf16_t>(A, lda, B, ldb, M, N, K, C, ldc, colsum_B, ws, ws_bytes, stream, pending);
 }
+/* two weight gradients that share nothing but the launch: both K-sliced (few output tiles), no column sums; any other pair is
+ * issued as two hsp_wgrad_partial_f32 launches */
+extern "C" int hsp_wgrad_partial_pair_f32(const float* A0, int lda0, const float* B0, int ldb0, int M0, int N0, int K0, float* C0,
+                                          int ldc0, void* ws0, size_t ws_bytes0, const float* A1, int lda1, const float* B1,
+                                          int ldb1, int M1, int N1, int K1, float* C1, int ldc1, void* ws1, size_t ws_bytes1,
+                                          HspWgradPending* pending, hspStream_t stream) {
+    if (!pending) return HSP_ERR_BAD_ARG;
+    int ks0, kb0, ks1, kb1;
+    const bool shapes_ok = A0 && B0 && C0 && A1 && B1 && C1 && M0 > 0 && N0 > 0 && K0 > 0 && M1 > 0 && N1 > 0 && K1 > 0 &&
+                           !((M0 | N0 | M1 | N1) & 63) && !((lda0 | ldb0 | lda1 | ldb1) & 1) && lda0 >= M0 && ldb0 >= N0 &&
+                           lda1 >= M1 && ldb1 >= N1 && ldc0 >= N0 && ldc1 >= N1;
+    if (shapes_ok) {
+        const int sk0 = wgrad_pick_sk(M0, N0, K0, &ks0, &kb0), sk1 = wgrad_pick_sk(M1, N1, K1, &ks1, &kb1);
+        if (kb0 == 4 && kb1 == 4 && ws0 && ws1 && ws_bytes0 >= hsp_wgrad_workspace_bytes(M0, N0, K0) &&
+            ws_bytes1 >= hsp_wgrad_workspace_bytes(M1, N1, K1)) {
+            const WgradProb p0{A0, B0, reinterpret_cast<float*>(ws0), lda0, ldb0, M0, N0, K0, sk0, ks0};
+            const WgradProb p1{A1, B1, reinterpret_cast<float*>(ws1), lda1, ldb1, M1, N1, K1, sk1, ks1};
+            const int blocks0 = (M0 >> 6) * (N0 >> 6) * (sk0 / 4), blocks1 = (M1 >> 6) * (N1 >> 6) * (sk1 / 4);
+            const size_t lds = (size_t)4 * 4 * 16 * 64 * sizeof(float) + (size_t)4 * 64 * sizeof(float2);
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pair_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(wgrad_pair_kernel, dim3(blocks0 + blocks1), dim3(256), lds, as_stream(stream), p0, p1, blocks0);
+            int rc = check_launch();
+            if (rc) return rc;
+            pending[0] = HspWgradPending{p0.part, nullptr, C0, nullptr, sk0 / 4, M0, N0, ldc0};
+            pending[1] = HspWgradPending{p1.part, nullptr, C1, nullptr, sk1 / 4, M1, N1, ldc1};
+            return HSP_OK;
+        }
+    }
+    int rc = wgrad_impl<float>(A0, lda0, B0, ldb0, M0, N0, K0, C0, ldc0, nullptr, ws0, ws_bytes0, stream, pending);
+    if (rc) return rc;
+    return wgrad_impl<float>(A1, lda1, B1, ldb1, M1, N1, K1, C1, ldc1, nullptr, ws1, ws_bytes1, stream, pending + 1);
+}
+
 extern "C" int hsp_wgrad_fold(const HspWgradPending* pending, int n, hspStream_t stream) {
     if (!pending || n <= 0 || n > 4) return HSP_ERR_BAD_ARG;
     WgradFoldTab tab;

@@ -244,6 +244,9 @@ class Pool_layer(nn.Module):
             sample_idx = torch.randperm(vertice_num)[:pool_num]
             sel = sample_idx.to(device=vertices.device, dtype=torch.int32)
         # only the kept rows are pooled (the reference pools all N rows, then selects)
+        if feature_map.dtype == torch.float32 and feature_map.shape[2] >= 12 and not vertices.requires_grad:
+            feature_map_pool, vertices_pool = ops.pool_layer(feature_map, vertices, neighbor_index, sel, self.neighbor_num)
+            return vertices_pool, feature_map_pool
         feature_map_pool = ops.gather_max(feature_map, neighbor_index, self.neighbor_num, qsel=sel)
         vertices_pool = ops.gather_rows(vertices, sel)
         return vertices_pool, feature_map_pool

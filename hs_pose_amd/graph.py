@@ -38,12 +38,32 @@ def draw_pool_indices(n_points, rate=4, levels=2):
 
 
 
+def alloc_pool_indices(n_points, device):
+    """the static index buffers of the two Pool_layers as views of ONE device buffer (so that both are uploaded by one copy)"""
+    n1 = int(n_points / 4)
+    n2 = int(n1 / 4)
+    flat = torch.empty(n1 + n2, dtype=torch.int32, device=device)
+    views = [flat[:n1], flat[n1:]]
+    views[0]._hsp_flat = flat
+    return views
+
+
 def upload_pool_indices(bufs, n_points):
     """draw the Pool_layer permutations (host generator, reference order) and queue their upload on the current
     stream WITHOUT blocking the host: the copy comes from a ring of pinned staging buffers (hs_pose_amd/staging.py),
     stream-ordered after the previous replay and before the next, so the host can enqueue step i+1 while step i is still
-    running."""
-    for buf, idx in zip(bufs, draw_pool_indices(n_points)):
+    running.  Buffers made by ``alloc_pool_indices`` travel in ONE copy (a copy kernel per pool cost ~5 us of every step)."""
+    draws = draw_pool_indices(n_points)
+    flat = getattr(bufs[0], "_hsp_flat", None)
+    if flat is not None:
+        def fill(pinned):
+            o = 0
+            for idx in draws:
+                pinned[o:o + idx.numel()].copy_(idx)
+                o += idx.numel()
+        staging.upload(fill, flat.shape, torch.int32, flat.device, out=flat)
+        return
+    for buf, idx in zip(bufs, draws):
         staging.upload(lambda pinned, idx=idx: pinned.copy_(idx), buf.shape, torch.int32, buf.device, out=buf)
 
 
@@ -90,8 +110,7 @@ class GraphedStep:
         B, N, _ = centred.shape
         self.n_points = N
         dev = centred.device
-        self.pool_idx = [torch.empty(int(N / 4), dtype=torch.int32, device=dev),
-                         torch.empty(int(int(N / 4) / 4), dtype=torch.int32, device=dev)]
+        self.pool_idx = alloc_pool_indices(N, dev)
         self.params = [p for p in face_recon.parameters() if p.requires_grad]
         self.feat = None
         self.flat_grad = self.flat_late = self.flat_early = None
@@ -247,8 +266,7 @@ class GraphedTrainStep:
         self.n_points = N
         dev = PC.device
         self.noise = torch.zeros_like(PC)
-        self.pool_idx = [torch.empty(int(N / 4), dtype=torch.int32, device=dev),
-                         torch.empty(int(int(N / 4) / 4), dtype=torch.int32, device=dev)]
+        self.pool_idx = alloc_pool_indices(N, dev)
         self.loss_dict, self.total = None, None
         self._host_draws()
         prev_timer = ops.set_timer(None)
@@ -338,8 +356,7 @@ class GraphedInference:
         n, N, _ = PC.shape
         self.n_points = N
         dev = PC.device
-        self.pool_idx = [torch.empty(int(N / 4), dtype=torch.int32, device=dev),
-                         torch.empty(int(int(N / 4) / 4), dtype=torch.int32, device=dev)]
+        self.pool_idx = alloc_pool_indices(N, dev)
         if network.training:
             raise RuntimeError("GraphedInference: put the network in eval() mode first")
         self._draw()
@@ -431,8 +448,7 @@ class GraphedNetwork:
         B, N, _ = PC.shape
         self.n_points = N
         dev = PC.device
-        self.pool_idx = [torch.empty(int(N / 4), dtype=torch.int32, device=dev),
-                         torch.empty(int(int(N / 4) / 4), dtype=torch.int32, device=dev)]
+        self.pool_idx = alloc_pool_indices(N, dev)
         self.params = [p for p in posenet.parameters() if p.requires_grad]
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)
         upload_pool_indices(self.pool_idx, N)

@@ -351,6 +351,44 @@ class _PointsMax(torch.autograd.Function):
         return gx
 
 
+class _PoolLayer(torch.autograd.Function):
+    """Pool_layer.forward (gcn3d.py:236-245) in one launch: (max over the k nearest of the kept rows, the kept rows' xyz)."""
+
+    @staticmethod
+    def forward(ctx, feat, xyz, idx, qsel, k):
+        feat = _req(feat, torch.float32, "pool.feat")
+        xyz = _req(xyz, torch.float32, "pool.xyz")
+        idx = _req(idx, torch.int32, "pool.idx")
+        qsel = _req(qsel, torch.int32, "pool.qsel")
+        B, N, C = feat.shape
+        Nq, kstride = qsel.numel(), idx.shape[2]
+        out = torch.empty(B, Nq, C, dtype=torch.float32, device=feat.device)
+        arg = torch.empty(B, Nq, C, dtype=torch.uint8, device=feat.device)
+        vsel = torch.empty(B, Nq, 3, dtype=torch.float32, device=feat.device)
+        _run("hsp_pool_fwd", (_p(feat), _p(xyz), _p(idx), _p(qsel), B, N, Nq, k, kstride, C, _p(out), _p(arg), _p(vsel), _stream()),
+             key=f"B{B}N{N}Nq{Nq}k{k}C{C}", abytes=B * (4 * N * C + Nq * (4 * k + 5 * C + 24)))
+        ctx.save_for_backward(idx, qsel, arg)
+        ctx.dims = (B, N, idx.shape[1], Nq, kstride, C)
+        ctx.mark_non_differentiable(vsel)
+        return out, vsel
+
+    @staticmethod
+    def backward(ctx, g, _gv):
+        idx, qsel, arg = ctx.saved_tensors
+        B, Nsrc, Nidx, Nq, kstride, C = ctx.dims
+        g = _req(g, torch.float32, "pool.grad")
+        gfeat = torch.empty(B, Nsrc, C, dtype=torch.float32, device=g.device)
+        _run("hsp_gather_max_bwd", (_p(g), 0, _p(idx), _p(qsel), _p(arg), B, Nsrc, Nidx, Nq, kstride, C, _p(gfeat), 0, _vp(0),
+                                    _stream()),
+             key=f"B{B}Ns{Nsrc}Nq{Nq}C{C}", abytes=B * (4 * Nsrc * C + Nq * (4 * kstride + 5 * C)))
+        return gfeat, None, None, None, None
+
+
+def pool_layer(feat, xyz, idx, qsel, k):
+    """(feature_map_pool (B,Nq,C), vertices_pool (B,Nq,3)) of Pool_layer for fp32 rows; xyz carries no gradient."""
+    return _PoolLayer.apply(feat, xyz, idx, qsel, k)
+
+
 def points_max(x):
     """max over dim 1 of a point-major (B,N,C) tensor -> (B,C)   (the heads' torch.max(x, 2)[0])."""
     return _PointsMax.apply(x)
@@ -491,6 +529,43 @@ def wgrad(A2, B2, out=None, colsum=False):
                 WgradBatch.current = held
             choice = _wgrad_choice[key] = "custom" if t_c <= t_l else "library"
     return _wgrad_custom(A2, B2, out, colsum) if choice == "custom" else _wgrad_library(A2, B2, out, colsum)
+
+
+def _wgrad_ok(A2, B2, out):
+    K, M = A2.shape
+    N = B2.shape[1]
+    return (M % 64 == 0 and N % 64 == 0 and A2.stride(1) == 1 and B2.stride(1) == 1 and out.stride(1) == 1
+            and A2.stride(0) % 2 == 0 and B2.stride(0) % 2 == 0 and A2.dtype == torch.float32 and A2.is_cuda)
+
+
+def wgrad_pair(A0, B0, out0, A1, B1, out1):
+    """(A0^T B0 -> out0, A1^T B1 -> out1) inside a ``WgradBatch``: ONE split-K launch for both when each is a K-sliced problem the
+    hand-written kernel takes (the two parameter gradients of an HS layer that depend only on the incoming gradient: g^T F and
+    g^T X -- each alone leaves most of the chip idle); otherwise two ``wgrad`` calls."""
+    batch = WgradBatch.current
+
+    def custom(A2, B2):
+        K, M = A2.shape
+        return WGRAD_MODE == "custom" or GEMM_MODE == "own" or _wgrad_choice.get((M, B2.shape[1], K, False)) == "custom"
+    if (batch is None or WGRAD_MODE == "library" or not _wgrad_ok(A0, B0, out0) or not _wgrad_ok(A1, B1, out1)
+            or not custom(A0, B0) or not custom(A1, B1)):
+        wgrad(A0, B0, out=out0)
+        wgrad(A1, B1, out=out1)
+        return
+    from ._lib import HspWgradPending
+    L = lib()
+    (K0, M0), N0 = A0.shape, B0.shape[1]
+    (K1, M1), N1 = A1.shape, B1.shape[1]
+    wsb0, wsb1 = L.hsp_wgrad_workspace_bytes(M0, N0, K0), L.hsp_wgrad_workspace_bytes(M1, N1, K1)
+    ws0, ws1 = _ws(wsb0, A0.device), _ws(wsb1, A0.device)
+    pend = (HspWgradPending * 2)()
+    _run("hsp_wgrad_partial_pair_f32", (_p(A0), A0.stride(0), _p(B0), B0.stride(0), M0, N0, K0, _p(out0), out0.stride(0), _p(ws0), wsb0,
+                                        _p(A1), A1.stride(0), _p(B1), B1.stride(0), M1, N1, K1, _p(out1), out1.stride(0), _p(ws1), wsb1,
+                                        pend, _stream()),
+         key=f"M{M0}N{N0}K{K0}+M{M1}N{N1}K{K1}", abytes=4 * (K0 * (M0 + N0) + M0 * N0 + K1 * (M1 + N1) + M1 * N1),
+         aflops=2 * (M0 * N0 * K0 + M1 * N1 * K1))
+    batch.items.append((HspWgradPending.from_buffer_copy(pend[0]), ws0))
+    batch.items.append((HspWgradPending.from_buffer_copy(pend[1]), ws1))
 
 
 def _ld(t):
@@ -875,7 +950,8 @@ class _HSLayer(torch.autograd.Function):
         gt = colsum_rows(g)                                                    # (B,C) = sum_i g
         g_conv2 = torch.empty_like(w_conv2)
         with WgradBatch():                                                     # the three parameter gradients: one fold launch
-            wgrad(g2, F2, out=g_conv2[:, :C])                                  # gWa, written in place (ldc = 2C)
+            g_ste = torch.empty(C, Cin, dtype=torch.float32, device=g.device)
+            wgrad_pair(g2, F2, g_conv2[:, :C], g2, X2, g_ste)                  # gWa (in place, ldc = 2C) and gWste: one split-K launch
             _tiny_tn(gt, fg, g_conv2[:, C:])                                   # gWb = gt^T fg (tiny), straight into its column block
             gF3 = torch.empty(B, N, C, dtype=torch.float32, device=g.device)
             _mm_nn(g2, Wa, out=gF3.view(B * N, C))                             # g Wa ...
@@ -883,7 +959,6 @@ class _HSLayer(torch.autograd.Function):
             gfm, gD = _rf_conv_bwd_raw(xyz, idx_f, directions, fm.view(B, N, -1), arg, gF3, S)
             gfm2 = gfm.view(B * N, -1)
             gW, gb = wgrad(X2, gfm2, colsum=True)                              # X^T gfm and the bias gradient
-            g_ste = wgrad(g2, X2)
             gX3 = torch.empty(B, N, Cin, dtype=torch.float32, device=g.device)
             _grad_in_rows(g2, w_ste, gfm2, weights, gX3.view(B * N, Cin))      # g Wste + gfm W^T
         return None, gX3, None, None, None, None, gW, gb, gD, g_ste.unsqueeze_(-1), g_conv2.unsqueeze_(-1)
@@ -1109,6 +1184,8 @@ def gather_rows(feat, idx):
 # feat assembly: nearest up-sampling + one-hot + concat in one kernel (FaceRecon.py:100-107)
 # ------------------------------------------------------------------------------------------------
 
+ONE_HOT_WIDTH = 6          # categories of a kind-3 (one-hot) segment; FaceRecon sets it from FLAGS.obj_c
+
 # feat row pitch: columns padded to a multiple of this many elements (8 = 16 bytes of bf16, 32 of fp32); 1 = no padding
 FEAT_PITCH_ALIGN = int(os.environ.get("HSP_FEAT_PITCH_ALIGN", "8"))
 
@@ -1116,7 +1193,8 @@ FEAT_PITCH_ALIGN = int(os.environ.get("HSP_FEAT_PITCH_ALIGN", "8"))
 class _AssembleFeat(torch.autograd.Function):
     """feat (B,N,W) = cat[ direct..., gathered(src, nearest idx)..., per-cloud... ] along channels.
     segs: list of (tensor, idx or None, kind) with kind 0 direct (B,N,w), 1 gathered rows of (B,Ns,w) by an
-    int32 (B,N) index, 2 per-cloud (B,w) broadcast over the points."""
+    int32 (B,N) index, 2 per-cloud (B,w) broadcast over the points, 3 a (B,) float id expanded to ``ONE_HOT_WIDTH`` one-hot
+    columns (the reference's zeros + scatter_, FaceRecon.py:80-85, without its three launches)."""
 
     @staticmethod
     def forward(ctx, kinds, idxs, *tensors):
@@ -1125,11 +1203,14 @@ class _AssembleFeat(torch.autograd.Function):
             if kd == 0:
                 B, N, dt = t.shape[0], t.shape[1], t.dtype
         # point-row segments share the feature dtype (fp32 or bf16); per-cloud rows (kind 2: the one-hot columns) are fp32
-        tensors = [(_req(t, torch.float32, "assemble_feat.src") if kd == 2 or dt == torch.float32 else
+        tensors = [(_req(t, torch.float32, "assemble_feat.src") if kd >= 2 or dt == torch.float32 else
                     _req(t, dt, "assemble_feat.src")) for t, kd in zip(tensors, kinds)]
         idxs = [(_req(i, torch.int32, "assemble_feat.idx") if i is not None else None) for i in idxs]
         n = len(tensors)
-        widths = [t.shape[-1] for t in tensors]
+        widths = [(t.shape[-1] if kd != 3 else ONE_HOT_WIDTH) for t, kd in zip(tensors, kinds)]
+        for t, kd in zip(tensors, kinds):
+            if kd == 3 and t.numel() != B:
+                raise HspError("assemble_feat: a kind-3 segment is one float id per cloud")
         W = sum(widths)
         # rows padded to a multiple of 16 bytes (1286 -> 1288 columns): the kernel then moves 16 bytes per access and the
         # heads' K = 1286 products read aligned rows; the result is the (B,N,W) view of the padded buffer
@@ -1152,7 +1233,7 @@ class _AssembleFeat(torch.autograd.Function):
                                              ctypes.cast(kd, _vp), ctypes.cast(ns, _vp), B, N, _p(full), P, _stream()),
                  key=f"B{B}N{N}W{W}", abytes=2 * es * B * N * W)
         ctx.kinds, ctx.widths = kinds, widths
-        ctx.nsrc = [t.shape[1] for t in tensors]
+        ctx.nsrc = [(t.shape[1] if t.dim() > 1 else 0) for t in tensors]
         ctx.save_for_backward(*[i for i in idxs if i is not None])
         ctx.has_idx = [i is not None for i in idxs]
         return out
@@ -1188,6 +1269,8 @@ class _AssembleFeat(torch.autograd.Function):
                     _run("hsp_gather_rows_bwd", (_p(gs), W, _p(idx), 0, B, Ns, N, w, _p(gfeat), _stream()),
                          key=f"B{B}Ns{Ns}Nq{N}C{w}", abytes=B * (4 * Ns * w + N * (4 + 4 * w)))
                 grads.append(gfeat)
+            elif kd == 3:
+                grads.append(None)                                 # ids carry no gradient
             else:
                 grads.append(gs.sum(dim=1))
             col += w

@@ -136,6 +136,10 @@ int hsp_gather_max_fwd(const float *feat, const int32_t *idx, const int32_t *qse
 /* grad_feat (B,Nsrc,C) is OVERWRITTEN.  grad_out is (B,Nq,C), or (B,C) broadcast over q when
  * grad_bcast != 0 (the ORL mean-over-points branch; integer counts in LDS => exactly reproducible).
  * Column-tile LDS scatter when a (Nsrc x 16-column) tile fits LDS, else memset + global atomics. */
+/* Pool_layer (gcn3d.py:220-246) in ONE launch: out (B,Nq,C) = max over the first k listed neighbours of the kept rows qsel
+ * (Nq ints, shared by the batch) + argmax, and xyz_sel (B,Nq,3) = xyz[:, qsel] (the reference's vertices[:, sample_idx]). */
+int hsp_pool_fwd(const float *feat, const float *xyz, const int32_t *idx, const int32_t *qsel, int B, int N, int Nq, int k,
+                 int kstride, int C, float *out, uint8_t *argmax, float *xyz_sel, hspStream_t stream);
 int hsp_gather_max_bwd(const float *grad_out, int grad_bcast, const int32_t *idx, const int32_t *qsel,
                        const uint8_t *argmax, int B, int Nsrc, int Nidx, int Nq, int kstride, int C,
                        float *grad_feat, int accumulate /* !=0: add into grad_feat instead of overwriting */,
@@ -175,6 +179,7 @@ int hsp_residual_bias(float *out, const float *f, const float *t, int B, int N, 
  * replaces the nearest-up-sampling gathers + one-hot repeat + torch.cat     FaceRecon.py:100-107
  * out (B,N,sum width): column segment s of row (b,i) is
  *   kind 0: src[s][(b*N+i)*w .. ]   kind 1: src[s][(b*nsrc[s] + idx[s][b*N+i])*w ..]   kind 2: src[s][b*w ..]
+ *   kind 3: (long) src[s][b] == c ? 1 : 0  -- one-hot columns from the (B) float category ids (FaceRecon.py:80-85)
  * (host arrays of nseg <= 8 entries; device pointers inside).  The backward of kind-1 segments is
  * hsp_gather_rows_bwd with grad_stride = total width.
  */
@@ -271,6 +276,12 @@ typedef struct HspWgradPending {
     int nparts, M, N, ldc;
 } HspWgradPending;
 int hsp_wgrad_fold(const HspWgradPending *pending, int n, hspStream_t stream);
+/* two pending weight gradients from ONE split-K launch (an HS layer's backward has two that depend only on the incoming
+ * gradient and are each too small to fill the chip: g^T F and g^T X -- autograd of gcn3d.py:186 and :149); pending[2] */
+int hsp_wgrad_partial_pair_f32(const float *A0, int lda0, const float *B0, int ldb0, int M0, int N0, int K0, float *C0, int ldc0,
+                               void *ws0, size_t ws_bytes0, const float *A1, int lda1, const float *B1, int ldb1, int M1, int N1,
+                               int K1, float *C1, int ldc1, void *ws1, size_t ws_bytes1, HspWgradPending *pending,
+                               hspStream_t stream);
 int hsp_wgrad_f32(const float *A, int lda, const float *B, int ldb, int M, int N, int K, float *C, int ldc,
                   float *colsum_B, void *ws, size_t ws_bytes, hspStream_t stream);
 int hsp_wgrad_partial_f32(const float *A, int lda, const float *B, int ldb, int M, int N, int K, float *C, int ldc,
@@ -406,7 +417,8 @@ int hsp_colsum_rows_bf16(const hsp_bf16_t *x, int B, int N, int C, float *out, v
                          hspStream_t stream);
 /* out_pitch: row pitch of out in elements (>= sum of widths; padding columns are zeroed when every segment is 16-byte
  * aligned -- the feat assembly -- and left untouched otherwise).  bf16 form: kind 0 / 1
- * sources are bf16, kind 2 (per-cloud rows, the one-hot category columns) fp32 */
+ * sources are bf16, kind 2 (per-cloud rows) and kind 3 (the (B) float
+ * category ids, expanded to one-hot columns in place) fp32 */
 int hsp_concat_rows_pitched(int nseg, const float *const *src, const int32_t *const *idx, const int *width, const int *kind,
                             const int *nsrc, int B, int N, float *out, int out_pitch, hspStream_t stream);
 int hsp_concat_rows_bf16(int nseg, const void *const *src, const int32_t *const *idx, const int *width, const int *kind,
