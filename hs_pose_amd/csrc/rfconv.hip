@@ -547,10 +547,19 @@ __global__ __launch_bounds__(RF_THREADS) void rf_conv_bwd_csr_kernel(
 // where gathering it from fm fetched a 64-byte sector per 4-byte value).  That gradient is
 // accumulated in registers, folded across the workgroup's point lanes in LDS in a fixed order and written
 // to gd_part[b][3][SC] (one writer per element); rf_dirs_reduce_kernel sums the B clouds.
-// Only the LDS float adds are order-dependent; hsp_rf_conv_bwd (CSR form) is the bit-reproducible twin.
+// (hsp_rf_conv_bwd, the CSR form, is the gather twin; both are bit-reproducible now that the tile adds integers.)
 // grid (SC/TC, B), block 512, dynamic LDS = max(N*TC (acc) + 3N (xyz), 512*12) floats
 // ------------------------------------------------------------------------------------------------
 #define RF_TILE_THREADS 512   // 8 waves: with one 78 KB tile per workgroup this doubles the waves per CU
+// The tile accumulates in 32-bit FIXED POINT: ds_add_u32 retires ~24x the lanes per clock of ds_add_f32 on gfx950
+// (tools/ubench/lds_atomic.hip), and with the winners' support values streamed (fwin) the float adds were what the
+// cache-resident layers waited on (measured: 52.7 -> 28.1 us at N = 257, C = 256; 83 -> 72 us at N = 1028).  The scale is
+// private to the workgroup -- a power of two chosen from the largest |grad_out| / S of the columns this tile reads, with
+// ceil(log2 N) bits of headroom: a (row, column) cell receives at most one term per point and every term is bounded by that
+// maximum (|theta| <= 1), so the sum cannot overflow; a term is rounded to 2^-(30 - log2 N) of the tile's largest one (1.2e-7
+// at N = 257, 1e-6 at N = 1028 -- the fp32 adds it replaces carried the same order) and the integer sum is exact and
+// order-independent: the scatter form is now bit-reproducible as well.
+#define RF_ACC_ADD(P, V) atomicAdd(reinterpret_cast<int*>(P), __float2int_rn((V) * fx_scale))
 
 // FWIN: the support values come from the forward's fwin stream; else they are gathered from fm (fine while a
 // cloud's fm stays L2-resident: small N)
@@ -584,6 +593,34 @@ __global__ __launch_bounds__(RF_TILE_THREADS) void rf_bwd_tile_kernel(
     if (!SURFACE)
         for (int q = tid; q < NR * G; q += RF_TILE_THREADS) *reinterpret_cast<float4*>(acc + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int q = tid; q < 3 * (r1 - r0); q += RF_TILE_THREADS) sx[q] = xb[r0 * 3 + q];
+    // fixed-point scale of this tile: max |grad_out| / S over the (point, channel) values it is going to route
+    float fx_scale = 1.f, fx_inv = 1.f;
+    if (!SURFACE) {
+        __shared__ float wmax[RF_TILE_THREADS / 64];
+        float vm = 0.f;
+        for (int p = pl; p < N; p += PL) {
+            const float4 gq = Feat<FT>::ld4(gout + ((size_t)b * N + p) * C + c);
+            vm = fmaxf(vm, fmaxf(fmaxf(fabsf(gq.x), fabsf(gq.y)), fmaxf(fabsf(gq.z), fabsf(gq.w))));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vm = fmaxf(vm, __shfl_xor(vm, o));
+        if ((tid & 63) == 0) wmax[tid >> 6] = vm;
+        __syncthreads();
+        vm = wmax[0];
+#pragma unroll
+        for (int w = 1; w < RF_TILE_THREADS / 64; ++w) vm = fmaxf(vm, wmax[w]);
+        vm *= invS;
+        if (vm > 0.f && vm < 3.0e38f) {            // (0 / inf / NaN gradients: scale 1 -- nothing sensible to preserve)
+            int ex;
+            frexpf(vm, &ex);                        // vm < 2^ex
+            int lg = 0;
+            while ((1 << lg) < N) ++lg;
+            int e = 30 - ex - lg;
+            e = e > 120 ? 120 : (e < -120 ? -120 : e);
+            fx_scale = ldexpf(1.f, e);
+            fx_inv = ldexpf(1.f, -e);
+        }
+    }
     float4 d0, d1, d2;
     load_dirs_normed(dirs, SC, j, d0, d1, d2);
     float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
@@ -624,7 +661,7 @@ __global__ __launch_bounds__(RF_TILE_THREADS) void rf_bwd_tile_kernel(
                 const float3 r = unit_dir_fast(px, py, pz, sx[m * 3], sx[m * 3 + 1], sx[m * 3 + 2]); \
                 const float z = __fmaf_rn(r.z, d2.X, __fmaf_rn(r.y, d1.X, mul_rn(r.x, d0.X)));       \
                 if (z > 0.f) {                                                                       \
-                    if (!SURFACE) atomicAdd(acc + m * TC + cg * 4 + E, ga.X * z);                    \
+                    if (!SURFACE) RF_ACC_ADD(acc + m * TC + cg * 4 + E, ga.X * z);                   \
                     const float w = ga.X * FV;                                                       \
                     g0.X += w * r.x; g1.X += w * r.y; g2.X += w * r.z;                               \
                 }                                                                                    \
@@ -638,8 +675,9 @@ __global__ __launch_bounds__(RF_TILE_THREADS) void rf_bwd_tile_kernel(
         // flush the tile: one 16-byte store per (row, group)
         for (int q = tid; q < (r1 - r0) * G; q += RF_TILE_THREADS) {
             const int m = q / G, g4 = q - m * G;
+            const int4 iv = *reinterpret_cast<const int4*>(acc + m * TC + g4 * 4);
             Feat<FT>::st4(gfm + ((size_t)b * N + r0 + m) * fstride + C + j0 + g4 * 4,
-                          *reinterpret_cast<const float4*>(acc + m * TC + g4 * 4));
+                          make_float4((float)iv.x * fx_inv, (float)iv.y * fx_inv, (float)iv.z * fx_inv, (float)iv.w * fx_inv));
         }
         if (j0 < C) {   // the first C/TC tiles also copy the centre columns grad_fm[b,m,c] = g[b,m,c]
             for (int q = tid; q < (r1 - r0) * G; q += RF_TILE_THREADS) {
@@ -822,8 +860,15 @@ extern "C" int hsp_rf_surface_fwd_bf16(const float* xyz, const int32_t* idx, con
 }
 
 // the forward's fwin stream pays off once a cloud's fm no longer stays in its XCD's L2 next to the other streams
+// (round 3: always.  With the tile kernel's adds in fixed point the 4-byte gathers of the winners' support values were what
+// the small clouds' backward waited on: 52.7 -> 28.1 us at N = 257, C = 256 for +5 us in the forward.  HSP_RF_FWIN_MIN=<bytes
+// of a cloud's fm> restores a threshold.)
+static size_t rf_fwin_min_bytes() {
+    static const size_t v = [] { const char* e = getenv("HSP_RF_FWIN_MIN"); return e ? (size_t)atoll(e) : (size_t)0; }();
+    return v;
+}
 extern "C" int hsp_rf_conv_wants_fwin(int N, int S, int C) {
-    return (size_t)N * (S + 1) * C * sizeof(float) >= ((size_t)3 << 20) ? 1 : 0;
+    return (size_t)N * (S + 1) * C * sizeof(float) >= rf_fwin_min_bytes() ? 1 : 0;
 }
 
 extern "C" int hsp_rf_conv_fwd(const float* xyz, const int32_t* idx, const float* dirs_n, const float* fm, int B,

@@ -419,7 +419,10 @@ def orl_global(feat, idx, k):
 # ------------------------------------------------------------------------------------------------
 
 _wgrad_choice = {}          # (M, N, K, colsum) -> "custom" | "library", measured at first use
-WGRAD_MODE = os.environ.get("HSP_WGRAD", "auto")     # auto | custom | library
+# custom (default) | auto | library.  "auto" times both forms once per shape at first use; its verdicts vary from run to run for
+# the small shapes (a first-use timing of a 10 us kernel) and the library form it then sometimes keeps -- a split-K GEMM, its
+# reduce kernel and a strided copy -- measured 29 us in the step where the hand-written kernel takes 10-12 us
+WGRAD_MODE = os.environ.get("HSP_WGRAD", "custom")
 
 
 def _wgrad_library(A2, B2, out, colsum):

@@ -394,9 +394,17 @@ def test_rf_conv_backward_fwin_stream_equals_fm_gather(dev, ref):
         _run("hsp_rf_conv_bwd_scatter", (_p(xyz), _p(dirs), _p(a_fm), _p(a_fw), _p(arg), _p(g), B, N, S, C, _p(gfm), _p(gd),
                                          _p(ws), wsb, _stream()))
         res.append((gfm, gd))
-    assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=1e-6)
+    # the tile accumulates in fixed point (integer LDS adds: exact, order-independent): both forms route the same terms
+    assert torch.equal(res[0][0], res[1][0])
     assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-5)
-    assert lib().hsp_rf_conv_wants_fwin(1028, 7, 128) == 1 and lib().hsp_rf_conv_wants_fwin(64, 7, 512) == 0
+    # ... and the same launch twice gives the same bits
+    gfm2 = torch.empty(B, N, (S + 1) * C, device=dev)
+    gd2 = torch.empty(3, SC, device=dev)
+    _run("hsp_rf_conv_bwd_scatter", (_p(xyz), _p(dirs), _p(None), _p(fwin), _p(arg), _p(g), B, N, S, C, _p(gfm2), _p(gd2),
+                                     _p(_ws(wsb, dev)), wsb, _stream()))
+    assert torch.equal(gfm2, res[1][0]) and torch.equal(gd2, res[1][1])
+    # round 3: the stream is always wanted (the backward's 4-byte gathers cost more than the forward's extra store)
+    assert lib().hsp_rf_conv_wants_fwin(1028, 7, 128) == 1 and lib().hsp_rf_conv_wants_fwin(64, 7, 512) == 1
 
 
 @pytest.mark.parametrize("B,Ns,Nq,C,W", [(3, 37, 150, 64, 200), (2, 64, 1028, 512, 1286), (2, 257, 1028, 256, 1286)])
