@@ -297,7 +297,10 @@ __global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const FT* __restr
     __syncthreads();
     // FL points per pass: their arg-max bytes / gradients first, then the dependent neighbour-index gathers, then the
     // LDS adds -- two global round trips per pass instead of two per point
-    constexpr int FL = 4;
+#ifndef SCATTER_FL
+#define SCATTER_FL 4
+#endif
+    constexpr int FL = SCATTER_FL;
     for (int q0 = pl; q0 < Nq; q0 += PL * FL) {
         if (MODE == 1) {
 #pragma unroll
@@ -414,7 +417,8 @@ __global__ __launch_bounds__(256) void residual_bias_kernel(float* __restrict__ 
 }
 
 static int pick_scatter_cols(int Nsrc, int C) {
-    for (int tc = 16; tc >= 4; tc >>= 1)
+    static const int cap = [] { const char* e = getenv("HSP_SCATTER_TC"); return e ? atoi(e) : 16; }();
+    for (int tc = cap; tc >= 4; tc >>= 1)
         if (C % tc == 0 && (size_t)Nsrc * tc * 4 <= 144 * 1024) return tc;
     return 0;
 }

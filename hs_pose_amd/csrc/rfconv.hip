@@ -550,6 +550,9 @@ __global__ __launch_bounds__(RF_THREADS) void rf_conv_bwd_csr_kernel(
 // (hsp_rf_conv_bwd, the CSR form, is the gather twin; both are bit-reproducible now that the tile adds integers.)
 // grid (SC/TC, B), block 512, dynamic LDS = max(N*TC (acc) + 3N (xyz), 512*12) floats
 // ------------------------------------------------------------------------------------------------
+#ifndef RF_BWD_CLOUD_PER_XCD
+#define RF_BWD_CLOUD_PER_XCD 1     // 0: only groups of 4 adjacent tiles share an XCD (measured 65.3 vs 60.7 us at N = 1028)
+#endif
 #define RF_TILE_THREADS 512   // 8 waves: with one 78 KB tile per workgroup this doubles the waves per CU
 // The tile accumulates in 32-bit FIXED POINT: ds_add_u32 retires ~24x the lanes per clock of ds_add_f32 on gfx950
 // (tools/ubench/lds_atomic.hip), and with the winners' support values streamed (fwin) the float adds were what the
@@ -583,8 +586,27 @@ __global__ __launch_bounds__(RF_TILE_THREADS) void rf_bwd_tile_kernel(
     const int SC = S * C;
     const int fstride = (S + 1) * C;
     const int tid = threadIdx.x;
-    const int b = blockIdx.y;
-    const int j0 = blockIdx.x * TC;
+    // (cloud, column tile) of this workgroup.  Neighbouring column tiles read neighbouring 32- / 64-byte pieces of the same
+    // argrow / fwin / grad_out lines; dispatched round-robin over the 8 XCDs each piece was fetched into another L2 (measured:
+    // 340 MB of HBM traffic for 164 MB algorithmic at N = 1028).  Groups of 4 adjacent tiles are therefore given to ONE XCD, as
+    // consecutive workgroups of it (block id = XCD + 8 k, observed placement: a speed choice only).
+    int b = blockIdx.y, tile = blockIdx.x;
+    {
+        const int T = gridDim.x, ngrp = (T >> 2) * (int)gridDim.y;
+            if (RF_BWD_CLOUD_PER_XCD && ((int)gridDim.y & 7) == 0) {     // every tile of a cloud on one XCD (grad_out is shared by its S tiles too)
+            const int L = blockIdx.x + T * blockIdx.y;
+            const int xcd = L & 7, k = L >> 3;
+            b = xcd + 8 * (k / T);
+            tile = k - (k / T) * T;
+        } else if ((T & 3) == 0 && (ngrp & 7) == 0) {
+            const int L = blockIdx.x + T * blockIdx.y;
+            const int xcd = L & 7, k = L >> 3;
+            const int gid = xcd + 8 * (k >> 2);
+            b = gid / (T >> 2);
+            tile = 4 * (gid - b * (T >> 2)) + (k & 3);
+        }
+    }
+    const int j0 = tile * TC;
     const int cg = tid % G, pl = tid / G;
     const int j = j0 + cg * 4;
     const int c = j % C;
