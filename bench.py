@@ -33,7 +33,14 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 MFMA_F32_PEAK_TFLOPS = 157.3   # same guide: v_mfma_f32_32x32x2_f32 dense peak (= the fp32 vector rate)
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # same guide: dense bf16 MFMA peak
 # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/refresh_profiles.sh)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02", "traffic.json")
+def _latest_traffic_json():
+    """profiles/rNN/traffic.json of the latest round that has one (written by tools/refresh_profiles.sh BEFORE the bench line)"""
+    base = os.path.join(ROOT, "profiles")
+    rounds = sorted(d for d in (os.listdir(base) if os.path.isdir(base) else []) if os.path.isfile(os.path.join(base, d, "traffic.json")))
+    return os.path.join(base, rounds[-1], "traffic.json") if rounds else os.path.join(base, "traffic.json")
+
+
+TRAFFIC_JSON = _latest_traffic_json()
 
 
 def u1_algorithmic(N, k=20, S=7):
@@ -350,7 +357,7 @@ def main():
             with open(TRAFFIC_JSON) as f:
                 tj = json.load(f)
             roof["traffic"] = tj.get(f"{kname}[{kkey}]", {}).get("hbm_bytes_per_launch")
-            roof["traffic_source"] = "profiles/r02/traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE passes of this command)"
+            roof["traffic_source"] = (os.path.relpath(TRAFFIC_JSON, ROOT) + " (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE passes of this command)")
         except Exception:
             pass
         sb = ops.design_stream_bytes.get((kname, kkey))

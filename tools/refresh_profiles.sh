@@ -10,21 +10,21 @@ RD=${1:-r02}
 O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O $R/profiles/$RD
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 4 --warmup 2 --no-graph --no-cpu-baseline --no-u3 > $O/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 4 --warmup 2 --no-graph --no-cpu-baseline --no-u3 --no-side > $O/pmc_$c.log 2>&1
   cp $(find $O/pmc_$c -name '*counter_collection.csv' | head -1) $O/k_pmc_$c.csv
 done
 python $R/tools/pmc_traffic.py $O/k_pmc_FETCH_SIZE.csv $O/k_pmc_WRITE_SIZE.csv $O/traffic.json > /dev/null
 cp $O/traffic.json $R/profiles/$RD/traffic.json
 python $R/bench.py > $O/k_bench.json 2> $O/bench.err
 tail -1 $O/k_bench.json | cut -c1-300
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline --no-u3 > $O/stats_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline --no-u3 --no-side > $O/stats_bench.log 2>&1
 cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/k_graph_kernel_stats.csv
 T=$(find $O/stats -name '*kernel_trace.csv' | head -1)
 python $R/tools/trace_by_shape.py $T auto > $O/k_per_shape_kernel_us.txt
-python $R/bench.py --steps 20 --warmup 5 --breakdown --no-cpu-baseline --no-u3 > $O/k_breakdown_eager_events.txt 2>&1
+python $R/bench.py --steps 20 --warmup 5 --breakdown --no-cpu-baseline --no-u3 --no-side > $O/k_breakdown_eager_events.txt 2>&1
 # own GEMMs only (no BLAS library on the layer path)
-HSP_GEMM=own python $R/bench.py --no-cpu-baseline --no-u3 > $O/k_bench_gemm_own.json 2>/dev/null
-HSP_GEMM=library python $R/bench.py --no-cpu-baseline --no-u3 > $O/k_bench_gemm_library.json 2>/dev/null
+HSP_GEMM=own python $R/bench.py --no-cpu-baseline --no-u3 --no-side > $O/k_bench_gemm_own.json 2>/dev/null
+HSP_GEMM=library python $R/bench.py --no-cpu-baseline --no-u3 --no-side > $O/k_bench_gemm_library.json 2>/dev/null
 # ---- bf16, B=64, N=4096
 BF="--dtype bf16 --points 4096 --batch 64 --no-cpu-baseline"
 for c in FETCH_SIZE WRITE_SIZE; do
