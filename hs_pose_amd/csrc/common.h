@@ -66,6 +66,13 @@ __device__ __forceinline__ float3 unit_dir_fast(float px, float py, float pz, fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// instruction-rate notes for gfx950 (tools/ubench/valu_rate.hip; clocks per wave64 instruction and SIMD, >= 2 waves resident):
+// v_mul / v_fmac / v_mov (VGPR source) / v_and / v_add / shifts ~2.3-2.8; v_max / v_min (f32 and i32), v_med3, v_cmp,
+// v_cndmask, anything with an SGPR or inline-constant operand ~4.2 ALONE -- but a stream that alternates them with the first
+// class runs at ~2.1 per instruction (max + mul pairs: 4.2 per pair), so a mixed loop prices every VALU instruction at ~2.1-2.5.
+// Measured and rejected in the receptive-field forward: running (max, arg, payload) updates as one compare + moves under a
+// narrowed EXEC (s_and_saveexec / v_cmpx) instead of selects: 106 vs 96 us at B16 N1028 C128 -- the asm blocks pin the schedule.
+// ------------------------------------------------------------------------------------------------
 // feature storage type of a kernel: fp32, or bfloat16 bits (BASELINE configs[3]: features / fm / gradients stored in
 // bf16, every kernel still computes in fp32 -- loads widen, stores round to nearest even).  xyz, support directions
 // and theta never go through these (gcn3d.py:57,59 keeps them fp32).

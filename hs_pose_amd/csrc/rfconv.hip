@@ -829,7 +829,8 @@ static int rf_fwd(const float* xyz, const int32_t* idx, const float* dirs, const
     }
     const size_t lds = (size_t)(S * C + 5 * k) * 4;
     if (lds > 64 * 1024) return HSP_ERR_UNSUPPORTED;
-    const int grid = persistent_blocks((long long)B * N, 8);
+    static const int bpc_env = [] { const char* e = getenv("HSP_RF_BPC"); return e ? atoi(e) : 0; }();
+    const int grid = persistent_blocks((long long)B * N, bpc_env > 0 ? bpc_env : 8);
     const int nch = ((S * C >> 2) + RF_THREADS - 1) / RF_THREADS;
     if (nch > 4) return HSP_ERR_UNSUPPORTED;              // S*C <= 4096
     {

@@ -134,3 +134,12 @@ def dev():
     from hs_pose_amd._lib import lib
     lib()   # hard error (not a skip) if the HIP extension is missing on a GPU box
     return torch.device("cuda:0")
+
+
+@pytest.fixture(params=["library", "own"])
+def gemm_mode(request, monkeypatch):
+    """the fp32 dense products of the layer / head nodes on the BLAS library through torch, or on the hand-written kernels only
+    (csrc/gemm_wave.hip, gemm_rows.hip, gemm.hip): the stack goldens hold for both"""
+    from hs_pose_amd import ops
+    monkeypatch.setattr(ops, "GEMM_MODE", request.param)
+    return request.param

@@ -247,25 +247,33 @@ def test_hs_stack_bf16_vs_fp32_path(dev, ref, flags, monkeypatch, B, N):
     e2 = (feat_w.float() - feat_f).abs().max().item() / scale
     print(f"BF16 STACK B{B} N{N} free-running: set agreement per layer {[round(a, 4) for a in rp.agree]}; feat max err {e2:.2e} of scale")
     assert torch.isfinite(feat_w.float()).all()
+    # measured (round 3), rows whose free-running neighbour SET equals the fp32 path's: 0.52 / 0.33 / 0.19 / 0.58 at N = 1028,
+    # 0.37 / 0.18 / 0.10 / 0.13 at N = 4096, feat max error 0.17-0.18 of scale: a bf16 ulp (4e-3) against near-tied expanded
+    # distances re-routes most rows' last neighbours, and every later layer inherits the earlier ones' re-routing.  Floors at
+    # about half the measured figures.
+    assert min(rp.agree) >= 0.05 and rp.agree[0] >= 0.2, rp.agree
+    assert e2 <= 0.5, e2
 
 
-def test_hs_layer_bf16_vs_cpu_oracle(dev, ref, flags):
-    """one HS layer (128 -> 128, N = 4096, k = 20) against the fp32 CPU ORACLE (oracle/ref_cpu.py) evaluated on the
-    bf16-rounded input and weights: forward 2e-2 of scale (the layer rounds fm, F and out to bf16), with the oracle's own
-    neighbour list."""
+@pytest.mark.parametrize("lname,N,Cin,k", [("conv_1", 4096, 128, 20), ("conv_2", 1024, 128, 20), ("conv_3", 1024, 256, 20),
+                                           ("conv_4", 256, 256, 20), ("conv_1", 1028, 128, 20)])
+def test_hs_layer_bf16_vs_cpu_oracle(dev, ref, flags, lname, N, Cin, k):
+    """every HS layer of the stack at the cloud sizes of BASELINE configs[3] (N = 4096 -> 1024 -> 256) against the fp32 CPU
+    ORACLE (oracle/ref_cpu.py) evaluated on the bf16-rounded input and weights, with the oracle's own neighbour list:
+    forward 1e-2 of scale (the layer rounds fm, F and out to bf16)."""
     from hs_pose_amd import gcn3d, ops, ops_bf16
     from hs_pose_amd.FaceRecon import FaceRecon
     flags.train = 0
     torch.manual_seed(0)
     net = FaceRecon().to(dev)
     net.set_feature_dtype(BF)
-    layer = net.conv_1
-    B, N, k = 1, 4096, 20
+    layer = getattr(net, lname)
+    B = 1
     xyz = _h(ref, (B, N, 3), 71, 0.05)
-    X = torch.relu(_h(ref, (B, N, 128), 72, 1.0)).bfloat16()
-    p = {f"conv_1.{n_}": v.detach().cpu().bfloat16().float() if n_ in ("weights", "STE_layer.weight", "conv2.weight") else v.detach().cpu()
+    X = torch.relu(_h(ref, (B, N, Cin), 72, 1.0)).bfloat16()
+    p = {f"{lname}.{n_}": v.detach().cpu().bfloat16().float() if n_ in ("weights", "STE_layer.weight", "conv2.weight") else v.detach().cpu()
          for n_, v in layer.state_dict().items()}
-    want = ref.hs_layer(p, "conv_1.", xyz, X.float(), k, 7)
+    want = ref.hs_layer(p, lname + ".", xyz, X.float(), k, 7)
     idx_f = ref.knn_index(X.float(), k).to(torch.int32).to(dev)
     net._bf16.refresh()
     with gcn3d.knn_scope():
@@ -273,5 +281,68 @@ def test_hs_layer_bf16_vs_cpu_oracle(dev, ref, flags):
             xyz.to(dev), X.to(dev), idx_f, ops.knn(xyz.to(dev), k), k, 7, layer.weights, layer.bias, layer.directions,
             layer.STE_layer.weight, layer.conv2.weight)
     err = (got.float().cpu() - want).abs().max().item() / want.abs().max().item()
-    print(f"bf16 HS layer vs fp32 CPU oracle (N=4096): max err {err:.2e} of scale")
+    print(f"bf16 {lname} vs fp32 CPU oracle (N={N}): max err {err:.2e} of scale")
     assert err <= 1e-2
+
+
+def test_bf16_config3_full_batch(dev, ref, flags):
+    """BASELINE configs[3] at its stated size, B = 64, N = 4096, bf16 feature storage: the hipGraph replay bench.py times equals
+    the eager step (feat and every parameter gradient), everything is finite, and the feature-space neighbour lists the
+    step used have the KNN properties (k distinct in-range rows per query; the list of a query equals the C-ABI kernel's on
+    the widened rows = the fp32 chain, on a sample of clouds)."""
+    from hs_pose_amd import gcn3d, ops
+    from hs_pose_amd.FaceRecon import FaceRecon
+    from hs_pose_amd.graph import GraphedStep
+    B, N = 64, 4096
+    g = torch.Generator().manual_seed(9)
+    pc = torch.randn(B, N, 3, generator=g) * 0.05
+    centred = (pc - pc.mean(dim=1, keepdim=True)).to(dev)
+    obj = torch.randint(0, 6, (B, 1), generator=g).float().to(dev)
+    dfeat = torch.randn(B, N, 1286, generator=g).bfloat16().to(dev)
+
+    def make():
+        flags.train = 0
+        torch.manual_seed(0)
+        return FaceRecon().to(dev).train().set_feature_dtype(BF)
+    net_g, net_e = make(), make()
+    torch.manual_seed(11)
+    graphed = GraphedStep(net_g, centred, obj, dfeat, warmup=1)
+    for _ in range(2):
+        feat_g = graphed.run()
+    torch.cuda.synchronize()
+    seen = []
+    real = ops.knn
+
+    def spy(x, k, drop_first=True):
+        out = real(x, k, drop_first)
+        if x.shape[-1] != 3:
+            seen.append((x, k, out))
+        return out
+    ops.knn = spy
+    try:
+        with gcn3d.pool_index_feed([p.clone() for p in graphed.pool_idx]):
+            _, _, feat_e = net_e(centred, obj)
+    finally:
+        ops.knn = real
+    feat_e.backward(dfeat)
+    torch.cuda.synchronize()
+    assert feat_g.dtype == BF and feat_g.shape == (B, N, 1286)
+    assert torch.isfinite(feat_g.float()).all() and torch.isfinite(feat_e.float()).all()
+    scale = feat_e.float().abs().max().item()
+    assert (feat_g.float() - feat_e.float()).abs().max().item() <= 1e-5 * scale        # same kernels, same order: equal
+    gmax = max(p.grad.abs().max().item() for p in net_e.parameters() if p.grad is not None)
+    for (k_, pg), (_, pe) in zip(net_g.named_parameters(), net_e.named_parameters()):
+        if pe.grad is None:
+            continue
+        assert torch.isfinite(pg.grad).all(), k_
+        # (the LDS-atomic backward kernels sum in arrival order: one bf16 ulp of a summand per element)
+        assert (pg.grad - pe.grad).abs().max().item() <= 2e-3 * gmax, k_
+    assert len(seen) == 4
+    for x, k, idx in seen:                                   # (B, n, C) bf16 rows, (B, n, k) lists
+        n = x.shape[1]
+        assert idx.shape == (B, n, k) and int(idx.min()) >= 0 and int(idx.max()) < n
+        srt = idx.sort(dim=2)[0]
+        assert bool((srt[:, :, 1:] != srt[:, :, :-1]).all()), "a neighbour list repeats a row"
+        wide = ops.knn(x[:2].float().contiguous(), k)        # the fp32 chain on the widened rows
+        same = (wide.sort(dim=2)[0] == idx[:2].sort(dim=2)[0]).all(dim=2).float().mean().item()
+        assert same > 0.97, same

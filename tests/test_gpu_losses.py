@@ -19,7 +19,7 @@ def test_augment_matches_reference_gpu(dev, ref, flags):
     check_augment(ref, dev, flags)
 
 
-def test_full_training_step_matches_reference(dev, ref, flags, monkeypatch):
+def test_full_training_step_matches_reference(dev, ref, flags, monkeypatch, gemm_mode):
     """engine/train.py:76-98: network(..., do_loss=True) -> 19 loss terms -> backward.  The reference's feature-space
     neighbour sets and Pool_layer draws are replayed; the loss terms then agree to 1e-3 of their size --
     they are sums over network outputs that agree to 1e-4."""

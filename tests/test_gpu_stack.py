@@ -81,7 +81,7 @@ class ForcedFeatKnn:
 
 
 @pytest.mark.parametrize("name", ["stack_eval_256", "stack_eval_1028", "stack_evalflags_trainbn_1028", "stack_train_256"])
-def test_posenet9d_golden(dev, ref, flags, monkeypatch, name):
+def test_posenet9d_golden(dev, ref, flags, monkeypatch, gemm_mode, name):
     """pose / size outputs of PoseNet9D within 1e-4 of the reference (BASELINE north_star)."""
     g = golden(name)
     train_flag, B, N, seed, bn_training = (int(v) for v in g["meta"])
@@ -129,7 +129,7 @@ def test_posenet9d_free_running_eval_256(dev, ref, flags, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["stack_evalflags_trainbn_1028", "stack_train_256"])
-def test_hs_stack_backward_golden(dev, ref, flags, monkeypatch, name):
+def test_hs_stack_backward_golden(dev, ref, flags, monkeypatch, gemm_mode, name):
     """unit U1: feat from the centred cloud (train-mode BN), backward from a closed-form dfeat to every
     HS-stack parameter; also BN running statistics after the step."""
     g = golden(name)

@@ -6,7 +6,7 @@ import torch
 from hs_pose_amd import ops
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-for B, N, C, k, S in ((16, 1028, 128, 20, 7), (16, 257, 256, 20, 7)):
+for B, N, C, k, S in ((16, 1028, 128, 20, 7), (16, 257, 256, 20, 7), (16, 64, 512, 8, 7)):
     SC = S * C
     xyz = torch.randn(B, N, 3, device=dev)
     X = torch.relu(torch.randn(B, N, C, device=dev))

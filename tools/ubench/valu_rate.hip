@@ -1,7 +1,7 @@
 // VALU issue rates on gfx950, whole chip: independent chains of one opcode per wave, W waves per SIMD.
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench/valu_rate.hip -o build_tmp/valu_rate && build_tmp/valu_rate
 // Prints wave-instructions per clock per SIMD (at the event-timed wall clock and an assumed 2.4 GHz) for
-// v_fma_f32, v_pk_fma_f32, v_cndmask_b32 (VCC and SGPR-pair mask), v_cmp_gt_f32 + v_cndmask, v_max_f32, ds_read_b128.
+// the opcodes of the selection / gather kernels (k_cmp_exec3mov / k_cmp_3cnd: clocks per GROUP -- a compare plus three conditional updates, by exec-masked moves or by v_cndmask).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>
@@ -32,6 +32,28 @@ KERNEL(k_max, asm volatile("v_max_f32_e32 %0, %0, %1" : "+v"(v[c]) : "v"(a));)
 KERNEL(k_cnd_vcc, asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(v[c]) : "v"(a) : );)
 KERNEL(k_cnd_sgpr, asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(v[c]) : "v"(a) : );)
 KERNEL(k_cmp_cnd, asm volatile("v_cmp_gt_f32_e32 vcc, %1, %0\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(v[c]) : "v"(a) : "vcc");)
+KERNEL(k_max_i32, asm volatile("v_max_i32_e32 %0, %0, %1" : "+v"(v[c]) : "v"(a));)
+KERNEL(k_max_i32_c0, asm volatile("v_max_i32_e32 %0, 0, %0" : "+v"(v[c]));)
+KERNEL(k_max_f32_c0, asm volatile("v_max_f32_e32 %0, 0, %0" : "+v"(v[c]));)
+KERNEL(k_min_f32, asm volatile("v_min_f32_e32 %0, %0, %1" : "+v"(v[c]) : "v"(a));)
+KERNEL(k_mov, asm volatile("v_mov_b32_e32 %0, %1" : "+v"(v[c]) : "v"(a));)
+KERNEL(k_mov_s, asm volatile("v_mov_b32_e32 %0, s20" : "+v"(v[c]));)
+KERNEL(k_add_u32, asm volatile("v_add_u32_e32 %0, %0, %1" : "+v"(v[c]) : "v"(a));)
+KERNEL(k_and, asm volatile("v_and_b32_e32 %0, %0, %1" : "+v"(v[c]) : "v"(a));)
+KERNEL(k_med3, asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(v[c]) : "v"(a), "v"(b));)
+KERNEL(k_max3, asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(v[c]) : "v"(a), "v"(b));)
+KERNEL(k_cmp, asm volatile("v_cmp_gt_f32_e32 vcc, %1, %0" : "+v"(v[c]) : "v"(a) : "vcc");)
+KERNEL(k_cmp_u32, asm volatile("v_cmp_gt_u32_e32 vcc, %1, %0" : "+v"(v[c]) : "v"(a) : "vcc");)
+KERNEL(k_fmac_s, asm volatile("v_fmac_f32_e32 %0, s20, %1" : "+v"(v[c]) : "v"(a));)
+KERNEL(k_mul_s, asm volatile("v_mul_f32_e32 %0, s20, %0" : "+v"(v[c]));)
+KERNEL(k_cmp_exec3mov, asm volatile("v_cmp_gt_f32_e32 vcc, %3, %0\n\ts_and_saveexec_b64 s[22:23], vcc\n\tv_mov_b32_e32 %0, %3\n\tv_mov_b32_e32 %1, %4\n\tv_mov_b32_e32 %2, s20\n\ts_mov_b64 exec, s[22:23]" : "+v"(v[c]), "+v"(v[(c + 5) & 15]), "+v"(v[(c + 9) & 15]) : "v"(a), "v"(b) : "vcc", "scc", "s22", "s23");)
+KERNEL(k_cmp_3cnd, asm volatile("v_cmp_gt_f32_e32 vcc, %3, %0\n\tv_cndmask_b32_e32 %0, %0, %3, vcc\n\tv_cndmask_b32_e32 %1, %1, %4, vcc\n\tv_cndmask_b32_e32 %2, %2, %3, vcc" : "+v"(v[c]), "+v"(v[(c + 5) & 15]), "+v"(v[(c + 9) & 15]) : "v"(a), "v"(b) : "vcc");)
+KERNEL(k_cmpx_3mov, asm volatile("s_mov_b64 s[22:23], exec\n\tv_cmpx_gt_f32_e32 vcc, %3, %0\n\tv_mov_b32_e32 %0, %3\n\tv_mov_b32_e32 %1, %4\n\tv_mov_b32_e32 %2, %4\n\ts_mov_b64 exec, s[22:23]" : "+v"(v[c]), "+v"(v[(c + 5) & 15]), "+v"(v[(c + 9) & 15]) : "v"(a), "v"(b) : "vcc", "s22", "s23");)
+KERNEL(k_fma_clamp, asm volatile("v_fma_f32 %0, %0, %1, %2 clamp" : "+v"(v[c]) : "v"(a), "v"(b));)
+KERNEL(k_max_mul, asm volatile("v_max_f32_e32 %0, 0, %0\n\tv_mul_f32_e32 %0, %0, %1" : "+v"(v[c]) : "v"(a));)
+KERNEL(k_lshl_or, asm volatile("v_lshl_or_b32 %0, %0, 5, %1" : "+v"(v[c]) : "v"(a));)
+KERNEL(k_bfi, asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(v[c]) : "v"(a), "v"(b));)
+KERNEL(k_ashr, asm volatile("v_ashrrev_i32_e32 %0, 31, %0" : "+v"(v[c]));)
 KERNEL(k_cmp_sgpr_cnd, asm volatile("v_cmp_gt_f32_e64 s[20:21], %1, %0\n\tv_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(v[c]) : "v"(a) : "s20", "s21");)
 
 template <int WPS>
@@ -105,7 +127,7 @@ static void run(const char* name, K kern, int wps, double inst_per_iter, const f
     // wave-instructions per SIMD: each SIMD hosts wps waves, each issuing inst_per_iter * iters
     const double winst = inst_per_iter * iters * wps;
     const double clk = best * 1e-3 * 2.4e9;
-    printf("%-28s wps %d: %8.1f us  %.2f clk per wave-instruction per SIMD (at 2.4 GHz)\n", name, wps, best * 1e3, clk / winst);
+    setvbuf(stdout, NULL, _IONBF, 0); printf("%-28s wps %d: %8.1f us  %.2f clk per wave-instruction per SIMD (at 2.4 GHz)\n", name, wps, best * 1e3, clk / winst);
 }
 
 int main() {
@@ -114,8 +136,11 @@ int main() {
     float *in, *out; hipMalloc(&in, 4096 * 4); hipMalloc(&out, 4096 * 256 * 4);
     hipMemcpy(in, h.data(), 4096 * 4, hipMemcpyHostToDevice);
     const double n = (double)NCHAIN * BODY_REPS;
-#define RUN(K, MULT) run(#K " wps1", K<1>, 1, n * MULT, in, out); run(#K " wps2", K<2>, 2, n * MULT, in, out); run(#K " wps4", K<4>, 4, n * MULT, in, out);
+#define RUN(K, MULT) run(#K, K<2>, 2, n * MULT, in, out); run(#K, K<4>, 4, n * MULT, in, out);
     RUN(k_fma, 1) RUN(k_fmac, 1) RUN(k_mul, 1) RUN(k_max, 1) RUN(k_pkfma, 1) RUN(k_pkmul, 1)
-    RUN(k_cnd_vcc, 1) RUN(k_cnd_sgpr, 1) RUN(k_cmp_cnd, 2) RUN(k_cmp_sgpr_cnd, 2) RUN(k_dsr128, 1)
+    RUN(k_cnd_sgpr, 1) RUN(k_cmp_cnd, 2) RUN(k_cmp_sgpr_cnd, 2)
+    RUN(k_max_i32, 1) RUN(k_max_i32_c0, 1) RUN(k_max_f32_c0, 1) RUN(k_min_f32, 1) RUN(k_mov, 1) RUN(k_mov_s, 1) RUN(k_add_u32, 1) RUN(k_and, 1)
+    RUN(k_med3, 1) RUN(k_max3, 1) RUN(k_cmp, 1) RUN(k_cmp_u32, 1) RUN(k_fmac_s, 1) RUN(k_mul_s, 1)
+    RUN(k_cmp_exec3mov, 1) RUN(k_cmp_3cnd, 1) RUN(k_cmpx_3mov, 1) RUN(k_fma_clamp, 1) RUN(k_max_mul, 2) RUN(k_lshl_or, 1) RUN(k_bfi, 1) RUN(k_ashr, 1)
     return 0;
 }
