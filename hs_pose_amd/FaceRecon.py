@@ -97,6 +97,8 @@ class FaceRecon(nn.Module):
         k = self.neighbor_num
         if self._bf16 is not None:
             self._bf16.refresh()                      # fp32 master weights -> this step's bf16 working copies (one launch)
+        else:
+            ops.x3_refresh()                          # fp32 weights -> the three bf16 slices of the x3 products (one launch)
         with gcn3d.knn_scope():
             fm_0 = F.relu(self.conv_0(vertices, k), inplace=True)
             od = self.feature_dtype if self.feature_dtype == torch.bfloat16 else None

@@ -47,6 +47,14 @@ SIGNATURES = {
     "hsp_gemm_wave_supported": (_i, [_i, _i, _i, _i, _i]),
     "hsp_gemm_wave_plan_info": (_i, [_i, _i, _i, _i, _i, _vp]),
     "hsp_gemm_wave_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, ctypes.c_float, _vp, _vp, _vp, _i, _i, _vp]),
+    "hsp_split_params_x3": (_i, [_vp, _i, _i, _vp]),
+    "hsp_gemm_x3_supported": (_i, [_i, _i, _i, _i]),
+    "hsp_gemm_x3_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "hsp_gemm_x3_f32": (_i, [_vp, _i, _vp, _i, ctypes.c_longlong, _i, _vp, _i, _vp, _i, ctypes.c_longlong, _i, _i, _i, _vp, _vp, _i, _vp, _i,
+                             ctypes.c_float, _vp, _i, _vp, _sz, _vp]),
+    "hsp_small_rows_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, ctypes.c_float, _vp, _i, _vp]),
+    "hsp_small_outer_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp]),
+    "hsp_colsum_rows_xyz": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "hsp_bn_relu_fwd_mixed": (_i, [_vp, _i, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "hsp_bn_relu_apply_mixed": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "hsp_bn_relu_bwd_mixed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -105,6 +113,13 @@ class HspLossCfg(ctypes.Structure):
         "rot_1_w", "rot_2_w", "rot_regular", "tran_w", "size_w", "r_con_w", "recon_n_w", "recon_d_w", "recon_f_w",
         "recon_v_w", "recon_bb_r_w", "recon_bb_t_w", "recon_bb_s_w", "recon_bb_self_w", "geo_p_w", "prop_pm_w",
         "prop_sym_w")] + [("smooth_l1", ctypes.c_int)]
+
+
+class HspSplitDesc(ctypes.Structure):
+    """include/hsp.h: HspSplitDesc (the table lives in DEVICE memory; built on the host, uploaded once)"""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("rows", ctypes.c_int), ("cols", ctypes.c_int),
+                ("ld", ctypes.c_int), ("transpose", ctypes.c_int), ("kp", ctypes.c_int), ("tile0", ctypes.c_int),
+                ("ps", ctypes.c_longlong)]
 
 
 class HspError(RuntimeError):

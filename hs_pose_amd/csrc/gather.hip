@@ -153,6 +153,43 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const FT* __restric
     }
 }
 
+// colsum + the three coordinate moments of the rows in one pass (HSlayer_surface backward: gt = sum_i g and the STE weight
+// gradient g^T xyz, gcn3d.py:85): part[b][chunk][slot][c], slot 0 = sum g, slot 1..3 = sum g * (x, y, z)
+__global__ __launch_bounds__(256) void colsum_xyz_partial_kernel(const float* __restrict__ x, const float* __restrict__ xyz, int N, int C,
+                                                                 float* __restrict__ part, int nchunk, int rows) {
+    __shared__ float4 red[4][256];
+    const int cq = C >> 2;
+    const int tid = threadIdx.x;
+    const int g = tid % cq, rl = tid / cq, RL = 256 / cq;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int r0 = chunk * rows, r1 = min(N, r0 + rows);
+    float4 s[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = r0 + rl; i < r1; i += RL) {
+        const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)b * N + i) * C + (g << 2));
+        const float* p3 = xyz + ((size_t)b * N + i) * 3;
+        const float w[3] = {p3[0], p3[1], p3[2]};
+        s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            s[q + 1].x = __fmaf_rn(v.x, w[q], s[q + 1].x); s[q + 1].y = __fmaf_rn(v.y, w[q], s[q + 1].y);
+            s[q + 1].z = __fmaf_rn(v.z, w[q], s[q + 1].z); s[q + 1].w = __fmaf_rn(v.w, w[q], s[q + 1].w);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[q][tid] = s[q];
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 a = s[q];
+            for (int l = 1; l < RL; ++l) { const float4 v = red[q][l * cq + g]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+            *reinterpret_cast<float4*>(part + (((size_t)b * nchunk + chunk) * 4 + q) * C + (g << 2)) = a;
+        }
+    }
+}
+
 // the same first stage for widths the float4 form does not take (C not a multiple of 4, or C/4 not dividing 256;
 // C <= 256): thread = (row lane, column), consecutive threads read consecutive words
 __global__ __launch_bounds__(256) void colsum_partial_scalar_kernel(const float* __restrict__ x, int N, int C,
@@ -885,6 +922,23 @@ extern "C" int hsp_colsum_rows(const float* x, int B, int N, int C, float* out, 
     else
         hipLaunchKernelGGL(colsum_partial_scalar_kernel, dim3(nchunk, B), dim3(256), 0, st, x, N, C, part, nchunk, rows);
     hipLaunchKernelGGL(chunk_fold_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, B, nchunk, C, 1.0f, out);
+    return check_launch();
+}
+
+/* out4 (B, 4, C): slot 0 = sum_i x[b][i][:] (the colsum of hsp_colsum_rows), slots 1..3 = sum_i x[b][i][:] * xyz[b][i][0..2]
+ * (per-cloud halves of the STE weight gradient g^T xyz of HSlayer_surface, gcn3d.py:85).  C a multiple of 4 with C/4 | 256;
+ * ws >= 4 * hsp_orl_workspace_bytes(B, N, C) */
+extern "C" int hsp_colsum_rows_xyz(const float* x, const float* xyz, int B, int N, int C, float* out4, void* ws, size_t ws_bytes,
+                                   hspStream_t stream) {
+    if (!x || !xyz || !out4 || B <= 0 || N <= 0 || C <= 0) return HSP_ERR_BAD_ARG;
+    if (!colsum_vec4(C)) return HSP_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < 4 * hsp_orl_workspace_bytes(B, N, C)) return HSP_ERR_WORKSPACE;
+    hipStream_t st = as_stream(stream);
+    const int rows = chunk_rows(B, N, C);
+    const int nchunk = (N + rows - 1) / rows;
+    float* part = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL(colsum_xyz_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, x, xyz, N, C, part, nchunk, rows);
+    hipLaunchKernelGGL(chunk_fold_kernel, dim3((B * 4 * C + 255) / 256), dim3(256), 0, st, part, B, nchunk, 4 * C, 1.0f, out4);
     return check_launch();
 }
 

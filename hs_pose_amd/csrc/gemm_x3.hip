@@ -1,0 +1,655 @@
+// gemm_x3.hip -- the fp32 dense per-point products of the HS stack and of the heads on the BF16 matrix cores of gfx950,
+// without giving up fp32 accuracy: every fp32 operand is split EXACTLY into three bf16 slices
+//       x = hi + mid + lo,   hi = x & 0xffff0000,  mid = (x - hi) & 0xffff0000,  lo = (x - hi) - mid
+// (truncations, so each difference is exact and lo has at most 8 significant bits: a bf16), and a product row is
+//       a.b ~= sum_k  ah.bh + ah.bm + am.bh + am.bm + ah.bl + al.bh
+// six slice products, each EXACT in fp32 (8 x 8 significant bits), accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The three
+// dropped terms (am.bl, al.bm, al.bl) are below 2^-23 |a||b| per product -- the size of the rounding an fp32 fma chain commits
+// on every step.  Measured against fp64 (tests/test_gpu_gemm_x3.py) the result is as close as the fp32-MFMA kernels'.
+//
+// Why: v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (157 TFLOP/s), a sixteenth of the bf16 rate; six bf16 MFMAs per 16 k
+// take 192 clocks where the fp32 form takes 512.  The dense products then stop being MFMA-bound (the K = 128 products become
+// bound by writing their output, the deep-K input-gradient products by streaming gfm once).
+//
+//   C[r][n] = alpha * ( sum_k A1[r][k] W1[n][k]  (+ sum_k A2[r][k] W2[n][k]) ) (+ bias[n]) (+ resid[r][n]) (+ cloud_bias[r / rpc][n])
+//
+// the contract of gemm_rows.hip (reference network/fs_net_repo/gcn3d.py:149,171,186 and their input gradients; the Conv1d(k=1)
+// layers of the heads, PoseR.py:16-39, PoseTs.py:18-45, FaceRecon.py:37-68) with the weight-side operand handed over ALREADY
+// SPLIT, in (N, K) form: three bf16 planes written once per step by split_params_x3_kernel (one launch for every weight of the
+// network, transposing where the product wants W^T).  The activation-side operand is split in the staging path of the kernel.
+//
+// Structure: 256-thread workgroup = 2 x 2 waves on a (64 WM) x 128 tile, K in blocks of 32; per block a thread fetches 8 WM
+// fp32 of A (split into 3 x 16 bytes) and six 16-byte pieces of the weight planes, all held in registers across the previous
+// block's MFMAs (global loads one block ahead), then written to a single LDS stage: rows of 64 bytes (32 bf16), the four
+// 16-byte chunks of row r stored at chunk ^ ((r >> 2) & 3) -- conflict-free for the 16-lane groups of ds_read_b128.  Two
+// workgroups per CU alternate staging and MFMA phases.
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace hsp {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+struct X3Args {
+    const float* A[2];                     // activation rows (M, K) fp32, row pitch lda (a multiple of 4)
+    const unsigned short* P[2];            // weight planes: 3 x (N, ldp) bf16, plane p at P + p * ps; zero beyond K
+    int lda[2], ldp[2], K[2];
+    long long ps[2];
+    float* C; int ldc;
+    int M, N;
+    const float* bias;
+    const float* resid; int ldr;
+    const float* cbias; int rpc;
+    float alpha;
+    int tiles_m, tiles_n, nsplit;
+    float* ws;                             // split-K partial tiles ws[split][M][N]
+};
+
+#define X3_BN 128
+#define X3_BK 32
+
+// 8 consecutive fp32 of a row -> the 16-byte bf16 chunks of the three planes
+__device__ __forceinline__ void x3_split8(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
+    float r1[8], r2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float h = __uint_as_float(__float_as_uint(x[i]) & 0xffff0000u);
+        r1[i] = x[i] - h;                                                  // exact
+        const float m = __uint_as_float(__float_as_uint(r1[i]) & 0xffff0000u);
+        r2[i] = r1[i] - m;                                                 // exact, <= 8 significant bits
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                          // v_perm_b32: high halves of two dwords
+        hi[i] = __builtin_amdgcn_perm(__float_as_uint(x[2 * i + 1]), __float_as_uint(x[2 * i]), 0x07060302u);
+        mid[i] = __builtin_amdgcn_perm(__float_as_uint(r1[2 * i + 1]), __float_as_uint(r1[2 * i]), 0x07060302u);
+        lo[i] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * i + 1]), __float_as_uint(r2[2 * i]), 0x07060302u);
+    }
+}
+
+// WM: 32-row blocks per wave along M (tile = 64 WM x 128).  TWO: second source.  EPI: bit 0 bias, bit 1 residual, bit 2
+// per-cloud bias (template parameters: a load inside a run-time branch costs a drained queue at the join)
+template <int WM, bool TWO, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
+    constexpr int BM = 64 * WM;
+    constexpr int A_PLANE = BM * 64, B_PLANE = X3_BN * 64;                 // bytes
+    constexpr int NAU = WM;                                                // 8-float A units per thread and block
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                                                       // 3 planes
+    char* sB = smem + 3 * A_PLANE;                                         // 3 planes
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm0 = (wave >> 1) * 32 * WM, wn0 = (wave & 1) * 64;
+
+    // ---- item: (tile, k split); tiles ordered tn fastest (the workgroups in flight share A rows in L2)
+    const int item = blockIdx.x;
+    const int o = item / g.nsplit, ks = item - o * g.nsplit;
+    const int tm = o / g.tiles_n, tn = o - tm * g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * X3_BN;
+    const int T0 = (g.K[0] + X3_BK - 1) / X3_BK;
+    const int T1 = TWO ? (g.K[1] + X3_BK - 1) / X3_BK : 0;
+    const int TT = T0 + T1;
+    const int per = (TT + g.nsplit - 1) / g.nsplit;
+    const int t_begin = ks * per, t_end = min(TT, t_begin + per);
+
+    f32x16 acc[WM][2];
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // ---- staging registers of one block (ONE set, loads one block ahead.  Two sets / two blocks ahead were measured: the
+    // 64-row kernels went from 112-128 to 146-158 VGPRs = one wave per SIMD fewer, and the step from 2.03 to 2.06 ms -- these
+    // products are bound by memory latency against the workgroups resident per CU, not by the loads in flight per workgroup)
+    float av[1][NAU][8];
+    u32x4 bv[1][6];
+    const __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.A[0]), 0, (int)((((size_t)g.M - 1) * g.lda[0] + g.K[0]) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(TWO ? g.A[1] : g.A[0]), 0, (int)((((size_t)g.M - 1) * g.lda[TWO ? 1 : 0] + g.K[TWO ? 1 : 0]) * 4), 0x00020000);
+    auto fetch = [&](auto setc, int t) {
+        constexpr int Q = decltype(setc)::value;
+        const int src = (TWO && t >= T0) ? 1 : 0;
+        const int kb = (src ? t - T0 : t) * X3_BK;
+        // A through a buffer descriptor: no branch around the loads (a load inside a run-time branch makes hipcc drain the
+        // queue at the join, which would undo the two-block prefetch); rows past M and bytes past the last row read 0, a
+        // ragged K is masked when the block is split (stash)
+        const __amdgpu_buffer_rsrc_t ra = src ? rsA1 : rsA0;
+        const unsigned lda = (unsigned)g.lda[src];
+#pragma unroll
+        for (int i = 0; i < NAU; ++i) {
+            const int u = tid + 256 * i, row = u >> 2, c8 = u & 3;
+            const int gr = m0 + row, k0 = kb + 8 * c8;
+            const unsigned off = gr < g.M ? ((unsigned)gr * lda + (unsigned)k0) * 4u : 0xfffffff0u;
+            const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0);
+            const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(ra, off, 16, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { av[Q][i][e] = __uint_as_float(v0[e]); av[Q][i][4 + e] = __uint_as_float(v1[e]); }
+        }
+        const unsigned short* P = g.P[src];
+        const int ldp = g.ldp[src];
+        const long long ps = g.ps[src];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int q = tid + 256 * i, plane = q >> 9, w = q & 511, row = w >> 2, c = w & 3;
+            bv[Q][i] = *reinterpret_cast<const u32x4*>(P + plane * ps + (size_t)(n0 + row) * ldp + kb + 8 * c);
+        }
+    };
+    auto stash = [&](auto setc, int t) {
+        constexpr int Q = decltype(setc)::value;
+        {   // ragged K: the last block of a source may reach past K (into the next row's bytes): zero those elements
+            const int src = (TWO && t >= T0) ? 1 : 0;
+            const int kb = (src ? t - T0 : t) * X3_BK, K = g.K[src];
+            if (kb + X3_BK > K) {
+#pragma unroll
+                for (int i = 0; i < NAU; ++i) {
+                    const int k0 = kb + 8 * ((tid + 256 * i) & 3);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) av[Q][i][e] = k0 + e < K ? av[Q][i][e] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NAU; ++i) {
+            const int u = tid + 256 * i, row = u >> 2, c8 = u & 3;
+            u32x4 h, m, l;
+            x3_split8(av[Q][i], h, m, l);
+            const int off = row * 64 + ((c8 ^ ((row >> 2) & 3)) << 4);
+            *reinterpret_cast<u32x4*>(sA + off) = h;
+            *reinterpret_cast<u32x4*>(sA + A_PLANE + off) = m;
+            *reinterpret_cast<u32x4*>(sA + 2 * A_PLANE + off) = l;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int q = tid + 256 * i, plane = q >> 9, w = q & 511, row = w >> 2, c = w & 3;
+            *reinterpret_cast<u32x4*>(sB + plane * B_PLANE + row * 64 + ((c ^ ((row >> 2) & 3)) << 4)) = bv[Q][i];
+        }
+    };
+    auto mma = [&]() {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 fa[WM][3], fb[2][3];
+            const int c = 2 * s + lh;
+#pragma unroll
+            for (int x = 0; x < WM; ++x) {
+                const int row = wm0 + 32 * x + li;
+                const int off = row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) fa[x][p] = *reinterpret_cast<const u32x4*>(sA + p * A_PLANE + off);
+            }
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const int row = wn0 + 32 * y + li;
+                const int off = row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) fb[y][p] = *reinterpret_cast<const u32x4*>(sB + p * B_PLANE + off);
+            }
+            // six slice products, small terms first: (h,l) (l,h) (m,m) (h,m) (m,h) (h,h)
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int x = 0; x < WM; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y)
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[x][PA[q]]),
+                                                                            __builtin_bit_cast(bf16x8, fb[y][PB[q]]), acc[x][y], 0, 0, 0);
+        }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    if (t_begin < t_end) fetch(S0{}, t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        __syncthreads();                       // the previous block's fragment reads are done
+        stash(S0{}, t);
+        __syncthreads();
+        if (t + 1 < t_end) fetch(S0{}, t + 1); // in flight under this block's MFMAs
+        mma();
+    }
+
+    // ---- epilogue: accumulator r of (x, y) <-> row m0 + wm0 + 32 x + (r & 3) + 8 (r >> 2) + 4 lh, column n0 + wn0 + 32 y + li
+    if (g.nsplit > 1) {
+        float* wsp = g.ws + (size_t)ks * g.M * g.N;
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int col = n0 + wn0 + 32 * y + li;
+#pragma unroll
+            for (int x = 0; x < WM; ++x)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm0 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < g.M) wsp[(size_t)row * g.N + col] = acc[x][y][r];
+                }
+        }
+        return;
+    }
+    constexpr bool HAS_BIAS = EPI & 1, HAS_RES = EPI & 2, HAS_CB = EPI & 4;
+    // per-cloud bias: a tile of BM rows spans at most two clouds when rows_per_cloud >= BM (boundary compare, no division)
+    const int c0 = m0 / g.rpc, nb = (c0 + 1) * g.rpc;
+    const bool two_clouds = g.rpc >= BM;
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        const int col = n0 + wn0 + 32 * y + li;
+        float bvv = 0.f, cb0 = 0.f, cb1 = 0.f;
+        if constexpr (HAS_BIAS) bvv = g.bias[col];
+        if constexpr (HAS_CB) {
+            cb0 = g.cbias[(size_t)c0 * g.N + col];
+            cb1 = g.cbias[(size_t)min(c0 + 1, (g.M - 1) / g.rpc) * g.N + col];
+        }
+#pragma unroll
+        for (int x = 0; x < WM; ++x) {
+#pragma unroll
+            for (int r4 = 0; r4 < 16; r4 += 4) {
+                float rv[4];
+                if constexpr (HAS_RES) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = min(m0 + wm0 + 32 * x + q + 8 * (r4 >> 2) + 4 * lh, g.M - 1);
+                        rv[q] = g.resid[(size_t)row * g.ldr + col];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = r4 + q;
+                    const int row = m0 + wm0 + 32 * x + q + 8 * (r4 >> 2) + 4 * lh;
+                    float v = g.alpha * acc[x][y][r] + bvv;
+                    if constexpr (HAS_RES) v += rv[q];
+                    if constexpr (HAS_CB) {
+                        if (two_clouds) v += row >= nb ? cb1 : cb0;
+                        else v += g.cbias[(size_t)(min(row, g.M - 1) / g.rpc) * g.N + col];
+                    }
+                    if (row < g.M) g.C[(size_t)row * g.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// sum of the split-K partial tiles (fixed order), scaled; the products that split carry no other epilogue
+__global__ __launch_bounds__(256) void gemm_x3_reduce_kernel(const float* __restrict__ ws, int nsplit, long long total4, int N4,
+                                                             float alpha, float* __restrict__ C, int ldc) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
+        float4 s = reinterpret_cast<const float4*>(ws)[e];
+        for (int sp = 1; sp < nsplit; ++sp) {
+            const float4 v = reinterpret_cast<const float4*>(ws)[(size_t)sp * total4 + e];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const long long row = e / N4;
+        const int c4 = (int)(e - row * N4);
+        *reinterpret_cast<float4*>(C + (size_t)row * ldc + 4 * c4) = make_float4(alpha * s.x, alpha * s.y, alpha * s.z, alpha * s.w);
+    }
+}
+
+// ---- fp32 parameters -> three bf16 planes in (N, K) form, every tensor of a step in ONE launch ------------------------------
+// entry e: src (rows, cols) fp32 with row pitch ld.  transpose == 0: src is (N, K) -> plane[p][n][k] = slice_p(src[n][k]);
+// transpose == 1: src is (K, N) -> plane[p][n][k] = slice_p(src[k][n]).  Plane row pitch kp (>= K rounded up to 32; the
+// columns k >= K are zero: written once when the buffer is allocated), plane stride ps elements.  32 x 32 tiles through LDS.
+__global__ __launch_bounds__(256) void split_params_x3_kernel(const HspSplitDesc* __restrict__ tab, int n) {
+    __shared__ float tile[32][33];
+    int e = 0;
+    while (e + 1 < n && (int)blockIdx.x >= tab[e + 1].tile0) ++e;
+    const HspSplitDesc d = tab[e];
+    const int t = (int)blockIdx.x - d.tile0;
+    const int tcols = (d.cols + 31) >> 5;
+    const int r0 = (t / tcols) * 32, c0 = (t % tcols) * 32;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ly + 8 * j, c = c0 + lx;
+        tile[ly + 8 * j][lx] = (r < d.rows && c < d.cols) ? d.src[(size_t)r * d.ld + c] : 0.f;
+    }
+    __syncthreads();
+    unsigned short* dst = reinterpret_cast<unsigned short*>(d.dst);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // output element (n, k): natural -> (r0 + ly + 8j, c0 + lx); transposed -> n = c0 + ly + 8j, k = r0 + lx
+        const int a = ly + 8 * j;
+        const float x = d.transpose ? tile[lx][a] : tile[a][lx];
+        const int nrow = d.transpose ? c0 + a : r0 + a, kcol = d.transpose ? r0 + lx : c0 + lx;
+        const int nmax = d.transpose ? d.cols : d.rows, kmax = d.transpose ? d.rows : d.cols;
+        if (nrow < nmax && kcol < kmax) {
+            const unsigned xb = __float_as_uint(x);
+            const float h = __uint_as_float(xb & 0xffff0000u);
+            const float r1 = x - h;
+            const float m = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+            const float r2 = r1 - m;
+            const size_t o = (size_t)nrow * d.kp + kcol;
+            dst[o] = (unsigned short)(xb >> 16);
+            dst[(size_t)d.ps + o] = (unsigned short)(__float_as_uint(r1) >> 16);
+            dst[2 * (size_t)d.ps + o] = (unsigned short)(__float_as_uint(r2) >> 16);
+        }
+    }
+}
+
+static int x3_pick_split(long long tiles, int TT) {
+    if (tiles >= 2 * HSP_NUM_CU || TT < 16) return 1;
+    int ns = (int)((2 * HSP_NUM_CU + tiles - 1) / tiles);
+    if (ns > TT / 8) ns = TT / 8;
+    if (ns > 16) ns = 16;
+    if (ns < 2) return 1;
+    const int per = (TT + ns - 1) / ns;
+    return (TT + per - 1) / per;
+}
+
+// tile height: 128 rows when that still gives every CU a tile (or K is short and the tile count is what fills the chip)
+static int x3_pick_wm(int M, int N) {
+    static const int force = [] { const char* e = getenv("HSP_X3_WM"); return e ? atoi(e) : 0; }();
+    if (force == 1 || force == 2) return force;
+    const long long t128 = (long long)((M + 127) / 128) * (N / X3_BN);
+    return t128 >= 2 * HSP_NUM_CU ? 2 : 1;
+}
+
+}  // namespace hsp
+
+using namespace hsp;
+
+extern "C" int hsp_split_params_x3(const HspSplitDesc* table_dev, int n, int total_tiles, hspStream_t stream) {
+    if (!table_dev || n <= 0 || total_tiles <= 0) return HSP_ERR_BAD_ARG;
+    hipLaunchKernelGGL(split_params_x3_kernel, dim3(total_tiles), dim3(256), 0, as_stream(stream), table_dev, n);
+    return check_launch();
+}
+
+/* 1 when hsp_gemm_x3_f32 takes the shape: N a multiple of 128, 16-byte aligned activation rows */
+extern "C" int hsp_gemm_x3_supported(int M, int N, int K1, int K2) {
+    if (!(M > 0 && N > 0 && N % X3_BN == 0 && K1 > 0 && K2 >= 0)) return 0;
+    // fewer than 128 (64-row) tiles and no K deep enough to split: the wave / tile kernels keep more of the chip busy
+    const long long t64 = (long long)((M + 63) / 64) * (N / X3_BN);
+    const int TT = (K1 + X3_BK - 1) / X3_BK + (K2 > 0 ? (K2 + X3_BK - 1) / X3_BK : 0);
+    return (t64 >= 128 || TT >= 32) ? 1 : 0;
+}
+
+extern "C" size_t hsp_gemm_x3_workspace_bytes(int M, int N, int K1, int K2) {
+    if (!hsp_gemm_x3_supported(M, N, K1, K2)) return 0;
+    const int wm = x3_pick_wm(M, N), bm = 64 * wm;
+    const int TT = (K1 + X3_BK - 1) / X3_BK + (K2 > 0 ? (K2 + X3_BK - 1) / X3_BK : 0);
+    const int ns = x3_pick_split((long long)((M + bm - 1) / bm) * (N / X3_BN), TT);
+    return ns > 1 ? (size_t)ns * M * N * sizeof(float) : 0;
+}
+
+extern "C" int hsp_gemm_x3_f32(const float* A1, int lda1, const hsp_bf16_t* P1, int ldp1, long long ps1, int K1,
+                               const float* A2, int lda2, const hsp_bf16_t* P2, int ldp2, long long ps2, int K2, int M, int N,
+                               const float* bias, const float* resid, int ldr, const float* cloud_bias, int rows_per_cloud,
+                               float alpha, float* C, int ldc, void* ws, size_t ws_bytes, hspStream_t stream) {
+    if (!A1 || !P1 || !C || M <= 0 || N <= 0 || K1 <= 0 || lda1 < K1 || ldc < N) return HSP_ERR_BAD_ARG;
+    const bool two = A2 != nullptr;
+    if (two && (!P2 || K2 <= 0 || lda2 < K2)) return HSP_ERR_BAD_ARG;
+    if (!two) K2 = 0;
+    if (resid && ldr < N) return HSP_ERR_BAD_ARG;
+    if (cloud_bias && rows_per_cloud <= 0) return HSP_ERR_BAD_ARG;
+    if (!hsp_gemm_x3_supported(M, N, K1, K2)) return HSP_ERR_UNSUPPORTED;
+    if ((long long)M * lda1 * 4 >= (1ll << 31) || (two && (long long)M * lda2 * 4 >= (1ll << 31))) return HSP_ERR_UNSUPPORTED;
+    auto al16 = [](const void* q, long long ld, int es) { return ((reinterpret_cast<size_t>(q) | ((size_t)ld * es)) & 15) == 0; };
+    const int kp1 = (K1 + X3_BK - 1) / X3_BK * X3_BK, kp2 = (K2 + X3_BK - 1) / X3_BK * X3_BK;
+    if (!al16(A1, lda1, 4) || !al16(P1, ldp1, 2) || (ps1 & 7) || ldp1 < kp1) return HSP_ERR_UNSUPPORTED;
+    if (two && (!al16(A2, lda2, 4) || !al16(P2, ldp2, 2) || (ps2 & 7) || ldp2 < kp2)) return HSP_ERR_UNSUPPORTED;
+    X3Args g{};
+    g.A[0] = A1; g.P[0] = P1; g.lda[0] = lda1; g.ldp[0] = ldp1; g.K[0] = K1; g.ps[0] = ps1;
+    g.A[1] = A2; g.P[1] = P2; g.lda[1] = lda2; g.ldp[1] = ldp2; g.K[1] = K2; g.ps[1] = ps2;
+    g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.bias = bias; g.resid = resid; g.ldr = ldr;
+    g.cbias = cloud_bias; g.rpc = rows_per_cloud > 0 ? rows_per_cloud : 1; g.alpha = alpha;
+    const int wm = x3_pick_wm(M, N), bm = 64 * wm;
+    g.tiles_m = (M + bm - 1) / bm; g.tiles_n = N / X3_BN;
+    const int TT = (K1 + X3_BK - 1) / X3_BK + (two ? (K2 + X3_BK - 1) / X3_BK : 0);
+    const int epi = (bias ? 1 : 0) | (resid ? 2 : 0) | (cloud_bias ? 4 : 0);
+    int ns = epi ? 1 : x3_pick_split((long long)g.tiles_m * g.tiles_n, TT);
+    if (ns > 1 && (!ws || (size_t)ns * M * N * sizeof(float) > ws_bytes)) ns = 1;
+    g.nsplit = ns; g.ws = ns > 1 ? reinterpret_cast<float*>(ws) : nullptr;
+    const long long items = (long long)g.tiles_m * g.tiles_n * ns;
+    if (items > (1ll << 30)) return HSP_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    const dim3 grid((unsigned)items), block(256);
+    // instantiated epilogues: 0 none, 1 bias, 6 residual + per-cloud bias (the layer's out product)
+    if (epi != 0 && epi != 1 && epi != 6) return HSP_ERR_UNSUPPORTED;
+#define X3_K(WM_, TWO_, EPI_)                                                                                      \
+    do {                                                                                                           \
+        auto kern = gemm_x3_kernel<WM_, TWO_, EPI_>;                                                               \
+        const size_t lds = 3 * (size_t)(64 * WM_ + X3_BN) * 64;                                                    \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, g);                                                         \
+    } while (0)
+#define X3_LAUNCH(WM_)                                             \
+    do {                                                           \
+        if (two) {                                                 \
+            if (epi == 0) X3_K(WM_, true, 0);                      \
+            else if (epi == 1) X3_K(WM_, true, 1);                 \
+            else X3_K(WM_, true, 6);                               \
+        } else {                                                   \
+            if (epi == 0) X3_K(WM_, false, 0);                     \
+            else if (epi == 1) X3_K(WM_, false, 1);                \
+            else X3_K(WM_, false, 6);                              \
+        }                                                          \
+    } while (0)
+    if (wm == 2) X3_LAUNCH(2); else X3_LAUNCH(1);
+#undef X3_LAUNCH
+#undef X3_K
+    int rc = check_launch();
+    if (rc || ns == 1) return rc;
+    const long long total4 = (long long)M * N / 4;
+    long long rg = (total4 + 255) / 256;
+    if (rg > HSP_NUM_CU * 8) rg = HSP_NUM_CU * 8;
+    hipLaunchKernelGGL(gemm_x3_reduce_kernel, dim3((unsigned)rg), dim3(256), 0, st, g.ws, ns, total4, N / 4, alpha, C, ldc);
+    return check_launch();
+}
+
+// ================================================================================================================================
+// the per-CLOUD products of the ORL branch: 16 rows (one per cloud of the batch) against a (C, C) weight block
+//   t   = fg Wb^T            (gcn3d.py:186, the f_global half of conv2)          "nt": out[m][n] = sum_k A[m][k] W[n][k]
+//   gfg = (gt Wb) / N        (its input gradient)                                "nn": out[m][n] = alpha sum_k A[m][k] W[k][n]
+//   gWb = gt^T fg            (its weight gradient)                               outer: out[i][j] = sum_b a[b][i] c[b][j]
+// Three tiny kernels, one launch each (the tile kernels need split-K + a fold for a 16-row product: two launches of ~7 us).
+// fp32 fma chains in a fixed order (bit-reproducible).
+// ================================================================================================================================
+namespace hsp {
+
+#define SR_MAXM 16
+
+// "nt": lanes along k (coalesced rows of W), a wave per output column pair, wave-level tree reduction (fixed order)
+__global__ __launch_bounds__(256) void small_rows_nt_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                                            int M, int N, int K, float alpha, float* __restrict__ out, int ldo) {
+    extern __shared__ float sA[];                              // M x K
+    for (int e = threadIdx.x; e < M * K; e += 256) sA[e] = A[(size_t)(e / K) * lda + (e % K)];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int n = blockIdx.x * 8 + wave; n < min(N, (int)blockIdx.x * 8 + 8); n += 4) {
+        float p[SR_MAXM];
+#pragma unroll
+        for (int m = 0; m < SR_MAXM; ++m) p[m] = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            const float w = W[(size_t)n * ldw + k];
+#pragma unroll
+            for (int m = 0; m < SR_MAXM; ++m)
+                if (m < M) p[m] = __fmaf_rn(sA[m * K + k], w, p[m]);
+        }
+#pragma unroll
+        for (int m = 0; m < SR_MAXM; ++m) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) p[m] += __shfl_xor(p[m], o, 64);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < SR_MAXM; ++m)
+                if (m < M) out[(size_t)m * ldo + n] = alpha * p[m];
+        }
+    }
+}
+
+// "nn": a thread per output column (coalesced rows of W), four k slices per workgroup folded through LDS in slice order
+__global__ __launch_bounds__(256) void small_rows_nn_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                                            int M, int N, int K, float alpha, float* __restrict__ out, int ldo) {
+    extern __shared__ float smem_f[];
+    float* sA = smem_f;                                        // M x K
+    float* red = smem_f + M * K;                               // 3 x 64 x SR_MAXM
+    for (int e = threadIdx.x; e < M * K; e += 256) sA[e] = A[(size_t)(e / K) * lda + (e % K)];
+    __syncthreads();
+    const int cl = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + cl;
+    const int kper = (K + 3) / 4, k0 = ks * kper, k1 = min(K, k0 + kper);
+    float p[SR_MAXM];
+#pragma unroll
+    for (int m = 0; m < SR_MAXM; ++m) p[m] = 0.f;
+    if (n < N) {
+        for (int k = k0; k < k1; ++k) {
+            const float w = W[(size_t)k * ldw + n];
+#pragma unroll
+            for (int m = 0; m < SR_MAXM; ++m)
+                if (m < M) p[m] = __fmaf_rn(sA[m * K + k], w, p[m]);
+        }
+    }
+    if (ks > 0) {
+#pragma unroll
+        for (int m = 0; m < SR_MAXM; ++m) red[((ks - 1) * 64 + cl) * SR_MAXM + m] = p[m];
+    }
+    __syncthreads();
+    if (ks == 0 && n < N) {
+#pragma unroll
+        for (int m = 0; m < SR_MAXM; ++m) {
+            if (m < M) {
+                float s = p[m];
+                for (int q = 0; q < 3; ++q) s += red[(q * 64 + cl) * SR_MAXM + m];
+                out[(size_t)m * ldo + n] = alpha * s;
+            }
+        }
+    }
+}
+
+// the fast form of both layouts (K a multiple of 128, 16-byte aligned rows): v_mfma_f32_16x16x4_f32, a workgroup per 16 output
+// columns, its four waves take a quarter of K each (every operand load of a wave's quarter is issued before the first MFMA: one
+// memory round trip) and fold through LDS in wave order.  "nt" lanes fetch 16 bytes = 4 consecutive k of their row: MFMA e of a
+// group of four multiplies the k set {e, 4+e, 8+e, 12+e} -- the same permutation on both operands, the same products.
+using f32x4v = __attribute__((ext_vector_type(4))) float;
+template <bool NN>
+__global__ __launch_bounds__(256) void small_rows_mfma_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                                              int M, int N, int K, float alpha, float* __restrict__ out, int ldo) {
+    __shared__ float red[3][64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int n = blockIdx.x * 16 + j, nc = min(n, N - 1), mc = min(j, M - 1);
+    const float amask = j < M ? 1.f : 0.f;
+    const int kper = K >> 2, k0 = wave * kper;
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (NN) {
+        // kper <= 128 (K <= 512): every load of the quarter in flight at once; deeper K in rounds of 128
+        for (int kb = 0; kb < kper; kb += 128) {
+            float a[32], b[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const int k = k0 + min(kb + 4 * u, kper - 4) + kk;
+                b[u] = W[(size_t)k * ldw + nc];
+                a[u] = A[(size_t)mc * lda + k];
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+                if (kb + 4 * u < kper) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u] * amask, b[u], acc, 0, 0, 0);
+        }
+    } else {
+        for (int kb = 0; kb < kper; kb += 128) {
+            float4 a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + min(kb + 16 * u, kper - 16) + 4 * kk;
+                b[u] = *reinterpret_cast<const float4*>(W + (size_t)nc * ldw + k);
+                a[u] = *reinterpret_cast<const float4*>(A + (size_t)mc * lda + k);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (kb + 16 * u < kper) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x * amask, b[u].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y * amask, b[u].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z * amask, b[u].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w * amask, b[u].w, acc, 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave - 1][lane][r] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0 && n < N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * kk + r;
+            if (row < M) out[(size_t)row * ldo + n] = alpha * (((acc[r] + red[0][lane][r]) + red[1][lane][r]) + red[2][lane][r]);
+        }
+    }
+}
+
+// out (Ma, Nb) = a^T c over the B (<= 16) per-cloud rows: a (B, Ma), c (B, Nb)
+__global__ __launch_bounds__(256) void small_outer_kernel(const float* __restrict__ a, int lda, const float* __restrict__ c, int ldc_,
+                                                          int B, int Ma, int Nb, float* __restrict__ out, int ldo,
+                                                          const float* __restrict__ mom, int ldm, int Cm, float* __restrict__ gste) {
+    const long long total = (long long)Ma * Nb;
+    // rider job (HSlayer_surface): gste[c][j] = sum_b mom[b][j * Cm + c], j = 0..2 -- the per-cloud coordinate moments of g
+    // (hsp_colsum_rows_xyz) summed over the batch, in cloud order
+    if (mom) {
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < 3 * Cm; e += gridDim.x * 256) {
+            float s = 0.f;
+            for (int b = 0; b < B; ++b) s += mom[(size_t)b * ldm + e];
+            const int j = e / Cm, cc = e - j * Cm;
+            gste[cc * 3 + j] = s;
+        }
+    }
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int i = (int)(e / Nb), j = (int)(e - (long long)i * Nb);
+        float s = 0.f;
+        for (int b0 = 0; b0 < B; b0 += 16) {                   // 32 loads in flight, then the chain in row order
+            float av[16], cv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int b = min(b0 + u, B - 1);
+                av[u] = a[(size_t)b * lda + i]; cv[u] = c[(size_t)b * ldc_ + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (b0 + u < B) s = __fmaf_rn(av[u], cv[u], s);
+        }
+        out[(size_t)i * ldo + j] = s;
+    }
+}
+
+}  // namespace hsp
+
+/* out (M, N) = alpha * A (M, K) op(W): w_layout 0 = W is (N, K) ("nt"), 1 = W is (K, N) ("nn"); M <= 16 rows (one per cloud),
+ * K <= 2048.  gcn3d.py:186 (the f_global half of conv2) and its input gradient. */
+extern "C" int hsp_small_rows_f32(const float* A, int lda, const float* W, int ldw, int w_layout, int M, int N, int K, float alpha,
+                                  float* out, int ldo, hspStream_t stream) {
+    if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || lda < K || ldo < N) return HSP_ERR_BAD_ARG;
+    if (M > SR_MAXM || K > 2048) return HSP_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    if (w_layout != 0 && w_layout != 1) return HSP_ERR_BAD_ARG;
+    const bool al = ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(W) | ((size_t)lda * 4) | ((size_t)ldw * 4)) & 15) == 0;
+    if (K % 128 == 0 && (w_layout == 1 || al)) {
+        if (w_layout == 1)
+            hipLaunchKernelGGL(small_rows_mfma_kernel<true>, dim3((N + 15) / 16), dim3(256), 0, st, A, lda, W, ldw, M, N, K, alpha, out, ldo);
+        else
+            hipLaunchKernelGGL(small_rows_mfma_kernel<false>, dim3((N + 15) / 16), dim3(256), 0, st, A, lda, W, ldw, M, N, K, alpha, out, ldo);
+        return check_launch();
+    }
+    if (w_layout == 0)
+        hipLaunchKernelGGL(small_rows_nt_kernel, dim3((N + 7) / 8), dim3(256), (size_t)M * K * 4, st, A, lda, W, ldw, M, N, K, alpha, out, ldo);
+    else if (w_layout == 1) {
+        const size_t lds = ((size_t)M * K + 3 * 64 * SR_MAXM) * 4;
+        if (lds > 64 * 1024) return HSP_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(small_rows_nn_kernel, dim3((N + 63) / 64), dim3(256), lds, st, A, lda, W, ldw, M, N, K, alpha, out, ldo);
+    } else return HSP_ERR_BAD_ARG;
+    return check_launch();
+}
+
+/* out (Ma, Nb) = a^T c for per-cloud rows a (B, Ma), c (B, Nb), B <= 16: the weight gradient of the f_global half of conv2 */
+extern "C" int hsp_small_outer_f32(const float* a, int lda, const float* c, int ldc, int B, int Ma, int Nb, float* out, int ldo,
+                                   const float* mom, int ldm, int Cm, float* gste, hspStream_t stream) {
+    if (!a || !c || !out || B <= 0 || Ma <= 0 || Nb <= 0 || lda < Ma || ldc < Nb || ldo < Nb) return HSP_ERR_BAD_ARG;
+    if (mom && (!gste || Cm <= 0 || ldm < 3 * Cm)) return HSP_ERR_BAD_ARG;
+    if (B > 64) return HSP_ERR_UNSUPPORTED;
+    const long long total = (long long)Ma * Nb;
+    long long g = (total + 255) / 256;
+    if (g > HSP_NUM_CU * 8) g = HSP_NUM_CU * 8;
+    hipLaunchKernelGGL(small_outer_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), a, lda, c, ldc, B, Ma, Nb, out, ldo,
+                       mom, ldm, Cm, gste);
+    return check_launch();
+}

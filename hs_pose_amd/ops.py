@@ -660,6 +660,119 @@ def gemm_wave(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=N
 
 
 # ------------------------------------------------------------------------------------------------
+# fp32 products on the bf16 matrix cores (csrc/gemm_x3.hip): the weight-side operand is kept as three exact bf16 slices in
+# (N, K) form.  ``X3Planes`` owns the slices of every weight matrix the products have asked for; ``refresh()`` re-splits all
+# of them from the fp32 masters in ONE launch (FaceRecon / PoseNet9D call it at the start of a forward: the optimizer has
+# moved the weights since the last one), a matrix seen for the first time is registered and split on the spot.
+# ------------------------------------------------------------------------------------------------
+class X3Planes:
+    def __init__(self):
+        self.entries = {}            # key -> dict(src=tensor (kept alive), planes, N, K, kp, transpose)
+        self.table = None            # device table of every entry (rebuilt when an entry is added)
+        self.total_tiles = 0
+
+    @staticmethod
+    def _key(W, transpose):
+        return (W.data_ptr(), tuple(W.shape), W.stride(0), bool(transpose))
+
+    def planes(self, W, transpose):
+        """(planes (3, N, kp) bf16, kp, plane stride) of the fp32 matrix W: (N, K) rows, or (K, N) rows with ``transpose``"""
+        k_ = self._key(W, transpose)
+        e = self.entries.get(k_)
+        if e is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise HspError("gemm_x3: a weight matrix was first seen inside a graph capture (run one eager step first)")
+            if W.dim() != 2 or W.stride(1) != 1 or W.dtype != torch.float32 or not W.is_cuda:
+                raise HspError("gemm_x3: weights must be 2-D fp32 GPU matrices with contiguous rows")
+            N, K = (W.shape[1], W.shape[0]) if transpose else (W.shape[0], W.shape[1])
+            kp = (K + 31) // 32 * 32
+            e = dict(src=W.detach(), planes=torch.zeros(3, N, kp, dtype=torch.bfloat16, device=W.device), N=N, K=K, kp=kp,
+                     transpose=bool(transpose))
+            self.entries[k_] = e
+            self._split([e])                                   # this matrix now ...
+            self.table, self.total_tiles = self._table_of(list(self.entries.values()))   # ... and the table of all for refresh()
+        return e["planes"], e["kp"], e["N"] * e["kp"]
+
+    def _table_of(self, ents):
+        from ._lib import HspSplitDesc
+        tab = (HspSplitDesc * len(ents))()
+        tile0 = 0
+        for i, e in enumerate(ents):
+            W = e["src"]
+            tab[i].src, tab[i].dst = W.data_ptr(), e["planes"].data_ptr()
+            tab[i].rows, tab[i].cols, tab[i].ld = W.shape[0], W.shape[1], W.stride(0)
+            tab[i].transpose, tab[i].kp, tab[i].tile0, tab[i].ps = int(e["transpose"]), e["kp"], tile0, e["N"] * e["kp"]
+            tile0 += ((W.shape[0] + 31) // 32) * ((W.shape[1] + 31) // 32)
+        host = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8)
+        return host.to(ents[0]["src"].device), tile0
+
+    def _split(self, ents):
+        tab, tiles = self._table_of(ents)
+        _run("hsp_split_params_x3", (_p(tab), len(ents), tiles, _stream()), key=f"n{len(ents)}")
+        return tab
+
+    def refresh(self):
+        if not self.entries:
+            return
+        ents = list(self.entries.values())
+        _run("hsp_split_params_x3", (_p(self.table), len(ents), self.total_tiles, _stream()), key=f"n{len(ents)}",
+             abytes=sum(10 * e["N"] * e["K"] for e in ents))
+
+
+x3_planes = X3Planes()
+# HSP_GEMM_X3=0: the hand-written path stays on the fp32 matrix cores (gemm_wave / gemm_rows) everywhere
+GEMM_X3 = os.environ.get("HSP_GEMM_X3", "1") != "0"
+
+
+def x3_refresh():
+    """re-split every registered weight matrix (one launch); call once per forward, before the first product"""
+    if GEMM_X3 and GEMM_MODE != "library":
+        x3_planes.refresh()
+
+
+def gemm_x3_ok(A1, B1, A2, B2, bias, resid, cloud_bias, xyz3, out, M, N):
+    if not GEMM_X3 or xyz3 is not None or N % 128 or A1.dtype != torch.float32:
+        return False
+    K2 = A2.shape[1] if A2 is not None else 0
+    if not lib().hsp_gemm_x3_supported(M, N, A1.shape[1], K2):
+        return False
+    epi = (1 if bias is not None else 0) | (2 if resid is not None else 0) | (4 if cloud_bias is not None else 0)
+    if epi not in (0, 1, 6):
+        return False
+    if epi and ((M + 63) // 64) * (N // 128) < 128:            # (an epilogue rules out split-K: too few workgroups)
+        return False
+    for t_ in (A1, A2):
+        if t_ is not None and (t_.data_ptr() % 16 or (t_.stride(0) * 4) % 16):
+            return False
+    return True
+
+
+def gemm_x3(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=None, cloud_bias=None, rows_per_cloud=0, out=None,
+            alpha=1.0):
+    """the contract of ``gemm_rows`` (fp32 in, fp32 out) with the products formed on the bf16 matrix cores from exact three-way
+    bf16 splits of both operands (csrc/gemm_x3.hip): B* are the fp32 weight matrices, split (and transposed where ``nn``) by
+    ``x3_planes``"""
+    M, K1 = A1.shape
+    N = B1.shape[1] if nn1 else B1.shape[0]
+    P1, ldp1, ps1 = x3_planes.planes(B1, nn1)
+    K2, P2, ldp2, ps2 = 0, None, 0, 0
+    if A2 is not None:
+        K2 = A2.shape[1]
+        P2, ldp2, ps2 = x3_planes.planes(B2, nn2)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A1.device)
+    wsb = lib().hsp_gemm_x3_workspace_bytes(M, N, K1, K2)
+    ws = _ws(wsb, A1.device) if wsb else None
+    flops = 2 * M * N * (K1 + K2)
+    ab = 4 * (M * (K1 + K2) + M * N * (2 if resid is not None else 1)) + 6 * N * (K1 + K2)
+    _run("hsp_gemm_x3_f32", (_p(A1), _ld(A1), _p(P1), ldp1, ps1, K1, _p(A2), _ld(A2) if A2 is not None else 0, _p(P2), ldp2, ps2, K2,
+                             M, N, _p(bias), _p(resid), _ld(resid) if resid is not None else 0, _p(cloud_bias), int(rows_per_cloud),
+                             float(alpha), _p(out), _ld(out), _p(ws), wsb, _stream()),
+         key=f"M{M}N{N}K{K1}" + (f"+{K2}" if K2 else ""), abytes=ab, aflops=flops)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # dense per-point products of a layer: the hand-written fused kernel (csrc/gemm_rows.hip) or the BLAS library through
 # torch.  HSP_GEMM = library (default for fp32 rows) | own | auto: "own" runs no library GEMM at all on the layer path
 # (measured, round 2, B=16 N=1028: 2.30 ms / step against 2.06 ms with the tuned library -- the hand-written kernel reaches
@@ -711,6 +824,12 @@ def gemm_own(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=No
     M, K1 = A1.shape
     N = B1.shape[1] if nn1 else B1.shape[0]
     K2 = A2.shape[1] if A2 is not None else 0
+    if (M <= 16 and A2 is None and bias is None and resid is None and cloud_bias is None and xyz3 is None and K1 <= 2048
+            and A1.dtype == torch.float32 and A1.stride(1) == 1 and B1.stride(1) == 1):
+        return small_rows(A1, B1, nn1, out=out, alpha=alpha)          # a row per cloud: one small launch
+    if M >= 256 and gemm_x3_ok(A1, B1, A2, B2, bias, resid, cloud_bias, xyz3, out, M, N) and (out is None or _al16(out)):
+        return gemm_x3(A1, B1, nn1, A2, B2, nn2, bias=bias, resid=resid, cloud_bias=cloud_bias, rows_per_cloud=rows_per_cloud,
+                       out=out, alpha=alpha)
     two, rc = A2 is not None, resid is not None and cloud_bias is not None
     plain = bias is None and resid is None and cloud_bias is None and xyz3 is None
     # the forms gemm_wave.hip instantiates: fm (nn + bias), g W (nn), x W^T (nt [+ bias]), out (nt + nt, residual + cloud bias),
@@ -795,11 +914,28 @@ def _grad_in_rows(g2, w_ste, gfm2, weights, out):
                  lambda: gemm_own(g2, w_ste, True, gfm2, weights, False, out=out), lib)
 
 
-def _tiny_tn(a, b, out):
-    """out = a^T b for per-cloud rows a (B,M), b (B,N) (B = 16: one library launch; the split-K weight-gradient kernel needs
-    two launches for it and is used only when no library GEMM may run, HSP_GEMM=own)"""
+def small_rows(A, W, nn=False, out=None, alpha=1.0):
+    """out (M,N) = alpha * A (M,K) op(W) for M <= 16 per-cloud rows (csrc/gemm_x3.hip, one launch): W (N,K), or (K,N) with ``nn``"""
+    M, K = A.shape
+    N = W.shape[1] if nn else W.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    _run("hsp_small_rows_f32", (_p(A), _ld(A), _p(W), _ld(W), 1 if nn else 0, M, N, K, float(alpha), _p(out), _ld(out), _stream()),
+         key=f"M{M}N{N}K{K}{'nn' if nn else 'nt'}", abytes=4 * (M * K + N * K + M * N))
+    return out
+
+
+def _tiny_tn(a, b, out, mom=None, gste=None):
+    """out = a^T b for per-cloud rows a (B,M), b (B,N) (B = 16): one library launch, or one small hand-written launch when no
+    library GEMM may run (HSP_GEMM=own)"""
     if GEMM_MODE == "own":
-        return wgrad(a, b, out=out)
+        B, Ma = a.shape
+        Cm = mom.shape[1] // 4 if mom is not None else 0
+        _run("hsp_small_outer_f32", (_p(a), _ld(a), _p(b), _ld(b), B, Ma, b.shape[1], _p(out), _ld(out),
+                                     _p(mom[:, Cm:]) if mom is not None else None, _ld(mom) if mom is not None else 0, Cm,
+                                     _p(gste), _stream()),
+             key=f"B{B}M{Ma}N{b.shape[1]}", abytes=4 * (B * (Ma + b.shape[1]) + Ma * b.shape[1]))
+        return out
     return torch.mm(a.t(), b, out=out)
 
 
@@ -1004,10 +1140,25 @@ class _SurfaceLayer(torch.autograd.Function):
         SC = directions.shape[1]
         g2, F2, x2 = g.view(B * N, C), F3.view(B * N, C), xyz.view(B * N, 3)
         Wa, Wb = w_conv2[:, :C], w_conv2[:, C:]
-        gt = colsum_rows(g)
         g_conv2 = torch.empty_like(w_conv2)
+        own_ste = GEMM_MODE == "own" and C % 4 == 0 and 256 % (C // 4) == 0
+        if own_ste:
+            # gt = sum_i g and the per-cloud coordinate moments of g in one pass; the STE gradient g^T xyz is their sum over the
+            # batch, taken as a rider of the gt^T fg launch: no library GEMM for the (C, 3) product
+            mom = torch.empty(B, 4 * C, dtype=torch.float32, device=g.device)
+            wsb = 4 * lib().hsp_orl_workspace_bytes(B, N, C)
+            ws = _ws(wsb, g.device)
+            _run("hsp_colsum_rows_xyz", (_p(g), _p(xyz), B, N, C, _p(mom), _p(ws), wsb, _stream()), key=f"B{B}N{N}C{C}",
+                 abytes=4 * B * N * (C + 3))
+            gt = mom[:, :C]
+            g_ste = torch.empty(C, 3, dtype=torch.float32, device=g.device)
+        else:
+            gt = colsum_rows(g)
         wgrad(g2, F2, out=g_conv2[:, :C])
-        _tiny_tn(gt, fg, g_conv2[:, C:])
+        if own_ste:
+            _tiny_tn(gt, fg, g_conv2[:, C:], mom=mom, gste=g_ste)
+        else:
+            _tiny_tn(gt, fg, g_conv2[:, C:])
         gF3 = torch.empty(B, N, C, dtype=torch.float32, device=g.device)
         _mm_nn(g2, Wa, out=gF3.view(B * N, C))
         _orl_bwd_accumulate_raw(_mm_nn(gt, Wb, alpha=1.0 / N), idx_x, arg_o, k, gF3, extra=g)
@@ -1017,7 +1168,8 @@ class _SurfaceLayer(torch.autograd.Function):
         ws = _ws(wsb, g.device)
         _run("hsp_rf_surface_bwd", (_p(xyz), _p(directions), _p(arg), _p(gF3), B, N, S, C, _p(gD), _p(ws), wsb, _stream()),
              key=f"B{B}N{N}S{S}C{C}", abytes=B * N * (12 + 4 * C + SC) + 24 * SC)
-        g_ste = g2.t() @ x2
+        if not own_ste:
+            g_ste = g2.t() @ x2
         return None, None, None, None, gD, g_ste.unsqueeze_(-1), g_conv2.unsqueeze_(-1)
 
 

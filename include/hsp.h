@@ -252,6 +252,43 @@ int hsp_gemm_wave_f32(const float *A1, int lda1, const float *B1, int ldb1, int 
                       const float *bias, const float *resid, int ldr, const float *cloud_bias, int rows_per_cloud,
                       float alpha, const float *xyz3, const float *w3, float *C, int ldc, int cfg, hspStream_t stream);
 
+/* ---- fp32 dense products on the bf16 matrix cores, fp32-accurate (csrc/gemm_x3.hip) ---------------------------------------
+ * replaces the same reference lines as hsp_gemm_rows_f32 (gcn3d.py:149,171,186 and their input gradients; the Conv1d(k=1)
+ * layers of PoseR.py:16-39, PoseTs.py:18-45, FaceRecon.py:37-68):
+ *   C = alpha * (A1 W1^T (+ A2 W2^T)) (+ bias) (+ resid) (+ cloud_bias[row / rows_per_cloud])        A*: fp32 rows (M, K*)
+ * Every fp32 operand is split EXACTLY into three bf16 slices (x = hi + mid + lo, truncations) and six slice products per k
+ * -- each exact in fp32 -- are accumulated in fp32 by v_mfma_f32_32x32x16_bf16; the dropped terms are below 2^-23 |a||b| per
+ * product (the rounding an fp32 fma chain commits per step).  The weight-side operand comes ALREADY SPLIT in (N, K) form:
+ * three bf16 planes (N, ldp), plane p at P + p * ps elements, columns k >= K zero, ldp >= K rounded up to 32 -- written once
+ * per step for every weight by hsp_split_params_x3 (HspSplitDesc: src (rows, cols) fp32 with pitch ld; transpose = 0: src is
+ * (N, K); 1: src is (K, N), i.e. the product wants src^T; kp = plane row pitch, ps = plane stride, both in elements; tile0 =
+ * number of 32 x 32 tiles of the entries before; table in DEVICE memory).  Covers N a multiple of 128 and 16-byte aligned
+ * activation rows (hsp_gemm_x3_supported; anything else: hsp_gemm_rows_f32); epilogues: none, bias, resid + cloud_bias.
+ * Deep-K products with few tiles split K over workgroups (ws: hsp_gemm_x3_workspace_bytes) and fold in a fixed order. */
+typedef struct HspSplitDesc { const float *src; void *dst; int rows, cols, ld, transpose, kp, tile0; long long ps; } HspSplitDesc;
+int hsp_split_params_x3(const HspSplitDesc *table_dev, int n, int total_tiles, hspStream_t stream);
+int hsp_gemm_x3_supported(int M, int N, int K1, int K2);
+size_t hsp_gemm_x3_workspace_bytes(int M, int N, int K1, int K2);
+int hsp_gemm_x3_f32(const float *A1, int lda1, const hsp_bf16_t *P1, int ldp1, long long ps1, int K1,
+                    const float *A2, int lda2, const hsp_bf16_t *P2, int ldp2, long long ps2, int K2, int M, int N,
+                    const float *bias, const float *resid, int ldr, const float *cloud_bias, int rows_per_cloud,
+                    float alpha, float *C, int ldc, void *ws, size_t ws_bytes, hspStream_t stream);
+
+/* the per-CLOUD products of the ORL branch (gcn3d.py:186: the f_global half of conv2, one row per cloud of the batch), one
+ * launch each, fp32 fma chains in a fixed order:
+ *   hsp_small_rows_f32:  out (M, N) = alpha * A (M, K) op(W), M <= 16; w_layout 0: W is (N, K) (t = fg Wb^T), 1: W is (K, N)
+ *                        (gfg = gt Wb / N); K <= 2048
+ *   hsp_small_outer_f32: out (Ma, Nb) = a^T c over the B <= 64 rows of a (B, Ma), c (B, Nb) (gWb = gt^T fg) */
+int hsp_small_rows_f32(const float *A, int lda, const float *W, int ldw, int w_layout, int M, int N, int K, float alpha,
+                       float *out, int ldo, hspStream_t stream);
+int hsp_small_outer_f32(const float *a, int lda, const float *c, int ldc, int B, int Ma, int Nb, float *out, int ldo,
+                        const float *mom, int ldm, int Cm, float *gste, hspStream_t stream);
+/* (mom != NULL: the same launch also writes gste (Cm, 3) = sum over the B rows of mom (B, >= 3 Cm) [j * Cm + c] -- the STE weight
+ * gradient of HSlayer_surface, g^T xyz (gcn3d.py:85), from the per-cloud coordinate moments of hsp_colsum_rows_xyz:
+ * out4 (B, 4, C), slot 0 = sum_i g[b][i][:], slots 1..3 = sum_i g[b][i][:] * xyz[b][i][0..2]; ws >= 4 * hsp_orl_workspace_bytes) */
+int hsp_colsum_rows_xyz(const float *x, const float *xyz, int B, int N, int C, float *out4, void *ws, size_t ws_bytes,
+                        hspStream_t stream);
+
 /* fp32 master parameters -> bf16 working copies for the *_bf16 entry points, every tensor of a step in one launch:
  * entry e copies src (rows, cols; row pitch ld) to dst (rows, cols) and / or dstT (cols, rows) -- either may be NULL --
  * rounding to nearest even.  tile0 = number of 32 x 32 tiles of the entries before e; table_dev lives in DEVICE memory. */

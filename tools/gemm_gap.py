@@ -27,7 +27,9 @@ def timeit(fn, reps=20):
 B = 16
 layers = [("conv_1", 1028, 128, 128), ("conv_2", 257, 128, 256), ("conv_3", 257, 256, 256), ("conv_4", 64, 256, 512)]
 S = 7
-tot = {"own": 0.0, "library": 0.0}
+tot = {}
+from hs_pose_amd import gemm_tuning
+gemm_tuning.enable()
 rows = []
 for name, N, Cin, C in layers:
     M = B * N
@@ -45,10 +47,12 @@ for name, N, Cin, C in layers:
     ]
     for cname, fl, fn in comps:
         t = {}
-        for mode in ("own", "library"):
-            ops.GEMM_MODE = mode
+        for mode in ("x3", "own", "library"):
+            ops.GEMM_MODE = "library" if mode == "library" else "own"
+            ops.GEMM_X3 = mode == "x3"
             t[mode] = timeit(fn)
-            tot[mode] += t[mode]
-        print(f"{name} {cname:4s} M{M:6d} Cin{Cin:4d} C{C:4d}  {fl / 1e9:6.2f} GF   own {t['own']:7.1f} us {fl / t['own'] / 1e6:6.1f} TF   "
-              f"library {t['library']:7.1f} us {fl / t['library'] / 1e6:6.1f} TF   ideal {fl / 155e6:6.1f} us", flush=True)
-print(f"total own {tot['own']:.1f} us   library {tot['library']:.1f} us")
+            tot[mode] = tot.get(mode, 0.0) + t[mode]
+        print(f"{name} {cname:4s} M{M:6d} Cin{Cin:4d} C{C:4d}  {fl / 1e9:6.2f} GF   x3 {t['x3']:7.1f} us {fl / t['x3'] / 1e6:6.1f} TF   "
+              f"own-f32 {t['own']:7.1f} us {fl / t['own'] / 1e6:6.1f} TF   library {t['library']:7.1f} us {fl / t['library'] / 1e6:6.1f} TF   "
+              f"fp32-MFMA ideal {fl / 155e6:6.1f} us", flush=True)
+print(f"total x3 {tot['x3']:.1f} us   own-f32 {tot['own']:.1f} us   library {tot['library']:.1f} us")
