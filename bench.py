@@ -231,9 +231,9 @@ def main():
 
     rank, world, device = init_distributed()
     assert device.type == "cuda", "bench.py measures the HIP path; it needs a GPU"
-    if not args.no_gemm_tuning:
-        from hs_pose_amd import gemm_tuning
-        gemm_tuning.enable()                            # library-GEMM solution selection (warm-up only)
+    if not args.no_gemm_tuning and ops.GEMM_MODE != "own":
+        from tools import gemm_tuning                   # only the HSP_GEMM=library comparison figure calls the BLAS library
+        gemm_tuning.enable()                            # (solution selection during the warm-up steps)
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}: launch one rank per GPU (or plain `python bench.py --gpus N`)"
     B, N = args.batch, args.points
 

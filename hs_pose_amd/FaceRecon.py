@@ -131,8 +131,8 @@ class FaceRecon(nn.Module):
             r = _conv_bn_relu_rows(self.recon_head, h, 1)
             last = self.recon_head[3]
             recon = ops.linear_rows(r, last.weight.squeeze(-1), last.bias).view(bs, vertice_num, -1)
-            face_in = torch.cat([f_global.unsqueeze(1).expand(-1, vertice_num, -1).reshape(bs * vertice_num, -1), h,
-                                 vertices.reshape(bs * vertice_num, 3)], dim=1)
+            face_in = ops.cat_rows_pitched([f_global.unsqueeze(1).expand(-1, vertice_num, -1).reshape(bs * vertice_num, -1), h,
+                                            vertices.reshape(bs * vertice_num, 3)])
             f = _conv_bn_relu_rows(self.face_head, face_in, 3)
             last = self.face_head[9]
             face = ops.linear_rows(f, last.weight.squeeze(-1), last.bias).view(bs, vertice_num, -1)

@@ -3,6 +3,7 @@
 import torch
 import torch.nn as nn
 
+from . import ops
 from .config import FLAGS
 from .FaceRecon import FaceRecon
 from .PoseR import Rot_green, Rot_red
@@ -49,6 +50,6 @@ class PoseNet9D(nn.Module):
             recon = None
         p_green_R, f_green_R = _axis_and_confidence(self.rot_green.forward_rows(feat))
         p_red_R, f_red_R = _axis_and_confidence(self.rot_red.forward_rows(feat))
-        shift, size = self.ts.forward_rows(torch.cat([feat, local], dim=2))
+        shift, size = self.ts.forward_rows(ops.cat_rows_pitched([feat, local]))
         return (recon, face_normal, face_dis, face_f, p_green_R, p_red_R, f_green_R, f_red_R,
                 shift + centre.squeeze(1), size)

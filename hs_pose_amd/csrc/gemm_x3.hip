@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int q = tid + 256 * i, plane = q >> 9, w = q & 511, row = w >> 2, c = w & 3;
-            bv[Q][i] = *reinterpret_cast<const u32x4*>(P + plane * ps + (size_t)(n0 + row) * ldp + kb + 8 * c);
+            bv[Q][i] = *reinterpret_cast<const u32x4*>(P + plane * ps + (size_t)min(n0 + row, g.N - 1) * ldp + kb + 8 * c);
         }
     };
     auto stash = [&](auto setc, int t) {
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm0 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (row < g.M) wsp[(size_t)row * g.N + col] = acc[x][y][r];
+                    if (row < g.M && col < g.N) wsp[(size_t)row * g.N + col] = acc[x][y][r];
                 }
         }
         return;
@@ -235,11 +235,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
 #pragma unroll
     for (int y = 0; y < 2; ++y) {
         const int col = n0 + wn0 + 32 * y + li;
+        const bool cok = col < g.N;
+        const int colc = min(col, g.N - 1);
         float bvv = 0.f, cb0 = 0.f, cb1 = 0.f;
-        if constexpr (HAS_BIAS) bvv = g.bias[col];
+        if constexpr (HAS_BIAS) bvv = g.bias[colc];
         if constexpr (HAS_CB) {
-            cb0 = g.cbias[(size_t)c0 * g.N + col];
-            cb1 = g.cbias[(size_t)min(c0 + 1, (g.M - 1) / g.rpc) * g.N + col];
+            cb0 = g.cbias[(size_t)c0 * g.N + colc];
+            cb1 = g.cbias[(size_t)min(c0 + 1, (g.M - 1) / g.rpc) * g.N + colc];
         }
 #pragma unroll
         for (int x = 0; x < WM; ++x) {
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int row = min(m0 + wm0 + 32 * x + q + 8 * (r4 >> 2) + 4 * lh, g.M - 1);
-                        rv[q] = g.resid[(size_t)row * g.ldr + col];
+                        rv[q] = g.resid[(size_t)row * g.ldr + colc];
                     }
                 }
 #pragma unroll
@@ -261,9 +263,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
                     if constexpr (HAS_RES) v += rv[q];
                     if constexpr (HAS_CB) {
                         if (two_clouds) v += row >= nb ? cb1 : cb0;
-                        else v += g.cbias[(size_t)(min(row, g.M - 1) / g.rpc) * g.N + col];
+                        else v += g.cbias[(size_t)(min(row, g.M - 1) / g.rpc) * g.N + colc];
                     }
-                    if (row < g.M) g.C[(size_t)row * g.ldc + col] = v;
+                    if (row < g.M && cok) g.C[(size_t)row * g.ldc + col] = v;
                 }
             }
         }
@@ -271,58 +273,85 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
 }
 
 // sum of the split-K partial tiles (fixed order), scaled; the products that split carry no other epilogue
-__global__ __launch_bounds__(256) void gemm_x3_reduce_kernel(const float* __restrict__ ws, int nsplit, long long total4, int N4,
+__global__ __launch_bounds__(256) void gemm_x3_reduce_kernel(const float* __restrict__ ws, int nsplit, long long total, int N,
                                                              float alpha, float* __restrict__ C, int ldc) {
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
-        float4 s = reinterpret_cast<const float4*>(ws)[e];
-        for (int sp = 1; sp < nsplit; ++sp) {
-            const float4 v = reinterpret_cast<const float4*>(ws)[(size_t)sp * total4 + e];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    if ((N & 3) == 0 && (ldc & 3) == 0) {
+        const long long total4 = total >> 2;
+        const int N4 = N >> 2;
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
+            float4 s = reinterpret_cast<const float4*>(ws)[e];
+            for (int sp = 1; sp < nsplit; ++sp) {
+                const float4 v = reinterpret_cast<const float4*>(ws)[(size_t)sp * total4 + e];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            const long long row = e / N4;
+            const int c4 = (int)(e - row * N4);
+            *reinterpret_cast<float4*>(C + (size_t)row * ldc + 4 * c4) = make_float4(alpha * s.x, alpha * s.y, alpha * s.z, alpha * s.w);
         }
-        const long long row = e / N4;
-        const int c4 = (int)(e - row * N4);
-        *reinterpret_cast<float4*>(C + (size_t)row * ldc + 4 * c4) = make_float4(alpha * s.x, alpha * s.y, alpha * s.z, alpha * s.w);
+    } else {
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+            float s = ws[e];
+            for (int sp = 1; sp < nsplit; ++sp) s += ws[(size_t)sp * total + e];
+            const long long row = e / N;
+            C[(size_t)row * ldc + (int)(e - row * N)] = alpha * s;
+        }
     }
 }
 
 // ---- fp32 parameters -> three bf16 planes in (N, K) form, every tensor of a step in ONE launch ------------------------------
 // entry e: src (rows, cols) fp32 with row pitch ld.  transpose == 0: src is (N, K) -> plane[p][n][k] = slice_p(src[n][k]);
 // transpose == 1: src is (K, N) -> plane[p][n][k] = slice_p(src[k][n]).  Plane row pitch kp (>= K rounded up to 32; the
-// columns k >= K are zero: written once when the buffer is allocated), plane stride ps elements.  32 x 32 tiles through LDS.
+// columns k >= K are zero: written once when the buffer is allocated), plane stride ps elements.  tile0 counts pieces of
+// 32 (n) x 64 (k) OUTPUT elements: ceil(N / 32) * ceil(K / 64) per entry.
 __global__ __launch_bounds__(256) void split_params_x3_kernel(const HspSplitDesc* __restrict__ tab, int n) {
-    __shared__ float tile[32][33];
+    // a workgroup writes a 32 (n) x 64 (k) piece of the three planes; a thread owns k PAIRS (one dword store per plane)
+    __shared__ float tile[64][33];
     int e = 0;
     while (e + 1 < n && (int)blockIdx.x >= tab[e + 1].tile0) ++e;
     const HspSplitDesc d = tab[e];
     const int t = (int)blockIdx.x - d.tile0;
-    const int tcols = (d.cols + 31) >> 5;
-    const int r0 = (t / tcols) * 32, c0 = (t % tcols) * 32;
+    const int Nn = d.transpose ? d.cols : d.rows, Kk = d.transpose ? d.rows : d.cols;
+    const int tk = (Kk + 63) >> 6;
+    const int n0 = (t / tk) * 32, k0 = (t % tk) * 64;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    unsigned* dst = reinterpret_cast<unsigned*>(d.dst);               // (kp and ps are even: dword-aligned pairs)
+    float x0[4], x1[4];
+    if (d.transpose) {                                                 // src rows = k, cols = n
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = r0 + ly + 8 * j, c = c0 + lx;
-        tile[ly + 8 * j][lx] = (r < d.rows && c < d.cols) ? d.src[(size_t)r * d.ld + c] : 0.f;
-    }
-    __syncthreads();
-    unsigned short* dst = reinterpret_cast<unsigned short*>(d.dst);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        // output element (n, k): natural -> (r0 + ly + 8j, c0 + lx); transposed -> n = c0 + ly + 8j, k = r0 + lx
-        const int a = ly + 8 * j;
-        const float x = d.transpose ? tile[lx][a] : tile[a][lx];
-        const int nrow = d.transpose ? c0 + a : r0 + a, kcol = d.transpose ? r0 + lx : c0 + lx;
-        const int nmax = d.transpose ? d.cols : d.rows, kmax = d.transpose ? d.rows : d.cols;
-        if (nrow < nmax && kcol < kmax) {
-            const unsigned xb = __float_as_uint(x);
-            const float h = __uint_as_float(xb & 0xffff0000u);
-            const float r1 = x - h;
-            const float m = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
-            const float r2 = r1 - m;
-            const size_t o = (size_t)nrow * d.kp + kcol;
-            dst[o] = (unsigned short)(xb >> 16);
-            dst[(size_t)d.ps + o] = (unsigned short)(__float_as_uint(r1) >> 16);
-            dst[2 * (size_t)d.ps + o] = (unsigned short)(__float_as_uint(r2) >> 16);
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + ly + 8 * j, nn = n0 + lx;
+            tile[ly + 8 * j][lx] = (k < Kk && nn < Nn) ? d.src[(size_t)k * d.ld + nn] : 0.f;
         }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x0[j] = tile[2 * lx][ly + 8 * j]; x1[j] = tile[2 * lx + 1][ly + 8 * j]; }
+    } else {                                                           // src rows = n, cols = k
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nn = n0 + ly + 8 * j, k = k0 + 2 * lx;
+            const float* p = d.src + (size_t)min(nn, Nn - 1) * d.ld;
+            x0[j] = (nn < Nn && k < Kk) ? p[k] : 0.f;
+            x1[j] = (nn < Nn && k + 1 < Kk) ? p[k + 1] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int nn = n0 + ly + 8 * j, k = k0 + 2 * lx;
+        if (nn >= Nn || k >= Kk) continue;
+        float r1[2], r2[2];
+        const float xs[2] = {x0[j], x1[j]};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float h = __uint_as_float(__float_as_uint(xs[q]) & 0xffff0000u);
+            r1[q] = xs[q] - h;
+            const float m = __uint_as_float(__float_as_uint(r1[q]) & 0xffff0000u);
+            r2[q] = r1[q] - m;
+        }
+        const size_t o = ((size_t)nn * d.kp + k) >> 1;                 // dword index inside a plane
+        const size_t psd = (size_t)d.ps >> 1;
+        dst[o] = __builtin_amdgcn_perm(__float_as_uint(xs[1]), __float_as_uint(xs[0]), 0x07060302u);
+        dst[psd + o] = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), 0x07060302u);
+        dst[2 * psd + o] = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u);
     }
 }
 
@@ -340,7 +369,7 @@ static int x3_pick_split(long long tiles, int TT) {
 static int x3_pick_wm(int M, int N) {
     static const int force = [] { const char* e = getenv("HSP_X3_WM"); return e ? atoi(e) : 0; }();
     if (force == 1 || force == 2) return force;
-    const long long t128 = (long long)((M + 127) / 128) * (N / X3_BN);
+    const long long t128 = (long long)((M + 127) / 128) * ((N + X3_BN - 1) / X3_BN);
     return t128 >= 2 * HSP_NUM_CU ? 2 : 1;
 }
 
@@ -354,11 +383,11 @@ extern "C" int hsp_split_params_x3(const HspSplitDesc* table_dev, int n, int tot
     return check_launch();
 }
 
-/* 1 when hsp_gemm_x3_f32 takes the shape: N a multiple of 128, 16-byte aligned activation rows */
+/* 1 when hsp_gemm_x3_f32 takes the shape (N >= 64; the activation rows must also be 16-byte aligned) */
 extern "C" int hsp_gemm_x3_supported(int M, int N, int K1, int K2) {
-    if (!(M > 0 && N > 0 && N % X3_BN == 0 && K1 > 0 && K2 >= 0)) return 0;
+    if (!(M > 0 && N >= 64 && K1 > 0 && K2 >= 0)) return 0;
     // fewer than 128 (64-row) tiles and no K deep enough to split: the wave / tile kernels keep more of the chip busy
-    const long long t64 = (long long)((M + 63) / 64) * (N / X3_BN);
+    const long long t64 = (long long)((M + 63) / 64) * ((N + X3_BN - 1) / X3_BN);
     const int TT = (K1 + X3_BK - 1) / X3_BK + (K2 > 0 ? (K2 + X3_BK - 1) / X3_BK : 0);
     return (t64 >= 128 || TT >= 32) ? 1 : 0;
 }
@@ -367,7 +396,7 @@ extern "C" size_t hsp_gemm_x3_workspace_bytes(int M, int N, int K1, int K2) {
     if (!hsp_gemm_x3_supported(M, N, K1, K2)) return 0;
     const int wm = x3_pick_wm(M, N), bm = 64 * wm;
     const int TT = (K1 + X3_BK - 1) / X3_BK + (K2 > 0 ? (K2 + X3_BK - 1) / X3_BK : 0);
-    const int ns = x3_pick_split((long long)((M + bm - 1) / bm) * (N / X3_BN), TT);
+    const int ns = x3_pick_split((long long)((M + bm - 1) / bm) * ((N + X3_BN - 1) / X3_BN), TT);
     return ns > 1 ? (size_t)ns * M * N * sizeof(float) : 0;
 }
 
@@ -393,7 +422,7 @@ extern "C" int hsp_gemm_x3_f32(const float* A1, int lda1, const hsp_bf16_t* P1, 
     g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.bias = bias; g.resid = resid; g.ldr = ldr;
     g.cbias = cloud_bias; g.rpc = rows_per_cloud > 0 ? rows_per_cloud : 1; g.alpha = alpha;
     const int wm = x3_pick_wm(M, N), bm = 64 * wm;
-    g.tiles_m = (M + bm - 1) / bm; g.tiles_n = N / X3_BN;
+    g.tiles_m = (M + bm - 1) / bm; g.tiles_n = (N + X3_BN - 1) / X3_BN;
     const int TT = (K1 + X3_BK - 1) / X3_BK + (two ? (K2 + X3_BK - 1) / X3_BK : 0);
     const int epi = (bias ? 1 : 0) | (resid ? 2 : 0) | (cloud_bias ? 4 : 0);
     int ns = epi ? 1 : x3_pick_split((long long)g.tiles_m * g.tiles_n, TT);
@@ -428,10 +457,10 @@ extern "C" int hsp_gemm_x3_f32(const float* A1, int lda1, const hsp_bf16_t* P1, 
 #undef X3_K
     int rc = check_launch();
     if (rc || ns == 1) return rc;
-    const long long total4 = (long long)M * N / 4;
-    long long rg = (total4 + 255) / 256;
+    const long long total = (long long)M * N;
+    long long rg = (total / 4 + 255) / 256;
     if (rg > HSP_NUM_CU * 8) rg = HSP_NUM_CU * 8;
-    hipLaunchKernelGGL(gemm_x3_reduce_kernel, dim3((unsigned)rg), dim3(256), 0, st, g.ws, ns, total4, N / 4, alpha, C, ldc);
+    hipLaunchKernelGGL(gemm_x3_reduce_kernel, dim3((unsigned)rg), dim3(256), 0, st, g.ws, ns, total, N, alpha, C, ldc);
     return check_launch();
 }
 

@@ -702,7 +702,7 @@ class X3Planes:
             tab[i].src, tab[i].dst = W.data_ptr(), e["planes"].data_ptr()
             tab[i].rows, tab[i].cols, tab[i].ld = W.shape[0], W.shape[1], W.stride(0)
             tab[i].transpose, tab[i].kp, tab[i].tile0, tab[i].ps = int(e["transpose"]), e["kp"], tile0, e["N"] * e["kp"]
-            tile0 += ((W.shape[0] + 31) // 32) * ((W.shape[1] + 31) // 32)
+            tile0 += ((e["N"] + 31) // 32) * ((e["K"] + 63) // 64)        # pieces of 32 (n) x 64 (k) output elements
         host = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8)
         return host.to(ents[0]["src"].device), tile0
 
@@ -731,7 +731,7 @@ def x3_refresh():
 
 
 def gemm_x3_ok(A1, B1, A2, B2, bias, resid, cloud_bias, xyz3, out, M, N):
-    if not GEMM_X3 or xyz3 is not None or N % 128 or A1.dtype != torch.float32:
+    if not GEMM_X3 or xyz3 is not None or N < 64 or A1.dtype != torch.float32:
         return False
     K2 = A2.shape[1] if A2 is not None else 0
     if not lib().hsp_gemm_x3_supported(M, N, A1.shape[1], K2):
@@ -739,7 +739,7 @@ def gemm_x3_ok(A1, B1, A2, B2, bias, resid, cloud_bias, xyz3, out, M, N):
     epi = (1 if bias is not None else 0) | (2 if resid is not None else 0) | (4 if cloud_bias is not None else 0)
     if epi not in (0, 1, 6):
         return False
-    if epi and ((M + 63) // 64) * (N // 128) < 128:            # (an epilogue rules out split-K: too few workgroups)
+    if epi and ((M + 63) // 64) * ((N + 127) // 128) < 128:            # (an epilogue rules out split-K: too few workgroups)
         return False
     for t_ in (A1, A2):
         if t_ is not None and (t_.data_ptr() % 16 or (t_.stride(0) * 4) % 16):
@@ -773,15 +773,16 @@ def gemm_x3(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=Non
 
 
 # ------------------------------------------------------------------------------------------------
-# dense per-point products of a layer: the hand-written fused kernel (csrc/gemm_rows.hip) or the BLAS library through
-# torch.  HSP_GEMM = library (default for fp32 rows) | own | auto: "own" runs no library GEMM at all on the layer path
-# (measured, round 2, B=16 N=1028: 2.30 ms / step against 2.06 ms with the tuned library -- the hand-written kernel reaches
-# 60-78 TFLOP/s on the layer's shapes, the TunableOp-selected Tensile kernels 90-120); "auto" times both forms of a composite
-# once per shape (outside any graph capture, on the real buffers -- both forms write the same result) and keeps the faster
-# (isolated timings are host-launch-bound for the small shapes and flatter the fused form: 2.10 ms).  bf16 rows always run on
-# the hand-written kernel (ops_bf16.py).  ``gemm_choices()`` reports what "auto" picked.
+# dense per-point products of a layer.  HSP_GEMM = own (default) | library | auto.
+#   own:     hand-written kernels only -- csrc/gemm_x3.hip (fp32 products from exact three-way bf16 splits on the bf16 matrix
+#            cores) for every product it covers, csrc/gemm_wave.hip / gemm_rows.hip (fp32 matrix cores) for the rest, the
+#            small per-cloud kernels for the 16-row ORL products, csrc/gemm.hip for the parameter gradients.  No BLAS call.
+#   library: the BLAS library through torch (kept as the comparison figure of bench.py; round 3, B=16 N=1028: 1.93 ms / step
+#            with the TunableOp-selected Tensile kernels against 1.95 ms own)
+#   auto:    times both forms of a composite once per shape (outside any graph capture) and keeps the faster
+# bf16 rows always run on the hand-written kernels (ops_bf16.py).  ``gemm_choices()`` reports what "auto" picked.
 # ------------------------------------------------------------------------------------------------
-GEMM_MODE = os.environ.get("HSP_GEMM", "library")
+GEMM_MODE = os.environ.get("HSP_GEMM", "own")
 _gemm_choice = {}
 
 
@@ -1215,6 +1216,18 @@ class _LinearRows(torch.autograd.Function):
             if ctx.has_bias:
                 gb = colsum_rows(g.view(1, R, Cout)).view(Cout)
         return gx, gw, (gb if ctx.has_bias else None)
+
+
+def cat_rows_pitched(parts):
+    """torch.cat(parts, dim=-1) whose rows sit on a 16-byte pitch: the result is the (..., K) view of a (..., K rounded up to 4)
+    buffer with zero pad columns, so the dense kernels that want aligned rows (csrc/gemm_x3.hip) take a K = 1289 / 1283 input
+    (PoseTs.py:32 on cat[feat, xyz]; the face head on cat[f_global, h, xyz], FaceRecon.py:116) without a fallback"""
+    K = sum(p.shape[-1] for p in parts)
+    pad = (-K) % 4
+    if pad == 0 or parts[0].dtype != torch.float32:
+        return torch.cat(parts, dim=-1)
+    z = torch.zeros(*parts[0].shape[:-1], pad, dtype=parts[0].dtype, device=parts[0].device)
+    return torch.cat(list(parts) + [z], dim=-1)[..., :K]
 
 
 def linear_rows(x2, weight, bias=None):

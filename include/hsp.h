@@ -261,8 +261,8 @@ int hsp_gemm_wave_f32(const float *A1, int lda1, const float *B1, int ldb1, int 
  * product (the rounding an fp32 fma chain commits per step).  The weight-side operand comes ALREADY SPLIT in (N, K) form:
  * three bf16 planes (N, ldp), plane p at P + p * ps elements, columns k >= K zero, ldp >= K rounded up to 32 -- written once
  * per step for every weight by hsp_split_params_x3 (HspSplitDesc: src (rows, cols) fp32 with pitch ld; transpose = 0: src is
- * (N, K); 1: src is (K, N), i.e. the product wants src^T; kp = plane row pitch, ps = plane stride, both in elements; tile0 =
- * number of 32 x 32 tiles of the entries before; table in DEVICE memory).  Covers N a multiple of 128 and 16-byte aligned
+ * (N, K); 1: src is (K, N), i.e. the product wants src^T; kp = plane row pitch, ps = plane stride, both in elements and even; tile0 =
+ * number of 32 (n) x 64 (k) output pieces, ceil(N / 32) * ceil(K / 64) each, of the entries before; table in DEVICE memory).  Covers N >= 64 and 16-byte aligned
  * activation rows (hsp_gemm_x3_supported; anything else: hsp_gemm_rows_f32); epilogues: none, bias, resid + cloud_bias.
  * Deep-K products with few tiles split K over workgroups (ws: hsp_gemm_x3_workspace_bytes) and fold in a fixed order. */
 typedef struct HspSplitDesc { const float *src; void *dst; int rows, cols, ld, transpose, kp, tile0; long long ps; } HspSplitDesc;

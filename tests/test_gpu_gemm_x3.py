@@ -34,6 +34,8 @@ CASES = [  # M, N, K1, nn1, K2, nn2, epilogue, rows per cloud
     (5777, 256, 40, True, 24, False, "none", 0),
     (16448, 1024, 1286, False, 0, False, "bias", 0),          # a head tower's first layer on feat rows (pitch 1288)
     (16448, 256, 1024, False, 0, False, "bias", 0),
+    (16448, 1286, 1024, True, 0, False, "none", 0),           # its input gradient: N = 1286 (ragged last column tile)
+    (4112, 200, 2048, False, 0, False, "none", 0),            # ragged N with split-K
 ]
 
 

@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--images", type=int, default=200)
     ap.add_argument("--points", type=int, default=1028)
     args = ap.parse_args()
-    from hs_pose_amd import gemm_tuning
+    from tools import gemm_tuning
     from hs_pose_amd.config import FLAGS
     from hs_pose_amd.geom_utils import generate_RT
     from hs_pose_amd.graph import GraphedInference

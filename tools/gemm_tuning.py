@@ -1,10 +1,11 @@
-"""Library-GEMM solution selection for the dense fp32 GEMMs of the path (fm / STE / conv2 / heads).
+"""COMPARISON TOOLING (not on the product path: the shipped step runs no BLAS-library GEMM, hs_pose_amd/ops.py HSP_GEMM=own).
+Library-GEMM solution selection for the `HSP_GEMM=library` baseline figure of bench.py and tools/.
 
 The GEMMs that are not hand-written (everything except the split-K weight-gradient kernel in
 csrc/gemm.hip) go to hipBLASLt / rocBLAS through torch.  Their default heuristics pick poor tiles for
 the tall-skinny fp32 shapes of this workload (measured 37-50 TF/s); PyTorch's TunableOp times the
 available solutions per shape and keeps the best (85-108 TF/s on the large ones).  ``enable()`` turns
-it on with the MI355X table shipped in hs_pose_amd/tuning/ and lets it tune any shape that is missing
+it on with the MI355X table kept in tools/tuning/ and lets it tune any shape that is missing
 during the first (eager, un-captured) iterations.
 """
 import os
@@ -48,7 +49,7 @@ def enable(tune_missing=True, max_tuning_ms=30):
 
 
 def save(path=None):
-    """write the merged table (shipped entries + what this process tuned) -- how hs_pose_amd/tuning/ is regenerated:
+    """write the merged table (shipped entries + what this process tuned) -- how tools/tuning/ is regenerated:
     HSP_TUNABLEOP_OUT=<file> python tools/bench_train_step.py ; python tools/bench_infer.py ; python bench.py"""
     path = path or os.environ.get("HSP_TUNABLEOP_OUT")
     fn = getattr(torch.cuda.tunable, "write_file", None)    # (this torch build appends to the file as it tunes)

@@ -7,7 +7,7 @@ import bench
 from hs_pose_amd.config import FLAGS
 from hs_pose_amd.HSPose import HSPose
 from hs_pose_amd.train import TrainDriver
-from hs_pose_amd import gemm_tuning
+from tools import gemm_tuning
 
 gemm_tuning.enable()
 dev = torch.device("cuda:0")
