@@ -55,6 +55,7 @@ SIGNATURES = {
     "hsp_small_rows_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, ctypes.c_float, _vp, _i, _vp]),
     "hsp_small_outer_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp]),
     "hsp_colsum_rows_xyz": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "hsp_colsum_rows_xyz_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "hsp_bn_relu_fwd_mixed": (_i, [_vp, _i, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "hsp_bn_relu_apply_mixed": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "hsp_bn_relu_bwd_mixed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

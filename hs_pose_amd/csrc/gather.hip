@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const FT* __restric
 
 // colsum + the three coordinate moments of the rows in one pass (HSlayer_surface backward: gt = sum_i g and the STE weight
 // gradient g^T xyz, gcn3d.py:85): part[b][chunk][slot][c], slot 0 = sum g, slot 1..3 = sum g * (x, y, z)
-__global__ __launch_bounds__(256) void colsum_xyz_partial_kernel(const float* __restrict__ x, const float* __restrict__ xyz, int N, int C,
+template <typename FT>
+__global__ __launch_bounds__(256) void colsum_xyz_partial_kernel(const FT* __restrict__ x, const float* __restrict__ xyz, int N, int C,
                                                                  float* __restrict__ part, int nchunk, int rows) {
     __shared__ float4 red[4][256];
     const int cq = C >> 2;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void colsum_xyz_partial_kernel(const float* __
 #pragma unroll
     for (int q = 0; q < 4; ++q) s[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = r0 + rl; i < r1; i += RL) {
-        const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)b * N + i) * C + (g << 2));
+        const float4 v = Feat<FT>::ld4(x + ((size_t)b * N + i) * C + (g << 2));
         const float* p3 = xyz + ((size_t)b * N + i) * 3;
         const float w[3] = {p3[0], p3[1], p3[2]};
         s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
@@ -928,8 +929,9 @@ extern "C" int hsp_colsum_rows(const float* x, int B, int N, int C, float* out, 
 /* out4 (B, 4, C): slot 0 = sum_i x[b][i][:] (the colsum of hsp_colsum_rows), slots 1..3 = sum_i x[b][i][:] * xyz[b][i][0..2]
  * (per-cloud halves of the STE weight gradient g^T xyz of HSlayer_surface, gcn3d.py:85).  C a multiple of 4 with C/4 | 256;
  * ws >= 4 * hsp_orl_workspace_bytes(B, N, C) */
-extern "C" int hsp_colsum_rows_xyz(const float* x, const float* xyz, int B, int N, int C, float* out4, void* ws, size_t ws_bytes,
-                                   hspStream_t stream) {
+template <typename FT>
+static int colsum_rows_xyz_impl(const FT* x, const float* xyz, int B, int N, int C, float* out4, void* ws, size_t ws_bytes,
+                                hspStream_t stream) {
     if (!x || !xyz || !out4 || B <= 0 || N <= 0 || C <= 0) return HSP_ERR_BAD_ARG;
     if (!colsum_vec4(C)) return HSP_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < 4 * hsp_orl_workspace_bytes(B, N, C)) return HSP_ERR_WORKSPACE;
@@ -937,9 +939,17 @@ extern "C" int hsp_colsum_rows_xyz(const float* x, const float* xyz, int B, int 
     const int rows = chunk_rows(B, N, C);
     const int nchunk = (N + rows - 1) / rows;
     float* part = reinterpret_cast<float*>(ws);
-    hipLaunchKernelGGL(colsum_xyz_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, x, xyz, N, C, part, nchunk, rows);
+    hipLaunchKernelGGL(colsum_xyz_partial_kernel<FT>, dim3(nchunk, B), dim3(256), 0, st, x, xyz, N, C, part, nchunk, rows);
     hipLaunchKernelGGL(chunk_fold_kernel, dim3((B * 4 * C + 255) / 256), dim3(256), 0, st, part, B, nchunk, 4 * C, 1.0f, out4);
     return check_launch();
+}
+extern "C" int hsp_colsum_rows_xyz(const float* x, const float* xyz, int B, int N, int C, float* out4, void* ws, size_t ws_bytes,
+                                   hspStream_t stream) {
+    return colsum_rows_xyz_impl<float>(x, xyz, B, N, C, out4, ws, ws_bytes, stream);
+}
+extern "C" int hsp_colsum_rows_xyz_bf16(const hsp_bf16_t* x, const float* xyz, int B, int N, int C, float* out4, void* ws,
+                                        size_t ws_bytes, hspStream_t stream) {
+    return colsum_rows_xyz_impl<bf16_t>(x, xyz, B, N, C, out4, ws, ws_bytes, stream);
 }
 
 extern "C" int hsp_colsum_rows_bf16(const hsp_bf16_t* x, int B, int N, int C, float* out, void* ws, size_t ws_bytes,

@@ -556,8 +556,9 @@ __global__ __launch_bounds__(256) void small_rows_mfma_kernel(const float* __res
     __shared__ float red[3][64][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kk = lane >> 4;
-    const int n = blockIdx.x * 16 + j, nc = min(n, N - 1), mc = min(j, M - 1);
-    const float amask = j < M ? 1.f : 0.f;
+    const int mbase = blockIdx.y * 16;                         // 16-row blocks along grid.y (M up to 64: one row per cloud)
+    const int n = blockIdx.x * 16 + j, nc = min(n, N - 1), mc = min(mbase + j, M - 1);
+    const float amask = mbase + j < M ? 1.f : 0.f;
     const int kper = K >> 2, k0 = wave * kper;
     f32x4v acc = {0.f, 0.f, 0.f, 0.f};
     if constexpr (NN) {
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(256) void small_rows_mfma_kernel(const float* __res
     if (wave == 0 && n < N) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = 4 * kk + r;
+            const int row = mbase + 4 * kk + r;
             if (row < M) out[(size_t)row * ldo + n] = alpha * (((acc[r] + red[0][lane][r]) + red[1][lane][r]) + red[2][lane][r]);
         }
     }
@@ -648,17 +649,19 @@ __global__ __launch_bounds__(256) void small_outer_kernel(const float* __restric
 extern "C" int hsp_small_rows_f32(const float* A, int lda, const float* W, int ldw, int w_layout, int M, int N, int K, float alpha,
                                   float* out, int ldo, hspStream_t stream) {
     if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || lda < K || ldo < N) return HSP_ERR_BAD_ARG;
-    if (M > SR_MAXM || K > 2048) return HSP_ERR_UNSUPPORTED;
+    if (K > 2048 || M > 64) return HSP_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);
     if (w_layout != 0 && w_layout != 1) return HSP_ERR_BAD_ARG;
     const bool al = ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(W) | ((size_t)lda * 4) | ((size_t)ldw * 4)) & 15) == 0;
     if (K % 128 == 0 && (w_layout == 1 || al)) {
+        const dim3 grid((N + 15) / 16, (M + 15) / 16);
         if (w_layout == 1)
-            hipLaunchKernelGGL(small_rows_mfma_kernel<true>, dim3((N + 15) / 16), dim3(256), 0, st, A, lda, W, ldw, M, N, K, alpha, out, ldo);
+            hipLaunchKernelGGL(small_rows_mfma_kernel<true>, grid, dim3(256), 0, st, A, lda, W, ldw, M, N, K, alpha, out, ldo);
         else
-            hipLaunchKernelGGL(small_rows_mfma_kernel<false>, dim3((N + 15) / 16), dim3(256), 0, st, A, lda, W, ldw, M, N, K, alpha, out, ldo);
+            hipLaunchKernelGGL(small_rows_mfma_kernel<false>, grid, dim3(256), 0, st, A, lda, W, ldw, M, N, K, alpha, out, ldo);
         return check_launch();
     }
+    if (M > SR_MAXM) return HSP_ERR_UNSUPPORTED;
     if (w_layout == 0)
         hipLaunchKernelGGL(small_rows_nt_kernel, dim3((N + 7) / 8), dim3(256), (size_t)M * K * 4, st, A, lda, W, ldw, M, N, K, alpha, out, ldo);
     else if (w_layout == 1) {

@@ -825,7 +825,8 @@ def gemm_own(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=No
     M, K1 = A1.shape
     N = B1.shape[1] if nn1 else B1.shape[0]
     K2 = A2.shape[1] if A2 is not None else 0
-    if (M <= 16 and A2 is None and bias is None and resid is None and cloud_bias is None and xyz3 is None and K1 <= 2048
+    if ((M <= 16 or (M <= 64 and K1 % 128 == 0 and (nn1 or all(_al16(t) for t in (A1, B1))))) and A2 is None and bias is None
+            and resid is None and cloud_bias is None and xyz3 is None and K1 <= 2048
             and A1.dtype == torch.float32 and A1.stride(1) == 1 and B1.stride(1) == 1):
         return small_rows(A1, B1, nn1, out=out, alpha=alpha)          # a row per cloud: one small launch
     if M >= 256 and gemm_x3_ok(A1, B1, A2, B2, bias, resid, cloud_bias, xyz3, out, M, N) and (out is None or _al16(out)):
@@ -971,6 +972,18 @@ def colsum_rows(x3):
     ws = _ws(wsb, x3.device)
     _run("hsp_colsum_rows", (_p(x3), B, N, C, _p(out), _p(ws), wsb, _stream()), key=f"B{B}N{N}C{C}", abytes=4 * B * N * C)
     return out
+
+
+def colsum_rows_xyz(g, xyz):
+    """(B, 4C) fp32: per-cloud column sums of g (B,N,C) fp32 / bf16 in [:, :C] and its three coordinate moments
+    sum_i g[b,i,:] * xyz[b,i,j] in [:, (1+j)C:(2+j)C] -- one pass (the surface layer's gt and its STE weight gradient)"""
+    B, N, C = g.shape
+    mom = torch.empty(B, 4 * C, dtype=torch.float32, device=g.device)
+    wsb = 4 * lib().hsp_orl_workspace_bytes(B, N, C)
+    ws = _ws(wsb, g.device)
+    _run("hsp_colsum_rows_xyz" + _sfx(g), (_p(g), _p(xyz), B, N, C, _p(mom), _p(ws), wsb, _stream()), key=f"B{B}N{N}C{C}",
+         abytes=B * N * (_es(g) * C + 12))
+    return mom
 
 
 def _orl_bwd_accumulate_raw(gfg_over_n, idx_x, arg, k, gF3, extra=None):
@@ -1146,11 +1159,7 @@ class _SurfaceLayer(torch.autograd.Function):
         if own_ste:
             # gt = sum_i g and the per-cloud coordinate moments of g in one pass; the STE gradient g^T xyz is their sum over the
             # batch, taken as a rider of the gt^T fg launch: no library GEMM for the (C, 3) product
-            mom = torch.empty(B, 4 * C, dtype=torch.float32, device=g.device)
-            wsb = 4 * lib().hsp_orl_workspace_bytes(B, N, C)
-            ws = _ws(wsb, g.device)
-            _run("hsp_colsum_rows_xyz", (_p(g), _p(xyz), B, N, C, _p(mom), _p(ws), wsb, _stream()), key=f"B{B}N{N}C{C}",
-                 abytes=4 * B * N * (C + 3))
+            mom = colsum_rows_xyz(g, xyz)
             gt = mom[:, :C]
             g_ste = torch.empty(C, 3, dtype=torch.float32, device=g.device)
         else:

@@ -264,10 +264,19 @@ class _SurfaceLayerBf16(torch.autograd.Function):
         _, c2T_b = copies_of(w_conv2)
         g2, F2, x2 = g.view(B * N, C), F3.view(B * N, C), xyz.view(B * N, 3)
         Wb = w_conv2[:, C:]
-        gt = _colsum(g)
+        own_ste = ops.GEMM_MODE == "own" and C % 4 == 0 and 256 % (C // 4) == 0 and B <= 64
         g_conv2 = torch.empty_like(w_conv2)
+        if own_ste:      # gt and the coordinate moments of g in one pass; g^T xyz = their sum over the batch (no cast, no GEMM)
+            mom = ops.colsum_rows_xyz(g, xyz)
+            gt = mom[:, :C]
+            g_ste = torch.empty(C, 3, dtype=torch.float32, device=g.device)
+        else:
+            gt = _colsum(g)
         _wgrad(g2, F2, out=g_conv2[:, :C])
-        ops._tiny_tn(gt, fg, g_conv2[:, C:])
+        if own_ste:
+            ops._tiny_tn(gt, fg, g_conv2[:, C:], mom=mom, gste=g_ste)
+        else:
+            ops._tiny_tn(gt, fg, g_conv2[:, C:])
         gF3 = torch.empty(B, N, C, dtype=BF16, device=g.device)
         ops.gemm_rows(g2, c2T_b[:C], out=gF3.view(B * N, C))
         _orl_bwd_accumulate(ops._mm_nn(gt, Wb, alpha=1.0 / N), idx_x, arg_o, gF3, g)
@@ -276,7 +285,8 @@ class _SurfaceLayerBf16(torch.autograd.Function):
         ws = _ws(wsb, g.device)
         _run("hsp_rf_surface_bwd_bf16", (_p(xyz), _p(directions), _p(arg), _p(gF3), B, N, S, C, _p(gD), _p(ws), wsb, _stream()),
              key=f"B{B}N{N}S{S}C{C}", abytes=B * N * (12 + 2 * C + 2 * SC) + 24 * SC)
-        g_ste = g2.float().t() @ x2                               # (C,3): three columns -- not a matrix-core shape
+        if not own_ste:
+            g_ste = g2.float().t() @ x2                           # (C,3): three columns -- not a matrix-core shape
         return None, None, None, None, gD, g_ste.unsqueeze_(-1), g_conv2.unsqueeze_(-1)
 
 

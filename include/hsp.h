@@ -276,7 +276,7 @@ int hsp_gemm_x3_f32(const float *A1, int lda1, const hsp_bf16_t *P1, int ldp1, l
 
 /* the per-CLOUD products of the ORL branch (gcn3d.py:186: the f_global half of conv2, one row per cloud of the batch), one
  * launch each, fp32 fma chains in a fixed order:
- *   hsp_small_rows_f32:  out (M, N) = alpha * A (M, K) op(W), M <= 16; w_layout 0: W is (N, K) (t = fg Wb^T), 1: W is (K, N)
+ *   hsp_small_rows_f32:  out (M, N) = alpha * A (M, K) op(W), M <= 64 (<= 16 unless K is a multiple of 128); w_layout 0: W is (N, K) (t = fg Wb^T), 1: W is (K, N)
  *                        (gfg = gt Wb / N); K <= 2048
  *   hsp_small_outer_f32: out (Ma, Nb) = a^T c over the B <= 64 rows of a (B, Ma), c (B, Nb) (gWb = gt^T fg) */
 int hsp_small_rows_f32(const float *A, int lda, const float *W, int ldw, int w_layout, int M, int N, int K, float alpha,
@@ -288,6 +288,8 @@ int hsp_small_outer_f32(const float *a, int lda, const float *c, int ldc, int B,
  * out4 (B, 4, C), slot 0 = sum_i g[b][i][:], slots 1..3 = sum_i g[b][i][:] * xyz[b][i][0..2]; ws >= 4 * hsp_orl_workspace_bytes) */
 int hsp_colsum_rows_xyz(const float *x, const float *xyz, int B, int N, int C, float *out4, void *ws, size_t ws_bytes,
                         hspStream_t stream);
+int hsp_colsum_rows_xyz_bf16(const hsp_bf16_t *x, const float *xyz, int B, int N, int C, float *out4, void *ws, size_t ws_bytes,
+                             hspStream_t stream);
 
 /* fp32 master parameters -> bf16 working copies for the *_bf16 entry points, every tensor of a step in one launch:
  * entry e copies src (rows, cols; row pitch ld) to dst (rows, cols) and / or dstT (cols, rows) -- either may be NULL --

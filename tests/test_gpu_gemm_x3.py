@@ -100,7 +100,7 @@ def test_gemm_x3_split_is_exact(dev):
         assert bool((planes[:, :, K:] == 0).all())
 
 
-@pytest.mark.parametrize("M,N,K", [(16, 128, 128), (16, 512, 512), (16, 256, 256), (2, 128, 256), (5, 96, 40)])
+@pytest.mark.parametrize("M,N,K", [(16, 128, 128), (16, 512, 512), (16, 256, 256), (2, 128, 256), (5, 96, 40), (64, 128, 128), (40, 512, 256)])
 def test_small_rows_and_outer(dev, M, N, K):
     """the per-cloud products of the ORL branch (one row per cloud): both weight layouts, a strided weight block, the outer
     product; against fp64"""
@@ -125,3 +125,32 @@ def test_small_rows_and_outer(dev, M, N, K):
         ops.GEMM_MODE = prev
     want = A.double().t() @ c.double()
     assert (out[:, N:].double() - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_colsum_rows_xyz(dev, dtype):
+    """per-cloud column sums + coordinate moments of a gradient tensor in one pass, and the (C, 3) STE gradient summed over the
+    batch as a rider of the outer-product launch (gcn3d.py:85), fp32 and bf16 rows, against fp64"""
+    from hs_pose_amd import ops
+    B, N, C = 5, 777, 128
+    g_ = torch.Generator().manual_seed(11)
+    g = torch.randn(B, N, C, generator=g_).to(dev).to(dtype)
+    xyz = (torch.randn(B, N, 3, generator=g_) * 0.1).to(dev)
+    mom = ops.colsum_rows_xyz(g, xyz)
+    gd = g.double()
+    want0 = gd.sum(dim=1)
+    assert (mom[:, :C].double() - want0).abs().max().item() <= 1e-5 * want0.abs().max().item()
+    for j in range(3):
+        w = (gd * xyz[:, :, j:j + 1].double()).sum(dim=1)
+        assert (mom[:, (1 + j) * C:(2 + j) * C].double() - w).abs().max().item() <= 1e-5 * max(1.0, w.abs().max().item())
+    fg = torch.randn(B, C, generator=g_).to(dev)
+    out = torch.empty(C, C, device=dev)
+    gste = torch.empty(C, 3, device=dev)
+    prev, ops.GEMM_MODE = ops.GEMM_MODE, "own"
+    try:
+        ops._tiny_tn(mom[:, :C], fg, out, mom=mom, gste=gste)
+    finally:
+        ops.GEMM_MODE = prev
+    want = gd.reshape(B * N, C).t() @ xyz.double().reshape(B * N, 3)
+    assert (gste.double() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+    assert (out.double() - want0.t() @ fg.double()).abs().max().item() <= 1e-4 * max(1.0, (want0.t() @ fg.double()).abs().max().item())
