@@ -6,6 +6,8 @@ state_dict loads here with strict=True.  Execution differs: point-major (B,N,C) 
 (BatchNorm and the 1x1 convolutions run on the flattened (B*N, C) view: same statistics, no
 transposes), one shared xyz-KNN per resolution, fused graph-conv kernels.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -102,16 +104,29 @@ class FaceRecon(nn.Module):
         with gcn3d.knn_scope():
             fm_0 = F.relu(self.conv_0(vertices, k), inplace=True)
             od = self.feature_dtype if self.feature_dtype == torch.bfloat16 else None
-            fm_1 = ops.bn_relu(self.conv_1(vertices, fm_0, k), self.bn1, out_dtype=od)
-            v_pool_1, fm_pool_1 = self.pool_1(vertices, fm_1)
-            k1 = min(k, v_pool_1.shape[1] // 8)
-            fm_2 = ops.bn_relu(self.conv_2(v_pool_1, fm_pool_1, k1), self.bn2, out_dtype=od)
-            # The coarse levels and the concat read the fine levels through aliases (no kernels): every path from feat
-            # down to an alias stays above the others, so a backward pass can stop at them and be resumed
-            # (graph.py::GraphedStep(split=True) reduces the coarse levels' gradients while the fine levels still run).
-            a_0, a_1, a_2 = fm_0.view_as(fm_0), fm_1.view_as(fm_1), fm_2.view_as(fm_2)
-            self.backward_cut = (a_0, a_1, a_2) if self.keep_backward_cut else None   # holds the autograd graph: opt-in
-            fm_3 = ops.bn_relu(self.conv_3(v_pool_1, a_2, k1), self.bn3, out_dtype=od)
+            # fm_1 .. fm_3 have two consumers each (the next level and the concat): the BatchNorm node hands out one tensor per
+            # consumer (``fork``), so their gradients meet inside its backward kernels instead of in an element-wise add.  The
+            # two-graph split (keep_backward_cut) cuts at single aliases and keeps the plain form.
+            fork = od is None and not self.keep_backward_cut and os.environ.get("HSP_BN_FORK", "1") != "0"
+            if fork:
+                fm_1, a_1 = ops.bn_relu(self.conv_1(vertices, fm_0, k), self.bn1, fork=True)
+                v_pool_1, fm_pool_1 = self.pool_1(vertices, fm_1)
+                k1 = min(k, v_pool_1.shape[1] // 8)
+                fm_2, a_2 = ops.bn_relu(self.conv_2(v_pool_1, fm_pool_1, k1), self.bn2, fork=True)
+                a_0 = fm_0.view_as(fm_0)
+                self.backward_cut = None
+                fm_3, a_3 = ops.bn_relu(self.conv_3(v_pool_1, fm_2, k1), self.bn3, fork=True)
+            else:
+                fm_1 = ops.bn_relu(self.conv_1(vertices, fm_0, k), self.bn1, out_dtype=od)
+                v_pool_1, fm_pool_1 = self.pool_1(vertices, fm_1)
+                k1 = min(k, v_pool_1.shape[1] // 8)
+                fm_2 = ops.bn_relu(self.conv_2(v_pool_1, fm_pool_1, k1), self.bn2, out_dtype=od)
+                # The coarse levels and the concat read the fine levels through aliases (no kernels): every path from feat
+                # down to an alias stays above the others, so a backward pass can stop at them and be resumed
+                # (graph.py::GraphedStep(split=True) reduces the coarse levels' gradients while the fine levels still run).
+                a_0, a_1, a_2 = fm_0.view_as(fm_0), fm_1.view_as(fm_1), fm_2.view_as(fm_2)
+                self.backward_cut = (a_0, a_1, a_2) if self.keep_backward_cut else None   # holds the autograd graph: opt-in
+                fm_3 = a_3 = ops.bn_relu(self.conv_3(v_pool_1, a_2, k1), self.bn3, out_dtype=od)
             v_pool_2, fm_pool_2 = self.pool_2(v_pool_1, fm_3)
             k2 = min(k, v_pool_2.shape[1] // 8)
             fm_4 = self.conv_4(v_pool_2, fm_pool_2, k2)
@@ -121,7 +136,7 @@ class FaceRecon(nn.Module):
         # nearest up-sampling of the coarse levels, the one-hot category columns and the concat in one kernel
         # (the reference's one_hot = zeros(bs, obj_c).scatter_(1, cat_id.long(), 1), FaceRecon.py:80-85, is built inside the kernel)
         ops.ONE_HOT_WIDTH = FLAGS.obj_c
-        feat = ops.assemble_feat([(a_0, None, 0), (a_1, None, 0), (a_2, nearest_pool_1, 1), (fm_3, nearest_pool_1, 1),
+        feat = ops.assemble_feat([(a_0, None, 0), (a_1, None, 0), (a_2, nearest_pool_1, 1), (a_3, nearest_pool_1, 1),
                                   (fm_4, nearest_pool_2, 1), (cat_id.detach().reshape(-1).float(), None, 3)])
 
         if FLAGS.train:

@@ -18,6 +18,19 @@
 namespace hsp {
 
 #define BN_THREADS 256
+
+// four consecutive values of a row whose pitch is only 8-byte aligned (an even fp32 pitch such as feat's 1286: a gradient
+// column block of a dense (B, N, 1286) tensor): two 8-byte loads
+template <typename FT>
+__device__ __forceinline__ float4 bn_ld4_pitch(const FT* p, int ld) {
+    if constexpr (sizeof(FT) == 4) {
+        if (ld & 3) {
+            const float2 a = *reinterpret_cast<const float2*>(p), b = *reinterpret_cast<const float2*>(p + 2);
+            return make_float4(a.x, a.y, b.x, b.y);
+        }
+    }
+    return Feat<FT>::ld4(p);
+}
 #define BN_MAX_PARTIALS 512       // row chunks (workgroups of the partial kernels); folded 16-way parallel by finalize
 
 // partial[blk][0][c] = sum_r v1, partial[blk][1][c] = sum_r v2 over the rows of chunk blk, where
@@ -32,7 +45,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const XT* __rest
                                                                 const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, int relu,
-                                                                float* __restrict__ partial, int rows_per_block) {
+                                                                float* __restrict__ partial, int rows_per_block,
+                                                                int ldy = 0, const FT* __restrict__ dy2 = nullptr, int ldy2 = 0) {
     __shared__ float4 red[2][BN_THREADS];
     const int cq = C >> 2;                       // float4 groups per row
     const int tid = threadIdx.x;
@@ -57,7 +71,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const XT* __rest
             s1.x += a; s1.y += b; s1.z += c; s1.w += d;
             s2.x += a * a; s2.y += b * b; s2.z += c * c; s2.w += d * d;
         } else {
-            float4 dz = Feat<FT>::ld4(dy + (size_t)r * C + (g << 2));
+            // dy: rows of pitch ldy (a column block of a wider gradient tensor is consumed in place); dy2: a second incoming
+            // gradient of the same tensor (two consumers: the sum autograd would form with a separate kernel)
+            float4 dz = bn_ld4_pitch<FT>(dy + (size_t)r * (ldy ? ldy : C) + (g << 2), ldy);
+            if (dy2) {
+                const float4 d2 = bn_ld4_pitch<FT>(dy2 + (size_t)r * ldy2 + (g << 2), ldy2);
+                dz.x += d2.x; dz.y += d2.y; dz.z += d2.z; dz.w += d2.w;
+            }
             const float4 xh = make_float4((v.x - mu.x) * is.x, (v.y - mu.y) * is.y, (v.z - mu.z) * is.z, (v.w - mu.w) * is.w);
             if (relu) {
                 if (!(xh.x * ga.x + be.x > 0.f)) dz.x = 0.f;
@@ -174,13 +194,24 @@ __global__ __launch_bounds__(256) void bn_dx_kernel(const XT* __restrict__ x, co
                                                     long long total4, int R, int C, const float* __restrict__ mean,
                                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, const float* __restrict__ dgamma,
-                                                    const float* __restrict__ dbeta, int relu, FT* __restrict__ dx) {
+                                                    const float* __restrict__ dbeta, int relu, FT* __restrict__ dx,
+                                                    int ldy = 0, const FT* __restrict__ dy2 = nullptr, int ldy2 = 0) {
     const int cq = C >> 2;
     const float invR = 1.0f / (float)R;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
         const int g = (int)(e % cq);
         const float4 v = Feat<XT>::ld4(x + e * 4);
-        float4 dz = Feat<FT>::ld4(dy + e * 4);
+        float4 dz;
+        if (ldy || dy2) {
+            const unsigned row = (unsigned)((unsigned long long)e / (unsigned)cq);          // (32-bit quotient: R < 2^32)
+            dz = bn_ld4_pitch<FT>(dy + (size_t)row * (ldy ? ldy : C) + (g << 2), ldy);
+            if (dy2) {
+                const float4 d2 = bn_ld4_pitch<FT>(dy2 + (size_t)row * ldy2 + (g << 2), ldy2);
+                dz.x += d2.x; dz.y += d2.y; dz.z += d2.z; dz.w += d2.w;
+            }
+        } else {
+            dz = Feat<FT>::ld4(dy + e * 4);
+        }
         const float4 mu = *reinterpret_cast<const float4*>(mean + (g << 2));
         const float4 is = *reinterpret_cast<const float4*>(invstd + (g << 2));
         const float4 ga = *reinterpret_cast<const float4*>(gamma + (g << 2));
@@ -270,8 +301,13 @@ static int bn_relu_apply_impl(const XT* x, int R, int C, const float* mean, cons
 template <typename FT, typename XT>
 static int bn_relu_bwd_impl(const XT* x, const FT* dy, int R, int C, const float* gamma, const float* beta,
                                const float* save_mean, const float* save_invstd, int relu, FT* dx, float* dgamma,
-                               float* dbeta, void* ws, size_t ws_bytes, hspStream_t stream) {
+                               float* dbeta, void* ws, size_t ws_bytes, hspStream_t stream, int ldy = 0, const FT* dy2 = nullptr,
+                               int ldy2 = 0) {
     if (!x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta) return HSP_ERR_BAD_ARG;
+    if ((ldy && (ldy < C || (ldy & 1))) || (dy2 && (ldy2 < C || (ldy2 & 1)))) return HSP_ERR_BAD_ARG;     // 8-byte aligned rows
+    if ((reinterpret_cast<size_t>(dy) & 7) || (reinterpret_cast<size_t>(dy2) & 7)) return HSP_ERR_BAD_ARG;
+    if (sizeof(FT) != 4 && ((ldy & 3) || (ldy2 & 3))) return HSP_ERR_UNSUPPORTED;
+    if (ldy == C) ldy = 0;
     int rc = bn_check(R, C);
     if (rc) return rc;
     if (!ws || ws_bytes < hsp_bn_workspace_bytes(R, C)) return HSP_ERR_WORKSPACE;
@@ -279,12 +315,12 @@ static int bn_relu_bwd_impl(const XT* x, const FT* dy, int R, int C, const float
     float* part = reinterpret_cast<float*>(ws);
     const int nblk = bn_blocks(R);
     hipLaunchKernelGGL((bn_partial_kernel<1, FT, XT>), dim3(nblk), dim3(BN_THREADS), 0, st, x, dy, R, C, save_mean, save_invstd, gamma,
-                       beta, relu, part, bn_rows_per_block(R));
+                       beta, relu, part, bn_rows_per_block(R), ldy, dy2, ldy2);
     hipLaunchKernelGGL((bn_finalize_kernel<1, XT>), dim3((C + 15) / 16), dim3(1024), 0, st, part, nblk, R, C, x, 0.f, 0.f, dgamma,
                        dbeta, nullptr, nullptr, nullptr);
     const long long total4 = (long long)R * (C >> 2);
     hipLaunchKernelGGL((bn_dx_kernel<FT, XT>), dim3(stream_grid4(total4)), dim3(256), 0, st, x, dy, total4, R, C, save_mean,
-                       save_invstd, gamma, beta, dgamma, dbeta, relu, dx);
+                       save_invstd, gamma, beta, dgamma, dbeta, relu, dx, ldy, dy2, ldy2);
     return check_launch();
 }
 
@@ -315,6 +351,16 @@ extern "C" int hsp_bn_relu_bwd(const float* x, const float* dy, int R, int C, co
                                float* dbeta, void* ws, size_t ws_bytes, hspStream_t stream) {
     return bn_relu_bwd_impl<float, float>(x, dy, R, C, gamma, beta, save_mean, save_invstd, relu, dx, dgamma, dbeta, ws, ws_bytes,
                                    stream);
+}
+/* hsp_bn_relu_bwd for a tensor with TWO consumers: dy (rows of pitch ldy >= C elements, a multiple of 4 -- e.g. a column block of
+ * a wider gradient tensor, consumed in place) plus an optional second incoming gradient dy2 (pitch ldy2); the kernels add them
+ * as they read (the sum autograd would otherwise form with a separate element-wise kernel) */
+extern "C" int hsp_bn_relu_bwd2(const float* x, const float* dy, int ldy, const float* dy2, int ldy2, int R, int C,
+                                const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, int relu,
+                                float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, hspStream_t stream) {
+    if (ldy <= 0) return HSP_ERR_BAD_ARG;
+    return bn_relu_bwd_impl<float, float>(x, dy, R, C, gamma, beta, save_mean, save_invstd, relu, dx, dgamma, dbeta, ws, ws_bytes,
+                                          stream, ldy, dy2, ldy2);
 }
 extern "C" int hsp_bn_relu_bwd_bf16(const hsp_bf16_t* x, const hsp_bf16_t* dy, int R, int C, const float* gamma,
                                     const float* beta, const float* save_mean, const float* save_invstd, int relu,

@@ -1248,9 +1248,22 @@ def linear_rows(x2, weight, bias=None):
 # fused train-mode BatchNorm1d + ReLU over point rows
 # ------------------------------------------------------------------------------------------------
 
+def _rows_pitch(t, C):
+    """(tensor, row pitch in elements) when ``t`` (..., C) is a set of equally pitched rows a kernel can walk in place (contiguous,
+    or an 8-byte aligned column block of a wider row-major tensor with an even pitch); else (a contiguous copy, C)"""
+    ok = t.stride(-1) == 1 and t.data_ptr() % 8 == 0
+    ld = t.stride(-2) if t.dim() >= 2 else C
+    if ok and t.dim() >= 2:
+        for d in range(t.dim() - 2):                          # leading dims must collapse onto the row pitch
+            ok = ok and t.stride(d) == t.stride(d + 1) * t.shape[d + 1]
+    if ok and ld >= C and ld % 2 == 0:
+        return t, ld
+    return t.contiguous(), C
+
+
 class _BNRelu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, num_batches, eps, momentum, relu, out_dtype=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, num_batches, eps, momentum, relu, out_dtype=None, fork=False):
         x = _reqf(x, "bn_relu.x")
         C = x.shape[-1]
         R = x.numel() // C
@@ -1269,31 +1282,51 @@ class _BNRelu(torch.autograd.Function):
              key=f"R{R}C{C}", abytes=(_es(x) + _es(y)) * R * C)
         ctx.save_for_backward(x, weight, bias, mean, invstd)
         ctx.relu = relu
+        ctx.fork = fork
         ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, num_batches) if t is not None])
+        if fork:
+            # TWO outputs over the same rows, one per consumer: autograd then hands their gradients to backward separately and the
+            # BatchNorm kernels add them as they read (no element-wise add kernel, no copy of a strided column block)
+            ctx.set_materialize_grads(False)
+            return y, y.view_as(y)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, *dys):
         x, weight, bias, mean, invstd = ctx.saved_tensors
-        dy = _reqf(dy, "bn_relu.grad", like=None if ctx.mixed else x)
         C = x.shape[-1]
         R = x.numel() // C
-        dx = torch.empty_like(dy)
-        dg = torch.empty_like(weight)
-        db = torch.empty_like(bias)
+        dys = [d for d in dys if d is not None]
+        if not dys:
+            return (None,) * 11
         L = lib()
         wsb = L.hsp_bn_workspace_bytes(R, C)
         ws = _ws(wsb, x.device)
+        dg = torch.empty_like(weight)
+        db = torch.empty_like(bias)
+        if ctx.fork and not ctx.mixed and x.dtype == torch.float32 and all(d.is_cuda and d.dtype == torch.float32 for d in dys):
+            (d0, ld0) = _rows_pitch(dys[0], C)
+            (d1, ld1) = _rows_pitch(dys[1], C) if len(dys) > 1 else (None, 0)
+            dx = torch.empty_like(x)
+            _run("hsp_bn_relu_bwd2", (_p(x), _p(d0), ld0, _p(d1), ld1, R, C, _p(weight), _p(bias), _p(mean), _p(invstd),
+                                      1 if ctx.relu else 0, _p(dx), _p(dg), _p(db), _p(ws), wsb, _stream()),
+                 key=f"R{R}C{C}", abytes=4 * (2 + len(dys)) * R * C)
+            return dx, dg, db, None, None, None, None, None, None, None, None
+        dy = dys[0] if len(dys) == 1 else dys[0] + dys[1]
+        dy = _reqf(dy, "bn_relu.grad", like=None if ctx.mixed else x)
+        dx = torch.empty_like(dy)
         _run("hsp_bn_relu_bwd" + ("_mixed" if ctx.mixed else _sfx(x)), (_p(x), _p(dy), R, C, _p(weight), _p(bias), _p(mean), _p(invstd),
                                            1 if ctx.relu else 0, _p(dx), _p(dg), _p(db), _p(ws), wsb, _stream()),
              key=f"R{R}C{C}", abytes=(_es(x) + 2 * _es(dy)) * R * C)
-        return dx, dg, db, None, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None, None, None, None, None
 
 
-def bn_relu(x, bn, relu=True, out_dtype=None):
+def bn_relu(x, bn, relu=True, out_dtype=None, fork=False):
     """relu(bn(x)) for point rows x (..., C) with an nn.BatchNorm1d module ``bn`` (its parameters, running
     statistics and train/eval state are honoured exactly like calling the module on the (R,C) view, which
-    is what the reference's transpose->BatchNorm1d->transpose computes, FaceRecon.py:90-95)."""
+    is what the reference's transpose->BatchNorm1d->transpose computes, FaceRecon.py:90-95).  ``fork``: return the result
+    TWICE (two tensors over the same rows) for a tensor with two consumers -- their gradients then reach the BatchNorm backward
+    separately and are added inside its kernels."""
     C = x.shape[-1]
     fused = (bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None and x.is_cuda
              and x.dtype in _FEAT_DTYPES and C % 4 == 0 and 256 % (C // 4) == 0)
@@ -1307,12 +1340,13 @@ def bn_relu(x, bn, relu=True, out_dtype=None):
         _run("hsp_bn_relu_apply" + ("_bf16" if xc.dtype == torch.bfloat16 else "_mixed"),
              (_p(xc), xc.numel() // C, C, _p(bn.running_mean), _p(invstd), _p(bn.weight), _p(bn.bias), 1 if relu else 0, _p(y),
               _stream()), key=f"R{xc.numel() // C}C{C}", abytes=(_es(xc) + 2) * xc.numel())
-        return y
+        return (y, y) if fork else y
     if not fused:                                   # eval mode / exotic configurations: not on the training hot path
         y = bn(x.reshape(-1, C)).view_as(x)
-        return torch.relu_(y) if relu else y
+        y = torch.relu_(y) if relu else y
+        return (y, y) if fork else y
     return _BNRelu.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
-                         bn.momentum, relu, out_dtype)
+                         bn.momentum, relu, out_dtype, fork)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -346,6 +346,11 @@ int hsp_bn_relu_apply(const float *x, int R, int C, const float *mean, const flo
 int hsp_bn_relu_bwd(const float *x, const float *dy, int R, int C, const float *gamma, const float *beta,
                     const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma,
                     float *dbeta, void *ws, size_t ws_bytes, hspStream_t stream);
+/* the same for a tensor with TWO consumers: dy rows of pitch ldy (>= C, even -- 8-byte aligned rows: a column block of a wider gradient
+ * tensor, e.g. of a dense (B, N, 1286) one, is consumed in place) plus an optional second incoming gradient dy2 (pitch ldy2, NULL: none), added as they are read */
+int hsp_bn_relu_bwd2(const float *x, const float *dy, int ldy, const float *dy2, int ldy2, int R, int C, const float *gamma,
+                     const float *beta, const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma,
+                     float *dbeta, void *ws, size_t ws_bytes, hspStream_t stream);
 
 /* ---- depth -> point cloud front end -------------------------------------------------------------
  * replaces the device work of PC_sample(obj_mask, Depth, camK, coor2d)    network/point_sample/pc_sample.py:8-77
