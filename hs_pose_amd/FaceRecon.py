@@ -102,8 +102,13 @@ class FaceRecon(nn.Module):
         else:
             ops.x3_refresh()                          # fp32 weights -> the three bf16 slices of the x3 products (one launch)
         with gcn3d.knn_scope():
-            fm_0 = F.relu(self.conv_0(vertices, k), inplace=True)
             od = self.feature_dtype if self.feature_dtype == torch.bfloat16 else None
+            fork0 = (od is None and not self.keep_backward_cut and os.environ.get("HSP_BN_FORK", "1") != "0"
+                     and torch.is_grad_enabled())
+            if fork0:
+                fm_0, a_0 = self.conv_0(vertices, k, relu_fork=True)          # relu in the node, one tensor per consumer
+            else:
+                fm_0 = F.relu(self.conv_0(vertices, k), inplace=True)
             # fm_1 .. fm_3 have two consumers each (the next level and the concat): the BatchNorm node hands out one tensor per
             # consumer (``fork``), so their gradients meet inside its backward kernels instead of in an element-wise add.  The
             # two-graph split (keep_backward_cut) cuts at single aliases and keeps the plain form.
@@ -113,7 +118,8 @@ class FaceRecon(nn.Module):
                 v_pool_1, fm_pool_1 = self.pool_1(vertices, fm_1)
                 k1 = min(k, v_pool_1.shape[1] // 8)
                 fm_2, a_2 = ops.bn_relu(self.conv_2(v_pool_1, fm_pool_1, k1), self.bn2, fork=True)
-                a_0 = fm_0.view_as(fm_0)
+                if not fork0:
+                    a_0 = fm_0.view_as(fm_0)
                 self.backward_cut = None
                 fm_3, a_3 = ops.bn_relu(self.conv_3(v_pool_1, fm_2, k1), self.bn3, fork=True)
             else:

@@ -454,6 +454,21 @@ __global__ __launch_bounds__(256) void residual_bias_kernel(float* __restrict__ 
     }
 }
 
+// out[r][c] = (ga[r][c] (+ gb[r][c])) * [y[r][c] > 0]: the backward of an in-place relu on a tensor with two consumers (fm_0 of
+// FaceRecon.py:88: conv_1 and the concat) -- autograd's add and threshold_backward in one pass; ga / gb rows of an even pitch
+__global__ __launch_bounds__(256) void add_relu_bwd_kernel(const float* __restrict__ ga, int lda, const float* __restrict__ gb, int ldb,
+                                                           const float* __restrict__ y, long long total2, int C2,
+                                                           float* __restrict__ out) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total2; e += (long long)gridDim.x * 256) {
+        const unsigned row = (unsigned)((unsigned long long)e / (unsigned)C2);
+        const int c = (int)(e - (long long)row * C2) * 2;
+        float2 a = *reinterpret_cast<const float2*>(ga + (size_t)row * lda + c);
+        if (gb) { const float2 b = *reinterpret_cast<const float2*>(gb + (size_t)row * ldb + c); a.x += b.x; a.y += b.y; }
+        const float2 yy = *reinterpret_cast<const float2*>(y + e * 2);
+        *reinterpret_cast<float2*>(out + e * 2) = make_float2(yy.x > 0.f ? a.x : 0.f, yy.y > 0.f ? a.y : 0.f);
+    }
+}
+
 static int pick_scatter_cols(int Nsrc, int C) {
     static const int cap = [] { const char* e = getenv("HSP_SCATTER_TC"); return e ? atoi(e) : 16; }();
     for (int tc = cap; tc >= 4; tc >>= 1)
@@ -1025,6 +1040,19 @@ extern "C" int hsp_concat_rows_bf16(int nseg, const void* const* src, const int3
                                     const int* kind, const int* nsrc, int B, int N, hsp_bf16_t* out, int out_pitch,
                                     hspStream_t stream) {
     return concat_rows_impl<bf16_t>(nseg, src, idx, width, kind, nsrc, B, N, out, out_pitch, stream);
+}
+
+/* out (R, C) = (ga + gb) * [y > 0]: relu backward fused with the gradient sum of a two-consumer tensor (FaceRecon.py:88);
+ * ga / gb: rows of pitch lda / ldb (even, 8-byte aligned bases), gb may be NULL; y, out dense; C even */
+extern "C" int hsp_add_relu_bwd(const float* ga, int lda, const float* gb, int ldb, const float* y, int R, int C, float* out,
+                                hspStream_t stream) {
+    if (!ga || !y || !out || R <= 0 || C <= 0 || lda < C || (gb && ldb < C)) return HSP_ERR_BAD_ARG;
+    if ((C & 1) || (lda & 1) || (gb && (ldb & 1)) || (reinterpret_cast<size_t>(ga) & 7) || (reinterpret_cast<size_t>(gb) & 7))
+        return HSP_ERR_UNSUPPORTED;
+    const long long total2 = (long long)R * (C >> 1);
+    hipLaunchKernelGGL(add_relu_bwd_kernel, dim3(stream_grid(total2)), dim3(256), 0, as_stream(stream), ga, lda, gb, ldb, y, total2,
+                       C >> 1, out);
+    return check_launch();
 }
 
 extern "C" int hsp_residual_bias(float* out, const float* f, const float* t, int B, int N, int C, hspStream_t stream) {

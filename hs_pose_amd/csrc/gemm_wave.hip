@@ -161,7 +161,7 @@ template <int RB, int NCB, int LB0, int LB1, bool TWO, int EPI, typename TileFn>
 __device__ __forceinline__ void gw_tiles(const GwArgs& g, const GwRsrc& rs, int count, int cs, TileFn tile_of) {
     const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     constexpr bool two = TWO;
-    constexpr bool HAS_BIAS = EPI & 1, HAS_RES = EPI & 2, HAS_XYZ = EPI & 4;
+    constexpr bool HAS_BIAS = EPI & 1, HAS_RES = EPI & 2, HAS_XYZ = EPI & 4, HAS_RELU = EPI & 8;
     auto seg_of = [&](int i, int src) {
         GwSeg<RB> sg;
         int row0, col0;
@@ -259,6 +259,10 @@ __device__ __forceinline__ void gw_tiles(const GwArgs& g, const GwRsrc& rs, int 
                 if constexpr (HAS_RES) {          // (the host sends tiles that could span three clouds to gemm_rows)
 #pragma unroll
                     for (int c = 0; c < NCB; ++c) v[c] += rowc >= nb ? cbv[1][c] : cbv[0][c];
+                }
+                if constexpr (HAS_RELU) {         // FaceRecon.py:88: relu(conv_0(...)) in the producing kernel
+#pragma unroll
+                    for (int c = 0; c < NCB; ++c) v[c] = fmaxf(v[c], 0.f);
                 }
                 const unsigned off = ((unsigned)row * g.ldc + colb) * 4u;       // rows >= M fall outside the descriptor: dropped
 #if GW_ABLATE == 3
@@ -368,6 +372,8 @@ static bool gw_plan(int M, int N, int K1, int K2, int cfg, GwPlan* p) {
 
 using namespace hsp;
 
+static inline bool has_rc_check(const void* r, const void* c) { return r && c; }
+
 /* host-only: the cut chosen for a shape -> out[10] = RB, NCB, waves per SIMD, tiles_m, tiles_n, tiles per wave, waves,
  * first leftover tile, 32 x 32 blocks of the leftover tiles, 0; returns 0 when the shape is not covered */
 extern "C" int hsp_gemm_wave_plan_info(int M, int N, int K1, int K2, int cfg, int* out) {
@@ -413,12 +419,13 @@ extern "C" int hsp_gemm_wave_f32(const float* A1, int lda1, const float* B1, int
     g.TM = p.TM; g.TN = p.TN; g.T0 = K1 / 8; g.T1 = K2 / 8;
     g.base = p.base; g.nwaves = p.nwaves; g.u_rem = p.u_rem; g.npieces = p.npieces;
     g.order = (cfg >> 28) & 1;
+    if (((cfg >> 29) & 1) && !(xyz3 && has_rc_check(resid, cloud_bias))) return HSP_ERR_UNSUPPORTED;   // relu: surface form only
     const dim3 grid((unsigned)((p.nwaves + 3) / 4)), block(256);
     hipStream_t st = as_stream(stream);
     // instantiated forms (anything else: HSP_ERR_UNSUPPORTED -> hsp_gemm_rows_f32):
     //   0 fm   "nn"        + bias                      1 g W      "nn"                      2 x W^T  "nt"
     //   3 x W^T "nt" + bias                            4 out      "nt" + "nt", residual + cloud bias
-    //   5 out0  "nt", residual + cloud bias + xyz3     6 gX       "nn" + "nt"
+    //   5 out0  "nt", residual + cloud bias + xyz3 (7: + relu, cfg bit 29)     6 gX       "nn" + "nt"
     const bool has_rc = resid && cloud_bias;
     int form = -1;
     if (!two && b1_layout == 1 && bias && !resid && !cloud_bias && !xyz3) form = 0;
@@ -426,7 +433,7 @@ extern "C" int hsp_gemm_wave_f32(const float* A1, int lda1, const float* B1, int
     else if (!two && b1_layout == 0 && !bias && !resid && !cloud_bias && !xyz3) form = 2;
     else if (!two && b1_layout == 0 && bias && !resid && !cloud_bias && !xyz3) form = 3;
     else if (two && b1_layout == 0 && b2_layout == 0 && !bias && has_rc && !xyz3) form = 4;
-    else if (!two && b1_layout == 0 && !bias && has_rc && xyz3) form = 5;
+    else if (!two && b1_layout == 0 && !bias && has_rc && xyz3) form = ((cfg >> 29) & 1) ? 7 : 5;       // 7: + relu
     else if (two && b1_layout == 1 && b2_layout == 0 && !bias && !resid && !cloud_bias && !xyz3) form = 6;
     if (form < 0) return HSP_ERR_UNSUPPORTED;
     if (has_rc && g.rpc < 32 * p.RB) return HSP_ERR_UNSUPPORTED;       // a tile may span at most two clouds
@@ -440,6 +447,7 @@ extern "C" int hsp_gemm_wave_f32(const float* A1, int lda1, const float* B1, int
             case 3: GW_K(R, C_, W_, 0, 0, false, 1); break;    \
             case 4: GW_K(R, C_, W_, 0, 0, true, 2); break;     \
             case 5: GW_K(R, C_, W_, 0, 0, false, 6); break;    \
+            case 7: GW_K(R, C_, W_, 0, 0, false, 14); break;   \
             default: GW_K(R, C_, W_, 1, 0, true, 0); break;    \
         }                                                      \
     } while (0)

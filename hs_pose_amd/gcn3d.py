@@ -154,11 +154,15 @@ class HSlayer_surface(nn.Module):
         stdv = 1. / math.sqrt(self.support_num * self.kernel_num)
         self.directions.data.uniform_(-stdv, stdv)
 
-    def forward(self, vertices: "(bs, vertice_num, 3)", neighbor_num: int):
-        """(bs, vertice_num, kernel_num) -- STE + RF-P graph conv + ORL as one fused autograd node"""
+    def forward(self, vertices: "(bs, vertice_num, 3)", neighbor_num: int, relu_fork: bool = False):
+        """(bs, vertice_num, kernel_num) -- STE + RF-P graph conv + ORL as one fused autograd node.  ``relu_fork`` (fp32 rows):
+        relu inside the node, the result returned twice (ops.surface_layer)."""
         idx = _xyz_knn(vertices, neighbor_num)                       # RF-P
         if idx.shape[2] != neighbor_num:
             idx = idx[:, :, :neighbor_num].contiguous()
+        if relu_fork and self.out_dtype != torch.bfloat16:
+            return ops.surface_layer(vertices, idx, neighbor_num, self.support_num, self.directions, self.STE_layer.weight,
+                                     self.conv2.weight, relu=True)
         layer = ops_bf16.surface_layer if self.out_dtype == torch.bfloat16 else ops.surface_layer
         return layer(vertices, idx, neighbor_num, self.support_num, self.directions, self.STE_layer.weight, self.conv2.weight)
 

@@ -817,7 +817,7 @@ def _al16(t):
 
 
 def gemm_own(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=None, cloud_bias=None, rows_per_cloud=0, out=None,
-             alpha=1.0, xyz3=None, w3=None):
+             alpha=1.0, xyz3=None, w3=None, relu=False):
     """the fp32 product of ``gemm_rows`` on whichever hand-written kernel suits the shape: the LDS-free wave-level kernel
     (csrc/gemm_wave.hip) when the output is large against a short K -- many tiles that each live for a few k-blocks: fm = X W + b
     and the g Wa products; measured 13-14 us against 15-19 us, 24-48 us against 36-67 us -- and the LDS-staged tile kernel
@@ -830,8 +830,9 @@ def gemm_own(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=No
             and A1.dtype == torch.float32 and A1.stride(1) == 1 and B1.stride(1) == 1):
         return small_rows(A1, B1, nn1, out=out, alpha=alpha)          # a row per cloud: one small launch
     if M >= 256 and gemm_x3_ok(A1, B1, A2, B2, bias, resid, cloud_bias, xyz3, out, M, N) and (out is None or _al16(out)):
-        return gemm_x3(A1, B1, nn1, A2, B2, nn2, bias=bias, resid=resid, cloud_bias=cloud_bias, rows_per_cloud=rows_per_cloud,
-                       out=out, alpha=alpha)
+        res = gemm_x3(A1, B1, nn1, A2, B2, nn2, bias=bias, resid=resid, cloud_bias=cloud_bias, rows_per_cloud=rows_per_cloud,
+                      out=out, alpha=alpha)
+        return torch.relu_(res) if relu else res
     two, rc = A2 is not None, resid is not None and cloud_bias is not None
     plain = bias is None and resid is None and cloud_bias is None and xyz3 is None
     # the forms gemm_wave.hip instantiates: fm (nn + bias), g W (nn), x W^T (nt [+ bias]), out (nt + nt, residual + cloud bias),
@@ -844,9 +845,10 @@ def gemm_own(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=No
     if (form and A1.dtype == torch.float32 and K1 + K2 <= 512 and M * N >= 512 * 1024 and K1 % 32 == 0 and K2 % 32 == 0
             and N % 32 == 0 and (not rc or rows_per_cloud >= 64) and all(_al16(t) for t in (A1, B1, A2, B2, resid, out))):
         return gemm_wave(A1, B1, nn1, A2, B2, nn2, bias=bias, resid=resid, cloud_bias=cloud_bias, rows_per_cloud=rows_per_cloud,
-                         out=out, alpha=alpha, xyz3=xyz3, w3=w3)
-    return gemm_rows(A1, B1, nn1, A2, B2, nn2, bias=bias, resid=resid, cloud_bias=cloud_bias, rows_per_cloud=rows_per_cloud,
-                     out=out, alpha=alpha, xyz3=xyz3, w3=w3)
+                         out=out, alpha=alpha, xyz3=xyz3, w3=w3, cfg=(1 << 29) if relu else 0)
+    res = gemm_rows(A1, B1, nn1, A2, B2, nn2, bias=bias, resid=resid, cloud_bias=cloud_bias, rows_per_cloud=rows_per_cloud,
+                    out=out, alpha=alpha, xyz3=xyz3, w3=w3)
+    return torch.relu_(res) if relu else res
 
 
 def _fm_rows(X2, weights, bias, out=None):
@@ -858,7 +860,7 @@ def _fm_rows(X2, weights, bias, out=None):
                  lambda: torch.addmm(bias, X2, weights) if out is None else torch.addmm(bias, X2, weights, out=out))
 
 
-def _layer_out_rows(x2, w_ste, F2, Wa, t2, out3):
+def _layer_out_rows(x2, w_ste, F2, Wa, t2, out3, relu=False):
     """out = x Wste^T + F Wa^T + F + t[cloud]   (gcn3d.py:149,186,156): one fused launch, or GEMM + GEMM + residual pass"""
     B, N, C = out3.shape
     out = out3.view(B * N, C)
@@ -867,13 +869,15 @@ def _layer_out_rows(x2, w_ste, F2, Wa, t2, out3):
         torch.mm(x2, w_ste.t(), out=out)
         out.addmm_(F2, Wa.t())
         _residual_bias(out3, F2.view(B, N, C), t2)
-        return out3
+        return torch.relu_(out3) if relu else out3
     def own():
         if x2.shape[1] == 3:                                  # HSlayer_surface: the K = 3 STE on raw coordinates rides in the epilogue
             gemm_own(F2, Wa, False, resid=F2, cloud_bias=t2.contiguous(), rows_per_cloud=N, out=out, xyz3=x2,
-                     w3=w_ste.contiguous())
+                     w3=w_ste.contiguous(), relu=relu)       # (... and so does the relu that follows conv_0)
         else:
             gemm_own(x2, w_ste, False, F2, Wa, False, resid=F2, cloud_bias=t2.contiguous(), rows_per_cloud=N, out=out)
+            if relu:
+                torch.relu_(out3)
         return out3
     return _pick(f"out[R{B * N}K{x2.shape[1]}+{C}N{C}]", own, lib)
 
@@ -1121,7 +1125,7 @@ class _SurfaceLayer(torch.autograd.Function):
     """HSlayer_surface.forward (gcn3d.py:79-90) as one node; xyz carries no gradient."""
 
     @staticmethod
-    def forward(ctx, xyz, idx_x, k, S, directions, w_ste3, w_conv23):
+    def forward(ctx, xyz, idx_x, k, S, directions, w_ste3, w_conv23, relu=False):
         w_ste, w_conv2 = w_ste3.squeeze(-1), w_conv23.squeeze(-1)
         xyz = _req(xyz, torch.float32, "surface_layer.xyz")
         idx_x = _req(idx_x, torch.int32, "surface_layer.idx")
@@ -1139,14 +1143,33 @@ class _SurfaceLayer(torch.autograd.Function):
         F2, x2 = F3.view(B * N, C), xyz.view(B * N, 3)
         out3 = torch.empty(B, N, C, dtype=torch.float32, device=xyz.device)
         t2 = _mm_nt(fg, w_conv2[:, C:])
-        _layer_out_rows(x2, w_ste, F2, w_conv2[:, :C], t2, out3)
+        _layer_out_rows(x2, w_ste, F2, w_conv2[:, :C], t2, out3, relu=relu)
+        ctx.k, ctx.S, ctx.relu = k, S, relu
+        if relu:
+            # relu(conv_0(...)) (FaceRecon.py:88) inside the node: the relu rides in the product's epilogue, the result is handed
+            # out TWICE (conv_1 and the concat read it) and the two gradients + the relu mask meet in ONE pass in backward
+            ctx.save_for_backward(xyz, idx_x, arg, F3, arg_o, fg, directions, w_conv23, out3)
+            ctx.set_materialize_grads(False)
+            return out3, out3.view_as(out3)
         ctx.save_for_backward(xyz, idx_x, arg, F3, arg_o, fg, directions, w_conv23)
-        ctx.k, ctx.S = k, S
         return out3
 
     @staticmethod
-    def backward(ctx, g):
-        xyz, idx_x, arg, F3, arg_o, fg, directions, w_conv23 = ctx.saved_tensors
+    def backward(ctx, *gs):
+        if ctx.relu:
+            xyz, idx_x, arg, F3, arg_o, fg, directions, w_conv23, y = ctx.saved_tensors
+            gs = [t for t in gs if t is not None]
+            if not gs:
+                return (None,) * 8
+            B, N, C = F3.shape
+            (ga, lda) = _rows_pitch(gs[0], C)
+            (gb, ldb) = _rows_pitch(gs[1], C) if len(gs) > 1 else (None, 0)
+            g = torch.empty(B, N, C, dtype=torch.float32, device=y.device)
+            _run("hsp_add_relu_bwd", (_p(ga), lda, _p(gb), ldb, _p(y), B * N, C, _p(g), _stream()), key=f"R{B * N}C{C}",
+                 abytes=4 * (2 + len(gs)) * B * N * C)
+        else:
+            xyz, idx_x, arg, F3, arg_o, fg, directions, w_conv23 = ctx.saved_tensors
+            g = gs[0]
         w_conv2 = w_conv23.squeeze(-1)
         k, S = ctx.k, ctx.S
         g = _req(g, torch.float32, "surface_layer.grad")
@@ -1180,7 +1203,7 @@ class _SurfaceLayer(torch.autograd.Function):
              key=f"B{B}N{N}S{S}C{C}", abytes=B * N * (12 + 4 * C + SC) + 24 * SC)
         if not own_ste:
             g_ste = g2.t() @ x2
-        return None, None, None, None, gD, g_ste.unsqueeze_(-1), g_conv2.unsqueeze_(-1)
+        return None, None, None, None, gD, g_ste.unsqueeze_(-1), g_conv2.unsqueeze_(-1), None
 
 
 def hs_layer(xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste, w_conv2):
@@ -1189,9 +1212,10 @@ def hs_layer(xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste, w_con
     return _HSLayer.apply(xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste, w_conv2)
 
 
-def surface_layer(xyz, idx_x, k, S, directions, w_ste, w_conv2):
-    """HSlayer_surface.forward (gcn3d.py:79-90) given the xyz neighbour index (exactly k columns)."""
-    return _SurfaceLayer.apply(xyz, idx_x, k, S, directions, w_ste, w_conv2)
+def surface_layer(xyz, idx_x, k, S, directions, w_ste, w_conv2, relu=False):
+    """HSlayer_surface.forward (gcn3d.py:79-90) given the xyz neighbour index (exactly k columns).  ``relu``: apply the relu
+    that follows the layer (FaceRecon.py:88) inside the node and return the result TWICE (one tensor per consumer)."""
+    return _SurfaceLayer.apply(xyz, idx_x, k, S, directions, w_ste, w_conv2, relu)
 
 
 class _LinearRows(torch.autograd.Function):

@@ -173,6 +173,10 @@ int hsp_colsum_rows(const float *x, int B, int N, int C, float *out, void *ws, s
 
 /* out (B,N,C) += f (B,N,C) + t (B,C) broadcast over the points: the "+ feature" residual and the per-cloud
  * half of conv2 of an HS layer (gcn3d.py:112,186) in one pass. */
+/* out (R, C) = (ga + gb) * [y > 0]: the backward of relu(conv_0(...)) (FaceRecon.py:88) fused with the sum of the two gradients
+ * that reach fm_0 (conv_1 and the concat); ga / gb rows of an even pitch lda / ldb (8-byte aligned), gb may be NULL; C even */
+int hsp_add_relu_bwd(const float *ga, int lda, const float *gb, int ldb, const float *y, int R, int C, float *out,
+                     hspStream_t stream);
 int hsp_residual_bias(float *out, const float *f, const float *t, int B, int N, int C, hspStream_t stream);
 
 /* ---- feature assembly ---------------------------------------------------------------------------
@@ -242,7 +246,8 @@ int hsp_gemm_rows_bf16(const hsp_bf16_t *A1, int lda1, const hsp_bf16_t *B1, int
  * blocks -- so there are no partial sums and the result does not depend on the cut.  Covers K1, K2 multiples of 32, N a
  * multiple of 32, 16-byte aligned rows (hsp_gemm_wave_supported; anything else: hsp_gemm_rows_f32); fp32 on
  * v_mfma_f32_32x32x2_f32.  cfg: 0 = automatic tile / cut; otherwise RB | NCB << 4 | waves_per_simd << 16 | order << 28
- * (tuning: rows / 32 and columns / 32 of the wave tile, occupancy, 1 = row panels fastest in the tile order). */
+ * (tuning: rows / 32 and columns / 32 of the wave tile, occupancy, 1 = row panels fastest in the tile order); bit 29 of cfg:
+ * relu on the result (the xyz3 + residual + per-cloud-bias form only: relu(conv_0(...)) of FaceRecon.py:88 in the epilogue). */
 int hsp_gemm_wave_supported(int M, int N, int K1, int K2, int cfg);
 /* host-only: out[10] = rows / 32 and columns / 32 of the wave tile, waves per SIMD, tiles along M and N, whole tiles per wave,
  * waves, first leftover tile, 32 x 32 blocks of the leftover tiles, 0; returns 0 when the shape is not covered */
