@@ -71,7 +71,8 @@ __device__ __forceinline__ void x3_split8(const float (&x)[8], u32x4& hi, u32x4&
 
 // WM: 32-row blocks per wave along M (tile = 64 WM x 128).  TWO: second source.  EPI: bit 0 bias, bit 1 residual, bit 2
 // per-cloud bias (template parameters: a load inside a run-time branch costs a drained queue at the join)
-template <int WM, bool TWO, int EPI>
+// PA > 0: short-K form, all activation blocks (<= PA) fetched up front.
+template <int WM, bool TWO, int EPI, int PA = 0>
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
     constexpr int BM = 64 * WM;
     constexpr int A_PLANE = BM * 64, B_PLANE = X3_BN * 64;                 // bytes
@@ -107,19 +108,16 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
     // ---- staging registers of one block (ONE set, loads one block ahead.  Two sets / two blocks ahead were measured: the
     // 64-row kernels went from 112-128 to 146-158 VGPRs = one wave per SIMD fewer, and the step from 2.03 to 2.06 ms -- these
     // products are bound by memory latency against the workgroups resident per CU, not by the loads in flight per workgroup)
-    float av[1][NAU][8];
-    u32x4 bv[1][6];
+    u32x4 bv[6];
     const __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(g.A[0]), 0, (int)((((size_t)g.M - 1) * g.lda[0] + g.K[0]) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsA1 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(TWO ? g.A[1] : g.A[0]), 0, (int)((((size_t)g.M - 1) * g.lda[TWO ? 1 : 0] + g.K[TWO ? 1 : 0]) * 4), 0x00020000);
-    auto fetch = [&](auto setc, int t) {
-        constexpr int Q = decltype(setc)::value;
+    // A through a buffer descriptor: no branch around the loads (a load inside a run-time branch makes hipcc drain the queue at
+    // the join); rows past M and bytes past the last row read 0, a ragged K is masked when the block is split (stashA)
+    auto fetchA = [&](float (&dst)[NAU][8], int t) {
         const int src = (TWO && t >= T0) ? 1 : 0;
         const int kb = (src ? t - T0 : t) * X3_BK;
-        // A through a buffer descriptor: no branch around the loads (a load inside a run-time branch makes hipcc drain the
-        // queue at the join, which would undo the two-block prefetch); rows past M and bytes past the last row read 0, a
-        // ragged K is masked when the block is split (stash)
         const __amdgpu_buffer_rsrc_t ra = src ? rsA1 : rsA0;
         const unsigned lda = (unsigned)g.lda[src];
 #pragma unroll
@@ -130,19 +128,22 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
             const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0);
             const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(ra, off, 16, 0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { av[Q][i][e] = __uint_as_float(v0[e]); av[Q][i][4 + e] = __uint_as_float(v1[e]); }
+            for (int e = 0; e < 4; ++e) { dst[i][e] = __uint_as_float(v0[e]); dst[i][4 + e] = __uint_as_float(v1[e]); }
         }
+    };
+    auto fetchB = [&](int t) {
+        const int src = (TWO && t >= T0) ? 1 : 0;
+        const int kb = (src ? t - T0 : t) * X3_BK;
         const unsigned short* P = g.P[src];
         const int ldp = g.ldp[src];
         const long long ps = g.ps[src];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int q = tid + 256 * i, plane = q >> 9, w = q & 511, row = w >> 2, c = w & 3;
-            bv[Q][i] = *reinterpret_cast<const u32x4*>(P + plane * ps + (size_t)min(n0 + row, g.N - 1) * ldp + kb + 8 * c);
+            bv[i] = *reinterpret_cast<const u32x4*>(P + plane * ps + (size_t)min(n0 + row, g.N - 1) * ldp + kb + 8 * c);
         }
     };
-    auto stash = [&](auto setc, int t) {
-        constexpr int Q = decltype(setc)::value;
+    auto stashA = [&](float (&srcv)[NAU][8], int t) {
         {   // ragged K: the last block of a source may reach past K (into the next row's bytes): zero those elements
             const int src = (TWO && t >= T0) ? 1 : 0;
             const int kb = (src ? t - T0 : t) * X3_BK, K = g.K[src];
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
                 for (int i = 0; i < NAU; ++i) {
                     const int k0 = kb + 8 * ((tid + 256 * i) & 3);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) av[Q][i][e] = k0 + e < K ? av[Q][i][e] : 0.f;
+                    for (int e = 0; e < 8; ++e) srcv[i][e] = k0 + e < K ? srcv[i][e] : 0.f;
                 }
             }
         }
@@ -159,16 +160,18 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
         for (int i = 0; i < NAU; ++i) {
             const int u = tid + 256 * i, row = u >> 2, c8 = u & 3;
             u32x4 h, m, l;
-            x3_split8(av[Q][i], h, m, l);
+            x3_split8(srcv[i], h, m, l);
             const int off = row * 64 + ((c8 ^ ((row >> 2) & 3)) << 4);
             *reinterpret_cast<u32x4*>(sA + off) = h;
             *reinterpret_cast<u32x4*>(sA + A_PLANE + off) = m;
             *reinterpret_cast<u32x4*>(sA + 2 * A_PLANE + off) = l;
         }
+    };
+    auto stashB = [&]() {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int q = tid + 256 * i, plane = q >> 9, w = q & 511, row = w >> 2, c = w & 3;
-            *reinterpret_cast<u32x4*>(sB + plane * B_PLANE + row * 64 + ((c ^ ((row >> 2) & 3)) << 4)) = bv[Q][i];
+            *reinterpret_cast<u32x4*>(sB + plane * B_PLANE + row * 64 + ((c ^ ((row >> 2) & 3)) << 4)) = bv[i];
         }
     };
     auto mma = [&]() {
@@ -191,25 +194,49 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
                 for (int p = 0; p < 3; ++p) fb[y][p] = *reinterpret_cast<const u32x4*>(sB + p * B_PLANE + off);
             }
             // six slice products, small terms first: (h,l) (l,h) (m,m) (h,m) (m,h) (h,h)
-            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+            constexpr int SA[6] = {0, 2, 1, 0, 1, 0}, SB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
             for (int q = 0; q < 6; ++q)
 #pragma unroll
                 for (int x = 0; x < WM; ++x)
 #pragma unroll
                     for (int y = 0; y < 2; ++y)
-                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[x][PA[q]]),
-                                                                            __builtin_bit_cast(bf16x8, fb[y][PB[q]]), acc[x][y], 0, 0, 0);
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[x][SA[q]]),
+                                                                            __builtin_bit_cast(bf16x8, fb[y][SB[q]]), acc[x][y], 0, 0, 0);
         }
     };
-    using S0 = std::integral_constant<int, 0>;
-    if (t_begin < t_end) fetch(S0{}, t_begin);
-    for (int t = t_begin; t < t_end; ++t) {
-        __syncthreads();                       // the previous block's fragment reads are done
-        stash(S0{}, t);
-        __syncthreads();
-        if (t + 1 < t_end) fetch(S0{}, t + 1); // in flight under this block's MFMAs
-        mma();
+    if constexpr (PA > 0) {
+        // SHORT K (at most PA blocks, e.g. the layer's out / gF products: K = 128 ... 256 on 257 workgroups -- about one per CU,
+        // nothing to overlap with): every activation load of the tile is issued before the first block, so the tile pays ONE
+        // HBM round trip instead of one per block; the weight planes (L2) stay one block ahead.  Loads past the last block
+        // re-read it (no branch around a load).
+        float ava[PA][NAU][8];
+#pragma unroll
+        for (int tt = 0; tt < PA; ++tt) fetchA(ava[tt], min(t_begin + tt, t_end - 1));
+        fetchB(t_begin);
+#pragma unroll
+        for (int tt = 0; tt < PA; ++tt) {
+            const int t = t_begin + tt;
+            if (t < t_end) {
+                __syncthreads();
+                stashA(ava[tt], t);
+                stashB();
+                __syncthreads();
+            }
+            fetchB(min(t + 1, t_end - 1));
+            if (t < t_end) mma();
+        }
+    } else {
+        float av[NAU][8];
+        if (t_begin < t_end) { fetchA(av, t_begin); fetchB(t_begin); }
+        for (int t = t_begin; t < t_end; ++t) {
+            __syncthreads();                   // the previous block's fragment reads are done
+            stashA(av, t);
+            stashB();
+            __syncthreads();
+            if (t + 1 < t_end) { fetchA(av, t + 1); fetchB(t + 1); }   // in flight under this block's MFMAs
+            mma();
+        }
     }
 
     // ---- epilogue: accumulator r of (x, y) <-> row m0 + wm0 + 32 x + (r & 3) + 8 (r >> 2) + 4 lh, column n0 + wn0 + 32 y + li
@@ -434,25 +461,31 @@ extern "C" int hsp_gemm_x3_f32(const float* A1, int lda1, const hsp_bf16_t* P1, 
     const dim3 grid((unsigned)items), block(256);
     // instantiated epilogues: 0 none, 1 bias, 6 residual + per-cloud bias (the layer's out product)
     if (epi != 0 && epi != 1 && epi != 6) return HSP_ERR_UNSUPPORTED;
-#define X3_K(WM_, TWO_, EPI_)                                                                                      \
+    // (measured, B=16 N=1028: 1.93 ms/step with the short-K form against 1.92 without -- the tile's time is the weight planes'
+    // round trips as much as the activations' -- so it is opt-in: HSP_X3_PA=1)
+    static const bool pa_on = [] { const char* e = getenv("HSP_X3_PA"); return e && e[0] == '1'; }();
+    const bool short_k = pa_on && wm == 1 && ns == 1 && TT <= 8;
+#define X3_K(WM_, TWO_, EPI_, PA_)                                                                                 \
     do {                                                                                                           \
-        auto kern = gemm_x3_kernel<WM_, TWO_, EPI_>;                                                               \
+        auto kern = gemm_x3_kernel<WM_, TWO_, EPI_, PA_>;                                                          \
         const size_t lds = 3 * (size_t)(64 * WM_ + X3_BN) * 64;                                                    \
         hipLaunchKernelGGL(kern, grid, block, lds, st, g);                                                         \
     } while (0)
-#define X3_LAUNCH(WM_)                                             \
+#define X3_LAUNCH(WM_, PA_)                                        \
     do {                                                           \
         if (two) {                                                 \
-            if (epi == 0) X3_K(WM_, true, 0);                      \
-            else if (epi == 1) X3_K(WM_, true, 1);                 \
-            else X3_K(WM_, true, 6);                               \
+            if (epi == 0) X3_K(WM_, true, 0, PA_);                 \
+            else if (epi == 1) X3_K(WM_, true, 1, PA_);            \
+            else X3_K(WM_, true, 6, PA_);                          \
         } else {                                                   \
-            if (epi == 0) X3_K(WM_, false, 0);                     \
-            else if (epi == 1) X3_K(WM_, false, 1);                \
-            else X3_K(WM_, false, 6);                              \
+            if (epi == 0) X3_K(WM_, false, 0, PA_);                \
+            else if (epi == 1) X3_K(WM_, false, 1, PA_);           \
+            else X3_K(WM_, false, 6, PA_);                         \
         }                                                          \
     } while (0)
-    if (wm == 2) X3_LAUNCH(2); else X3_LAUNCH(1);
+    if (wm == 2) X3_LAUNCH(2, 0);
+    else if (short_k) X3_LAUNCH(1, 8);
+    else X3_LAUNCH(1, 0);
 #undef X3_LAUNCH
 #undef X3_K
     int rc = check_launch();

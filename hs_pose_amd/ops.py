@@ -370,6 +370,7 @@ class _PoolLayer(torch.autograd.Function):
         ctx.save_for_backward(idx, qsel, arg)
         ctx.dims = (B, N, idx.shape[1], Nq, kstride, C)
         ctx.mark_non_differentiable(vsel)
+        ctx.set_materialize_grads(False)          # (else autograd fills a zero gradient for vsel every step: two fill kernels)
         return out, vsel
 
     @staticmethod
