@@ -63,6 +63,7 @@ class FaceRecon(nn.Module):
             self.face_head = nn.Sequential(*cbr(FLAGS.feat_face + 3, 512), *cbr(512, 256), *cbr(256, 128),
                                            nn.Conv1d(128, self.face_recon_num, 1))
 
+    _x3 = None                       # ops.X3Planes of this network (created on first use; PoseNet9D shares it with the heads)
     keep_backward_cut = False
     backward_cut = None
     feature_dtype = torch.float32
@@ -95,6 +96,14 @@ class FaceRecon(nn.Module):
 
     def forward(self, vertices: "tensor (bs, vetice_num, 3)", cat_id: "tensor (bs, 1)"):
         """-> (recon (bs,N,3) | None, face (bs,N,face_recon_c) | None, feat (bs,N,1286))"""
+        bs, vertice_num, _ = vertices.size()
+        k = self.neighbor_num
+        if self._x3 is None:
+            self._x3 = ops.X3Planes()
+        with ops.x3_scope(self._x3):
+            return self._forward(vertices, cat_id)
+
+    def _forward(self, vertices, cat_id):
         bs, vertice_num, _ = vertices.size()
         k = self.neighbor_num
         if self._bf16 is not None:

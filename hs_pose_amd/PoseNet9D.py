@@ -39,6 +39,12 @@ class PoseNet9D(nn.Module):
         self.ts = Pose_Ts()
 
     def forward(self, points, obj_id):
+        if self.face_recon._x3 is None:
+            self.face_recon._x3 = ops.X3Planes()
+        with ops.x3_scope(self.face_recon._x3):          # the heads' weight planes live in the backbone's registry
+            return self._forward(points, obj_id)
+
+    def _forward(self, points, obj_id):
         centre = points.mean(dim=1, keepdim=True)
         local = points - centre                                  # the network sees clouds centred on their mean
         recon, face, feat = self.face_recon(local, obj_id)

@@ -667,10 +667,16 @@ def gemm_wave(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=N
 # moved the weights since the last one), a matrix seen for the first time is registered and split on the spot.
 # ------------------------------------------------------------------------------------------------
 class X3Planes:
+    """The registry of ONE network (FaceRecon / PoseNet9D own one and make it current for their forward; the autograd nodes
+    remember it for their backward).  Entries keep a reference to the weight view they split, so an address cannot be reused by
+    another matrix while its entry lives; the registry -- tables, planes and references -- goes away with the network.  A table
+    that was replaced (a matrix registered later) is parked, not freed: a captured hipGraph may still point to it."""
+
     def __init__(self):
-        self.entries = {}            # key -> dict(src=tensor (kept alive), planes, N, K, kp, transpose)
+        self.entries = {}            # key -> dict(src (kept alive), planes, N, K, kp, transpose)
         self.table = None            # device table of every entry (rebuilt when an entry is added)
         self.total_tiles = 0
+        self._old_tables = []
 
     @staticmethod
     def _key(W, transpose):
@@ -691,6 +697,8 @@ class X3Planes:
                      transpose=bool(transpose))
             self.entries[k_] = e
             self._split([e])                                   # this matrix now ...
+            if self.table is not None:
+                self._old_tables.append(self.table)
             self.table, self.total_tiles = self._table_of(list(self.entries.values()))   # ... and the table of all for refresh()
         return e["planes"], e["kp"], e["N"] * e["kp"]
 
@@ -720,13 +728,32 @@ class X3Planes:
              abytes=sum(10 * e["N"] * e["K"] for e in ents))
 
 
-x3_planes = X3Planes()
+x3_planes = X3Planes()               # the CURRENT registry (a process-wide one until a network installs its own: x3_scope)
+
+
+class x3_scope:
+    """``with ops.x3_scope(reg):`` makes ``reg`` the registry the x3 products look their weight planes up in"""
+
+    def __init__(self, reg):
+        self.reg = reg
+
+    def __enter__(self):
+        global x3_planes
+        self.prev, x3_planes = x3_planes, (self.reg if self.reg is not None else x3_planes)
+        return self.reg
+
+    def __exit__(self, *exc):
+        global x3_planes
+        x3_planes = self.prev
+        return False
+
+
 # HSP_GEMM_X3=0: the hand-written path stays on the fp32 matrix cores (gemm_wave / gemm_rows) everywhere
 GEMM_X3 = os.environ.get("HSP_GEMM_X3", "1") != "0"
 
 
 def x3_refresh():
-    """re-split every registered weight matrix (one launch); call once per forward, before the first product"""
+    """re-split every weight matrix of the current registry (one launch); call once per forward, before the first product"""
     if GEMM_X3 and GEMM_MODE != "library":
         x3_planes.refresh()
 
@@ -1092,7 +1119,7 @@ class _HSLayer(torch.autograd.Function):
         t2 = _mm_nt(fg, w_conv2[:, C:])                                        # (B,C): the per-cloud half of conv2
         _layer_out_rows(X2, w_ste, F2, w_conv2[:, :C], t2, out3)               # X Wste^T + F Wa^T + F + t[b]
         ctx.save_for_backward(xyz, X, idx_f, idx_x, fm, arg, F3, arg_o, fg, weights, directions, w_ste3, w_conv23)
-        ctx.k, ctx.S = k, S
+        ctx.k, ctx.S, ctx.x3 = k, S, x3_planes
         return out3
 
     @staticmethod
@@ -1107,7 +1134,7 @@ class _HSLayer(torch.autograd.Function):
         Wa, Wb = w_conv2[:, :C], w_conv2[:, C:]
         gt = colsum_rows(g)                                                    # (B,C) = sum_i g
         g_conv2 = torch.empty_like(w_conv2)
-        with WgradBatch():                                                     # the three parameter gradients: one fold launch
+        with WgradBatch(), x3_scope(ctx.x3):                                   # the three parameter gradients: one fold launch
             g_ste = torch.empty(C, Cin, dtype=torch.float32, device=g.device)
             wgrad_pair(g2, F2, g_conv2[:, :C], g2, X2, g_ste)                  # gWa (in place, ldc = 2C) and gWste: one split-K launch
             _tiny_tn(gt, fg, g_conv2[:, C:])                                   # gWb = gt^T fg (tiny), straight into its column block
@@ -1145,7 +1172,7 @@ class _SurfaceLayer(torch.autograd.Function):
         out3 = torch.empty(B, N, C, dtype=torch.float32, device=xyz.device)
         t2 = _mm_nt(fg, w_conv2[:, C:])
         _layer_out_rows(x2, w_ste, F2, w_conv2[:, :C], t2, out3, relu=relu)
-        ctx.k, ctx.S, ctx.relu = k, S, relu
+        ctx.k, ctx.S, ctx.relu, ctx.x3 = k, S, relu, x3_planes
         if relu:
             # relu(conv_0(...)) (FaceRecon.py:88) inside the node: the relu rides in the product's epilogue, the result is handed
             # out TWICE (conv_1 and the concat read it) and the two gradients + the relu mask meet in ONE pass in backward
@@ -1194,7 +1221,8 @@ class _SurfaceLayer(torch.autograd.Function):
         else:
             _tiny_tn(gt, fg, g_conv2[:, C:])
         gF3 = torch.empty(B, N, C, dtype=torch.float32, device=g.device)
-        _mm_nn(g2, Wa, out=gF3.view(B * N, C))
+        with x3_scope(ctx.x3):
+            _mm_nn(g2, Wa, out=gF3.view(B * N, C))
         _orl_bwd_accumulate_raw(_mm_nn(gt, Wb, alpha=1.0 / N), idx_x, arg_o, k, gF3, extra=g)
         gD = torch.empty_like(directions)
         L = lib()
@@ -1233,13 +1261,15 @@ class _LinearRows(torch.autograd.Function):
             x2 = _req(x2, torch.float32, "linear_rows.x")
         ctx.save_for_backward(x2, weight)
         ctx.has_bias = bias is not None
+        ctx.x3 = x3_planes
         return _mm_nt(x2, weight, bias)
 
     @staticmethod
     def backward(ctx, g):
         x2, weight = ctx.saved_tensors
         g = _req(g, torch.float32, "linear_rows.grad")
-        gx = _mm_nn(g, weight) if ctx.needs_input_grad[0] else None
+        with x3_scope(ctx.x3):
+            gx = _mm_nn(g, weight) if ctx.needs_input_grad[0] else None
         R, Cout = g.shape
         gb = None
         if Cout % 64 == 0 and x2.shape[1] % 64 == 0:
