@@ -444,6 +444,160 @@ __global__ __launch_bounds__(256) void wgrad_bf16_mfma_kernel(const unsigned sho
 }
 
 // slices for the bf16-MFMA form: ~512 workgroups, >= 4 blocks of 64 rows per slice, <= 128 partial copies
+// ---- fp32 point rows on the BF16 matrix cores, fp32-accurate: C = A^T B from exact three-way bf16 splits ------------------------
+// (the weight-gradient twin of csrc/gemm_x3.hip: x = hi + mid + lo by truncation, six exact slice products per k accumulated
+// in fp32 by v_mfma_f32_32x32x16_bf16; the dropped terms are < 2^-23 |a||b| per product.)  wgrad_kernel holds 135 TFLOP/s = 87 %
+// of the fp32-MFMA peak on the two large shapes of the step -- it IS matrix-core-bound -- and six bf16 MFMAs per 16 k take 192
+// clocks where the fp32 form takes 512.  128 x 128 tile x K slice per workgroup; a staging thread loads 8 (k) x 4 (m) fp32
+// (eight 16-byte row pieces, 512 contiguous bytes per k row and half-wave), splits them and writes, per column and plane, the
+// 16-byte (m, 8 k) chunk the MFMA wants -- the k-major -> m-major transpose costs nothing extra because every fp32 sits in its own
+// register (one v_perm_b32 per bf16 pair).  LDS: 6 planes of 128 rows x 80 bytes (64 of k + 16 of pad: the 16 lanes of a
+// ds_read_b128 group hit 16 disjoint bank quads without a swizzle), one stage, two workgroups per CU.
+template <bool COLSUM>
+__global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                          int M, int N, int K, int kslice, float* __restrict__ part,
+                                                          float* __restrict__ cs_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PITCH = 80, PLANE = 128 * PITCH;             // bytes
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_m = M >> 7, tiles = tiles_m * (N >> 7);
+    const int slice = blockIdx.x / tiles, t = blockIdx.x - slice * tiles;
+    const int tn = t / tiles_m, tm = t - tn * tiles_m;
+    const int m0 = tm << 7, n0 = tn << 7;
+    const int k0 = slice * kslice, k1 = min(K, k0 + kslice);
+    const int nblk = (k1 - k0 + 31) >> 5;
+
+    // staging role: waves 0,1 take A, waves 2,3 take B; thread = (k octet kb8 of the 32-row block, column quad mc)
+    const int half = tid >> 7, id = tid & 127;
+    const int kb8 = id >> 5, mc = id & 31;
+    const float* src = half ? B + n0 + mc * 4 : A + m0 + mc * 4;
+    const int ld = half ? ldb : lda;
+    char* const img = smem + half * 3 * PLANE;
+
+    float4 r[8];
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int b) {
+        const int kr = k0 + (b << 5) + (kb8 << 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = kr + j < k1 ? kr + j : k1 - 1;                  // clamped (branch-free); zeroed in stash
+            r[j] = *reinterpret_cast<const float4*>(src + (size_t)row * ld);
+        }
+    };
+    auto stash = [&](int b) {
+        const int kr = k0 + (b << 5) + (kb8 << 3);
+        if (kr + 8 > k1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (kr + j >= k1) r[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (COLSUM && half == 1 && tm == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { cs[0] += r[j].x; cs[1] += r[j].y; cs[2] += r[j].z; cs[3] += r[j].w; }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v[8], r1[8], r2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = e == 0 ? r[j].x : e == 1 ? r[j].y : e == 2 ? r[j].z : r[j].w;
+                const float h = __uint_as_float(__float_as_uint(v[j]) & 0xffff0000u);
+                r1[j] = v[j] - h;
+                const float mm = __uint_as_float(__float_as_uint(r1[j]) & 0xffff0000u);
+                r2[j] = r1[j] - mm;
+            }
+            uint4 ch, cm, cl;
+            unsigned* ph = reinterpret_cast<unsigned*>(&ch);
+            unsigned* pm = reinterpret_cast<unsigned*>(&cm);
+            unsigned* pl = reinterpret_cast<unsigned*>(&cl);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ph[i] = __builtin_amdgcn_perm(__float_as_uint(v[2 * i + 1]), __float_as_uint(v[2 * i]), 0x07060302u);
+                pm[i] = __builtin_amdgcn_perm(__float_as_uint(r1[2 * i + 1]), __float_as_uint(r1[2 * i]), 0x07060302u);
+                pl[i] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * i + 1]), __float_as_uint(r2[2 * i]), 0x07060302u);
+            }
+            char* dst = img + ((mc << 2) + e) * PITCH + (kb8 << 4);
+            *reinterpret_cast<uint4*>(dst) = ch;
+            *reinterpret_cast<uint4*>(dst + PLANE) = cm;
+            *reinterpret_cast<uint4*>(dst + 2 * PLANE) = cl;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int li = lane & 31, lh = lane >> 5;
+    auto compute = [&]() {
+        const char* sa = smem + (wm0 + li) * PITCH;
+        const char* sb = smem + 3 * PLANE + (wn0 + li) * PITCH;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int coff = (2 * s2 + lh) << 4;
+            uint4 fa[2][3], fb[2][3];
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) fa[x][p] = *reinterpret_cast<const uint4*>(sa + p * PLANE + x * 32 * PITCH + coff);
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) fb[y][p] = *reinterpret_cast<const uint4*>(sb + p * PLANE + y * 32 * PITCH + coff);
+            constexpr int SA[6] = {0, 2, 1, 0, 1, 0}, SB[6] = {2, 0, 1, 1, 0, 0};     // small terms first
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y)
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[x][SA[q]]),
+                                                                            __builtin_bit_cast(bf16x8_t, fb[y][SB[q]]), acc[x][y], 0, 0, 0);
+        }
+    };
+
+    if (nblk > 0) fetch(0);
+    for (int b = 0; b < nblk; ++b) {
+        __syncthreads();                       // the previous block's fragment reads are done
+        stash(b);
+        __syncthreads();
+        if (b + 1 < nblk) fetch(b + 1);
+        compute();
+    }
+    float* pc = part + (size_t)slice * M * N;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = m0 + wm0 + 32 * x + (q & 3) + 8 * (q >> 2) + 4 * lh;
+                pc[(size_t)row * N + n0 + wn0 + 32 * y + li] = acc[x][y][q];
+            }
+    if (COLSUM && tm == 0) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);          // [4 k octets][128 columns]  (the stage is dead here)
+        if (half == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[kb8 * 128 + mc * 4 + e] = cs[e];
+        }
+        __syncthreads();
+        if (tid < 128) cs_part[(size_t)slice * N + n0 + tid] = ((red[tid] + red[128 + tid]) + red[256 + tid]) + red[384 + tid];
+    }
+}
+
+static bool wgrad_x3_ok(const void* A, int lda, const void* B, int ldb, int M, int N) {
+    static const bool off = [] { const char* e = getenv("HSP_WGRAD_X3"); return e && e[0] == '0'; }();
+    // (>= 4 output tiles: a single 128 x 128 tile leaves the K slices as the only parallelism -- 65 workgroups at K = 16448 --
+    // and the fp32 kernel's 4-slices-per-workgroup form is faster there: 9.8 vs 18.3 us)
+    return !off && (M & 127) == 0 && (N & 127) == 0 && (M >> 7) * (N >> 7) >= 4 && (lda & 3) == 0 && (ldb & 3) == 0 &&
+           ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(B)) & 15) == 0;
+}
+
 static int wgrad_bf16_pick(int M, int N, int K, int* kslice) {
     const int tiles = (M >> 7) * (N >> 7);
     int sk = tiles > 0 ? (512 + tiles - 1) / tiles : 1;
@@ -558,6 +712,24 @@ static int wgrad_impl(const FT* A, int lda, const FT* B, int ldb, int M, int N, 
     } while (0)
             if (colsum_B) WG_BF16_LAUNCH(true); else WG_BF16_LAUNCH(false);
 #undef WG_BF16_LAUNCH
+            int rc = check_launch();
+            if (rc) return rc;
+            if (pending) { *pending = HspWgradPending{part, cs_part, C, colsum_B, sk2, M, N, ldc}; return HSP_OK; }
+            const long long total = (long long)M * (N >> 2) + (colsum_B ? (N >> 2) : 0);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, part, sk2, M, N, C, ldc,
+                               cs_part, colsum_B);
+            return check_launch();
+        }
+    }
+    if constexpr (sizeof(FT) == 4) {
+        if (wgrad_x3_ok(A, lda, B, ldb, M, N)) {
+            const int sk2 = wgrad_bf16_pick(M, N, K, &ks);
+            float* part = reinterpret_cast<float*>(ws);
+            float* cs_part = part + (size_t)sk2 * M * N;
+            const int grid = (M >> 7) * (N >> 7) * sk2;
+            const int lds = 6 * 128 * 80;
+            if (colsum_B) hipLaunchKernelGGL(wgrad_x3_kernel<true>, dim3(grid), dim3(256), lds, st, A, lda, B, ldb, M, N, K, ks, part, cs_part);
+            else hipLaunchKernelGGL(wgrad_x3_kernel<false>, dim3(grid), dim3(256), lds, st, A, lda, B, ldb, M, N, K, ks, part, cs_part);
             int rc = check_launch();
             if (rc) return rc;
             if (pending) { *pending = HspWgradPending{part, cs_part, C, colsum_B, sk2, M, N, ldc}; return HSP_OK; }
