@@ -122,26 +122,35 @@ class FaceRecon(nn.Module):
             # consumer (``fork``), so their gradients meet inside its backward kernels instead of in an element-wise add.  The
             # two-graph split (keep_backward_cut) cuts at single aliases and keeps the plain form.
             fork = od is None and not self.keep_backward_cut and os.environ.get("HSP_BN_FORK", "1") != "0"
+
+            def layer_bn(conv, bn, *a):
+                """bn_relu(conv(...)); fp32 rows in train mode: the layer's out product also leaves the first pass of the
+                BatchNorm statistics (ops.hs_layer bn_shift), whatever the fork mode -- graph and eager twins stay bit-equal"""
+                if (od is None and bn.training and bn.track_running_stats and torch.is_grad_enabled()
+                        and os.environ.get("HSP_BN_EPILOGUE", "1") != "0"):
+                    out, part = conv(*a, bn_shift=True)
+                    return ops.bn_relu(out, bn, fork=fork, partial=part)
+                return ops.bn_relu(conv(*a), bn, out_dtype=od, fork=fork)
             if fork:
-                fm_1, a_1 = ops.bn_relu(self.conv_1(vertices, fm_0, k), self.bn1, fork=True)
+                fm_1, a_1 = layer_bn(self.conv_1, self.bn1, vertices, fm_0, k)
                 v_pool_1, fm_pool_1 = self.pool_1(vertices, fm_1)
                 k1 = min(k, v_pool_1.shape[1] // 8)
-                fm_2, a_2 = ops.bn_relu(self.conv_2(v_pool_1, fm_pool_1, k1), self.bn2, fork=True)
+                fm_2, a_2 = layer_bn(self.conv_2, self.bn2, v_pool_1, fm_pool_1, k1)
                 if not fork0:
                     a_0 = fm_0.view_as(fm_0)
                 self.backward_cut = None
-                fm_3, a_3 = ops.bn_relu(self.conv_3(v_pool_1, fm_2, k1), self.bn3, fork=True)
+                fm_3, a_3 = layer_bn(self.conv_3, self.bn3, v_pool_1, fm_2, k1)
             else:
-                fm_1 = ops.bn_relu(self.conv_1(vertices, fm_0, k), self.bn1, out_dtype=od)
+                fm_1 = layer_bn(self.conv_1, self.bn1, vertices, fm_0, k)
                 v_pool_1, fm_pool_1 = self.pool_1(vertices, fm_1)
                 k1 = min(k, v_pool_1.shape[1] // 8)
-                fm_2 = ops.bn_relu(self.conv_2(v_pool_1, fm_pool_1, k1), self.bn2, out_dtype=od)
+                fm_2 = layer_bn(self.conv_2, self.bn2, v_pool_1, fm_pool_1, k1)
                 # The coarse levels and the concat read the fine levels through aliases (no kernels): every path from feat
                 # down to an alias stays above the others, so a backward pass can stop at them and be resumed
                 # (graph.py::GraphedStep(split=True) reduces the coarse levels' gradients while the fine levels still run).
                 a_0, a_1, a_2 = fm_0.view_as(fm_0), fm_1.view_as(fm_1), fm_2.view_as(fm_2)
                 self.backward_cut = (a_0, a_1, a_2) if self.keep_backward_cut else None   # holds the autograd graph: opt-in
-                fm_3 = a_3 = ops.bn_relu(self.conv_3(v_pool_1, a_2, k1), self.bn3, out_dtype=od)
+                fm_3 = a_3 = layer_bn(self.conv_3, self.bn3, v_pool_1, a_2, k1)
             v_pool_2, fm_pool_2 = self.pool_2(v_pool_1, fm_3)
             k2 = min(k, v_pool_2.shape[1] // 8)
             fm_4 = self.conv_4(v_pool_2, fm_pool_2, k2)

@@ -46,6 +46,8 @@ struct X3Args {
     float alpha;
     int tiles_m, tiles_n, nsplit;
     float* ws;                             // split-K partial tiles ws[split][M][N]
+    float* bn_shift;                       // EPI bit 3: per-column shift (N), WRITTEN here: resid[0][n] + cloud_bias[0][n] ...
+    float* bn_part;                        // ... and the BatchNorm partial sums [tile_m][2][N] of the RESULT rows
 };
 
 #define X3_BN 128
@@ -255,7 +257,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
         }
         return;
     }
-    constexpr bool HAS_BIAS = EPI & 1, HAS_RES = EPI & 2, HAS_CB = EPI & 4;
+    constexpr bool HAS_BIAS = EPI & 1, HAS_RES = EPI & 2, HAS_CB = EPI & 4, HAS_BN = EPI & 8;
+    float bn1[2] = {0.f, 0.f}, bn2[2] = {0.f, 0.f};           // per column of this lane: sum (v - shift), sum (v - shift)^2
     // per-cloud bias: a tile of BM rows spans at most two clouds when rows_per_cloud >= BM (boundary compare, no division)
     const int c0 = m0 / g.rpc, nb = (c0 + 1) * g.rpc;
     const bool two_clouds = g.rpc >= BM;
@@ -264,8 +267,15 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
         const int col = n0 + wn0 + 32 * y + li;
         const bool cok = col < g.N;
         const int colc = min(col, g.N - 1);
-        float bvv = 0.f, cb0 = 0.f, cb1 = 0.f;
+        float bvv = 0.f, cb0 = 0.f, cb1 = 0.f, bsh = 0.f;
         if constexpr (HAS_BIAS) bvv = g.bias[colc];
+        if constexpr (HAS_BN) {
+            // the shift of the shifted sums: any per-column value every tile agrees on and that sits near the column's mean --
+            // the residual + per-cloud-bias part of ROW 0 of the result (data of this step only: a replayed graph and an eager
+            // step compute identical bits; a running statistic would not give that)
+            bsh = g.resid[colc] + g.cbias[colc];
+            if (tm == 0 && wm0 == 0 && lh == 0 && cok) g.bn_shift[col] = bsh;
+        }
         if constexpr (HAS_CB) {
             cb0 = g.cbias[(size_t)c0 * g.N + colc];
             cb1 = g.cbias[(size_t)min(c0 + 1, (g.M - 1) / g.rpc) * g.N + colc];
@@ -293,8 +303,33 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
                         else v += g.cbias[(size_t)(min(row, g.M - 1) / g.rpc) * g.N + colc];
                     }
                     if (row < g.M && cok) g.C[(size_t)row * g.ldc + col] = v;
+                    if constexpr (HAS_BN) {
+                        const float d = row < g.M ? v - bsh : 0.f;
+                        bn1[y] += d;
+                        bn2[y] += d * d;
+                    }
                 }
             }
+        }
+    }
+    if constexpr (HAS_BN) {
+        // the train-mode BatchNorm that follows the layer (FaceRecon.py:90-95) gets its first pass here: per-tile shifted column
+        // sums of the rows just written, in the layout bn_finalize_kernel folds ([row tile][2][C]; fixed order: lane halves,
+        // then the two row waves)
+        __syncthreads();                                       // every wave is past its last fragment read: smem is free
+        float* red = reinterpret_cast<float*>(smem);           // [row wave][2][128]
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const float a = bn1[y] + __shfl_xor(bn1[y], 32, 64), b = bn2[y] + __shfl_xor(bn2[y], 32, 64);
+            if (lh == 0) {
+                red[((wave >> 1) * 2 + 0) * 128 + wn0 + 32 * y + li] = a;
+                red[((wave >> 1) * 2 + 1) * 128 + wn0 + 32 * y + li] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < g.N) {
+            g.bn_part[((size_t)tm * 2 + 0) * g.N + n0 + tid] = red[0 * 128 + tid] + red[2 * 128 + tid];
+            g.bn_part[((size_t)tm * 2 + 1) * g.N + n0 + tid] = red[1 * 128 + tid] + red[3 * 128 + tid];
         }
     }
 }
@@ -427,10 +462,11 @@ extern "C" size_t hsp_gemm_x3_workspace_bytes(int M, int N, int K1, int K2) {
     return ns > 1 ? (size_t)ns * M * N * sizeof(float) : 0;
 }
 
-extern "C" int hsp_gemm_x3_f32(const float* A1, int lda1, const hsp_bf16_t* P1, int ldp1, long long ps1, int K1,
-                               const float* A2, int lda2, const hsp_bf16_t* P2, int ldp2, long long ps2, int K2, int M, int N,
-                               const float* bias, const float* resid, int ldr, const float* cloud_bias, int rows_per_cloud,
-                               float alpha, float* C, int ldc, void* ws, size_t ws_bytes, hspStream_t stream) {
+static int gemm_x3_impl(const float* A1, int lda1, const hsp_bf16_t* P1, int ldp1, long long ps1, int K1,
+                        const float* A2, int lda2, const hsp_bf16_t* P2, int ldp2, long long ps2, int K2, int M, int N,
+                        const float* bias, const float* resid, int ldr, const float* cloud_bias, int rows_per_cloud,
+                        float alpha, float* C, int ldc, void* ws, size_t ws_bytes, float* bn_shift, float* bn_part,
+                        hspStream_t stream) {
     if (!A1 || !P1 || !C || M <= 0 || N <= 0 || K1 <= 0 || lda1 < K1 || ldc < N) return HSP_ERR_BAD_ARG;
     const bool two = A2 != nullptr;
     if (two && (!P2 || K2 <= 0 || lda2 < K2)) return HSP_ERR_BAD_ARG;
@@ -448,7 +484,10 @@ extern "C" int hsp_gemm_x3_f32(const float* A1, int lda1, const hsp_bf16_t* P1, 
     g.A[1] = A2; g.P[1] = P2; g.lda[1] = lda2; g.ldp[1] = ldp2; g.K[1] = K2; g.ps[1] = ps2;
     g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.bias = bias; g.resid = resid; g.ldr = ldr;
     g.cbias = cloud_bias; g.rpc = rows_per_cloud > 0 ? rows_per_cloud : 1; g.alpha = alpha;
-    const int wm = x3_pick_wm(M, N), bm = 64 * wm;
+    g.bn_shift = bn_shift; g.bn_part = bn_part;
+    const bool bn = bn_shift != nullptr;
+    if (bn && (!bn_part || !(resid && cloud_bias) || bias)) return HSP_ERR_UNSUPPORTED;     // the layer's out product only
+    const int wm = bn ? 1 : x3_pick_wm(M, N), bm = 64 * wm;
     g.tiles_m = (M + bm - 1) / bm; g.tiles_n = (N + X3_BN - 1) / X3_BN;
     const int TT = (K1 + X3_BK - 1) / X3_BK + (two ? (K2 + X3_BK - 1) / X3_BK : 0);
     const int epi = (bias ? 1 : 0) | (resid ? 2 : 0) | (cloud_bias ? 4 : 0);
@@ -459,8 +498,13 @@ extern "C" int hsp_gemm_x3_f32(const float* A1, int lda1, const hsp_bf16_t* P1, 
     if (items > (1ll << 30)) return HSP_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);
     const dim3 grid((unsigned)items), block(256);
-    // instantiated epilogues: 0 none, 1 bias, 6 residual + per-cloud bias (the layer's out product)
+    // instantiated epilogues: 0 none, 1 bias, 6 residual + per-cloud bias (the layer's out product), 14 = 6 + BatchNorm partials
     if (epi != 0 && epi != 1 && epi != 6) return HSP_ERR_UNSUPPORTED;
+    if (bn) {
+        if (two) hipLaunchKernelGGL((gemm_x3_kernel<1, true, 14, 0>), grid, block, 3 * (size_t)(64 + X3_BN) * 64, st, g);
+        else hipLaunchKernelGGL((gemm_x3_kernel<1, false, 14, 0>), grid, block, 3 * (size_t)(64 + X3_BN) * 64, st, g);
+        return check_launch();
+    }
     // (measured, B=16 N=1028: 1.93 ms/step with the short-K form against 1.92 without -- the tile's time is the weight planes'
     // round trips as much as the activations' -- so it is opt-in: HSP_X3_PA=1)
     static const bool pa_on = [] { const char* e = getenv("HSP_X3_PA"); return e && e[0] == '1'; }();
@@ -717,4 +761,25 @@ extern "C" int hsp_small_outer_f32(const float* a, int lda, const float* c, int 
     hipLaunchKernelGGL(small_outer_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), a, lda, c, ldc, B, Ma, Nb, out, ldo,
                        mom, ldm, Cm, gste);
     return check_launch();
+}
+
+extern "C" int hsp_gemm_x3_f32(const float* A1, int lda1, const hsp_bf16_t* P1, int ldp1, long long ps1, int K1,
+                               const float* A2, int lda2, const hsp_bf16_t* P2, int ldp2, long long ps2, int K2, int M, int N,
+                               const float* bias, const float* resid, int ldr, const float* cloud_bias, int rows_per_cloud,
+                               float alpha, float* C, int ldc, void* ws, size_t ws_bytes, hspStream_t stream) {
+    return gemm_x3_impl(A1, lda1, P1, ldp1, ps1, K1, A2, lda2, P2, ldp2, ps2, K2, M, N, bias, resid, ldr, cloud_bias, rows_per_cloud,
+                        alpha, C, ldc, ws, ws_bytes, nullptr, nullptr, stream);
+}
+
+/* the layer's out product (residual + per-cloud bias) that ALSO leaves the first pass of the train-mode BatchNorm that follows
+ * it: bn_part[(M + 63) / 64][2][N] = per 64-row tile, sum (c - s) and sum (c - s)^2 over the tile's rows of the result c, with
+ * the shift s[n] = resid[0][n] + cloud_bias[0][n] written to bn_shift (N floats); fold with hsp_bn_relu_fwd_partials
+ * (nblk = (M + 63) / 64, shift = bn_shift) */
+extern "C" int hsp_gemm_x3_bn_f32(const float* A1, int lda1, const hsp_bf16_t* P1, int ldp1, long long ps1, int K1,
+                                  const float* A2, int lda2, const hsp_bf16_t* P2, int ldp2, long long ps2, int K2, int M, int N,
+                                  const float* resid, int ldr, const float* cloud_bias, int rows_per_cloud, float* C, int ldc,
+                                  float* bn_shift, float* bn_part, hspStream_t stream) {
+    if (!bn_shift || !bn_part || (M + 63) / 64 > 512) return HSP_ERR_BAD_ARG;
+    return gemm_x3_impl(A1, lda1, P1, ldp1, ps1, K1, A2, lda2, P2, ldp2, ps2, K2, M, N, nullptr, resid, ldr, cloud_bias,
+                        rows_per_cloud, 1.0f, C, ldc, nullptr, 0, bn_shift, bn_part, stream);
 }

@@ -331,6 +331,25 @@ extern "C" int hsp_bn_relu_fwd(const float* x, int R, int C, const float* gamma,
     return bn_relu_fwd_impl<float, float>(x, R, C, gamma, beta, eps, momentum, relu, y, save_mean, save_invstd, running_mean,
                                    running_var, num_batches_tracked, ws, ws_bytes, stream);
 }
+/* hsp_bn_relu_fwd whose first pass was done by the producer of x (hsp_gemm_x3_bn_f32): partial[nblk][2][C] shifted sums with
+ * the per-column shift `shift` (C floats: any vector known before x is -- the running mean is the natural choice) */
+extern "C" int hsp_bn_relu_fwd_partials(const float* x, int R, int C, const float* gamma, const float* beta, float eps,
+                                        float momentum, int relu, float* y, float* save_mean, float* save_invstd,
+                                        float* running_mean, float* running_var, long long* num_batches_tracked,
+                                        const float* partial, int nblk, const float* shift, hspStream_t stream) {
+    if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !partial || !shift || nblk <= 0 || nblk > BN_MAX_PARTIALS)
+        return HSP_ERR_BAD_ARG;
+    int rc = bn_check(R, C);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    // (finalize reads its shift through the `x` argument: element c of the first row)
+    hipLaunchKernelGGL((bn_finalize_kernel<0, float>), dim3((C + 15) / 16), dim3(1024), 0, st, partial, nblk, R, C, shift, eps, momentum,
+                       save_mean, save_invstd, running_mean, running_var, num_batches_tracked);
+    const long long total4 = (long long)R * (C >> 2);
+    hipLaunchKernelGGL((bn_apply_kernel<float, float>), dim3(stream_grid4(total4)), dim3(256), 0, st, x, total4, C, save_mean, save_invstd,
+                       gamma, beta, relu, y);
+    return check_launch();
+}
 extern "C" int hsp_bn_relu_fwd_bf16(const hsp_bf16_t* x, int R, int C, const float* gamma, const float* beta, float eps,
                                     float momentum, int relu, hsp_bf16_t* y, float* save_mean, float* save_invstd,
                                     float* running_mean, float* running_var, long long* num_batches_tracked, void* ws,

@@ -206,15 +206,17 @@ class HS_layer(nn.Module):
         self.directions.data.uniform_(-stdv, stdv)
 
     def forward(self, vertices: "(bs, vertice_num, 3)", feature_map: "(bs, vertice_num, in_channel)",
-                neighbor_num: int):
-        """(bs, vertice_num, out_channel) -- STE + fm GEMM + RF-F graph conv + ORL as one fused autograd node"""
+                neighbor_num: int, bn_shift=None):
+        """(bs, vertice_num, out_channel) -- STE + fm GEMM + RF-F graph conv + ORL as one fused autograd node.  ``bn_shift``
+        (fp32 rows): see ops.hs_layer -- returns (out, BatchNorm partial sums)."""
         neighbor_index = ops.knn(feature_map, neighbor_num)          # RF-F: neighbours in feature space
         if feature_map.dtype == torch.bfloat16:                      # bf16 feature rows in -> out (fp32 out ahead of a BatchNorm)
             return ops_bf16.hs_layer(vertices, feature_map, neighbor_index, _xyz_knn(vertices, neighbor_num), neighbor_num,
                                      self.support_num, self.weights, self.bias, self.directions, self.STE_layer.weight,
                                      self.conv2.weight, out_f32=self.out_fp32)
         return ops.hs_layer(vertices, feature_map, neighbor_index, _xyz_knn(vertices, neighbor_num), neighbor_num,
-                            self.support_num, self.weights, self.bias, self.directions, self.STE_layer.weight, self.conv2.weight)
+                            self.support_num, self.weights, self.bias, self.directions, self.STE_layer.weight, self.conv2.weight,
+                            bn_shift=bn_shift)
 
     def graph_conv(self, neighbor_index, feature_map, vertices, neighbor_num):
         """reference :158-181 with the gather, theta product, max and mean fused into one kernel."""

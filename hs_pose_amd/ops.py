@@ -775,6 +775,24 @@ def gemm_x3_ok(A1, B1, A2, B2, bias, resid, cloud_bias, xyz3, out, M, N):
     return True
 
 
+def gemm_x3_bn(A1, B1, A2, B2, resid, cloud_bias, rows_per_cloud, out):
+    """the layer's out product  A1 B1^T + A2 B2^T + resid + cloud_bias[cloud]  on csrc/gemm_x3.hip that also leaves the first pass
+    of the BatchNorm that follows: returns ONE tensor (1 + 2 tiles, N): row 0 = the shift the kernel chose, rows 1.. = the
+    (tiles, 2, N) shifted partial sums"""
+    M, K1 = A1.shape
+    N = B1.shape[0]
+    P1, ldp1, ps1 = x3_planes.planes(B1, False)
+    P2, ldp2, ps2 = x3_planes.planes(B2, False)
+    buf = torch.empty(1 + 2 * ((M + 63) // 64), N, dtype=torch.float32, device=A1.device)
+    bn_shift, part = buf[0], buf[1:]
+    _run("hsp_gemm_x3_bn_f32", (_p(A1), _ld(A1), _p(P1), ldp1, ps1, K1, _p(A2), _ld(A2), _p(P2), ldp2, ps2, A2.shape[1], M, N,
+                                _p(resid), _ld(resid), _p(cloud_bias), int(rows_per_cloud), _p(out), _ld(out), _p(bn_shift),
+                                _p(part), _stream()),
+         key=f"M{M}N{N}K{K1}+{A2.shape[1]}bn", abytes=4 * (M * (K1 + A2.shape[1]) + 2 * M * N) + 6 * N * (K1 + A2.shape[1]),
+         aflops=2 * M * N * (K1 + A2.shape[1]))
+    return buf
+
+
 def gemm_x3(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=None, cloud_bias=None, rows_per_cloud=0, out=None,
             alpha=1.0):
     """the contract of ``gemm_rows`` (fp32 in, fp32 out) with the products formed on the bf16 matrix cores from exact three-way
@@ -888,7 +906,18 @@ def _fm_rows(X2, weights, bias, out=None):
                  lambda: torch.addmm(bias, X2, weights) if out is None else torch.addmm(bias, X2, weights, out=out))
 
 
-def _layer_out_rows(x2, w_ste, F2, Wa, t2, out3, relu=False):
+def _layer_out_rows(x2, w_ste, F2, Wa, t2, out3, relu=False, bn_shift=None):
+    """... ``bn_shift`` not None (own mode, x3 shapes): also returns the BatchNorm first-pass buffer of the result (else None)"""
+    if (bn_shift is not None and GEMM_MODE == "own" and x2.shape[1] != 3 and not relu
+            and gemm_x3_ok(x2, w_ste, F2, Wa, None, F2, t2, None, None, x2.shape[0], out3.shape[2])
+            and (x2.shape[0] + 63) // 64 <= 512 and out3.shape[1] >= 64):
+        B_, N_, C_ = out3.shape
+        return gemm_x3_bn(x2, w_ste, F2, Wa, F2, t2.contiguous(), N_, out3.view(B_ * N_, C_))
+    _layer_out_rows_plain(x2, w_ste, F2, Wa, t2, out3, relu)
+    return None
+
+
+def _layer_out_rows_plain(x2, w_ste, F2, Wa, t2, out3, relu=False):
     """out = x Wste^T + F Wa^T + F + t[cloud]   (gcn3d.py:149,186,156): one fused launch, or GEMM + GEMM + residual pass"""
     B, N, C = out3.shape
     out = out3.view(B * N, C)
@@ -1094,7 +1123,7 @@ def _scaled_mm(a, b, alpha):
 
 class _HSLayer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste3, w_conv23):
+    def forward(ctx, xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste3, w_conv23, bn_shift=None):
         # Conv1d weights arrive in their native (out, in, 1) shape and their gradients are returned in it:
         # a squeezed view would make AccumulateGrad clone every gradient (one D2D copy per tensor and step)
         w_ste, w_conv2 = w_ste3.squeeze(-1), w_conv23.squeeze(-1)
@@ -1117,13 +1146,22 @@ class _HSLayer(torch.autograd.Function):
         F2 = F3.view(B * N, C)
         out3 = torch.empty(B, N, C, dtype=torch.float32, device=X.device)      # (returned as is: not a view)
         t2 = _mm_nt(fg, w_conv2[:, C:])                                        # (B,C): the per-cloud half of conv2
-        _layer_out_rows(X2, w_ste, F2, w_conv2[:, :C], t2, out3)               # X Wste^T + F Wa^T + F + t[b]
+        part = _layer_out_rows(X2, w_ste, F2, w_conv2[:, :C], t2, out3, bn_shift=bn_shift)   # X Wste^T + F Wa^T + F + t[b]
         ctx.save_for_backward(xyz, X, idx_f, idx_x, fm, arg, F3, arg_o, fg, weights, directions, w_ste3, w_conv23)
         ctx.k, ctx.S, ctx.x3 = k, S, x3_planes
+        ctx.with_part = bn_shift is not None
+        if bn_shift is not None:
+            # second output: the BatchNorm partial sums of out3 (or an empty tensor when the product that ran does not leave
+            # them); not differentiable
+            if part is None:
+                part = torch.empty(0, dtype=torch.float32, device=out3.device)
+            ctx.mark_non_differentiable(part)
+            ctx.set_materialize_grads(False)
+            return out3, part
         return out3
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _gpart=None):
         xyz, X, idx_f, idx_x, fm, arg, F3, arg_o, fg, weights, directions, w_ste3, w_conv23 = ctx.saved_tensors
         w_ste, w_conv2 = w_ste3.squeeze(-1), w_conv23.squeeze(-1)
         k, S = ctx.k, ctx.S
@@ -1146,7 +1184,7 @@ class _HSLayer(torch.autograd.Function):
             gW, gb = wgrad(X2, gfm2, colsum=True)                              # X^T gfm and the bias gradient
             gX3 = torch.empty(B, N, Cin, dtype=torch.float32, device=g.device)
             _grad_in_rows(g2, w_ste, gfm2, weights, gX3.view(B * N, Cin))      # g Wste + gfm W^T
-        return None, gX3, None, None, None, None, gW, gb, gD, g_ste.unsqueeze_(-1), g_conv2.unsqueeze_(-1)
+        return None, gX3, None, None, None, None, gW, gb, gD, g_ste.unsqueeze_(-1), g_conv2.unsqueeze_(-1), None
 
 
 class _SurfaceLayer(torch.autograd.Function):
@@ -1235,10 +1273,15 @@ class _SurfaceLayer(torch.autograd.Function):
         return None, None, None, None, gD, g_ste.unsqueeze_(-1), g_conv2.unsqueeze_(-1), None
 
 
-def hs_layer(xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste, w_conv2):
+def hs_layer(xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste, w_conv2, bn_shift=None):
     """HS_layer.forward (gcn3d.py:143-156) given the feature-space (idx_f, exactly k columns) and xyz-space
-    (idx_x, >= k columns) neighbour indices; w_ste (Cout,Cin,1), w_conv2 (Cout,2*Cout,1): the Conv1d weights."""
-    return _HSLayer.apply(xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste, w_conv2)
+    (idx_x, >= k columns) neighbour indices; w_ste (Cout,Cin,1), w_conv2 (Cout,2*Cout,1): the Conv1d weights.
+    ``bn_shift`` not None (a train-mode BatchNorm follows): returns (out, partial) where ``partial`` holds the first pass of that
+    BatchNorm's statistics, left by the out product's epilogue (empty when that product did not run on the kernel that does
+    it); pass both to ``bn_relu(out, bn, partial=partial)``."""
+    if bn_shift is None:
+        return _HSLayer.apply(xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste, w_conv2)
+    return _HSLayer.apply(xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste, w_conv2, bn_shift)
 
 
 def surface_layer(xyz, idx_x, k, S, directions, w_ste, w_conv2, relu=False):
@@ -1318,7 +1361,8 @@ def _rows_pitch(t, C):
 
 class _BNRelu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, num_batches, eps, momentum, relu, out_dtype=None, fork=False):
+    def forward(ctx, x, weight, bias, running_mean, running_var, num_batches, eps, momentum, relu, out_dtype=None, fork=False,
+                partial=None):
         x = _reqf(x, "bn_relu.x")
         C = x.shape[-1]
         R = x.numel() // C
@@ -1331,10 +1375,18 @@ class _BNRelu(torch.autograd.Function):
         L = lib()
         wsb = L.hsp_bn_workspace_bytes(R, C)
         ws = _ws(wsb, x.device)
-        _run("hsp_bn_relu_fwd" + ("_mixed" if mixed else _sfx(x)), (_p(x), R, C, _p(weight), _p(bias), float(eps), float(momentum), 1 if relu else 0,
-                                           _p(y), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(num_batches),
-                                           _p(ws), wsb, _stream()),
-             key=f"R{R}C{C}", abytes=(_es(x) + _es(y)) * R * C)
+        if partial is not None and partial.numel() and not mixed and x.dtype == torch.float32 and running_mean is not None:
+            # the first pass (row 0 of ``partial``: the shift; then the shifted column sums per row tile) was left by the producer's
+            # epilogue (hsp_gemm_x3_bn_f32): fold + apply only
+            _run("hsp_bn_relu_fwd_partials", (_p(x), R, C, _p(weight), _p(bias), float(eps), float(momentum), 1 if relu else 0, _p(y),
+                                              _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(num_batches),
+                                              _p(partial[1:]), (partial.shape[0] - 1) // 2, _p(partial[0]), _stream()),
+                 key=f"R{R}C{C}", abytes=8 * R * C)
+        else:
+            _run("hsp_bn_relu_fwd" + ("_mixed" if mixed else _sfx(x)), (_p(x), R, C, _p(weight), _p(bias), float(eps), float(momentum), 1 if relu else 0,
+                                               _p(y), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(num_batches),
+                                               _p(ws), wsb, _stream()),
+                 key=f"R{R}C{C}", abytes=(_es(x) + _es(y)) * R * C)
         ctx.save_for_backward(x, weight, bias, mean, invstd)
         ctx.relu = relu
         ctx.fork = fork
@@ -1353,7 +1405,7 @@ class _BNRelu(torch.autograd.Function):
         R = x.numel() // C
         dys = [d for d in dys if d is not None]
         if not dys:
-            return (None,) * 11
+            return (None,) * 12
         L = lib()
         wsb = L.hsp_bn_workspace_bytes(R, C)
         ws = _ws(wsb, x.device)
@@ -1366,17 +1418,17 @@ class _BNRelu(torch.autograd.Function):
             _run("hsp_bn_relu_bwd2", (_p(x), _p(d0), ld0, _p(d1), ld1, R, C, _p(weight), _p(bias), _p(mean), _p(invstd),
                                       1 if ctx.relu else 0, _p(dx), _p(dg), _p(db), _p(ws), wsb, _stream()),
                  key=f"R{R}C{C}", abytes=4 * (2 + len(dys)) * R * C)
-            return dx, dg, db, None, None, None, None, None, None, None, None
+            return dx, dg, db, None, None, None, None, None, None, None, None, None
         dy = dys[0] if len(dys) == 1 else dys[0] + dys[1]
         dy = _reqf(dy, "bn_relu.grad", like=None if ctx.mixed else x)
         dx = torch.empty_like(dy)
         _run("hsp_bn_relu_bwd" + ("_mixed" if ctx.mixed else _sfx(x)), (_p(x), _p(dy), R, C, _p(weight), _p(bias), _p(mean), _p(invstd),
                                            1 if ctx.relu else 0, _p(dx), _p(dg), _p(db), _p(ws), wsb, _stream()),
              key=f"R{R}C{C}", abytes=(_es(x) + 2 * _es(dy)) * R * C)
-        return dx, dg, db, None, None, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None, None, None, None, None, None
 
 
-def bn_relu(x, bn, relu=True, out_dtype=None, fork=False):
+def bn_relu(x, bn, relu=True, out_dtype=None, fork=False, partial=None):
     """relu(bn(x)) for point rows x (..., C) with an nn.BatchNorm1d module ``bn`` (its parameters, running
     statistics and train/eval state are honoured exactly like calling the module on the (R,C) view, which
     is what the reference's transpose->BatchNorm1d->transpose computes, FaceRecon.py:90-95).  ``fork``: return the result
@@ -1401,7 +1453,7 @@ def bn_relu(x, bn, relu=True, out_dtype=None, fork=False):
         y = torch.relu_(y) if relu else y
         return (y, y) if fork else y
     return _BNRelu.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
-                         bn.momentum, relu, out_dtype, fork)
+                         bn.momentum, relu, out_dtype, fork, partial)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -278,6 +278,14 @@ int hsp_gemm_x3_f32(const float *A1, int lda1, const hsp_bf16_t *P1, int ldp1, l
                     const float *A2, int lda2, const hsp_bf16_t *P2, int ldp2, long long ps2, int K2, int M, int N,
                     const float *bias, const float *resid, int ldr, const float *cloud_bias, int rows_per_cloud,
                     float alpha, float *C, int ldc, void *ws, size_t ws_bytes, hspStream_t stream);
+/* the layer's out product (residual + per-cloud bias) that also leaves the FIRST PASS of the train-mode BatchNorm that follows it
+ * (FaceRecon.py:90-95): bn_part[(M + 63) / 64][2][N] = per 64-row tile, sum (c - s[n]) and sum (c - s[n])^2 over the tile's rows
+ * of the result, with the shift s[n] = resid[0][n] + cloud_bias[0][n] (this step's data only, so a replayed graph and an eager
+ * step agree bit for bit) written to bn_shift (N floats); hsp_bn_relu_fwd_partials folds them (nblk = (M + 63) / 64 <= 512) */
+int hsp_gemm_x3_bn_f32(const float *A1, int lda1, const hsp_bf16_t *P1, int ldp1, long long ps1, int K1,
+                       const float *A2, int lda2, const hsp_bf16_t *P2, int ldp2, long long ps2, int K2, int M, int N,
+                       const float *resid, int ldr, const float *cloud_bias, int rows_per_cloud, float *C, int ldc,
+                       float *bn_shift, float *bn_part, hspStream_t stream);
 
 /* the per-CLOUD products of the ORL branch (gcn3d.py:186: the f_global half of conv2, one row per cloud of the batch), one
  * launch each, fp32 fma chains in a fixed order:
@@ -353,6 +361,10 @@ int hsp_bn_relu_bwd(const float *x, const float *dy, int R, int C, const float *
                     float *dbeta, void *ws, size_t ws_bytes, hspStream_t stream);
 /* the same for a tensor with TWO consumers: dy rows of pitch ldy (>= C, even -- 8-byte aligned rows: a column block of a wider gradient
  * tensor, e.g. of a dense (B, N, 1286) one, is consumed in place) plus an optional second incoming gradient dy2 (pitch ldy2, NULL: none), added as they are read */
+int hsp_bn_relu_fwd_partials(const float *x, int R, int C, const float *gamma, const float *beta, float eps, float momentum,
+                             int relu, float *y, float *save_mean, float *save_invstd, float *running_mean, float *running_var,
+                             long long *num_batches_tracked, const float *partial, int nblk, const float *shift,
+                             hspStream_t stream);
 int hsp_bn_relu_bwd2(const float *x, const float *dy, int ldy, const float *dy2, int ldy2, int R, int C, const float *gamma,
                      const float *beta, const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma,
                      float *dbeta, void *ws, size_t ws_bytes, hspStream_t stream);
