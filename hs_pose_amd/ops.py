@@ -1002,6 +1002,26 @@ def _tiny_tn(a, b, out, mom=None, gste=None):
     return torch.mm(a.t(), b, out=out)
 
 
+_tickets = None            # zeroed ticket words handed to libhsp (hsp_set_ticket_buffer): one buffer, one device, per process
+
+
+def _ensure_tickets(device):
+    """HSP_TICKET_FOLD=1 (opt-in): give libhsp its zero-initialised ticket words (once, outside any graph capture); the per-cloud
+    two-stage reductions then fold inside their first launch (the last workgroup of a cloud folds it).  Measured (round 3,
+    B=16 N=1028, ten folds per step): with agent-scope release / acquire fences +60 us per step (a release writes back the XCD's
+    whole dirty L2), fence-free with write-through partials + a ticket +20 us -- the in-kernel fold is the same dependent-load
+    chain as the 4.5 us fold launch, run by ONE workgroup per cloud at the kernel's tail, plus a drained queue in every
+    workgroup.  The separate launch stays the default."""
+    global _tickets
+    if _tickets is None:
+        if os.environ.get("HSP_TICKET_FOLD", "0") != "1" or torch.cuda.is_current_stream_capturing():
+            return
+        _tickets = torch.zeros(256, dtype=torch.int32, device=device)
+        lib().hsp_set_ticket_buffer(_tickets.data_ptr(), _tickets.numel())
+    elif _tickets.device != device:                        # a second device in this process: back to the two-launch form
+        lib().hsp_set_ticket_buffer(None, 0)
+
+
 def _orl_fwd_raw(F3, idx_x, k):
     """(fg (B,C), argmax (B,N,C) uint8): mean over points of the neighbourhood max, one pass, no (B,N,C) max tensor"""
     B, N, C = F3.shape
@@ -1010,6 +1030,7 @@ def _orl_fwd_raw(F3, idx_x, k):
     L = lib()
     wsb = L.hsp_orl_workspace_bytes(B, N, C)
     ws = _ws(wsb, F3.device)
+    _ensure_tickets(F3.device)
     _run("hsp_orl_global_fwd", (_p(F3), _p(idx_x), B, N, k, idx_x.shape[2], C, _p(fg), _p(arg), _p(ws), wsb, _stream()),
          key=f"B{B}N{N}k{k}C{C}", abytes=B * N * (4 * C + 4 * k + C))
     return fg, arg
@@ -1031,6 +1052,7 @@ def colsum_rows(x3):
     L = lib()
     wsb = L.hsp_orl_workspace_bytes(B, N, C)
     ws = _ws(wsb, x3.device)
+    _ensure_tickets(x3.device)
     _run("hsp_colsum_rows", (_p(x3), B, N, C, _p(out), _p(ws), wsb, _stream()), key=f"B{B}N{N}C{C}", abytes=4 * B * N * C)
     return out
 
@@ -1042,6 +1064,7 @@ def colsum_rows_xyz(g, xyz):
     mom = torch.empty(B, 4 * C, dtype=torch.float32, device=g.device)
     wsb = 4 * lib().hsp_orl_workspace_bytes(B, N, C)
     ws = _ws(wsb, g.device)
+    _ensure_tickets(g.device)
     _run("hsp_colsum_rows_xyz" + _sfx(g), (_p(g), _p(xyz), B, N, C, _p(mom), _p(ws), wsb, _stream()), key=f"B{B}N{N}C{C}",
          abytes=B * N * (_es(g) * C + 12))
     return mom
