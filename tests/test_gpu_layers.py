@@ -487,3 +487,84 @@ def test_assemble_feat_pitched_rows(dev, ref, monkeypatch, dtype, align):
     ref_c4.scatter_add_(1, near2.long().unsqueeze(-1).expand(-1, -1, 512), up[:, :, 768:1280].float())
     tol = 1e-5 if dtype == "f32" else 2.0 ** -7
     assert float((c4.grad.float() - ref_c4).abs().max()) <= tol * max(1.0, float(ref_c4.abs().max()))
+
+
+# ---- round 3: two-consumer nodes and the BatchNorm first pass from the producing product ---------------------------------------
+
+def test_add_relu_bwd_kernel(dev):
+    """hsp_add_relu_bwd: (ga + gb) * [y > 0] with gb a column block of a wider, 8-byte pitched tensor; against torch"""
+    from hs_pose_amd import ops
+    from hs_pose_amd._lib import lib, check
+    g_ = torch.Generator().manual_seed(5)
+    R, C = 1000, 128
+    y = torch.randn(R, C, generator=g_).to(dev)
+    ga = torch.randn(R, C, generator=g_).to(dev)
+    wide = torch.randn(R, 1286, generator=g_).to(dev)
+    gb = wide[:, 130:130 + C]                                  # pitch 1286 (even), 8-byte aligned, not 16
+    out = torch.empty(R, C, device=dev)
+    check(lib().hsp_add_relu_bwd(ga.data_ptr(), C, gb.data_ptr(), 1286, y.data_ptr(), R, C, out.data_ptr(), ops._stream()), "add_relu_bwd")
+    assert torch.equal(out, (ga + gb) * (y > 0))
+    check(lib().hsp_add_relu_bwd(ga.data_ptr(), C, None, 0, y.data_ptr(), R, C, out.data_ptr(), ops._stream()), "add_relu_bwd")
+    assert torch.equal(out, ga * (y > 0))
+
+
+@pytest.mark.parametrize("R,C", [(4112, 256), (16448, 128), (300, 64)])
+def test_bn_relu_fork_equals_plain(dev, R, C):
+    """the forked BatchNorm node (one output per consumer, both gradients -- one a pitched column block -- added inside the
+    backward kernels) gives the gradients of the plain node fed with their sum, bit for bit"""
+    from hs_pose_amd import ops
+    g_ = torch.Generator().manual_seed(R + C)
+    x0 = torch.randn(R, C, generator=g_).to(dev) * 2 + 3
+    d1 = torch.randn(R, C, generator=g_).to(dev)
+    wide = torch.randn(R, C + 70, generator=g_).to(dev)
+    d2 = wide[:, 6:6 + C]
+    res = []
+    for fork in (False, True):
+        bn = torch.nn.BatchNorm1d(C).to(dev).train()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+        bn.weight.data.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.data.copy_(torch.linspace(-0.5, 0.5, C))
+        x = x0.clone().requires_grad_(True)
+        if fork:
+            ya, yb = ops.bn_relu(x, bn, fork=True)
+            assert ya.data_ptr() == yb.data_ptr()
+            torch.autograd.backward([ya, yb], [d1, d2])
+        else:
+            ya = ops.bn_relu(x, bn)
+            ya.backward(d1 + d2)
+        res.append((ya.detach().clone(), x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_var.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,N,Cin,C", [(16, 1028, 128, 128), (16, 257, 128, 256), (3, 300, 64, 128)])
+def test_out_product_leaves_batchnorm_first_pass(dev, B, N, Cin, C):
+    """hsp_gemm_x3_bn_f32 + hsp_bn_relu_fwd_partials: the layer's out product with the BatchNorm statistics' first pass in its
+    epilogue against the plain product followed by the three-launch BatchNorm (mean / invstd / y to 1e-5 of scale: the shifted
+    sums are cut into other chunks)"""
+    from hs_pose_amd import ops
+    g_ = torch.Generator().manual_seed(B * N + C)
+    M = B * N
+    x2 = torch.randn(M, Cin, generator=g_).to(dev)
+    F2 = torch.relu(torch.randn(M, C, generator=g_)).to(dev) + 2.0
+    w_ste = (torch.randn(C, Cin, generator=g_) * 0.05).to(dev)
+    Wa = (torch.randn(C, 2 * C, generator=g_) * 0.05).to(dev)[:, :C]
+    t2 = torch.randn(B, C, generator=g_).to(dev)
+    prev, ops.GEMM_MODE = ops.GEMM_MODE, "own"
+    try:
+        out_a = torch.empty(B, N, C, device=dev)
+        part = ops._layer_out_rows(x2, w_ste, F2, Wa, t2, out_a, bn_shift=True)
+        out_b = torch.empty(B, N, C, device=dev)
+        assert ops._layer_out_rows(x2, w_ste, F2, Wa, t2, out_b) is None
+    finally:
+        ops.GEMM_MODE = prev
+    if part is None:
+        pytest.skip("shape not taken by the x3 out product")
+    assert torch.equal(out_a, out_b)
+    outs = []
+    for p_ in (part, None):
+        bn = torch.nn.BatchNorm1d(C).to(dev).train()
+        y = ops.bn_relu(out_a, bn, partial=p_)
+        outs.append((y, bn.running_mean.clone(), bn.running_var.clone()))
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item())
