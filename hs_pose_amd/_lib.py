@@ -110,6 +110,11 @@ SIGNATURES = {
     "hsp_wgrad_partial_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _sz, _vp, _vp]),
     "hsp_wgrad_partial_bf16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _sz, _vp, _vp]),
     "hsp_wgrad_fold": (_i, [_vp, _i, _vp]),
+    "hsp_step_fold": (_i, [_vp, _i, _vp, _i, _vp]),
+    "hsp_rf_surface_bwd_partial": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp]),
+    "hsp_rf_conv_bwd_scatter_partial": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "hsp_rf_surface_bwd_partial_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp]),
+    "hsp_rf_conv_bwd_scatter_partial_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "hsp_wgrad_partial_pair_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _sz] * 2 + [_vp, _vp]),
     "hsp_pose_augment": (_i, [_vp] * 14 + [_i, _i, _i] + [ctypes.c_float] * 4 + [_vp] * 5),
 }
@@ -164,3 +169,9 @@ class HspWgradPending(ctypes.Structure):
     """include/hsp.h: HspWgradPending (a HOST struct)"""
     _fields_ = [("part", ctypes.c_void_p), ("cs_part", ctypes.c_void_p), ("C", ctypes.c_void_p), ("colsum", ctypes.c_void_p),
                 ("nparts", ctypes.c_int), ("M", ctypes.c_int), ("N", ctypes.c_int), ("ldc", ctypes.c_int)]
+
+
+class HspDirsPending(ctypes.Structure):
+    """include/hsp.h: HspDirsPending (a HOST struct)"""
+    _fields_ = [("part", ctypes.c_void_p), ("dirs", ctypes.c_void_p), ("grad_dirs", ctypes.c_void_p),
+                ("nparts", ctypes.c_int), ("SC", ctypes.c_int)]

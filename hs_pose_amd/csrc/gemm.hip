@@ -18,6 +18,7 @@
 // and are folded in a fixed order (deterministic) by wgrad_reduce_kernel, which writes C with an
 // arbitrary leading dimension (so a gradient can land in a column block of a larger tensor).
 #include "common.h"
+#include "folds.h"
 
 namespace hsp {
 
@@ -235,59 +236,45 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-// the same fold for up to 4 weight-gradient problems in ONE launch (the three parameter gradients of an HS layer's backward
-// are folded together: two kernel boundaries fewer per layer).  Block ranges: problem p owns blocks [first[p], first[p+1]).
+// the same fold for up to HSP_FOLD_MAX_WGRAD weight-gradient problems in ONE launch (the three parameter gradients of an HS
+// layer's backward are folded together, or -- hsp_step_fold -- every pending fold of a whole backward pass).  Block ranges:
+// problem p owns blocks [first[p], first[p+1]).
 struct WgradFoldTab {
     int n;
-    int first[5];
-    HspWgradPending p[4];
+    int first[HSP_FOLD_MAX_WGRAD + 1];
+    HspWgradPending p[HSP_FOLD_MAX_WGRAD];
 };
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WgradFoldTab tab) {
     __shared__ float4 red[4][64];
     int q = 0;
     while (q + 1 < tab.n && (int)blockIdx.x >= tab.first[q + 1]) ++q;
-    const HspWgradPending pr = tab.p[q];
-    const float* part = reinterpret_cast<const float*>(pr.part);
-    const float* cs_part = reinterpret_cast<const float*>(pr.cs_part);
-    const int SK = pr.nparts, M = pr.M, N = pr.N;
-    const int le = threadIdx.x & 63, sg = threadIdx.x >> 6;
-    const int nq = N >> 2;
-    const long long total = (long long)M * nq;
-    const long long ncs = pr.colsum ? (N >> 2) : 0;
-    const long long e = (long long)((int)blockIdx.x - tab.first[q]) * 64 + le;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* src = nullptr;
-    size_t stride = 0;
-    if (e < total) { src = part + (size_t)e * 4; stride = (size_t)M * N; }
-    else if (e < total + ncs) { src = cs_part + (size_t)(e - total) * 4; stride = (size_t)N; }
-    if (src) {
-        float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f);
-        int sl = sg;
-        for (; sl + 4 < SK; sl += 8) {
-            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)sl * stride);
-            const float4 u = *reinterpret_cast<const float4*>(src + (size_t)(sl + 4) * stride);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-            s2.x += u.x; s2.y += u.y; s2.z += u.z; s2.w += u.w;
-        }
-        if (sl < SK) {
-            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)sl * stride);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-        s.x += s2.x; s.y += s2.y; s.z += s2.z; s.w += s2.w;
-    }
-    red[sg][le] = s;
-    __syncthreads();
-    if (sg == 0 && src) {
-        float4 r = red[0][le];
-#pragma unroll
-        for (int g = 1; g < 4; ++g) { const float4 v = red[g][le]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
-        if (e < total) {
-            const int m = (int)(e / nq), qq = (int)(e - (long long)m * nq);
-            float* c = reinterpret_cast<float*>(pr.C) + (size_t)m * pr.ldc + (qq << 2);
-            c[0] = r.x; c[1] = r.y; c[2] = r.z; c[3] = r.w;
-        } else {
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(pr.colsum) + (size_t)(e - total) * 4) = r;
-        }
+    wgrad_fold_body(tab.p[q], (int)blockIdx.x - tab.first[q], red);
+}
+
+// every fold a backward pass left pending, in one launch: blocks [0, wfirst[nw]) fold parameter-gradient partials, the blocks
+// after them fold the support-direction partials of the receptive-field layers (rfconv.hip) -- nothing before the optimizer
+// reads either, so the step's ten fold launches become one
+struct StepFoldTab {
+    int nw, nd;
+    int wfirst[HSP_FOLD_MAX_WGRAD + 1];
+    int dfirst[HSP_FOLD_MAX_DIRS + 1];                      // (relative to wfirst[nw])
+    HspWgradPending w[HSP_FOLD_MAX_WGRAD];
+    HspDirsPending d[HSP_FOLD_MAX_DIRS];
+};
+__global__ __launch_bounds__(256) void step_fold_kernel(const StepFoldTab tab) {
+    __shared__ __attribute__((aligned(16))) float smem[16 * 3 * 64];
+    const int nwb = tab.wfirst[tab.nw];
+    if ((int)blockIdx.x < nwb) {
+        int q = 0;
+        while (q + 1 < tab.nw && (int)blockIdx.x >= tab.wfirst[q + 1]) ++q;
+        wgrad_fold_body(tab.w[q], (int)blockIdx.x - tab.wfirst[q], reinterpret_cast<float4(*)[64]>(smem));
+    } else {
+        const int blk = (int)blockIdx.x - nwb;
+        int q = 0;
+        while (q + 1 < tab.nd && blk >= tab.dfirst[q + 1]) ++q;
+        const HspDirsPending pd = tab.d[q];
+        dirs_fold_body<256>(reinterpret_cast<const float*>(pd.part), pd.nparts, pd.SC, reinterpret_cast<const float*>(pd.dirs),
+                            reinterpret_cast<float*>(pd.grad_dirs), blk - tab.dfirst[q], reinterpret_cast<float(*)[3][64]>(smem));
     }
 }
 
@@ -818,7 +805,7 @@ extern "C" int hsp_wgrad_partial_pair_f32(const float* A0, int lda0, const float
 }
 
 extern "C" int hsp_wgrad_fold(const HspWgradPending* pending, int n, hspStream_t stream) {
-    if (!pending || n <= 0 || n > 4) return HSP_ERR_BAD_ARG;
+    if (!pending || n <= 0 || n > HSP_FOLD_MAX_WGRAD) return HSP_ERR_BAD_ARG;
     WgradFoldTab tab;
     tab.n = n;
     int blocks = 0;
@@ -833,5 +820,37 @@ extern "C" int hsp_wgrad_fold(const HspWgradPending* pending, int n, hspStream_t
     }
     tab.first[n] = blocks;
     hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), tab);
+    return check_launch();
+}
+
+static bool wgrad_pending_ok(const HspWgradPending& p) {
+    return p.part && p.C && p.nparts > 0 && p.M > 0 && p.N > 0 && !(p.N & 3) && p.ldc >= p.N && !(p.colsum && !p.cs_part);
+}
+
+extern "C" int hsp_step_fold(const HspWgradPending* wgrads, int nw, const HspDirsPending* dirs, int nd, hspStream_t stream) {
+    if (nw < 0 || nd < 0 || nw > HSP_FOLD_MAX_WGRAD || nd > HSP_FOLD_MAX_DIRS || (nw && !wgrads) || (nd && !dirs)) return HSP_ERR_BAD_ARG;
+    if (nw + nd == 0) return HSP_OK;
+    StepFoldTab tab;
+    tab.nw = nw; tab.nd = nd;
+    int blocks = 0;
+    for (int i = 0; i < nw; ++i) {
+        const HspWgradPending& p = wgrads[i];
+        if (!wgrad_pending_ok(p)) return HSP_ERR_BAD_ARG;
+        tab.wfirst[i] = blocks;
+        const long long total = (long long)p.M * (p.N >> 2) + (p.colsum ? (p.N >> 2) : 0);
+        blocks += (int)((total + 63) / 64);
+        tab.w[i] = p;
+    }
+    tab.wfirst[nw] = blocks;
+    int dblocks = 0;
+    for (int i = 0; i < nd; ++i) {
+        const HspDirsPending& p = dirs[i];
+        if (!p.part || !p.dirs || !p.grad_dirs || p.nparts <= 0 || p.SC <= 0) return HSP_ERR_BAD_ARG;
+        tab.dfirst[i] = dblocks;
+        dblocks += (p.SC + 63) / 64;
+        tab.d[i] = p;
+    }
+    tab.dfirst[nd] = dblocks;
+    hipLaunchKernelGGL(step_fold_kernel, dim3((unsigned)(blocks + dblocks)), dim3(256), 0, as_stream(stream), tab);
     return check_launch();
 }

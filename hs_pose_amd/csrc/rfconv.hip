@@ -11,6 +11,7 @@
 // Layout: column j of the S*C axis <-> (s = j / C, c = j % C)  (gcn3d.py:104,177).
 // HBM-bound kernels: algorithmic bytes/point (fwd) = k*S*C*4 (gather, L2) + (S+1)*C*4/own row ... see DESIGN.md.
 #include "common.h"
+#include "folds.h"
 #include <stdlib.h>
 
 namespace hsp {
@@ -735,41 +736,7 @@ __global__ __launch_bounds__(1024) void rf_dirs_reduce_kernel(const float* __res
                                                               const float* __restrict__ dirs,
                                                               float* __restrict__ out) {
     __shared__ float red[16][3][64];
-    const int lj = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + lj;
-    const int n3 = 3 * SC;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
-    if (j < SC) {
-        int b = sl;
-        for (; b + 16 < nblk; b += 32) {
-            const float* p = ws + (size_t)b * n3 + j;
-            const float* q = ws + (size_t)(b + 16) * n3 + j;
-            a0 += p[0]; a1 += p[SC]; a2 += p[2 * SC];
-            b0 += q[0]; b1 += q[SC]; b2 += q[2 * SC];
-        }
-        for (; b < nblk; b += 16) {
-            const float* p = ws + (size_t)b * n3 + j;
-            a0 += p[0]; a1 += p[SC]; a2 += p[2 * SC];
-        }
-    }
-    red[sl][0][lj] = a0 + b0; red[sl][1][lj] = a1 + b1; red[sl][2][lj] = a2 + b2;
-    __syncthreads();
-    if (sl == 0 && j < SC) {
-        float g0 = red[0][0][lj], g1 = red[0][1][lj], g2 = red[0][2][lj];
-#pragma unroll
-        for (int t = 1; t < 16; ++t) { g0 += red[t][0][lj]; g1 += red[t][1][lj]; g2 += red[t][2][lj]; }
-        const float x = dirs[j], y = dirs[SC + j], z = dirs[2 * SC + j];
-        const float nrm = __fsqrt_rn(add_rn(add_rn(mul_rn(x, x), mul_rn(y, y)), mul_rn(z, z)));
-        if (nrm > 1e-12f) {
-            const float hx = x / nrm, hy = y / nrm, hz = z / nrm;
-            const float dot = hx * g0 + hy * g1 + hz * g2;
-            out[j] = (g0 - hx * dot) / nrm;
-            out[SC + j] = (g1 - hy * dot) / nrm;
-            out[2 * SC + j] = (g2 - hz * dot) / nrm;
-        } else {
-            out[j] = g0 / 1e-12f; out[SC + j] = g1 / 1e-12f; out[2 * SC + j] = g2 / 1e-12f;
-        }
-    }
+    dirs_fold_body<1024>(ws, nblk, SC, dirs, out, (int)blockIdx.x, red);          // (folds.h; also inside hsp_step_fold)
 }
 
 // backward grid: persistent, capped so that the per-block direction-gradient partials stay <= 8 MiB
@@ -978,7 +945,7 @@ static bool rf_use_row_split(int N, int C, bool surface, int tc_whole) {
 template <bool SURFACE, bool FWIN, typename FT>
 static int rf_bwd_scatter(const float* xyz, const float* dirs, const FT* fm, const uint16_t* argrow,
                           const FT* gout, int B, int N, int S, int C, FT* gfm, float* gdirs, void* ws,
-                          size_t ws_bytes, hspStream_t stream) {
+                          size_t ws_bytes, hspStream_t stream, HspDirsPending* pending = nullptr) {
     int rc = rf_check(xyz, dirs, argrow, B, N, 1, S, C);
     if (rc) return rc;
     if (!gout || !gdirs || (!SURFACE && (!fm || !gfm))) return HSP_ERR_BAD_ARG;
@@ -996,6 +963,7 @@ static int rf_bwd_scatter(const float* xyz, const float* dirs, const FT* fm, con
         hipLaunchKernelGGL(kern, dim3(SC / 16, B, 2), dim3(RF_TILE_THREADS), lds2, st, xyz, dirs, fm, argrow, gout, B, N, S, C, gfm, part);
         rc = check_launch();
         if (rc) return rc;
+        if (pending) { *pending = HspDirsPending{part, dirs, gdirs, 2 * B, SC}; return HSP_OK; }
         hipLaunchKernelGGL(rf_dirs_reduce_kernel, dim3((SC + 63) / 64), dim3(1024), 0, st, part, 2 * B, SC, dirs, gdirs);
         return check_launch();
     }
@@ -1018,6 +986,7 @@ static int rf_bwd_scatter(const float* xyz, const float* dirs, const FT* fm, con
 #undef RF_TILE_LAUNCH
     rc = check_launch();
     if (rc) return rc;
+    if (pending) { *pending = HspDirsPending{part, dirs, gdirs, B, SC}; return HSP_OK; }
     hipLaunchKernelGGL(rf_dirs_reduce_kernel, dim3((SC + 63) / 64), dim3(1024), 0, st, part, B, SC, dirs, gdirs);
     return check_launch();
 }
@@ -1054,4 +1023,42 @@ extern "C" int hsp_rf_conv_bwd_scatter_bf16(const float* xyz, const float* dirs_
                                                    ws_bytes, stream);
     return rf_bwd_scatter<false, false, bf16_t>(xyz, dirs_n, fm, argrow, grad_out, B, N, S, C, grad_fm, grad_dirs_n, ws,
                                                 ws_bytes, stream);
+}
+
+// the same backward launches with the direction-gradient fold left pending (hsp_step_fold runs it with the step's other folds)
+extern "C" int hsp_rf_surface_bwd_partial(const float* xyz, const float* dirs_n, const uint16_t* argrow, const float* grad_out,
+                                          int B, int N, int S, int K, float* grad_dirs_n, void* ws, size_t ws_bytes,
+                                          HspDirsPending* pending, hspStream_t stream) {
+    if (!pending) return HSP_ERR_BAD_ARG;
+    return rf_bwd_scatter<true, false, float>(xyz, dirs_n, nullptr, argrow, grad_out, B, N, S, K, nullptr, grad_dirs_n, ws,
+                                              ws_bytes, stream, pending);
+}
+extern "C" int hsp_rf_surface_bwd_partial_bf16(const float* xyz, const float* dirs_n, const uint16_t* argrow,
+                                               const hsp_bf16_t* grad_out, int B, int N, int S, int K, float* grad_dirs_n,
+                                               void* ws, size_t ws_bytes, HspDirsPending* pending, hspStream_t stream) {
+    if (!pending) return HSP_ERR_BAD_ARG;
+    return rf_bwd_scatter<true, false, bf16_t>(xyz, dirs_n, nullptr, argrow, grad_out, B, N, S, K, nullptr, grad_dirs_n, ws,
+                                               ws_bytes, stream, pending);
+}
+extern "C" int hsp_rf_conv_bwd_scatter_partial(const float* xyz, const float* dirs_n, const float* fm, const float* fwin,
+                                               const uint16_t* argrow, const float* grad_out, int B, int N, int S, int C,
+                                               float* grad_fm, float* grad_dirs_n, void* ws, size_t ws_bytes,
+                                               HspDirsPending* pending, hspStream_t stream) {
+    if (!pending) return HSP_ERR_BAD_ARG;
+    if (fwin)
+        return rf_bwd_scatter<false, true, float>(xyz, dirs_n, fwin, argrow, grad_out, B, N, S, C, grad_fm, grad_dirs_n, ws,
+                                                  ws_bytes, stream, pending);
+    return rf_bwd_scatter<false, false, float>(xyz, dirs_n, fm, argrow, grad_out, B, N, S, C, grad_fm, grad_dirs_n, ws,
+                                               ws_bytes, stream, pending);
+}
+extern "C" int hsp_rf_conv_bwd_scatter_partial_bf16(const float* xyz, const float* dirs_n, const hsp_bf16_t* fm,
+                                                    const hsp_bf16_t* fwin, const uint16_t* argrow, const hsp_bf16_t* grad_out,
+                                                    int B, int N, int S, int C, hsp_bf16_t* grad_fm, float* grad_dirs_n,
+                                                    void* ws, size_t ws_bytes, HspDirsPending* pending, hspStream_t stream) {
+    if (!pending) return HSP_ERR_BAD_ARG;
+    if (fwin)
+        return rf_bwd_scatter<false, true, bf16_t>(xyz, dirs_n, fwin, argrow, grad_out, B, N, S, C, grad_fm, grad_dirs_n, ws,
+                                                   ws_bytes, stream, pending);
+    return rf_bwd_scatter<false, false, bf16_t>(xyz, dirs_n, fm, argrow, grad_out, B, N, S, C, grad_fm, grad_dirs_n, ws,
+                                                ws_bytes, stream, pending);
 }

@@ -153,7 +153,8 @@ class GraphedStep:
             p.grad = None
         with gcn3d.pool_index_feed(self.pool_idx):
             _, _, feat = self.net(self.centred, self.obj)
-        feat.backward(self.dfeat)
+        with ops.StepFolds():                           # every p.grad is None: the backward's folds go out in one launch
+            feat.backward(self.dfeat)
         self.feat = feat.detach()                       # (keeping the autograd graph alive would pin its accumulators' streams)
         if self.flat_grad is not None:
             torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params],
@@ -184,13 +185,15 @@ class GraphedStep:
         self.feat = feat.detach()
         cut = list(self.net.backward_cut)
         self.net.backward_cut = None
-        grads = torch.autograd.grad(feat, cut + self.late, self.dfeat, allow_unused=True)
+        with ops.StepFolds():
+            grads = torch.autograd.grad(feat, cut + self.late, self.dfeat, allow_unused=True)
         self._cut, self._cut_grads = cut, list(grads[:len(cut)])
         torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1) for p, g in zip(self.late, grads[len(cut):])],
                   out=self.flat_late)
 
     def _body_second(self):
-        torch.autograd.backward(self._cut, self._cut_grads, inputs=self.early)
+        with ops.StepFolds():
+            torch.autograd.backward(self._cut, self._cut_grads, inputs=self.early)
         torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.early],
                   out=self.flat_early)
         self._cut = self._cut_grads = None
@@ -303,7 +306,8 @@ class GraphedTrainStep:
             _, ld = self.net(do_loss=True, **self.batch)
         total = sum(ld['fsnet_loss'].values()) + sum(ld['recon_loss'].values()) + sum(ld['geo_loss'].values()) \
             + sum(ld['prop_loss'].values())
-        total.backward()
+        with ops.StepFolds():
+            total.backward()
         torch._foreach_copy_(views, [p.grad if p.grad is not None else torch.zeros_like(p) for p in params])
         for p, v in zip(params, views):
             p.grad = v
@@ -473,7 +477,8 @@ class GraphedNetwork:
             self.gouts = [torch.zeros_like(o) for o in self.outs]
             self.graph_bwd = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_bwd, pool=self.graph_fwd.pool(), **_CAPTURE):
-                self.pgrads = list(torch.autograd.grad(self.outs, self.params, self.gouts, allow_unused=True))
+                with ops.StepFolds(bare_wgrad=True):    # (before the .contiguous() copies below read the gradients)
+                    self.pgrads = list(torch.autograd.grad(self.outs, self.params, self.gouts, allow_unused=True))
                 # contiguous static gradients (copies inside the graph where autograd hands back a transposed view): the
                 # multi-tensor add below then takes its fused path instead of one small kernel per parameter
                 self.pgrads = [g if g is None or g.is_contiguous() else g.contiguous() for g in self.pgrads]

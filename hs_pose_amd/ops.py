@@ -17,6 +17,7 @@ _vp = ctypes.c_void_p
 # reverse-edge index (fixed summation order, bit-reproducible gradients) instead of the faster
 # column-tile LDS scatter, whose fp32 LDS adds are order-dependent in the last bits.
 DETERMINISTIC = os.environ.get("HSP_DETERMINISTIC", "0") == "1"
+STEP_FOLDS = os.environ.get("HSP_STEP_FOLDS", "1") != "0"     # ops.StepFolds: one fold launch per backward pass (0: a launch per fold)
 
 
 def _p(t):
@@ -209,9 +210,8 @@ class _RFSurface(torch.autograd.Function):
         L = lib()
         wsb = L.hsp_rf_bwd_scatter_workspace_bytes(B, SC)
         ws = _ws(wsb, g.device)
-        _run("hsp_rf_surface_bwd", (_p(xyz), _p(dirs_n), _p(arg), _p(g), B, N, ctx.S, SC // ctx.S, _p(gd), _p(ws), wsb,
-                                    _stream()),
-             key=f"B{B}N{N}S{ctx.S}C{SC // ctx.S}", abytes=B * N * (12 + 4 * (SC // ctx.S) + SC) + 24 * SC)
+        _rf_bwd_dirs_call("hsp_rf_surface_bwd", (_p(xyz), _p(dirs_n), _p(arg), _p(g), B, N, ctx.S, SC // ctx.S, _p(gd)), ws, wsb,
+                          (dirs_n, gd), key=f"B{B}N{N}S{ctx.S}C{SC // ctx.S}", abytes=B * N * (12 + 4 * (SC // ctx.S) + SC) + 24 * SC)
         return None, None, gd, None
 
 
@@ -455,15 +455,89 @@ class WgradBatch:
     def __exit__(self, *exc):
         WgradBatch.current = self.prev
         if exc[0] is None:
-            self.flush()
+            if StepFolds.current is not None:          # the whole backward's folds go out together (StepFolds)
+                StepFolds.current.wgrads.extend(self.items)
+                self.items = []
+            else:
+                self.flush()
         return False
 
     def flush(self):
         from ._lib import HspWgradPending
+        cap = StepFolds.MAX_WGRAD
         while self.items:
-            chunk, self.items = self.items[:4], self.items[4:]
+            chunk, self.items = self.items[:cap], self.items[cap:]
             arr = (HspWgradPending * len(chunk))(*[c[0] for c in chunk])
             _run("hsp_wgrad_fold", (arr, len(chunk), _stream()), key=f"n{len(chunk)}")
+
+
+class StepFolds:
+    """Every fold a backward pass leaves pending, in ONE launch at its end (``hsp_step_fold``): the split-K folds of the
+    parameter gradients (``WgradBatch`` hands its items over instead of flushing per layer) and the per-cloud folds of the
+    receptive-field layers' direction gradients.  Nothing before the optimizer reads those results, and each fold is a 4-8 us
+    dependent launch: an HS stack's backward has ten.  Same summation order as the stand-alone folds: same bits
+    (tests/test_gpu_step_folds.py).
+
+    ``with StepFolds(): loss.backward()`` -- the parameter gradients are NOT valid until the block exits, so the scope is only
+    for callers that own the whole backward and start it with ``p.grad = None`` for every parameter (autograd then keeps the
+    very tensors the nodes return; an accumulation into an existing ``.grad`` would read them before the fold):
+    ``graph.GraphedStep`` and ``graph.GraphedNetwork``, whose captures replay the fold with the rest of the step."""
+    current = None
+    MAX_WGRAD, MAX_DIRS = 24, 8        # include/hsp.h: HSP_FOLD_MAX_WGRAD, HSP_FOLD_MAX_DIRS
+
+    def __init__(self, bare_wgrad=False):
+        """bare_wgrad: also defer ``wgrad`` calls made outside a ``WgradBatch`` (``linear_rows``' backward, which returns a
+        TRANSPOSED view of its result: fine under ``torch.autograd.grad``, which hands the view back, not under
+        ``.backward()``, whose gradient accumulator clones a view the moment it arrives)."""
+        self.bare_wgrad = bare_wgrad
+        self.wgrads = []                  # (HspWgradPending, workspace kept alive)
+        self.dirs = []                    # (HspDirsPending, workspace, directions, grad kept alive)
+
+    def __enter__(self):
+        if StepFolds.current is not None:
+            raise HspError("StepFolds: scopes do not nest")
+        if STEP_FOLDS:                    # (HSP_STEP_FOLDS=0: the scope is inert, every fold stays its own launch -- the A/B knob)
+            StepFolds.current = self
+        return self
+
+    def __exit__(self, *exc):
+        StepFolds.current = None
+        if exc[0] is None:
+            self.flush()
+        else:
+            self.wgrads, self.dirs = [], []
+        return False
+
+    def flush(self):
+        from ._lib import HspWgradPending, HspDirsPending
+        while self.wgrads or self.dirs:
+            w, self.wgrads = self.wgrads[:self.MAX_WGRAD], self.wgrads[self.MAX_WGRAD:]
+            d, self.dirs = self.dirs[:self.MAX_DIRS], self.dirs[self.MAX_DIRS:]
+            wa = (HspWgradPending * max(len(w), 1))(*[c[0] for c in w])
+            da = (HspDirsPending * max(len(d), 1))(*[c[0] for c in d])
+            _run("hsp_step_fold", (wa, len(w), da, len(d), _stream()), key=f"w{len(w)}d{len(d)}")
+
+
+def _hold(t):
+    """keep a pending fold's output MEMORY alive without holding the tensor: autograd's gradient accumulator keeps the very
+    tensor a node returns only while nobody else references it (it clones otherwise, and the clone would be taken before
+    the fold has run); the storage object pins the bytes, not the tensor."""
+    return None if t is None else t.untyped_storage()
+
+
+def _rf_bwd_dirs_call(name, args_before_ws, ws, wsb, keep, key, abytes):
+    """run a receptive-field backward entry point ``name`` (args ..., ws, ws_bytes, stream); inside a ``StepFolds`` scope its
+    ``_partial`` form, whose direction-gradient fold goes out with the step's other folds.  keep: tensors the pending fold
+    reads / writes (kept alive until it has run)."""
+    sf = StepFolds.current
+    if sf is None:
+        _run(name, (*args_before_ws, _p(ws), wsb, _stream()), key=key, abytes=abytes)
+        return
+    from ._lib import HspDirsPending
+    pend = HspDirsPending()
+    pname = name.replace("_bf16", "") + "_partial" + ("_bf16" if name.endswith("_bf16") else "")
+    _run(pname, (*args_before_ws, _p(ws), wsb, ctypes.byref(pend), _stream()), key=key, abytes=abytes)
+    sf.dirs.append((pend, ws) + tuple(_hold(t) for t in keep))
 
 
 def _wgrad_custom(A2, B2, out, colsum):
@@ -476,13 +550,15 @@ def _wgrad_custom(A2, B2, out, colsum):
     sfx = "bf16" if A2.dtype == torch.bfloat16 else "f32"
     es = 2 if A2.dtype == torch.bfloat16 else 4
     batch = WgradBatch.current
-    if batch is not None:
+    sf = StepFolds.current
+    sink = batch.items if batch is not None else sf.wgrads if sf is not None and sf.bare_wgrad else None
+    if sink is not None:
         from ._lib import HspWgradPending
         pend = HspWgradPending()
         _run("hsp_wgrad_partial_" + sfx, (_p(A2), A2.stride(0), _p(B2), B2.stride(0), M, N, K, _p(out), out.stride(0), _p(cs),
                                           _p(ws), wsb, ctypes.byref(pend), _stream()),
              key=f"M{M}N{N}K{K}", abytes=es * K * (M + N) + 4 * M * N, aflops=2 * M * N * K)
-        batch.items.append((pend, ws))
+        sink.append((pend, ws, _hold(out), _hold(cs)))
     else:
         _run("hsp_wgrad_" + sfx, (_p(A2), A2.stride(0), _p(B2), B2.stride(0), M, N, K, _p(out), out.stride(0), _p(cs),
                                   _p(ws), wsb, _stream()),
@@ -526,11 +602,12 @@ def wgrad(A2, B2, out=None, colsum=False):
             choice = "custom"                       # cannot time here; decided on a later eager call
         else:
             held, WgradBatch.current = WgradBatch.current, None      # time the complete op, not the batched half
+            held_sf, StepFolds.current = StepFolds.current, None
             try:
                 t_c = _time_us(lambda: _wgrad_custom(A2, B2, out, colsum))
                 t_l = _time_us(lambda: _wgrad_library(A2, B2, out, colsum))
             finally:
-                WgradBatch.current = held
+                WgradBatch.current, StepFolds.current = held, held_sf
             choice = _wgrad_choice[key] = "custom" if t_c <= t_l else "library"
     return _wgrad_custom(A2, B2, out, colsum) if choice == "custom" else _wgrad_library(A2, B2, out, colsum)
 
@@ -568,8 +645,8 @@ def wgrad_pair(A0, B0, out0, A1, B1, out1):
                                         pend, _stream()),
          key=f"M{M0}N{N0}K{K0}+M{M1}N{N1}K{K1}", abytes=4 * (K0 * (M0 + N0) + M0 * N0 + K1 * (M1 + N1) + M1 * N1),
          aflops=2 * (M0 * N0 * K0 + M1 * N1 * K1))
-    batch.items.append((HspWgradPending.from_buffer_copy(pend[0]), ws0))
-    batch.items.append((HspWgradPending.from_buffer_copy(pend[1]), ws1))
+    batch.items.append((HspWgradPending.from_buffer_copy(pend[0]), ws0, _hold(out0)))
+    batch.items.append((HspWgradPending.from_buffer_copy(pend[1]), ws1, _hold(out1)))
 
 
 def _ld(t):
@@ -1132,9 +1209,9 @@ def _rf_conv_bwd_raw(xyz, idx, directions, fm, arg, gF3, S):
         ws = _ws(wsb, gF3.device)
         is_fwin = fm.shape[-1] == SC
         design_stream_bytes[("hsp_rf_conv_bwd_scatter", f"B{B}N{N}S{S}C{C}")] = B * N * (12 + 6 * SC + 4 * C + 4 * (S + 1) * C) + 24 * SC
-        _run("hsp_rf_conv_bwd_scatter", (_p(xyz), _p(directions), _p(None if is_fwin else fm), _p(fm if is_fwin else None),
-                                         _p(arg), _p(gF3), B, N, S, C, _p(gfm), _p(gd), _p(ws), wsb, _stream()),
-             key=f"B{B}N{N}S{S}C{C}", abytes=B * N * (12 + 5 * SC + 4 * C + 4 * (S + 1) * C) + 24 * SC)
+        _rf_bwd_dirs_call("hsp_rf_conv_bwd_scatter", (_p(xyz), _p(directions), _p(None if is_fwin else fm), _p(fm if is_fwin else None),
+                                                      _p(arg), _p(gF3), B, N, S, C, _p(gfm), _p(gd)), ws, wsb, (directions, gd),
+                          key=f"B{B}N{N}S{S}C{C}", abytes=B * N * (12 + 5 * SC + 4 * C + 4 * (S + 1) * C) + 24 * SC)
     return gfm, gd
 
 
@@ -1276,7 +1353,8 @@ class _SurfaceLayer(torch.autograd.Function):
             g_ste = torch.empty(C, 3, dtype=torch.float32, device=g.device)
         else:
             gt = colsum_rows(g)
-        wgrad(g2, F2, out=g_conv2[:, :C])
+        with WgradBatch():                                  # (its fold goes out with the step's folds inside a StepFolds scope)
+            wgrad(g2, F2, out=g_conv2[:, :C])
         if own_ste:
             _tiny_tn(gt, fg, g_conv2[:, C:], mom=mom, gste=g_ste)
         else:
@@ -1289,8 +1367,8 @@ class _SurfaceLayer(torch.autograd.Function):
         L = lib()
         wsb = L.hsp_rf_bwd_scatter_workspace_bytes(B, SC)
         ws = _ws(wsb, g.device)
-        _run("hsp_rf_surface_bwd", (_p(xyz), _p(directions), _p(arg), _p(gF3), B, N, S, C, _p(gD), _p(ws), wsb, _stream()),
-             key=f"B{B}N{N}S{S}C{C}", abytes=B * N * (12 + 4 * C + SC) + 24 * SC)
+        _rf_bwd_dirs_call("hsp_rf_surface_bwd", (_p(xyz), _p(directions), _p(arg), _p(gF3), B, N, S, C, _p(gD)), ws, wsb,
+                          (directions, gD), key=f"B{B}N{N}S{S}C{C}", abytes=B * N * (12 + 4 * C + SC) + 24 * SC)
         if not own_ste:
             g_ste = g2.t() @ x2
         return None, None, None, None, gD, g_ste.unsqueeze_(-1), g_conv2.unsqueeze_(-1), None

@@ -150,9 +150,10 @@ def _rf_conv_bwd(xyz, directions, fm, arg, gF3, S):
     wsb = lib().hsp_rf_bwd_scatter_workspace_bytes(B, SC)
     ws = _ws(wsb, gF3.device)
     is_fwin = fm.shape[-1] == SC
-    _run("hsp_rf_conv_bwd_scatter_bf16", (_p(xyz), _p(directions), _p(None if is_fwin else fm), _p(fm if is_fwin else None),
-                                          _p(arg), _p(gF3), B, N, S, C, _p(gfm), _p(gd), _p(ws), wsb, _stream()),
-         key=f"B{B}N{N}S{S}C{C}", abytes=B * N * (12 + 2 * SC + 2 * SC + 2 * C + 2 * (S + 1) * C) + 24 * SC)
+    ops._rf_bwd_dirs_call("hsp_rf_conv_bwd_scatter_bf16", (_p(xyz), _p(directions), _p(None if is_fwin else fm),
+                                                           _p(fm if is_fwin else None), _p(arg), _p(gF3), B, N, S, C, _p(gfm), _p(gd)),
+                          ws, wsb, (directions, gd), key=f"B{B}N{N}S{S}C{C}",
+                          abytes=B * N * (12 + 2 * SC + 2 * SC + 2 * C + 2 * (S + 1) * C) + 24 * SC)
     return gfm, gd
 
 
@@ -284,8 +285,8 @@ class _SurfaceLayerBf16(torch.autograd.Function):
         gD = torch.empty_like(directions)
         wsb = lib().hsp_rf_bwd_scatter_workspace_bytes(B, SC)
         ws = _ws(wsb, g.device)
-        _run("hsp_rf_surface_bwd_bf16", (_p(xyz), _p(directions), _p(arg), _p(gF3), B, N, S, C, _p(gD), _p(ws), wsb, _stream()),
-             key=f"B{B}N{N}S{S}C{C}", abytes=B * N * (12 + 2 * C + 2 * SC) + 24 * SC)
+        ops._rf_bwd_dirs_call("hsp_rf_surface_bwd_bf16", (_p(xyz), _p(directions), _p(arg), _p(gF3), B, N, S, C, _p(gD)), ws, wsb,
+                              (directions, gD), key=f"B{B}N{N}S{S}C{C}", abytes=B * N * (12 + 2 * C + 2 * SC) + 24 * SC)
         if not own_ste:
             g_ste = g2.float().t() @ x2                           # (C,3): three columns -- not a matrix-core shape
         return None, None, None, None, gD, g_ste.unsqueeze_(-1), g_conv2.unsqueeze_(-1)

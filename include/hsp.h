@@ -327,13 +327,43 @@ int hsp_cast_params_bf16(const HspCastDesc *table_dev, int n, int total_tiles, h
 size_t hsp_wgrad_workspace_bytes(int M, int N, int K);
 /* split forms for a backward that computes several parameter gradients (an HS layer has three): hsp_wgrad_partial_* runs the
  * split-K launch only and describes the pending fold in *pending (a HOST struct; the workspace must stay alive and untouched
- * until the fold); hsp_wgrad_fold folds up to 4 pending problems in ONE launch (same fixed order, same results). */
+ * until the fold); hsp_wgrad_fold folds up to HSP_FOLD_MAX_WGRAD pending problems in ONE launch (same fixed order, same
+ * results). */
+#define HSP_FOLD_MAX_WGRAD 24
+#define HSP_FOLD_MAX_DIRS 8
 typedef struct HspWgradPending {
     const void *part, *cs_part;   /* split-K partials in the problem's workspace */
     void *C, *colsum;             /* outputs (colsum may be NULL) */
     int nparts, M, N, ldc;
 } HspWgradPending;
 int hsp_wgrad_fold(const HspWgradPending *pending, int n, hspStream_t stream);
+/* the pending fold of a receptive-field layer's support-direction gradient (hsp_rf_*_bwd*_partial below): nparts per-cloud
+ * partials (3, SC) in the call's workspace -> grad_dirs (3, SC) through the Jacobian of F.normalize(directions, dim=0)
+ * (gcn3d.py:100,166).  A HOST struct; the workspace must stay alive and untouched until the fold. */
+typedef struct HspDirsPending {
+    const void *part, *dirs;      /* partials; the layer's RAW directions parameter (3, SC) */
+    void *grad_dirs;              /* output (3, SC) */
+    int nparts, SC;
+} HspDirsPending;
+/* every fold a backward pass left pending in ONE launch: nw <= HSP_FOLD_MAX_WGRAD parameter-gradient folds and
+ * nd <= HSP_FOLD_MAX_DIRS direction-gradient folds (autograd of gcn3d.py:149,171,186 and :166 produce them; nothing before the
+ * optimizer reads them).  Same summation order as the stand-alone folds: same bits. */
+int hsp_step_fold(const HspWgradPending *wgrads, int nw, const HspDirsPending *dirs, int nd, hspStream_t stream);
+/* hsp_rf_surface_bwd / hsp_rf_conv_bwd_scatter (and their bf16-storage twins) WITHOUT the direction-gradient fold: the tile
+ * launch only; *pending describes the fold that hsp_step_fold runs later (grad_dirs is not valid until then). */
+int hsp_rf_surface_bwd_partial(const float *xyz, const float *dirs, const uint16_t *argrow, const float *grad_out, int B, int N,
+                               int S, int K, float *grad_dirs, void *ws, size_t ws_bytes, HspDirsPending *pending,
+                               hspStream_t stream);
+int hsp_rf_conv_bwd_scatter_partial(const float *xyz, const float *dirs, const float *fm, const float *fwin,
+                                    const uint16_t *argrow, const float *grad_out, int B, int N, int S, int C, float *grad_fm,
+                                    float *grad_dirs, void *ws, size_t ws_bytes, HspDirsPending *pending, hspStream_t stream);
+int hsp_rf_surface_bwd_partial_bf16(const float *xyz, const float *dirs, const uint16_t *argrow, const hsp_bf16_t *grad_out,
+                                    int B, int N, int S, int K, float *grad_dirs, void *ws, size_t ws_bytes,
+                                    HspDirsPending *pending, hspStream_t stream);
+int hsp_rf_conv_bwd_scatter_partial_bf16(const float *xyz, const float *dirs, const hsp_bf16_t *fm, const hsp_bf16_t *fwin,
+                                         const uint16_t *argrow, const hsp_bf16_t *grad_out, int B, int N, int S, int C,
+                                         hsp_bf16_t *grad_fm, float *grad_dirs, void *ws, size_t ws_bytes,
+                                         HspDirsPending *pending, hspStream_t stream);
 /* two pending weight gradients from ONE split-K launch (an HS layer's backward has two that depend only on the incoming
  * gradient and are each too small to fill the chip: g^T F and g^T X -- autograd of gcn3d.py:186 and :149); pending[2] */
 int hsp_wgrad_partial_pair_f32(const float *A0, int lda0, const float *B0, int ldb0, int M0, int N0, int K0, float *C0, int ldc0,

@@ -151,6 +151,9 @@ def test_round2_entry_points_validate_arguments_without_gpu():
     assert L.hsp_pose_augment(*([one] * 13 + [null]), 2, 8, 4, *fl, one, one, one, one, null) == -1                   # no noise
     # split weight gradient: the fold checks its table
     pend = (HspWgradPending * 2)()
-    assert L.hsp_wgrad_fold(pend, 0, null) == -1 and L.hsp_wgrad_fold(pend, 5, null) == -1
+    assert L.hsp_wgrad_fold(pend, 0, null) == -1 and L.hsp_wgrad_fold(pend, 25, null) == -1
     assert L.hsp_wgrad_fold(pend, 1, null) == -1                                                                      # empty entry
+    assert L.hsp_step_fold(null, 1, null, 0, null) == -1 and L.hsp_step_fold(pend, 1, null, 0, null) == -1           # no table / empty entry
+    assert L.hsp_step_fold(pend, 0, null, 9, null) == -1 and L.hsp_step_fold(null, 0, null, 0, null) == 0            # nothing pending: no launch
+    assert L.hsp_rf_conv_bwd_scatter_partial(one, one, one, null, one, one, 2, 64, 7, 64, one, one, one, 1 << 20, null, null) == -1   # no pending
     assert L.hsp_wgrad_partial_f32(one, 128, one, 1024, 128, 1024, 4000, one, 1024, null, one, 1 << 30, null, null) == -1   # no pending
