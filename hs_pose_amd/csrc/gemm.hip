@@ -451,7 +451,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const float* __restric
     constexpr int PITCH = 80, PLANE = 128 * PITCH;             // bytes
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_m = M >> 7, tiles = tiles_m * (N >> 7);
+    // M need not be a multiple of 128 (nor of 4: the K = 1286 / 1289 / 771 inputs of the heads' first layers, PoseR.py:27,
+    // PoseTs.py:32, FaceRecon.py:38,116): the last row tile reads only the column quads below ceil4(M) <= lda -- the operand's rows
+    // sit on a 16-byte pitch (ops.assemble_feat / cat_rows_pitched) -- the quads above it enter as zeros, and the partial tile keeps
+    // its rows below M.  N (the other operand's width) stays a multiple of 128.
+    const int tiles_m = (M + 127) >> 7, tiles = tiles_m * (N >> 7);
     const int slice = blockIdx.x / tiles, t = blockIdx.x - slice * tiles;
     const int tn = t / tiles_m, tm = t - tn * tiles_m;
     const int m0 = tm << 7, n0 = tn << 7;
@@ -463,6 +467,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const float* __restric
     const int kb8 = id >> 5, mc = id & 31;
     const float* src = half ? B + n0 + mc * 4 : A + m0 + mc * 4;
     const int ld = half ? ldb : lda;
+    const bool live = half || m0 + mc * 4 < M;                 // (a column quad of A past the ragged edge)
     char* const img = smem + half * 3 * PLANE;
 
     float4 r[8];
@@ -472,7 +477,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int row = kr + j < k1 ? kr + j : k1 - 1;                  // clamped (branch-free); zeroed in stash
-            r[j] = *reinterpret_cast<const float4*>(src + (size_t)row * ld);
+            r[j] = live ? *reinterpret_cast<const float4*>(src + (size_t)row * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto stash = [&](int b) {
@@ -566,7 +571,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const float* __restric
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int row = m0 + wm0 + 32 * x + (q & 3) + 8 * (q >> 2) + 4 * lh;
-                pc[(size_t)row * N + n0 + wn0 + 32 * y + li] = acc[x][y][q];
+                if (row < M) pc[(size_t)row * N + n0 + wn0 + 32 * y + li] = acc[x][y][q];
             }
     if (COLSUM && tm == 0) {
         __syncthreads();
@@ -584,19 +589,31 @@ static bool wgrad_x3_ok(const void* A, int lda, const void* B, int ldb, int M, i
     static const bool off = [] { const char* e = getenv("HSP_WGRAD_X3"); return e && e[0] == '0'; }();
     // (>= 4 output tiles: a single 128 x 128 tile leaves the K slices as the only parallelism -- 65 workgroups at K = 16448 --
     // and the fp32 kernel's 4-slices-per-workgroup form is faster there: 9.8 vs 18.3 us)
-    return !off && (M & 127) == 0 && (N & 127) == 0 && (M >> 7) * (N >> 7) >= 4 && (lda & 3) == 0 && (ldb & 3) == 0 &&
+    // (ragged M: the last column quad of A is read whole, so its rows must reach ceil4(M))
+    return !off && (N & 127) == 0 && ((M + 127) >> 7) * (N >> 7) >= 4 && (lda & 3) == 0 && (ldb & 3) == 0 && lda >= ((M + 3) & ~3) &&
            ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(B)) & 15) == 0;
 }
+// shapes only the x3 form takes: M not a multiple of 64 (the heads' K = 1286 / 1289 / 771 first layers)
+static bool wgrad_ragged_m(int M, int N) { return (M & 63) != 0 && (N & 127) == 0 && M >= 128; }
 
 static int wgrad_bf16_pick(int M, int N, int K, int* kslice) {
-    const int tiles = (M >> 7) * (N >> 7);
+    const int tiles = ((M + 127) >> 7) * (N >> 7);
     int sk = tiles > 0 ? (512 + tiles - 1) / tiles : 1;
     const int max_sk = (K + 255) / 256;
     if (sk > max_sk) sk = max_sk;
     if (sk > 128) sk = 128;
     if (sk < 1) sk = 1;
-    int ks = (K + sk - 1) / sk;
-    ks = (ks + 63) / 64 * 64;
+    // two workgroups per CU: 512 run at once.  A tile count that does not divide 512 (the ragged shapes of the heads: 88, 44, 28
+    // tiles) would put 528 / 532 workgroups in TWO rounds with the rule above -- one slice fewer keeps it to one, longer, round
+    // (1286 x 1024 <- 16448: 385 -> 2xx us).  Cost = rounds x rows per slice; the rule above wins ties (every shape whose
+    // tile count divides 512 keeps its slices, so its bits).
+    auto ksof = [&](int s_) { int k_ = (K + s_ - 1) / s_; return (k_ + 63) / 64 * 64; };
+    auto cost = [&](int s_) { return (long long)((tiles * s_ + 511) / 512) * ksof(s_); };
+    int best = sk;
+    for (int c = sk - 1; c >= 1 && c >= sk - 2; --c)
+        if (cost(c) < cost(best)) best = c;
+    sk = best;
+    const int ks = ksof(sk);
     *kslice = ks;
     return (K + ks - 1) / ks;
 }
@@ -645,6 +662,10 @@ using namespace hsp;
 extern "C" size_t hsp_wgrad_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     int ks, kb;
+    if (wgrad_ragged_m(M, N)) {                                // (x3 form only)
+        const size_t p2 = (size_t)wgrad_bf16_pick(M, N, K, &ks);
+        return p2 * ((size_t)M * N + N) * sizeof(float);
+    }
     const int sk = wgrad_pick_sk(M, N, K, &ks, &kb);
     size_t parts = (size_t)(sk / kb);
     if ((M & 127) == 0 && (N & 127) == 0) {                    // the bf16-MFMA form may cut K finer
@@ -676,7 +697,9 @@ template <typename FT>
 static int wgrad_impl(const FT* A, int lda, const FT* B, int ldb, int M, int N, int K, float* C, int ldc,
                       float* colsum_B, void* ws, size_t ws_bytes, hspStream_t stream, HspWgradPending* pending = nullptr) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda < M || ldb < N || ldc < N) return HSP_ERR_BAD_ARG;
-    if ((M & 63) || (N & 63) || (lda & 1) || (ldb & 1)) return HSP_ERR_UNSUPPORTED;   // 64x64 wave tiles, float2 loads
+    const bool ragged = sizeof(FT) == 4 && wgrad_ragged_m(M, N);                       // fp32 rows, x3 form only
+    if (ragged && !wgrad_x3_ok(A, lda, B, ldb, M, N)) return HSP_ERR_UNSUPPORTED;
+    if (!ragged && ((M & 63) || (N & 63) || (lda & 1) || (ldb & 1))) return HSP_ERR_UNSUPPORTED;   // 64x64 wave tiles, float2 loads
     if (!ws || ws_bytes < hsp_wgrad_workspace_bytes(M, N, K)) return HSP_ERR_WORKSPACE;
     int ks, kb;
     hipStream_t st = as_stream(stream);
@@ -716,7 +739,7 @@ static int wgrad_impl(const FT* A, int lda, const FT* B, int ldb, int M, int N, 
             const int sk2 = wgrad_bf16_pick(M, N, K, &ks);
             float* part = reinterpret_cast<float*>(ws);
             float* cs_part = part + (size_t)sk2 * M * N;
-            const int grid = (M >> 7) * (N >> 7) * sk2;
+            const int grid = ((M + 127) >> 7) * (N >> 7) * sk2;
             const int lds = 6 * 128 * 80;
             if (colsum_B) hipLaunchKernelGGL(wgrad_x3_kernel<true>, dim3(grid), dim3(256), lds, st, A, lda, B, ldb, M, N, K, ks, part, cs_part);
             else hipLaunchKernelGGL(wgrad_x3_kernel<false>, dim3(grid), dim3(256), lds, st, A, lda, B, ldb, M, N, K, ks, part, cs_part);

@@ -589,6 +589,8 @@ def wgrad(A2, B2, out=None, colsum=False):
     N = B2.shape[1]
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=A2.device)
+    if _wgrad_ragged_ok(A2, B2, out) and WGRAD_MODE != "library":
+        return _wgrad_custom(A2, B2, out, colsum)               # (only the x3 kernel takes a ragged M; no library twin is timed)
     ok = (M % 64 == 0 and N % 64 == 0 and A2.stride(1) == 1 and B2.stride(1) == 1 and out.stride(1) == 1
           and A2.stride(0) % 2 == 0 and B2.stride(0) % 2 == 0 and A2.dtype == torch.float32 and A2.is_cuda)
     if not ok or WGRAD_MODE == "library":
@@ -610,6 +612,18 @@ def wgrad(A2, B2, out=None, colsum=False):
                 WgradBatch.current, StepFolds.current = held, held_sf
             choice = _wgrad_choice[key] = "custom" if t_c <= t_l else "library"
     return _wgrad_custom(A2, B2, out, colsum) if choice == "custom" else _wgrad_library(A2, B2, out, colsum)
+
+
+def _wgrad_ragged_ok(A2, B2, out):
+    """A2^T B2 with M = A2.shape[1] NOT a multiple of 64 (the heads' first layers: K = 1286 / 1289 / 771 input columns,
+    PoseR.py:27, PoseTs.py:32, FaceRecon.py:38,116) on the x3 kernel: fp32 rows of A2 on a 16-byte pitch that covers ceil4(M)
+    (``assemble_feat`` / ``cat_rows_pitched`` lay them out so), N a multiple of 128, own-GEMM mode"""
+    K, M = A2.shape
+    N = B2.shape[1]
+    return (GEMM_MODE == "own" and os.environ.get("HSP_WGRAD_X3", "1") != "0" and M % 64 != 0 and M >= 128 and N % 128 == 0
+            and -(-M // 128) * (N // 128) >= 4 and A2.dtype == torch.float32 and B2.dtype == torch.float32 and A2.is_cuda
+            and A2.stride(1) == 1 and B2.stride(1) == 1 and out.stride(1) == 1 and A2.stride(0) % 4 == 0 and B2.stride(0) % 4 == 0
+            and A2.stride(0) >= (M + 3) // 4 * 4 and A2.data_ptr() % 16 == 0 and B2.data_ptr() % 16 == 0)
 
 
 def _wgrad_ok(A2, B2, out):
@@ -1415,12 +1429,23 @@ class _LinearRows(torch.autograd.Function):
         with x3_scope(ctx.x3):
             gx = _mm_nn(g, weight) if ctx.needs_input_grad[0] else None
         R, Cout = g.shape
+        Cin = x2.shape[1]
         gb = None
-        if Cout % 64 == 0 and x2.shape[1] % 64 == 0:
+        if (Cout % 64 == 0 and Cin % 64 == 0) or _wgrad_ragged_ok(x2, g, g):
             gwt, gb = wgrad(x2, g, colsum=True)                 # (Cin, Cout) = dW^T, column sums of g = db
             gw = gwt.t()
+        elif GEMM_MODE == "own" and Cout < 64 and Cin % 64 == 0 and R >= 1024 and g.is_contiguous():
+            # a thin per-point output layer (the 3- and 30-wide last layers of FaceRecon.py:48,68 over B*N rows): g padded to
+            # 64 zero columns takes the split-K kernel -- the library's 16448-deep 30 x 128 product is a 100 us launch
+            gp = g.new_zeros(R, 64)
+            gp[:, :Cout] = g
+            gwt, gbp = wgrad(x2, gp, colsum=True)
+            gw, gb = gwt[:, :Cout].t(), gbp[:Cout]
         else:
-            gw = torch.mm(g.t(), x2)
+            if GEMM_MODE == "own" and R <= 64 and g.stride(1) == 1 and x2.stride(1) == 1:
+                gw = _tiny_tn(g, x2, torch.empty(Cout, Cin, dtype=torch.float32, device=g.device))   # per-cloud rows (the towers' conv4)
+            else:
+                gw = torch.mm(g.t(), x2)
             if ctx.has_bias:
                 gb = colsum_rows(g.view(1, R, Cout)).view(Cout)
         return gx, gw, (gb if ctx.has_bias else None)

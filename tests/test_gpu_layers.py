@@ -332,6 +332,66 @@ def test_wgrad_gemm(dev, ref, monkeypatch, K, M, N, lda_pad, ldc_pad):
     assert torch.equal(out2, out.contiguous())
 
 
+@pytest.mark.parametrize("K,M,N,pad_nan", [(16448, 1286, 1024, True), (5000, 1289, 1024, False), (4113, 771, 512, True),
+                                            (700, 130, 512, False)])
+def test_wgrad_ragged_m(dev, ref, K, M, N, pad_nan):
+    """the heads' first-layer weight gradients (K = 1286 / 1289 / 771 input columns: PoseR.py:27, PoseTs.py:32, FaceRecon.py:38,116)
+    on the x3 kernel: A's rows on a 16-byte pitch >= ceil4(M), the last row tile ragged.  vs fp64; the pad columns (whatever
+    they hold) reach no output; output rows past M are never written."""
+    from hs_pose_amd import ops
+    pitch = (M + 3) // 4 * 4
+    if pitch == M:
+        pitch += 4
+    Afull = ref.hash_tensor((K, pitch), 21, 1.0).to(dev)
+    if pad_nan:
+        Afull[:, M:] = float("nan")
+    A = Afull[:, :M]
+    Bm = ref.hash_tensor((K, N), 22, 1.0).to(dev)
+    assert ops._wgrad_ragged_ok(A, Bm, Bm)
+    guard = torch.full((M + 8, N), 7.0, device=dev)
+    out, cs = ops.wgrad(A, Bm, out=guard[:M], colsum=True)
+    want = A.double().t() @ Bm.double()
+    scale = want.abs().max().item()
+    assert torch.isfinite(out).all()
+    assert (out.double() - want).abs().max().item() <= 2e-6 * scale * max(1.0, (K / 1000) ** 0.5)
+    assert (cs.double() - Bm.double().sum(0)).abs().max().item() <= 2e-6 * Bm.double().sum(0).abs().max().item() + 1e-4
+    assert (guard[M:] == 7.0).all()
+    out2 = ops.wgrad(A, Bm)
+    assert torch.equal(out2, out)
+    # inside a WgradBatch the fold is left pending and runs at the exit: same bits
+    out3 = torch.empty(M, N, device=dev)
+    with ops.WgradBatch():
+        ops.wgrad(A, Bm, out=out3)
+    assert torch.equal(out3, out)
+
+
+@pytest.mark.parametrize("Cin,Cout", [(128, 3), (128, 30), (1286, 1024), (771, 512)])
+def test_linear_rows_backward_own_kernels(dev, ref, Cin, Cout):
+    """linear_rows' backward on the shapes that used to fall to the BLAS library (thin per-point outputs, ragged input widths):
+    weight / bias / input gradients vs fp64"""
+    from hs_pose_amd import ops
+    R = 16448
+    pitch = (Cin + 3) // 4 * 4
+    xfull = ref.hash_tensor((R, pitch), 31, 1.0).to(dev)
+    x = xfull[:, :Cin].requires_grad_(True) if pitch != Cin else xfull.requires_grad_(True)
+    w = (ref.hash_tensor((Cout, Cin), 32, 1.0) * 0.05).to(dev).requires_grad_(True)
+    b = ref.hash_tensor((Cout,), 33, 1.0).to(dev).requires_grad_(True)
+    up = ref.hash_tensor((R, Cout), 34, 1.0).to(dev)
+    timer = ops.KernelTimer()
+    prev = ops.set_timer(timer)
+    try:
+        y = ops.linear_rows(x, w, b)
+        gx, gw, gb = torch.autograd.grad(y, (x, w, b), up)
+    finally:
+        ops.set_timer(prev)
+    torch.cuda.synchronize()
+    assert any(r[0].startswith("hsp_wgrad") for r in timer.records)
+    xd, wd, ud = x.detach().double(), w.detach().double(), up.double()
+    for got, want in ((y, xd @ wd.t() + b.detach().double()), (gw, ud.t() @ xd), (gb, ud.sum(0)), (gx, ud @ wd)):
+        sc = want.abs().max().item()
+        assert (got.double() - want).abs().max().item() <= 1e-5 * sc, (Cin, Cout)
+
+
 @pytest.mark.parametrize("B,N,C,relu", [(16, 1028, 128, True), (2, 257, 256, True), (3, 100, 64, False)])
 def test_bn_relu_fused(dev, ref, B, N, C, relu):
     """fused train-mode BatchNorm1d+ReLU vs torch's module on the same rows: output, input / affine
