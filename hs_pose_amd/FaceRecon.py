@@ -22,11 +22,13 @@ def _bn_rows(bn, x):
     return bn(x.reshape(b * n, c)).view(b, n, c)
 
 
-def _conv_bn_relu_rows(seq, x, n_blocks):
-    """Apply n_blocks x (Conv1d k=1, BatchNorm1d, ReLU) of an nn.Sequential to (R, C) rows."""
+def _conv_bn_relu_rows(seq, x, n_blocks, first=None):
+    """Apply n_blocks x (Conv1d k=1, BatchNorm1d, ReLU) of an nn.Sequential to (R, C) rows.  first: the first Conv1d's output when
+    the caller already has it (``ops.fan_linear_rows``)."""
     for i in range(n_blocks):
         conv, bn = seq[3 * i], seq[3 * i + 1]
-        x = ops.bn_relu(ops.linear_rows(x, conv.weight.squeeze(-1), conv.bias), bn)         # fused BatchNorm + ReLU (norm.hip)
+        y = first if (i == 0 and first is not None) else ops.linear_rows(x, conv.weight.squeeze(-1), conv.bias)
+        x = ops.bn_relu(y, bn)                                                              # fused BatchNorm + ReLU (norm.hip)
     return x
 
 
@@ -64,6 +66,7 @@ class FaceRecon(nn.Module):
                                            nn.Conv1d(128, self.face_recon_num, 1))
 
     _x3 = None                       # ops.X3Planes of this network (created on first use; PoseNet9D shares it with the heads)
+    feat_consumers = None            # PoseNet9D: callable (feat rows, xyz) -> conv1d_block[0]'s output (ops.fan_linear_rows)
     keep_backward_cut = False
     backward_cut = None
     feature_dtype = torch.float32
@@ -166,7 +169,12 @@ class FaceRecon(nn.Module):
         if FLAGS.train:
             f_global = ops.points_max(fm_4)          # (FaceRecon.py:98 computes it unconditionally; only this branch reads it)
             rows = feat.reshape(bs * vertice_num, -1)
-            h = _conv_bn_relu_rows(self.conv1d_block, rows, 3)                       # (B*N, 256)
+            first = None
+            if self.feat_consumers is not None:
+                # the layers that read feat's rows -- this block's first Conv1d and, handed over by PoseNet9D, the first layers of
+                # the three pose heads -- as ONE node: their input gradients are summed in the products' epilogues
+                first = self.feat_consumers(rows, vertices)
+            h = _conv_bn_relu_rows(self.conv1d_block, rows, 3, first=first)          # (B*N, 256)
             r = _conv_bn_relu_rows(self.recon_head, h, 1)
             last = self.recon_head[3]
             recon = ops.linear_rows(r, last.weight.squeeze(-1), last.bias).view(bs, vertice_num, -1)

@@ -1,5 +1,7 @@
 """Host-side mirror of the reference's ``network/fs_net_repo/PoseNet9D.py`` (class name, sub-module names and the
 10-tuple it returns are the interface ``HSPose.forward`` relies on, HSPose.py:64-65)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -44,18 +46,45 @@ class PoseNet9D(nn.Module):
         with ops.x3_scope(self.face_recon._x3):          # the heads' weight planes live in the backbone's registry
             return self._forward(points, obj_id)
 
+    def _fan_first_layers(self, rows, xyz):
+        """the first Conv1d of every consumer of feat's rows (the three pose heads, PoseR.py:27 / PoseTs.py:32, and -- training --
+        the reconstruction block, FaceRecon.py:38) as one ``ops.fan_linear_rows`` node; keeps the heads' results for
+        ``_forward`` and returns the reconstruction block's.  None (the caller then runs its own layer) when the shapes /
+        GEMM mode are not the fused kernels'."""
+        heads = (self.rot_green, self.rot_red, self.ts)
+        layers = [(h.conv1.weight.squeeze(-1), h.conv1.bias) for h in heads]
+        blk = self.face_recon.conv1d_block[0] if FLAGS.train else None
+        if blk is not None:
+            layers.append((blk.weight.squeeze(-1), blk.bias))
+        if os.environ.get("HSP_FAN_HEADS", "1") == "0" or not ops.fan_linear_rows_ok(rows, xyz, [w for w, _ in layers]):
+            self._first = None
+            return None
+        outs = ops.fan_linear_rows(rows, xyz, layers)
+        self._first = outs[:3]
+        return outs[3] if blk is not None else None
+
     def _forward(self, points, obj_id):
         centre = points.mean(dim=1, keepdim=True)
         local = points - centre                                  # the network sees clouds centred on their mean
-        recon, face, feat = self.face_recon(local, obj_id)
+        self._first = None
+        self.face_recon.feat_consumers = self._fan_first_layers if FLAGS.train else None
+        try:
+            recon, face, feat = self.face_recon(local, obj_id)
+        finally:
+            self.face_recon.feat_consumers = None
+        if not FLAGS.train:
+            self._fan_first_layers(feat.reshape(-1, feat.shape[-1]), local)
+        first, self._first = self._first, None
+        fg, fr, ft = first if first is not None else (None, None, None)
         face_normal = face_dis = face_f = None
         if FLAGS.train:                                          # training-only heads (reconstruction, box faces)
             recon = recon + centre
             face_normal, face_dis, face_f = _split_face_head(face)
         else:
             recon = None
-        p_green_R, f_green_R = _axis_and_confidence(self.rot_green.forward_rows(feat))
-        p_red_R, f_red_R = _axis_and_confidence(self.rot_red.forward_rows(feat))
-        shift, size = self.ts.forward_rows(ops.cat_rows_pitched([feat, local]))
+        p_green_R, f_green_R = _axis_and_confidence(self.rot_green.forward_rows(feat, fg))
+        p_red_R, f_red_R = _axis_and_confidence(self.rot_red.forward_rows(feat, fr))
+        # (fused: conv1 of the translation / size head read cat[feat, local] as the two sources of its product)
+        shift, size = self.ts.forward_rows(feat if ft is not None else ops.cat_rows_pitched([feat, local]), ft)
         return (recon, face_normal, face_dis, face_f, p_green_R, p_red_R, f_green_R, f_red_R,
                 shift + centre.squeeze(1), size)

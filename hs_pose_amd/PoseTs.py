@@ -14,6 +14,6 @@ class Pose_Ts(_PointMLPHead):
         self.relu2 = nn.ReLU()
         self.relu3 = nn.ReLU()
 
-    def forward_rows(self, x):
-        out = super().forward_rows(x)
+    def forward_rows(self, x, first=None):
+        out = super().forward_rows(x, first)
         return out[:, 0:3], out[:, 3:6]

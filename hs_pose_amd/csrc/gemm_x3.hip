@@ -106,6 +106,28 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    if constexpr (EPI == 2) {
+        // residual ONLY (alpha == 1; the input-gradient chain of layers that share their input rows): the accumulators START from
+        // the residual -- its loads land in the registers the tile owns anyway and fly under the first blocks' staging, where an
+        // epilogue read costs its own registers (256 VGPRs = one workgroup per CU fewer) and an exposed round trip per row group
+        // (measured 324 vs 231 us on 16448 x 1286 <- 1024)
+        // (buffer loads: rows past M fall outside the descriptor and read 0, columns past N are sent there; one vector offset per
+        // column block, the row steps are scalar offsets -- no per-element address or select registers)
+        const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(g.resid), 0, (int)((size_t)g.M * g.ldr * 4), 0x00020000);
+        const unsigned ldr4 = (unsigned)g.ldr * 4u;
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int col = n0 + wn0 + 32 * y + li;
+            const unsigned voff = col < g.N ? (unsigned)(m0 + wm0 + 4 * lh) * ldr4 + (unsigned)col * 4u : 0xfffffff0u;
+#pragma unroll
+            for (int x = 0; x < WM; ++x)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[x][y][r] = __uint_as_float(
+                        __builtin_amdgcn_raw_buffer_load_b32(rsR, voff, (unsigned)(32 * x + (r & 3) + 8 * (r >> 2)) * ldr4, 0));
+        }
+    }
 
     // ---- staging registers of one block (ONE set, loads one block ahead.  Two sets / two blocks ahead were measured: the
     // 64-row kernels went from 112-128 to 146-158 VGPRs = one wave per SIMD fewer, and the step from 2.03 to 2.06 ms -- these
@@ -257,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
         }
         return;
     }
-    constexpr bool HAS_BIAS = EPI & 1, HAS_RES = EPI & 2, HAS_CB = EPI & 4, HAS_BN = EPI & 8;
+    constexpr bool HAS_BIAS = EPI & 1, HAS_RES = (EPI & 2) && EPI != 2, HAS_CB = EPI & 4, HAS_BN = EPI & 8;
     float bn1[2] = {0.f, 0.f}, bn2[2] = {0.f, 0.f};           // per column of this lane: sum (v - shift), sum (v - shift)^2
     // per-cloud bias: a tile of BM rows spans at most two clouds when rows_per_cloud >= BM (boundary compare, no division)
     const int c0 = m0 / g.rpc, nb = (c0 + 1) * g.rpc;
@@ -498,8 +520,10 @@ static int gemm_x3_impl(const float* A1, int lda1, const hsp_bf16_t* P1, int ldp
     if (items > (1ll << 30)) return HSP_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);
     const dim3 grid((unsigned)items), block(256);
-    // instantiated epilogues: 0 none, 1 bias, 6 residual + per-cloud bias (the layer's out product), 14 = 6 + BatchNorm partials
-    if (epi != 0 && epi != 1 && epi != 6) return HSP_ERR_UNSUPPORTED;
+    // instantiated epilogues: 0 none, 1 bias, 2 residual (one source: the input-gradient chain of layers that share their input
+    // rows -- C may BE resid: an element is read and written by the same thread), 6 residual + per-cloud bias (the layer's out
+    // product), 14 = 6 + BatchNorm partials
+    if (epi != 0 && epi != 1 && epi != 6 && !(epi == 2 && !two && alpha == 1.0f)) return HSP_ERR_UNSUPPORTED;
     if (bn) {
         if (two) hipLaunchKernelGGL((gemm_x3_kernel<1, true, 14, 0>), grid, block, 3 * (size_t)(64 + X3_BN) * 64, st, g);
         else hipLaunchKernelGGL((gemm_x3_kernel<1, false, 14, 0>), grid, block, 3 * (size_t)(64 + X3_BN) * 64, st, g);
@@ -524,6 +548,7 @@ static int gemm_x3_impl(const float* A1, int lda1, const hsp_bf16_t* P1, int ldp
         } else {                                                   \
             if (epi == 0) X3_K(WM_, false, 0, PA_);                \
             else if (epi == 1) X3_K(WM_, false, 1, PA_);           \
+            else if (epi == 2) X3_K(WM_, false, 2, 0);             \
             else X3_K(WM_, false, 6, PA_);                         \
         }                                                          \
     } while (0)

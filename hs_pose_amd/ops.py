@@ -856,7 +856,7 @@ def gemm_x3_ok(A1, B1, A2, B2, bias, resid, cloud_bias, xyz3, out, M, N):
     if not lib().hsp_gemm_x3_supported(M, N, A1.shape[1], K2):
         return False
     epi = (1 if bias is not None else 0) | (2 if resid is not None else 0) | (4 if cloud_bias is not None else 0)
-    if epi not in (0, 1, 6):
+    if epi not in (0, 1, 6) and not (epi == 2 and A2 is None):
         return False
     if epi and ((M + 63) // 64) * ((N + 127) // 128) < 128:            # (an epilogue rules out split-K: too few workgroups)
         return False
@@ -966,7 +966,9 @@ def gemm_own(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=No
             and resid is None and cloud_bias is None and xyz3 is None and K1 <= 2048
             and A1.dtype == torch.float32 and A1.stride(1) == 1 and B1.stride(1) == 1):
         return small_rows(A1, B1, nn1, out=out, alpha=alpha)          # a row per cloud: one small launch
-    if M >= 256 and gemm_x3_ok(A1, B1, A2, B2, bias, resid, cloud_bias, xyz3, out, M, N) and (out is None or _al16(out)):
+    # (the x3 kernel stores -- and reads its residual -- element by element: its output rows need no 16-byte pitch; a result it
+    # allocates itself for N = 1286 has none either)
+    if M >= 256 and gemm_x3_ok(A1, B1, A2, B2, bias, resid, cloud_bias, xyz3, out, M, N) and (out is None or out.stride(1) == 1):
         res = gemm_x3(A1, B1, nn1, A2, B2, nn2, bias=bias, resid=resid, cloud_bias=cloud_bias, rows_per_cloud=rows_per_cloud,
                       out=out, alpha=alpha)
         return torch.relu_(res) if relu else res
@@ -1449,6 +1451,80 @@ class _LinearRows(torch.autograd.Function):
             if ctx.has_bias:
                 gb = colsum_rows(g.view(1, R, Cout)).view(Cout)
         return gx, gw, (gb if ctx.has_bias else None)
+
+
+class _FanGroup:
+    """the consumers of one set of rows (one forward pass): the input-gradient buffer they accumulate into"""
+
+    def __init__(self):
+        self.gx = None
+
+
+class _FanMember(torch.autograd.Function):
+    """One of several Linear / Conv1d(k=1) layers fed by the SAME rows x (the first layers of the three pose heads and of the
+    reconstruction block all read ``feat``: PoseR.py:27, PoseTs.py:32 on cat[feat, xyz], FaceRecon.py:38).  Forward: the plain
+    product.  Backward: the layers' input gradients are ONE accumulation chain  gx = g_0 W_0;  gx = g_1 W_1 + gx;  ...  carried in
+    the products' epilogues (residual read and written in place) -- the member whose backward runs first allocates the buffer
+    and RETURNS it as the gradient of x, the others add into it in place and return None (= zero): autograd then has nothing to
+    sum (three 250 MB element-wise passes at B=16, N=1028), and every member still runs when ITS upstream gradient arrives,
+    while that gradient is still cache-resident (one node for all four was measured 0.2 ms SLOWER per step: it runs when the
+    last gradient arrives, after 270 MB of them have gone through a 256 MB cache).  Stream order makes the buffer complete
+    before x's producer reads it; x must have NO consumer outside the group (a foreign gradient arriving between two members
+    would be summed out of place and the later members' terms lost).  The layer on cat[x, xyz] (``xw``: the pitched concatenation) contributes through the first K
+    columns of its weight; the coordinates carry no gradient.  One backward pass per forward (no retain_graph)."""
+
+    @staticmethod
+    def forward(ctx, x, xw, group, w, b):
+        y = gemm_own(x if xw is None else xw, w, False, bias=b)
+        ctx.save_for_backward(x, xw, w)
+        ctx.group, ctx.has_bias, ctx.x3 = group, b is not None, x3_planes
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, xw, w = ctx.saved_tensors
+        R, K = x.shape
+        g = _req(g, torch.float32, "fan_linear_rows.grad")
+        grp, ret = ctx.group, None
+        if ctx.needs_input_grad[0]:
+            wk = w if w.shape[1] == K else w[:, :K]
+            with x3_scope(ctx.x3):
+                if grp.gx is None:
+                    grp.gx = ret = torch.empty(R, K, dtype=torch.float32, device=x.device)
+                    gemm_own(g, wk, True, out=grp.gx)
+                else:
+                    gemm_own(g, wk, True, resid=grp.gx, out=grp.gx)
+        gwt, gb = wgrad(x if xw is None else xw, g, colsum=True)                     # (Cin, Cout) = dW^T, column sums of g = db
+        return ret, None, None, gwt.t(), (gb if ctx.has_bias else None)
+
+
+def fan_linear_rows_ok(x, xyz, weights):
+    """shapes ``fan_linear_rows`` takes on the hand-written kernels (else the caller keeps one ``linear_rows`` per layer)"""
+    if GEMM_MODE != "own" or not GEMM_X3 or x.dtype != torch.float32 or not x.is_cuda or x.dim() != 2:
+        return False
+    R, K = x.shape
+    if R < 1024 or x.stride(1) != 1 or x.data_ptr() % 16 or (x.stride(0) * 4) % 16 or x.stride(0) < (K + 3) // 4 * 4:
+        return False
+    for w in weights:
+        if w.dim() != 2 or w.shape[0] % 128 or w.shape[1] not in (K, K + 3) or (w.shape[1] == K + 3 and xyz is None):
+            return False
+        if not _wgrad_ragged_ok(x, torch.empty(0, w.shape[0], device=x.device), x) and not (K % 64 == 0 and w.shape[0] % 64 == 0):
+            return False
+    return True
+
+
+def fan_linear_rows(x, xyz, layers):
+    """[F.linear(x or cat[x, xyz], W_i, b_i) for (W_i, b_i) in layers] for layers that share their input rows x (R, K) -- a
+    weight with K + 3 columns reads cat[x, xyz], xyz (B, N, 3) with R = B N -- whose input gradients meet in the products'
+    epilogues instead of in autograd's element-wise adds (``_FanMember``)."""
+    R, K = x.shape
+    group, xw, outs = _FanGroup(), None, []
+    for w, b in layers:
+        if w.shape[1] != K and xw is None:
+            with torch.no_grad():                                 # (its gradient is routed by the member, not through the cat)
+                xw = cat_rows_pitched([x, xyz.reshape(R, 3)])
+        outs.append(_FanMember.apply(x, None if w.shape[1] == K else xw, group, w, b))
+    return outs
 
 
 def cat_rows_pitched(parts):

@@ -392,6 +392,47 @@ def test_linear_rows_backward_own_kernels(dev, ref, Cin, Cout):
         assert (got.double() - want).abs().max().item() <= 1e-5 * sc, (Cin, Cout)
 
 
+@pytest.mark.parametrize("B,N", [(16, 1028), (3, 700)])
+def test_fan_linear_rows(dev, ref, B, N):
+    """the first layers of every consumer of feat's rows as one node (PoseR.py:27 x2, PoseTs.py:32 on cat[feat, xyz],
+    FaceRecon.py:38): outputs, the summed input gradient (accumulated in the products' epilogues), weight / bias gradients
+    incl. the coordinate columns of the (1024, 1289) weight -- vs fp64; one upstream gradient missing (an unused head)"""
+    from hs_pose_amd import ops
+    R, K = B * N, 1286
+    xfull = ref.hash_tensor((R, 1288), 41, 1.0).to(dev)
+    xfull[:, K:] = 0.0
+    x = xfull[:, :K].requires_grad_(True)
+    xyz = (ref.hash_tensor((B, N, 3), 42, 1.0) * 0.3).to(dev)
+    shapes = [(1024, K), (1024, K), (1024, K + 3), (512, K)]
+    ws = [(ref.hash_tensor(sh, 43 + i, 1.0) * 0.03).to(dev).requires_grad_(True) for i, sh in enumerate(shapes)]
+    bs = [ref.hash_tensor((sh[0],), 53 + i, 1.0).to(dev).requires_grad_(True) for i, sh in enumerate(shapes)]
+    ups = [ref.hash_tensor((R, sh[0]), 63 + i, 1.0).to(dev) for i, sh in enumerate(shapes)]
+    assert ops.fan_linear_rows_ok(x, xyz, ws)
+    ys = ops.fan_linear_rows(x, xyz, list(zip(ws, bs)))
+    xd = x.detach().double()
+    xcat = torch.cat([xd, xyz.reshape(R, 3).double()], dim=1)
+    want_gx = torch.zeros(R, K, dtype=torch.float64, device=dev)
+    for y, w, b, up in zip(ys, ws, bs, ups):
+        src = xd if w.shape[1] == K else xcat
+        want = src @ w.detach().double().t() + b.detach().double()
+        assert (y.double() - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+        want_gx += (up.double() @ w.detach().double())[:, :K]
+    grads = torch.autograd.grad(ys, [x] + ws + bs, ups)
+    gx, gws, gbs = grads[0], grads[1:5], grads[5:]
+    assert (gx.double() - want_gx).abs().max().item() <= 1e-5 * want_gx.abs().max().item()
+    for gw, gb, w, up in zip(gws, gbs, ws, ups):
+        src = xd if w.shape[1] == K else xcat
+        want_w = up.double().t() @ src
+        assert gw.shape == w.shape
+        assert (gw.double() - want_w).abs().max().item() <= 1e-5 * want_w.abs().max().item()
+        assert (gb.double() - up.double().sum(0)).abs().max().item() <= 1e-5 * up.double().sum(0).abs().max().item() + 1e-4
+    # one consumer without a gradient (its head's loss switched off): the chain skips it
+    ys = ops.fan_linear_rows(x, xyz, list(zip(ws, bs)))
+    (gx2,) = torch.autograd.grad([ys[0], ys[2], ys[3]], [x], [ups[0], ups[2], ups[3]])
+    want2 = sum((ups[i].double() @ ws[i].detach().double())[:, :K] for i in (0, 2, 3))
+    assert (gx2.double() - want2).abs().max().item() <= 1e-5 * want2.abs().max().item()
+
+
 @pytest.mark.parametrize("B,N,C,relu", [(16, 1028, 128, True), (2, 257, 256, True), (3, 100, 64, False)])
 def test_bn_relu_fused(dev, ref, B, N, C, relu):
     """fused train-mode BatchNorm1d+ReLU vs torch's module on the same rows: output, input / affine
