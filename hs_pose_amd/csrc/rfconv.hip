@@ -43,6 +43,13 @@ __device__ __forceinline__ void load_dirs_normed(const float* __restrict__ dirs,
 // difference from max(x, 0): a theta that rounding pushed an ulp or two ABOVE 1 (a neighbour exactly along a support
 // direction) reads 1.0 instead of 1.0000001 (2.4e-7 relative, inside every tolerance of section 2; NaN -> 0 either way).
 // -DRF_RELU_MAX restores the plain max.
+// RF_WF_POST=1: the pipelined forward fetches the winners' support values AFTER the neighbour loop (four 4-byte gathers per
+// float4 unit) instead of carrying them through it as a fourth v_cndmask per element.  Measured in isolation (round 3, same box,
+// alternating runs): 1.894 vs 1.874 ms per step at B=16 N=1028, 15.8-16.0 vs 15.63 ms on the bf16 dense clouds -- a wave's four
+// scattered 4-byte gathers touch up to 256 cache lines, more address-path work than the 80 selects they replace.  Off.
+#ifndef RF_WF_POST
+#define RF_WF_POST 0
+#endif
 #ifdef RF_RELU_MAX
 #define RF_RELU(X) fmaxf((X), 0.f)
 #else
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_pipe_kernel(const float* __
                         }
                         th.x = mul_rn(th.x, f.x); th.y = mul_rn(th.y, f.y);
                         th.z = mul_rn(th.z, f.z); th.w = mul_rn(th.w, f.w);
-                        if (WF) {
+                        if (WF && !RF_WF_POST) {
                             if (th.x > best.x) wf.x = f.x;
                             if (th.y > best.y) wf.y = f.y;
                             if (th.z > best.z) wf.z = f.z;
@@ -296,7 +303,23 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_pipe_kernel(const float* __
                     if (th.z > best.z) { best.z = th.z; a2 = n; }
                     if (th.w > best.w) { best.w = th.w; a3 = n; }
                 }
-                if (WF) Feat<FT>::st4_nt(fwin + pt * SC + j, wf);
+                if (WF && RF_WF_POST && !SURFACE) {
+                    // (opt-in, measured slower: see RF_WF_POST above)
+                    constexpr unsigned ES = (unsigned)sizeof(FT);
+                    const unsigned o0 = voff + sOff[a0], o1 = voff + sOff[a1] + ES, o2 = voff + sOff[a2] + 2 * ES,
+                                   o3 = voff + sOff[a3] + 3 * ES;
+                    if constexpr (sizeof(FT) == 4) {
+                        wf.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(frs, (int)o0, 0, 0));
+                        wf.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(frs, (int)o1, 0, 0));
+                        wf.z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(frs, (int)o2, 0, 0));
+                        wf.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(frs, (int)o3, 0, 0));
+                    } else {
+                        wf.x = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(frs, (int)o0, 0, 0) << 16);
+                        wf.y = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(frs, (int)o1, 0, 0) << 16);
+                        wf.z = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(frs, (int)o2, 0, 0) << 16);
+                        wf.w = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(frs, (int)o3, 0, 0) << 16);
+                    }
+                }
                 *reinterpret_cast<float4*>(smax + j) = best;
                 {
                     const unsigned lo = (unsigned)sIdx[a0] | ((unsigned)sIdx[a1] << 16);
@@ -304,6 +327,7 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_pipe_kernel(const float* __
                     unsigned* ap = reinterpret_cast<unsigned*>(argrow + pt * SC + j);
                     __builtin_nontemporal_store(lo, ap); __builtin_nontemporal_store(hi, ap + 1);
                 }
+                if (WF) Feat<FT>::st4_nt(fwin + pt * SC + j, wf);
             }
         }
         have_prev = true; prev_pt = pt;
