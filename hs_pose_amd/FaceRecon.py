@@ -24,11 +24,11 @@ def _bn_rows(bn, x):
 
 def _conv_bn_relu_rows(seq, x, n_blocks, first=None):
     """Apply n_blocks x (Conv1d k=1, BatchNorm1d, ReLU) of an nn.Sequential to (R, C) rows.  first: the first Conv1d's output when
-    the caller already has it (``ops.fan_linear_rows``)."""
+    the caller already has it, as (rows, BatchNorm first-pass buffer) (``ops.fan_linear_rows``)."""
     for i in range(n_blocks):
         conv, bn = seq[3 * i], seq[3 * i + 1]
-        y = first if (i == 0 and first is not None) else ops.linear_rows(x, conv.weight.squeeze(-1), conv.bias)
-        x = ops.bn_relu(y, bn)                                                              # fused BatchNorm + ReLU (norm.hip)
+        y, part = first if (i == 0 and first is not None) else ops.linear_rows(x, conv.weight.squeeze(-1), conv.bias, bn_partials=True)
+        x = ops.bn_relu(y, bn, partial=part)                       # fused BatchNorm + ReLU (norm.hip), first pass from the product
     return x
 
 

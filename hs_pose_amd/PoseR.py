@@ -30,13 +30,15 @@ class _PointMLPHead(nn.Module):
         self.bn3 = nn.BatchNorm1d(256)
 
     def forward_rows(self, x: "(B, N, f)", first=None):
-        """first: conv1's output rows (B*N, 1024) when the caller computed it with the other layers that read the same rows
-        (``ops.fan_linear_rows``, PoseNet9D); x then only gives the shape"""
+        """first: (conv1's output rows (B*N, 1024), BatchNorm first-pass buffer) when the caller computed it with the other
+        layers that read the same rows (``ops.fan_linear_rows``, PoseNet9D); x then only gives the shape"""
         b, n, c = x.shape
         if first is None:
-            first = ops.linear_rows(x.reshape(b * n, c), self.conv1.weight.squeeze(-1), self.conv1.bias)
-        h = ops.bn_relu(first, self.bn1)                                                                # fused BN + ReLU
-        h = ops.bn_relu(ops.linear_rows(h, self.conv2.weight.squeeze(-1), self.conv2.bias), self.bn2)
+            first = ops.linear_rows(x.reshape(b * n, c), self.conv1.weight.squeeze(-1), self.conv1.bias, bn_partials=True)
+        # fused BatchNorm + ReLU; the products leave the BatchNorms' first pass (per-tile column sums) in their epilogues
+        h = ops.bn_relu(first[0], self.bn1, partial=first[1])
+        y2, p2 = ops.linear_rows(h, self.conv2.weight.squeeze(-1), self.conv2.bias, bn_partials=True)
+        h = ops.bn_relu(y2, self.bn2, partial=p2)
         h = ops.points_max(h.view(b, n, -1))                                     # (B,256)
         h = ops.bn_relu(ops.linear_rows(h, self.conv3.weight.squeeze(-1), self.conv3.bias), self.bn3)
         h = self.drop1(h)

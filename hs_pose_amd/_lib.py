@@ -87,6 +87,8 @@ SIGNATURES = {
     "hsp_bn_relu_bwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "hsp_gemm_x3_bn_f32": (_i, [_vp, _i, _vp, _i, ctypes.c_longlong, _i, _vp, _i, _vp, _i, ctypes.c_longlong, _i, _i, _i, _vp, _i, _vp, _i,
                                 _vp, _i, _vp, _vp, _vp]),
+    "hsp_gemm_x3_bn_tiles": (_i, [_i, _i]),
+    "hsp_gemm_x3_bias_bn_f32": (_i, [_vp, _i, _vp, _i, ctypes.c_longlong, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "hsp_bn_relu_fwd_partials": (_i, [_vp, _i, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i,
                                       _vp, _vp]),
     "hsp_bn_relu_bwd2": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -294,8 +294,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
         if constexpr (HAS_BN) {
             // the shift of the shifted sums: any per-column value every tile agrees on and that sits near the column's mean --
             // the residual + per-cloud-bias part of ROW 0 of the result (data of this step only: a replayed graph and an eager
-            // step compute identical bits; a running statistic would not give that)
-            bsh = g.resid[colc] + g.cbias[colc];
+            // step compute identical bits; a running statistic would not give that); the heads' Linear + BatchNorm form
+            // (EPI 9) shifts by the layer's bias
+            if constexpr (HAS_RES) bsh = g.resid[colc] + g.cbias[colc];
+            else bsh = bvv;
             if (tm == 0 && wm0 == 0 && lh == 0 && cok) g.bn_shift[col] = bsh;
         }
         if constexpr (HAS_CB) {
@@ -508,8 +510,10 @@ static int gemm_x3_impl(const float* A1, int lda1, const hsp_bf16_t* P1, int ldp
     g.cbias = cloud_bias; g.rpc = rows_per_cloud > 0 ? rows_per_cloud : 1; g.alpha = alpha;
     g.bn_shift = bn_shift; g.bn_part = bn_part;
     const bool bn = bn_shift != nullptr;
-    if (bn && (!bn_part || !(resid && cloud_bias) || bias)) return HSP_ERR_UNSUPPORTED;     // the layer's out product only
-    const int wm = bn ? 1 : x3_pick_wm(M, N), bm = 64 * wm;
+    // BatchNorm partials: the layer's out product (residual + per-cloud bias; 64-row tiles) or a Linear with bias (one source)
+    const bool bn_out = bn && resid && cloud_bias && !bias, bn_lin = bn && bias && !resid && !cloud_bias && !two;
+    if (bn && (!bn_part || !(bn_out || bn_lin))) return HSP_ERR_UNSUPPORTED;
+    const int wm = bn_out ? 1 : x3_pick_wm(M, N), bm = 64 * wm;
     g.tiles_m = (M + bm - 1) / bm; g.tiles_n = (N + X3_BN - 1) / X3_BN;
     const int TT = (K1 + X3_BK - 1) / X3_BK + (two ? (K2 + X3_BK - 1) / X3_BK : 0);
     const int epi = (bias ? 1 : 0) | (resid ? 2 : 0) | (cloud_bias ? 4 : 0);
@@ -524,9 +528,15 @@ static int gemm_x3_impl(const float* A1, int lda1, const hsp_bf16_t* P1, int ldp
     // rows -- C may BE resid: an element is read and written by the same thread), 6 residual + per-cloud bias (the layer's out
     // product), 14 = 6 + BatchNorm partials
     if (epi != 0 && epi != 1 && epi != 6 && !(epi == 2 && !two && alpha == 1.0f)) return HSP_ERR_UNSUPPORTED;
-    if (bn) {
+    if (bn_out) {
         if (two) hipLaunchKernelGGL((gemm_x3_kernel<1, true, 14, 0>), grid, block, 3 * (size_t)(64 + X3_BN) * 64, st, g);
         else hipLaunchKernelGGL((gemm_x3_kernel<1, false, 14, 0>), grid, block, 3 * (size_t)(64 + X3_BN) * 64, st, g);
+        return check_launch();
+    }
+    if (bn_lin) {
+        if (g.tiles_m > 512) return HSP_ERR_UNSUPPORTED;                       // (BN_MAX_PARTIALS of norm.hip)
+        if (wm == 2) hipLaunchKernelGGL((gemm_x3_kernel<2, false, 9, 0>), grid, block, 3 * (size_t)(128 + X3_BN) * 64, st, g);
+        else hipLaunchKernelGGL((gemm_x3_kernel<1, false, 9, 0>), grid, block, 3 * (size_t)(64 + X3_BN) * 64, st, g);
         return check_launch();
     }
     // (measured, B=16 N=1028: 1.93 ms/step with the short-K form against 1.92 without -- the tile's time is the weight planes'
@@ -564,6 +574,20 @@ static int gemm_x3_impl(const float* A1, int lda1, const hsp_bf16_t* P1, int ldp
     if (rg > HSP_NUM_CU * 8) rg = HSP_NUM_CU * 8;
     hipLaunchKernelGGL(gemm_x3_reduce_kernel, dim3((unsigned)rg), dim3(256), 0, st, g.ws, ns, total, N, alpha, C, ldc);
     return check_launch();
+}
+
+/* a Linear / Conv1d(k=1) with bias whose result feeds a train-mode BatchNorm (the heads: PoseR.py:27-30, FaceRecon.py:37-47):
+ * C = A W^T + bias AND, per row tile, the shifted column sums of C (shift = bias, written to bn_shift): bn_part[tiles][2][N] with
+ * tiles = hsp_gemm_x3_bn_tiles(M, N); fold with hsp_bn_relu_fwd_partials(..., bn_part, tiles, bn_shift) */
+extern "C" int hsp_gemm_x3_bn_tiles(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return (M + 64 * x3_pick_wm(M, N) - 1) / (64 * x3_pick_wm(M, N));
+}
+extern "C" int hsp_gemm_x3_bias_bn_f32(const float* A1, int lda1, const hsp_bf16_t* P1, int ldp1, long long ps1, int K1, int M, int N,
+                                       const float* bias, float* C, int ldc, float* bn_shift, float* bn_part, hspStream_t stream) {
+    if (!bn_shift || !bn_part || !bias) return HSP_ERR_BAD_ARG;
+    return gemm_x3_impl(A1, lda1, P1, ldp1, ps1, K1, nullptr, 0, nullptr, 0, 0, 0, M, N, bias, nullptr, 0, nullptr, 0, 1.0f, C, ldc,
+                        nullptr, 0, bn_shift, bn_part, stream);
 }
 
 // ================================================================================================================================

@@ -884,6 +884,30 @@ def gemm_x3_bn(A1, B1, A2, B2, resid, cloud_bias, rows_per_cloud, out):
     return buf
 
 
+def linear_bn_part_ok(x2, W, bias):
+    """a Linear (R, K) x (N, K)^T + bias whose product can also leave the first pass of the train-mode BatchNorm behind it
+    (``hsp_gemm_x3_bias_bn_f32``)"""
+    R, N = x2.shape[0], W.shape[0]
+    return (GEMM_MODE == "own" and bias is not None and R >= 256 and x2.dtype == torch.float32 and N % 4 == 0 and 256 % (N // 4) == 0
+            and os.environ.get("HSP_BN_EPILOGUE", "1") != "0"
+            and gemm_x3_ok(x2, W, None, None, bias, None, None, None, None, R, N) and lib().hsp_gemm_x3_bn_tiles(R, N) <= 512)
+
+
+def linear_bn_part(x2, W, bias):
+    """(x2 W^T + bias,  BatchNorm first-pass buffer (1 + 2 tiles, N): row 0 = the shift (the bias), rows 1.. = (tiles, 2, N)
+    shifted column sums of the result) -- the layout ``bn_relu(..., partial=)`` folds"""
+    M, K1 = x2.shape
+    N = W.shape[0]
+    P1, ldp1, ps1 = x3_planes.planes(W, False)
+    tiles = lib().hsp_gemm_x3_bn_tiles(M, N)
+    out = torch.empty(M, N, dtype=torch.float32, device=x2.device)
+    buf = torch.empty(1 + 2 * tiles, N, dtype=torch.float32, device=x2.device)
+    _run("hsp_gemm_x3_bias_bn_f32", (_p(x2), _ld(x2), _p(P1), ldp1, ps1, K1, M, N, _p(bias), _p(out), N, _p(buf[0]), _p(buf[1:]),
+                                     _stream()),
+         key=f"M{M}N{N}K{K1}bn", abytes=4 * (M * K1 + M * N) + 6 * N * K1, aflops=2 * M * N * K1)
+    return out, buf
+
+
 def gemm_x3(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=None, cloud_bias=None, rows_per_cloud=0, out=None,
             alpha=1.0):
     """the contract of ``gemm_rows`` (fp32 in, fp32 out) with the products formed on the bf16 matrix cores from exact three-way
@@ -1414,7 +1438,7 @@ class _LinearRows(torch.autograd.Function):
     replayable inside a hipGraph (graph.py::GraphedNetwork)."""
 
     @staticmethod
-    def forward(ctx, x2, weight, bias):
+    def forward(ctx, x2, weight, bias, want_part=False):
         if x2.dim() == 2 and x2.stride(1) == 1 and x2.stride(0) >= x2.shape[1] and x2.dtype == torch.float32 and x2.is_cuda:
             pass                                    # rows of a wider buffer (feat's padded pitch): every consumer takes a row stride
         else:
@@ -1422,10 +1446,20 @@ class _LinearRows(torch.autograd.Function):
         ctx.save_for_backward(x2, weight)
         ctx.has_bias = bias is not None
         ctx.x3 = x3_planes
+        if want_part:
+            # second output: the first pass of the BatchNorm that follows (or an empty tensor when this product does not leave
+            # it); not differentiable
+            if linear_bn_part_ok(x2, weight, bias):
+                y, part = linear_bn_part(x2, weight, bias)
+            else:
+                y, part = _mm_nt(x2, weight, bias), torch.empty(0, dtype=torch.float32, device=x2.device)
+            ctx.mark_non_differentiable(part)
+            ctx.set_materialize_grads(False)
+            return y, part
         return _mm_nt(x2, weight, bias)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _gpart=None):
         x2, weight = ctx.saved_tensors
         g = _req(g, torch.float32, "linear_rows.grad")
         with x3_scope(ctx.x3):
@@ -1450,7 +1484,7 @@ class _LinearRows(torch.autograd.Function):
                 gw = torch.mm(g.t(), x2)
             if ctx.has_bias:
                 gb = colsum_rows(g.view(1, R, Cout)).view(Cout)
-        return gx, gw, (gb if ctx.has_bias else None)
+        return gx, gw, (gb if ctx.has_bias else None), None
 
 
 class _FanGroup:
@@ -1475,13 +1509,19 @@ class _FanMember(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, xw, group, w, b):
-        y = gemm_own(x if xw is None else xw, w, False, bias=b)
+        src = x if xw is None else xw
+        if linear_bn_part_ok(src, w, b):              # (every member is followed by a BatchNorm: its first pass rides along)
+            y, part = linear_bn_part(src, w, b)
+        else:
+            y, part = gemm_own(src, w, False, bias=b), torch.empty(0, dtype=torch.float32, device=x.device)
         ctx.save_for_backward(x, xw, w)
         ctx.group, ctx.has_bias, ctx.x3 = group, b is not None, x3_planes
-        return y
+        ctx.mark_non_differentiable(part)
+        ctx.set_materialize_grads(False)
+        return y, part
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _gpart=None):
         x, xw, w = ctx.saved_tensors
         R, K = x.shape
         g = _req(g, torch.float32, "fan_linear_rows.grad")
@@ -1516,7 +1556,8 @@ def fan_linear_rows_ok(x, xyz, weights):
 def fan_linear_rows(x, xyz, layers):
     """[F.linear(x or cat[x, xyz], W_i, b_i) for (W_i, b_i) in layers] for layers that share their input rows x (R, K) -- a
     weight with K + 3 columns reads cat[x, xyz], xyz (B, N, 3) with R = B N -- whose input gradients meet in the products'
-    epilogues instead of in autograd's element-wise adds (``_FanMember``)."""
+    epilogues instead of in autograd's element-wise adds (``_FanMember``).  Each entry of the result is (y, part): part = the
+    first pass of the train-mode BatchNorm behind the layer (``bn_relu(y, bn, partial=part)``), possibly empty."""
     R, K = x.shape
     group, xw, outs = _FanGroup(), None, []
     for w, b in layers:
@@ -1539,8 +1580,12 @@ def cat_rows_pitched(parts):
     return torch.cat(list(parts) + [z], dim=-1)[..., :K]
 
 
-def linear_rows(x2, weight, bias=None):
-    """F.linear(x2, weight, bias) for (R, Cin) rows with a graph-replayable backward."""
+def linear_rows(x2, weight, bias=None, bn_partials=False):
+    """F.linear(x2, weight, bias) for (R, Cin) rows with a graph-replayable backward.  ``bn_partials``: returns (y, part) where
+    ``part`` is the first pass of a train-mode BatchNorm over y left by the product's epilogue -- hand it to
+    ``bn_relu(y, bn, partial=part)`` -- or an empty tensor when this shape / mode does not produce it."""
+    if bn_partials:
+        return _LinearRows.apply(x2, weight, bias, True)
     return _LinearRows.apply(x2, weight, bias)
 
 

@@ -292,6 +292,12 @@ int hsp_gemm_x3_bn_f32(const float *A1, int lda1, const hsp_bf16_t *P1, int ldp1
                        const float *A2, int lda2, const hsp_bf16_t *P2, int ldp2, long long ps2, int K2, int M, int N,
                        const float *resid, int ldr, const float *cloud_bias, int rows_per_cloud, float *C, int ldc,
                        float *bn_shift, float *bn_part, hspStream_t stream);
+/* the same for a Linear / Conv1d(k=1) WITH BIAS that a train-mode BatchNorm follows (the heads: PoseR.py:27-30, PoseTs.py:32-36,
+ * FaceRecon.py:37-47): C = A W^T + bias plus bn_part[tiles][2][N], tiles = hsp_gemm_x3_bn_tiles(M, N) (64- or 128-row tiles by
+ * shape, <= 512), shift = bias (written to bn_shift) */
+int hsp_gemm_x3_bn_tiles(int M, int N);
+int hsp_gemm_x3_bias_bn_f32(const float *A1, int lda1, const hsp_bf16_t *P1, int ldp1, long long ps1, int K1, int M, int N,
+                            const float *bias, float *C, int ldc, float *bn_shift, float *bn_part, hspStream_t stream);
 
 /* the per-CLOUD products of the ORL branch (gcn3d.py:186: the f_global half of conv2, one row per cloud of the batch), one
  * launch each, fp32 fma chains in a fixed order:

@@ -392,6 +392,33 @@ def test_linear_rows_backward_own_kernels(dev, ref, Cin, Cout):
         assert (got.double() - want).abs().max().item() <= 1e-5 * sc, (Cin, Cout)
 
 
+@pytest.mark.parametrize("R,Cin,Cout", [(16448, 1024, 256), (16448, 512, 512), (2100, 256, 128)])
+def test_linear_rows_leaves_the_batchnorm_first_pass(dev, ref, R, Cin, Cout):
+    """linear_rows(..., bn_partials=True) + bn_relu(..., partial=) == linear_rows + bn_relu (the BatchNorm statistics from the
+    product's epilogue against the two-pass kernel): output, running statistics, input / weight gradients"""
+    from hs_pose_amd import ops
+    x = ref.hash_tensor((R, Cin), 71, 1.0).to(dev)
+    w = (ref.hash_tensor((Cout, Cin), 72, 1.0) * 0.05).to(dev)
+    b = (ref.hash_tensor((Cout,), 73, 1.0) * 3.0).to(dev)               # |mean| >> std for some columns
+    up = ref.hash_tensor((R, Cout), 74, 1.0).to(dev)
+    res = []
+    for fused in (False, True):
+        bn = torch.nn.BatchNorm1d(Cout).to(dev).train()
+        xx, ww, bb = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        if fused:
+            y, part = ops.linear_rows(xx, ww, bb, bn_partials=True)
+            assert (part.numel() > 0) == (R >= 16448)            # (too few tiles for the x3 kernel: an empty buffer, the plain path)
+            out = ops.bn_relu(y, bn, partial=part)
+        else:
+            out = ops.bn_relu(ops.linear_rows(xx, ww, bb), bn)
+        # (the Linear's bias gradient is identically zero behind a BatchNorm: rounding noise, not compared)
+        g = torch.autograd.grad(out, (xx, ww, bn.weight, bn.bias), up)
+        res.append((out.detach(), bn.running_mean.clone(), bn.running_var.clone(), *g))
+    for a, c in zip(*res):
+        sc = max(a.abs().max().item(), 1e-6)
+        assert (a - c).abs().max().item() <= 2e-5 * sc
+
+
 @pytest.mark.parametrize("B,N", [(16, 1028), (3, 700)])
 def test_fan_linear_rows(dev, ref, B, N):
     """the first layers of every consumer of feat's rows as one node (PoseR.py:27 x2, PoseTs.py:32 on cat[feat, xyz],
@@ -408,7 +435,16 @@ def test_fan_linear_rows(dev, ref, B, N):
     bs = [ref.hash_tensor((sh[0],), 53 + i, 1.0).to(dev).requires_grad_(True) for i, sh in enumerate(shapes)]
     ups = [ref.hash_tensor((R, sh[0]), 63 + i, 1.0).to(dev) for i, sh in enumerate(shapes)]
     assert ops.fan_linear_rows_ok(x, xyz, ws)
-    ys = ops.fan_linear_rows(x, xyz, list(zip(ws, bs)))
+    outs = ops.fan_linear_rows(x, xyz, list(zip(ws, bs)))
+    ys = [y for y, _ in outs]
+    for (y, part), w in zip(outs, ws):
+        # the BatchNorm first pass left by the product: row 0 = the shift, then per row tile the shifted column sums
+        assert part.numel() and part.shape[1] == w.shape[0] and (part.shape[0] - 1) % 2 == 0
+        tiles = (part.shape[0] - 1) // 2
+        sums = part[1:].view(tiles, 2, -1).double().sum(0)
+        d = y.detach().double() - part[0].double()
+        assert (sums[0] - d.sum(0)).abs().max().item() <= 1e-5 * d.abs().sum(0).max().item()
+        assert (sums[1] - (d * d).sum(0)).abs().max().item() <= 1e-5 * (d * d).sum(0).max().item()
     xd = x.detach().double()
     xcat = torch.cat([xd, xyz.reshape(R, 3).double()], dim=1)
     want_gx = torch.zeros(R, K, dtype=torch.float64, device=dev)
@@ -427,7 +463,7 @@ def test_fan_linear_rows(dev, ref, B, N):
         assert (gw.double() - want_w).abs().max().item() <= 1e-5 * want_w.abs().max().item()
         assert (gb.double() - up.double().sum(0)).abs().max().item() <= 1e-5 * up.double().sum(0).abs().max().item() + 1e-4
     # one consumer without a gradient (its head's loss switched off): the chain skips it
-    ys = ops.fan_linear_rows(x, xyz, list(zip(ws, bs)))
+    ys = [y for y, _ in ops.fan_linear_rows(x, xyz, list(zip(ws, bs)))]
     (gx2,) = torch.autograd.grad([ys[0], ys[2], ys[3]], [x], [ups[0], ups[2], ups[3]])
     want2 = sum((ups[i].double() @ ws[i].detach().double())[:, :K] for i in (0, 2, 3))
     assert (gx2.double() - want2).abs().max().item() <= 1e-5 * want2.abs().max().item()

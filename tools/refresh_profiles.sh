@@ -45,6 +45,9 @@ T=$(find $O/bstats -name '*kernel_trace.csv' | head -1)
 python $R/tools/trace_by_shape.py $T last3 > $O/b_per_shape_kernel_us_bf16.txt
 python $R/bench.py $BF --steps 5 --warmup 2 --breakdown > $O/b_breakdown_eager_events_bf16.txt 2>&1
 python $R/bench.py --points 4096 --batch 64 --steps 10 --warmup 3 --no-cpu-baseline --no-u3 > $O/b_bench_f32_same_shape.json 2>/dev/null
+# ---- the full training step (unit U3): kernels of one step by launch shape (no BLAS / Cijk row is left in it)
+bash $R/tools/prof_train_step.sh > $O/u3_prof.log 2>&1
+head -120 $R/gpurun_out/prof_u3/u3_per_shape_kernel_us.txt > $R/profiles/$RD/u3_per_shape_kernel_us_top120.txt
 # the judged copies (trimmed: the library tuning runs of the first steps fill the long tail of the bf16 tables)
 for f in k_bench.json k_bench_gemm_own_f32mfma.json k_bench_gemm_library.json k_graph_kernel_stats.csv k_per_shape_kernel_us.txt k_breakdown_eager_events.txt b_bench_bf16.json b_bench_f32_same_shape.json b_breakdown_eager_events_bf16.txt; do cp $O/$f $R/profiles/$RD/$f; done
 head -61 $O/b_per_shape_kernel_us_bf16.txt > $R/profiles/$RD/b_per_shape_kernel_us_bf16_top60.txt
