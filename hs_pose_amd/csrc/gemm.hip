@@ -800,7 +800,30 @@ extern "C" int hsp_wgrad_partial_pair_f32(const float* A0, int lda0, const float
                            !((M0 | N0 | M1 | N1) & 63) && !((lda0 | ldb0 | lda1 | ldb1) & 1) && lda0 >= M0 && ldb0 >= N0 &&
                            lda1 >= M1 && ldb1 >= N1 && ldc0 >= N0 && ldc1 >= N1;
     if (shapes_ok) {
-        const int sk0 = wgrad_pick_sk(M0, N0, K0, &ks0, &kb0), sk1 = wgrad_pick_sk(M1, N1, K1, &ks1, &kb1);
+        int sk0 = wgrad_pick_sk(M0, N0, K0, &ks0, &kb0), sk1 = wgrad_pick_sk(M1, N1, K1, &ks1, &kb1);
+        if (kb0 == 4 && kb1 == 4) {
+            // the two problems share ONE grid and the kernel's 66 KB of LDS let two workgroups live on a CU: 512 at once.  Each
+            // problem alone is sized for ~512 workgroups, so the pair came to 528 / 704 / 768 -- a second, mostly empty round that
+            // costs a whole slice time.  Fewer, longer K slices keep the pair inside one round (same kernel, same fold; the
+            // workspace rule is unchanged: fewer partials than it allows for).
+            constexpr int G = 4 * WG_UNROLL;
+            const int t0 = (M0 >> 6) * (N0 >> 6), t1 = (M1 >> 6) * (N1 >> 6);
+            static const bool fit_off = [] { const char* e = getenv("HSP_WGRAD_PAIR_FIT"); return e && e[0] == '0'; }();
+            int total = t0 * (sk0 / 4) + t1 * (sk1 / 4);
+            for (int it = 0; it < 8 && !fit_off && total > 2 * HSP_NUM_CU && sk0 > 8 && sk1 > 8; ++it) {
+                const double f = (double)(2 * HSP_NUM_CU) / total;
+                auto shrink = [&](int K, int& sk, int& ks) {
+                    int want = (int)(sk * f) & ~3;
+                    if (want >= sk) want = sk - 4;
+                    if (want < 8) want = 8;
+                    ks = ((K + want - 1) / want + G - 1) / G * G;
+                    sk = (((K + ks - 1) / ks) + 3) & ~3;
+                };
+                shrink(K0, sk0, ks0);
+                shrink(K1, sk1, ks1);
+                total = t0 * (sk0 / 4) + t1 * (sk1 / 4);
+            }
+        }
         if (kb0 == 4 && kb1 == 4 && ws0 && ws1 && ws_bytes0 >= hsp_wgrad_workspace_bytes(M0, N0, K0) &&
             ws_bytes1 >= hsp_wgrad_workspace_bytes(M1, N1, K1)) {
             const WgradProb p0{A0, B0, reinterpret_cast<float*>(ws0), lda0, ldb0, M0, N0, K0, sk0, ks0};
