@@ -114,9 +114,7 @@ def u3_full_step(B, N, device, steps=12, warmup=4):
 
     def step():
         _, ld = net(do_loss=True, **case)
-        total = sum(ld['fsnet_loss'].values()) + sum(ld['recon_loss'].values()) + sum(ld['geo_loss'].values()) \
-            + sum(ld['prop_loss'].values())
-        drv.step(total)
+        drv.step(net.total_loss(ld))                    # (= the sum over the four sub-dictionaries, engine/train.py:84-90)
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()

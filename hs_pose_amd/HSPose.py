@@ -103,6 +103,13 @@ class HSPose(nn.Module):
         loss_dict = {'fsnet_loss': fsnet_loss, 'recon_loss': recon_loss, 'geo_loss': geo_loss, 'prop_loss': prop_loss}
         return output_dict, loss_dict
 
+    @staticmethod
+    def total_loss(loss_dict):
+        """the scalar engine/train.py:84-90 backpropagates: the sum of every term of ``loss_dict`` (from the fused loss kernels'
+        own reduction when they produced the dict, hs_pose_amd/fused_losses.py::total_loss)"""
+        from .fused_losses import total_loss
+        return total_loss(loss_dict)
+
     graphed_posenet = None
     # device batches take the fused loss kernels; HSP_FUSED_LOSSES=0 keeps the torch-op composition of losses.py (A/B runs)
     fused_losses = os.environ.get("HSP_FUSED_LOSSES", "1") != "0"

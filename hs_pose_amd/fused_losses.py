@@ -48,6 +48,22 @@ def _f32(t, shape, name):
     return t
 
 
+class LossDict(dict):
+    """the reference's loss_dict (four sub-dictionaries of 0-dim terms) that also carries their sum (``total``)"""
+    total = None
+
+
+def total_loss(loss_dict):
+    """sum of every term of a loss_dict, i.e. what engine/train.py:84-90 computes with
+    ``sum(fsnet_loss.values()) + sum(recon_loss.values()) + sum(geo_loss.values()) + sum(prop_loss.values())`` -- taken from the
+    fused loss kernels' own reduction when the dict came from them (one launch forward, one in backward, instead of ~28)."""
+    t = getattr(loss_dict, "total", None)
+    if t is not None:
+        return t
+    return sum(sum(d.values()) for d in (loss_dict['fsnet_loss'], loss_dict['recon_loss'], loss_dict['geo_loss'],
+                                         loss_dict['prop_loss']))
+
+
 class _PoseLosses(torch.autograd.Function):
     """(network outputs..., ground truth...) -> the 19 terms as separate 0-dim tensors (views of one buffer)."""
 
@@ -67,8 +83,11 @@ class _PoseLosses(torch.autograd.Function):
                                                                     ws.numel(), ops._stream()])
         ctx.args, ctx.cfg, ctx.ws, ctx.dims = args, cfg, ws, (B, N)
         ctx.shapes = [t.shape for t in (recon, fn, fd, ff, pg, pr, fg, fr, T, s)]
+        ctx.set_materialize_grads(False)                   # an unused output's gradient arrives as None, not as a zero tensor
         out = tuple(terms[k:k + 1] if k == 2 else terms[k] for k in range(N_TERMS))        # Rot2 keeps the reference's (1,)
-        return out
+        # + their sum (engine/train.py:84-90 adds the 19 terms one by one: 18 launches forward and ten more in backward for
+        # what is one reduction over 19 floats; ``total_loss(loss_dict)`` hands this one out)
+        return out + (terms.sum(),)
 
     @staticmethod
     def backward(ctx, *grads):
@@ -76,16 +95,22 @@ class _PoseLosses(torch.autograd.Function):
         dev = ctx.args[0].device
         if all(g is None for g in grads):
             return (None,) * 17
-        zero = None
-        parts = []
-        for g in grads:
-            if g is None:
-                if zero is None:
-                    zero = torch.zeros(1, dtype=torch.float32, device=dev)
-                parts.append(zero)
-            else:
-                parts.append(g.reshape(1))
-        gw = torch.cat(parts).float().contiguous()
+        g_total, grads = grads[N_TERMS], grads[:N_TERMS]
+        if all(g is None for g in grads):                       # only the fused total was used: every term's weight is its gradient
+            gw = g_total.reshape(1).float().expand(N_TERMS).contiguous()
+        else:
+            zero = None
+            parts = []
+            for g in grads:
+                if g is None:
+                    if zero is None:
+                        zero = torch.zeros(1, dtype=torch.float32, device=dev)
+                    parts.append(zero)
+                else:
+                    parts.append(g.reshape(1))
+            gw = torch.cat(parts).float().contiguous()
+            if g_total is not None:
+                gw = gw + g_total.reshape(1).float()
         shapes = [(B, N, 3), (B, N, 6, 3), (B, N, 6), (B, N, 6), (B, 3), (B, 3), (B,), (B,), (B, 3), (B, 3)]
         outs = [torch.empty(s, dtype=torch.float32, device=dev) for s in shapes]
         scratch = torch.empty(B * 54, dtype=torch.float32, device=dev)
@@ -101,7 +126,8 @@ def pose_losses(net_out, PC, gt_R, gt_t, gt_s, mean_shape, sym, obj_id):
     """net_out: dict with the ten network outputs (HSPose._NET_OUTPUTS); returns the reference's loss_dict
     {'fsnet_loss': {...}, 'recon_loss': {...}, 'geo_loss': {...}, 'prop_loss': {...}}."""
     vals = _PoseLosses.apply(*[net_out[k] for k in _NET], PC, gt_R, gt_t, gt_s, mean_shape, sym, obj_id.reshape(-1).float())
-    out, k = {}, 0
+    out, k = LossDict(), 0
+    out.total = vals[N_TERMS]
     for group, keys in TERMS:
         out[group] = {}
         for key in keys:

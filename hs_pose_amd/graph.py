@@ -304,8 +304,7 @@ class GraphedTrainStep:
             p.grad = None
         with gcn3d.pool_index_feed(self.pool_idx), augment.jitter_noise_feed(self.noise):
             _, ld = self.net(do_loss=True, **self.batch)
-        total = sum(ld['fsnet_loss'].values()) + sum(ld['recon_loss'].values()) + sum(ld['geo_loss'].values()) \
-            + sum(ld['prop_loss'].values())
+        total = self.net.total_loss(ld)                     # (the sum over the four sub-dictionaries, engine/train.py:84-90)
         with ops.StepFolds():
             total.backward()
         torch._foreach_copy_(views, [p.grad if p.grad is not None else torch.zeros_like(p) for p in params])

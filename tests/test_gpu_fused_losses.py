@@ -117,6 +117,29 @@ def test_fused_losses_reproducible(dev, ref, flags):
         assert torch.equal(a, b)
 
 
+def test_fused_total_equals_the_term_by_term_sum(dev, ref, flags):
+    """HSPose.total_loss(loss_dict) -- the kernels' own reduction over the 19 terms -- against the sum engine/train.py:84-90
+    spells out: value, the gradient w.r.t. every network output (also when terms AND the total are both used), and the
+    plain-dict fallback"""
+    from hs_pose_amd.fused_losses import total_loss, LossDict
+    res = []
+    for mode in ("terms", "total", "both"):
+        gt, pred = case(ref, dev, n_points=128, seed=4100, repeat=2)
+        ld = fused(gt, pred)
+        assert isinstance(ld, LossDict) and {k: list(v) for k, v in ld.items()} == LOSS_KEYS
+        by_terms = sum(sum(d.values()) for d in ld.values())
+        total = {"terms": by_terms, "total": total_loss(ld), "both": 0.5 * by_terms + 0.5 * total_loss(ld)}[mode]
+        total = total.reshape(())
+        grads = torch.autograd.grad(total, [pred[k] for k in NET])
+        res.append((total.detach(), grads))
+    for tot, grads in res[1:]:
+        assert abs(float(tot) - float(res[0][0])) <= 2e-6 * abs(float(res[0][0]))
+        for a, b in zip(grads, res[0][1]):
+            assert (a - b).abs().max().item() <= 2e-6 * max(b.abs().max().item(), 1e-6)
+    plain = {k: dict(v) for k, v in ld.items()}
+    assert abs(float(total_loss(plain)) - float(res[0][0])) <= 2e-6 * abs(float(res[0][0]))
+
+
 def test_hspose_forward_uses_fused_losses(dev, flags):
     """HSPose.forward(do_loss=True) on a device batch returns the fused terms (same keys; finite; backward reaches the
     network) and HSP_FUSED_LOSSES-off instances agree with it"""
