@@ -852,3 +852,72 @@ extern "C" int hsp_pose_augment(const float* PC, const float* gt_R, const float*
                        R_out, t_out, s_out);
     return check_launch();
 }
+
+// ---- the face head's output split (PoseNet9D.py:31-35) ------------------------------------------------------------------------
+//   face (R, 30) -> normals (R, 6, 3) = face[:, :18] / ||.||_3 per face,  dis (R, 6) = face[:, 18:24],  conf (R, 6) = sigmoid(face[:, 24:])
+// One thread per (row, face): the reference's three slices, a norm, a division and a sigmoid are ~8 element-wise launches forward
+// and ~20 in autograd's backward (three zero-padded slice gradients, two adds, the norm's chain) over (R, 30) tensors.
+// No epsilon under the norm (a zero normal gives inf / nan as in the reference).
+namespace hsp {
+__global__ __launch_bounds__(256) void face_split_fwd_kernel(const float* __restrict__ face, long long total, float* __restrict__ nrm,
+                                                             float* __restrict__ dis, float* __restrict__ conf) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long r = e / 6;
+        const int f = (int)(e - r * 6);
+        const float* p = face + r * 30;
+        const float x = p[3 * f], y = p[3 * f + 1], z = p[3 * f + 2];
+        const float n = __fsqrt_rn(x * x + y * y + z * z);
+        nrm[e * 3] = x / n; nrm[e * 3 + 1] = y / n; nrm[e * 3 + 2] = z / n;
+        dis[e] = p[18 + f];
+        conf[e] = 1.0f / (1.0f + __expf(-p[24 + f]));
+    }
+}
+// g_face (R, 30) from the three incoming gradients (any may be null = zero): every element written once
+__global__ __launch_bounds__(256) void face_split_bwd_kernel(const float* __restrict__ face, const float* __restrict__ g_nrm,
+                                                             const float* __restrict__ g_dis, const float* __restrict__ g_conf,
+                                                             long long total, float* __restrict__ g_face) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long r = e / 6;
+        const int f = (int)(e - r * 6);
+        const float* p = face + r * 30;
+        float* g = g_face + r * 30;
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (g_nrm) {
+            const float x = p[3 * f], y = p[3 * f + 1], z = p[3 * f + 2];
+            const float n = __fsqrt_rn(x * x + y * y + z * z);
+            const float ux = x / n, uy = y / n, uz = z / n;
+            const float ax = g_nrm[e * 3], ay = g_nrm[e * 3 + 1], az = g_nrm[e * 3 + 2];
+            const float d = ax * ux + ay * uy + az * uz;
+            gx = (ax - ux * d) / n; gy = (ay - uy * d) / n; gz = (az - uz * d) / n;      // d(v / |v|) = (I - u u^T) / |v|
+        }
+        g[3 * f] = gx; g[3 * f + 1] = gy; g[3 * f + 2] = gz;
+        g[18 + f] = g_dis ? g_dis[e] : 0.f;
+        float gc = 0.f;
+        if (g_conf) {
+            const float sg = 1.0f / (1.0f + __expf(-p[24 + f]));
+            gc = g_conf[e] * sg * (1.0f - sg);
+        }
+        g[24 + f] = gc;
+    }
+}
+}  // namespace hsp
+
+extern "C" int hsp_face_split_fwd(const float* face, long long R, float* normals, float* dis, float* conf, hspStream_t stream) {
+    if (!face || !normals || !dis || !conf || R <= 0) return HSP_ERR_BAD_ARG;
+    const long long total = R * 6;
+    long long g = (total + 255) / 256;
+    if (g > HSP_NUM_CU * 8) g = HSP_NUM_CU * 8;
+    hipLaunchKernelGGL(hsp::face_split_fwd_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), face, total, normals, dis, conf);
+    return check_launch();
+}
+extern "C" int hsp_face_split_bwd(const float* face, const float* g_normals, const float* g_dis, const float* g_conf, long long R,
+                                  float* g_face, hspStream_t stream) {
+    if (!face || !g_face || R <= 0) return HSP_ERR_BAD_ARG;
+    const long long total = R * 6;
+    long long g = (total + 255) / 256;
+    if (g > HSP_NUM_CU * 8) g = HSP_NUM_CU * 8;
+    hipLaunchKernelGGL(hsp::face_split_bwd_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), face, g_normals, g_dis, g_conf,
+                       total, g_face);
+    return check_launch();
+}
+

@@ -1568,6 +1568,39 @@ def fan_linear_rows(x, xyz, layers):
     return outs
 
 
+class _FaceSplit(torch.autograd.Function):
+    """PoseNet9D.py:31-35 as one launch each way (``hsp_face_split_fwd / _bwd``)"""
+
+    @staticmethod
+    def forward(ctx, face):
+        face = _req(face, torch.float32, "face_split.face")
+        b, n, _ = face.shape
+        nrm = torch.empty(b, n, 6, 3, dtype=torch.float32, device=face.device)
+        dis = torch.empty(b, n, 6, dtype=torch.float32, device=face.device)
+        conf = torch.empty(b, n, 6, dtype=torch.float32, device=face.device)
+        _run("hsp_face_split_fwd", (_p(face), b * n, _p(nrm), _p(dis), _p(conf), _stream()), key=f"R{b * n}", abytes=4 * b * n * 60)
+        ctx.save_for_backward(face)
+        ctx.set_materialize_grads(False)
+        return nrm, dis, conf
+
+    @staticmethod
+    def backward(ctx, gn, gd, gc):
+        (face,) = ctx.saved_tensors
+        if gn is None and gd is None and gc is None:
+            return None
+        b, n, _ = face.shape
+        gs = [None if g is None else _req(g, torch.float32, "face_split.grad") for g in (gn, gd, gc)]
+        gf = torch.empty_like(face)
+        _run("hsp_face_split_bwd", (_p(face), _p(gs[0]), _p(gs[1]), _p(gs[2]), b * n, _p(gf), _stream()), key=f"R{b * n}",
+             abytes=4 * b * n * 90)
+        return gf
+
+
+def face_split(face):
+    """(B, N, 30) face-head output -> (unit normals (B, N, 6, 3), distances (B, N, 6), confidences (B, N, 6)); PoseNet9D.py:31-35"""
+    return _FaceSplit.apply(face)
+
+
 def cat_rows_pitched(parts):
     """torch.cat(parts, dim=-1) whose rows sit on a 16-byte pitch: the result is the (..., K) view of a (..., K rounded up to 4)
     buffer with zero pad columns, so the dense kernels that want aligned rows (csrc/gemm_x3.hip) take a K = 1289 / 1283 input

@@ -601,6 +601,13 @@ int hsp_pose_augment(const float *PC, const float *gt_R, const float *gt_t, cons
                      const float *noise, int B, int N, int M, float p_bb, float p_rt, float p_bc, float p_pc, float *PC_out,
                      float *R_out, float *t_out, float *s_out, hspStream_t stream);
 
+/* the face head's output split (PoseNet9D.py:31-35) in one launch each way: face (R, 30) -> unit normals (R, 6, 3) =
+ * face[:, :18] / its per-face 3-norm (no epsilon, as the reference), distances (R, 6) = face[:, 18:24], confidences (R, 6) =
+ * sigmoid(face[:, 24:]); backward: g_face (R, 30) from the three incoming gradients (each may be NULL = zero). */
+int hsp_face_split_fwd(const float *face, long long R, float *normals, float *dis, float *conf, hspStream_t stream);
+int hsp_face_split_bwd(const float *face, const float *g_normals, const float *g_dis, const float *g_conf, long long R,
+                       float *g_face, hspStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

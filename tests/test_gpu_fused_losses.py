@@ -140,6 +140,27 @@ def test_fused_total_equals_the_term_by_term_sum(dev, ref, flags):
     assert abs(float(total_loss(plain)) - float(res[0][0])) <= 2e-6 * abs(float(res[0][0]))
 
 
+@pytest.mark.parametrize("B,N", [(16, 1028), (3, 77)])
+def test_face_split_matches_torch_composition(dev, ref, monkeypatch, B, N):
+    """PoseNet9D.py:31-35 (three slices, per-face normalisation, sigmoid) as one launch each way against the torch composition:
+    the three outputs and the gradient of the (B, N, 30) face-head output, also with one output unused"""
+    from hs_pose_amd import PoseNet9D as P9
+    face0 = ref.hash_tensor((B, N, 30), 901, 1.0).to(dev)
+    ups = [ref.hash_tensor(sh, 902 + i, 1.0).to(dev) for i, sh in enumerate(((B, N, 6, 3), (B, N, 6), (B, N, 6)))]
+    res = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("HSP_FUSED_FACE_SPLIT", fused)
+        face = face0.clone().requires_grad_(True)
+        outs = P9._split_face_head(face)
+        assert [tuple(o.shape) for o in outs] == [(B, N, 6, 3), (B, N, 6), (B, N, 6)]
+        (g,) = torch.autograd.grad(outs, [face], ups)
+        outs2 = P9._split_face_head(face)
+        (g2,) = torch.autograd.grad([outs2[0], outs2[2]], [face], [ups[0], ups[2]])      # the distances unused
+        res.append([o.detach() for o in outs] + [g, g2])
+    for a, b in zip(*res):
+        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item())
+
+
 def test_hspose_forward_uses_fused_losses(dev, flags):
     """HSPose.forward(do_loss=True) on a device batch returns the fused terms (same keys; finite; backward reaches the
     network) and HSP_FUSED_LOSSES-off instances agree with it"""
