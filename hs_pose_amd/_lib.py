@@ -106,6 +106,8 @@ SIGNATURES = {
     "hsp_fps_workspace_bytes": (_sz, [_i, _i]),
     "hsp_fps_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "hsp_fps_f64": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "hsp_axis_conf_fwd": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "hsp_axis_conf_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "hsp_face_split_fwd": (_i, [_vp, ctypes.c_longlong, _vp, _vp, _vp, _vp]),
     "hsp_face_split_bwd": (_i, [_vp, _vp, _vp, _vp, ctypes.c_longlong, _vp, _vp]),
     "hsp_pose_losses_workspace_bytes": (_sz, [_i]),

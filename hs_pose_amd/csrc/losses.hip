@@ -921,3 +921,48 @@ extern "C" int hsp_face_split_bwd(const float* face, const float* g_normals, con
     return check_launch();
 }
 
+// ---- a rotation head's output split (PoseNet9D.py:40-46): h (B, 4) -> axis (B, 3) = h[:, 1:] / (||h[:, 1:]|| + 1e-6),
+// confidence (B,) = sigmoid(h[:, 0]).  One thread per row, one launch each way (the torch composition: 4 launches forward, ~14
+// in autograd's backward, on 16 x 4 numbers).
+namespace hsp {
+__global__ __launch_bounds__(64) void axis_conf_fwd_kernel(const float* __restrict__ h, int B, float* __restrict__ axis,
+                                                           float* __restrict__ conf) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const float x = h[4 * b + 1], y = h[4 * b + 2], z = h[4 * b + 3];
+    const float d = __fsqrt_rn(x * x + y * y + z * z) + 1e-6f;
+    axis[3 * b] = x / d; axis[3 * b + 1] = y / d; axis[3 * b + 2] = z / d;
+    conf[b] = 1.0f / (1.0f + __expf(-h[4 * b]));
+}
+__global__ __launch_bounds__(64) void axis_conf_bwd_kernel(const float* __restrict__ h, const float* __restrict__ g_axis,
+                                                           const float* __restrict__ g_conf, int B, float* __restrict__ g_h) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    float gx = 0.f, gy = 0.f, gz = 0.f, g0 = 0.f;
+    if (g_axis) {
+        const float x = h[4 * b + 1], y = h[4 * b + 2], z = h[4 * b + 3];
+        const float n = __fsqrt_rn(x * x + y * y + z * z), d = n + 1e-6f;
+        const float ax = g_axis[3 * b], ay = g_axis[3 * b + 1], az = g_axis[3 * b + 2];
+        // y = v / (|v| + eps):  g_v = g_y / d - (g_y . v) v / (|v| d^2); torch's norm backward gives 0 for the second term at v = 0
+        const float s = n > 0.f ? (ax * x + ay * y + az * z) / (n * d * d) : 0.f;
+        gx = ax / d - s * x; gy = ay / d - s * y; gz = az / d - s * z;
+    }
+    if (g_conf) {
+        const float sg = 1.0f / (1.0f + __expf(-h[4 * b]));
+        g0 = g_conf[b] * sg * (1.0f - sg);
+    }
+    g_h[4 * b] = g0; g_h[4 * b + 1] = gx; g_h[4 * b + 2] = gy; g_h[4 * b + 3] = gz;
+}
+}  // namespace hsp
+
+extern "C" int hsp_axis_conf_fwd(const float* h, int B, float* axis, float* conf, hspStream_t stream) {
+    if (!h || !axis || !conf || B <= 0) return HSP_ERR_BAD_ARG;
+    hipLaunchKernelGGL(hsp::axis_conf_fwd_kernel, dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), h, B, axis, conf);
+    return check_launch();
+}
+extern "C" int hsp_axis_conf_bwd(const float* h, const float* g_axis, const float* g_conf, int B, float* g_h, hspStream_t stream) {
+    if (!h || !g_h || B <= 0) return HSP_ERR_BAD_ARG;
+    hipLaunchKernelGGL(hsp::axis_conf_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), h, g_axis, g_conf, B, g_h);
+    return check_launch();
+}
+

@@ -1596,6 +1596,36 @@ class _FaceSplit(torch.autograd.Function):
         return gf
 
 
+class _AxisConf(torch.autograd.Function):
+    """PoseNet9D.py:40-46 as one launch each way (``hsp_axis_conf_fwd / _bwd``)"""
+
+    @staticmethod
+    def forward(ctx, h):
+        h = _req(h, torch.float32, "axis_conf.h")
+        B = h.shape[0]
+        axis = torch.empty(B, 3, dtype=torch.float32, device=h.device)
+        conf = torch.empty(B, dtype=torch.float32, device=h.device)
+        _run("hsp_axis_conf_fwd", (_p(h), B, _p(axis), _p(conf), _stream()), key=f"B{B}")
+        ctx.save_for_backward(h)
+        ctx.set_materialize_grads(False)
+        return axis, conf
+
+    @staticmethod
+    def backward(ctx, ga, gc):
+        (h,) = ctx.saved_tensors
+        if ga is None and gc is None:
+            return None
+        gs = [None if g is None else _req(g, torch.float32, "axis_conf.grad") for g in (ga, gc)]
+        gh = torch.empty_like(h)
+        _run("hsp_axis_conf_bwd", (_p(h), _p(gs[0]), _p(gs[1]), h.shape[0], _p(gh), _stream()), key=f"B{h.shape[0]}")
+        return gh
+
+
+def axis_conf(h):
+    """(B, 4) rotation-head output -> (unit axis (B, 3) with the reference's 1e-6 guard, sigmoid confidence (B,)); PoseNet9D.py:40-46"""
+    return _AxisConf.apply(h)
+
+
 def face_split(face):
     """(B, N, 30) face-head output -> (unit normals (B, N, 6, 3), distances (B, N, 6), confidences (B, N, 6)); PoseNet9D.py:31-35"""
     return _FaceSplit.apply(face)

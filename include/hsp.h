@@ -608,6 +608,11 @@ int hsp_face_split_fwd(const float *face, long long R, float *normals, float *di
 int hsp_face_split_bwd(const float *face, const float *g_normals, const float *g_dis, const float *g_conf, long long R,
                        float *g_face, hspStream_t stream);
 
+/* a rotation head's output split (PoseNet9D.py:40-46): h (B, 4) -> axis (B, 3) = h[:, 1:] / (||h[:, 1:]|| + 1e-6), confidence (B) =
+ * sigmoid(h[:, 0]); backward: g_h (B, 4) from g_axis / g_conf (each may be NULL = zero). */
+int hsp_axis_conf_fwd(const float *h, int B, float *axis, float *conf, hspStream_t stream);
+int hsp_axis_conf_bwd(const float *h, const float *g_axis, const float *g_conf, int B, float *g_h, hspStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -161,6 +161,25 @@ def test_face_split_matches_torch_composition(dev, ref, monkeypatch, B, N):
         assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item())
 
 
+def test_axis_conf_matches_torch_composition(dev, ref, monkeypatch):
+    """PoseNet9D.py:40-46 (axis = h[:, 1:] / (norm + 1e-6), confidence = sigmoid(h[:, 0])) as one launch each way against the torch
+    composition: outputs and the gradient of the head output, incl. a zero axis row and one output unused"""
+    from hs_pose_amd import PoseNet9D as P9
+    h0 = ref.hash_tensor((16, 4), 911, 1.0).to(dev)
+    h0[3, 1:] = 0.0
+    ups = [ref.hash_tensor((16, 3), 912, 1.0).to(dev), ref.hash_tensor((16,), 913, 1.0).to(dev)]
+    res = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("HSP_FUSED_FACE_SPLIT", fused)
+        h = h0.clone().requires_grad_(True)
+        outs = P9._axis_and_confidence(h)
+        (g,) = torch.autograd.grad(outs, [h], ups)
+        (g2,) = torch.autograd.grad(P9._axis_and_confidence(h)[0], [h], ups[0])
+        res.append([o.detach() for o in outs] + [g, g2])
+    for a, b in zip(*res):
+        assert a.shape == b.shape and (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item())
+
+
 def test_hspose_forward_uses_fused_losses(dev, flags):
     """HSPose.forward(do_loss=True) on a device batch returns the fused terms (same keys; finite; backward reaches the
     network) and HSP_FUSED_LOSSES-off instances agree with it"""
