@@ -178,9 +178,16 @@ class FaceRecon(nn.Module):
             r = _conv_bn_relu_rows(self.recon_head, h, 1)
             last = self.recon_head[3]
             recon = ops.linear_rows(r, last.weight.squeeze(-1), last.bias).view(bs, vertice_num, -1)
-            face_in = ops.cat_rows_pitched([f_global.unsqueeze(1).expand(-1, vertice_num, -1).reshape(bs * vertice_num, -1), h,
-                                            vertices.reshape(bs * vertice_num, 3)])
-            f = _conv_bn_relu_rows(self.face_head, face_in, 3)
+            w0 = self.face_head[0].weight.squeeze(-1)
+            if ops.cloud_cat_linear_ok(f_global, h, vertices, w0):
+                # cat[f_global over the cloud, h, xyz] (FaceRecon.py:113-116) is never formed: f_global's columns of the first
+                # Conv1d act as a per-cloud bias of a K = 259 product
+                y0 = ops.cloud_cat_linear(f_global, h, vertices, w0, self.face_head[0].bias)
+                f = _conv_bn_relu_rows(self.face_head, None, 3, first=(y0, None))
+            else:
+                face_in = ops.cat_rows_pitched([f_global.unsqueeze(1).expand(-1, vertice_num, -1).reshape(bs * vertice_num, -1), h,
+                                                vertices.reshape(bs * vertice_num, 3)])
+                f = _conv_bn_relu_rows(self.face_head, face_in, 3)
             last = self.face_head[9]
             face = ops.linear_rows(f, last.weight.squeeze(-1), last.bias).view(bs, vertice_num, -1)
             return recon, face, feat

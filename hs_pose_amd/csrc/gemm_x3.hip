@@ -527,7 +527,8 @@ static int gemm_x3_impl(const float* A1, int lda1, const hsp_bf16_t* P1, int ldp
     // instantiated epilogues: 0 none, 1 bias, 2 residual (one source: the input-gradient chain of layers that share their input
     // rows -- C may BE resid: an element is read and written by the same thread), 6 residual + per-cloud bias (the layer's out
     // product), 14 = 6 + BatchNorm partials
-    if (epi != 0 && epi != 1 && epi != 6 && !(epi == 2 && !two && alpha == 1.0f)) return HSP_ERR_UNSUPPORTED;
+    // 4: per-cloud bias alone (one source: a Linear whose input is cat[per-cloud vector, rows] -- the vector's columns become a bias)
+    if (epi != 0 && epi != 1 && epi != 6 && !(epi == 2 && !two && alpha == 1.0f) && !(epi == 4 && !two)) return HSP_ERR_UNSUPPORTED;
     if (bn_out) {
         if (two) hipLaunchKernelGGL((gemm_x3_kernel<1, true, 14, 0>), grid, block, 3 * (size_t)(64 + X3_BN) * 64, st, g);
         else hipLaunchKernelGGL((gemm_x3_kernel<1, false, 14, 0>), grid, block, 3 * (size_t)(64 + X3_BN) * 64, st, g);
@@ -559,6 +560,7 @@ static int gemm_x3_impl(const float* A1, int lda1, const hsp_bf16_t* P1, int ldp
             if (epi == 0) X3_K(WM_, false, 0, PA_);                \
             else if (epi == 1) X3_K(WM_, false, 1, PA_);           \
             else if (epi == 2) X3_K(WM_, false, 2, 0);             \
+            else if (epi == 4) X3_K(WM_, false, 4, 0);             \
             else X3_K(WM_, false, 6, PA_);                         \
         }                                                          \
     } while (0)

@@ -856,7 +856,7 @@ def gemm_x3_ok(A1, B1, A2, B2, bias, resid, cloud_bias, xyz3, out, M, N):
     if not lib().hsp_gemm_x3_supported(M, N, A1.shape[1], K2):
         return False
     epi = (1 if bias is not None else 0) | (2 if resid is not None else 0) | (4 if cloud_bias is not None else 0)
-    if epi not in (0, 1, 6) and not (epi == 2 and A2 is None):
+    if epi not in (0, 1, 6) and not (epi in (2, 4) and A2 is None):
         return False
     if epi and ((M + 63) // 64) * ((N + 127) // 128) < 128:            # (an epilogue rules out split-K: too few workgroups)
         return False
@@ -1566,6 +1566,68 @@ def fan_linear_rows(x, xyz, layers):
                 xw = cat_rows_pitched([x, xyz.reshape(R, 3)])
         outs.append(_FanMember.apply(x, None if w.shape[1] == K else xw, group, w, b))
     return outs
+
+
+class _CloudCatLinear(torch.autograd.Function):
+    """F.linear(cat[fg[cloud] repeated over the cloud's rows, x, xyz], W, b) WITHOUT the concatenation (FaceRecon.py:113-117: the
+    face head reads cat[f_global expanded to every point, the 256-wide block feature, the coordinates], 771 columns): the
+    f_global columns are constant over a cloud, so their part of the product is a per-cloud bias
+            y = cat[x, xyz] W[:, Cg:]^T + (fg W[:, :Cg]^T + b)[cloud]
+    -- the trick HS_layer's conv2 already uses (gcn3d.py:186) -- a K = 259 product instead of K = 771 on a (R, 771) copy; in
+    backward the f_global gradient and its weight block come from the per-cloud column sums of g (16 rows) instead of a sum over
+    an expanded (B, N, 512) gradient, and the input gradient is a 512 -> 256 product instead of 512 -> 771."""
+
+    @staticmethod
+    def forward(ctx, fg, x, xyz, W, b):
+        B, Cg = fg.shape
+        R, Cx = x.shape
+        N = R // B
+        t = gemm_own(fg, W[:, :Cg], False)                        # (B, Cout): one small launch
+        if b is not None:
+            t = t + b
+        xin = cat_rows_pitched([x, xyz.reshape(R, 3)])            # (R, Cx + 3) on a 16-byte pitch
+        y = gemm_own(xin, W[:, Cg:], False, cloud_bias=t, rows_per_cloud=N)
+        ctx.save_for_backward(fg, xin, W)
+        ctx.dims, ctx.has_bias, ctx.x3 = (B, N, Cg, Cx), b is not None, x3_planes
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        fg, xin, W = ctx.saved_tensors
+        B, N, Cg, Cx = ctx.dims
+        g = _req(g, torch.float32, "cloud_cat_linear.grad")
+        Cout = g.shape[1]
+        gt = colsum_rows(g.view(B, N, Cout))                      # (B, Cout) = the gradient of the per-cloud bias
+        gW = torch.empty(Cout, Cg + Cx + 3, dtype=torch.float32, device=g.device)
+        _tiny_tn(gt, fg, gW[:, :Cg])                              # the f_global block of dW
+        with x3_scope(ctx.x3):
+            g_fg = gemm_own(gt, W[:, :Cg], True) if ctx.needs_input_grad[0] else None
+            gx = gemm_own(g, W[:, Cg:Cg + Cx], True) if ctx.needs_input_grad[1] else None
+        sf = StepFolds.current                                    # (the result is re-laid out below: fold now, not at the step's end)
+        held = sf.bare_wgrad if sf is not None else None
+        if sf is not None:
+            sf.bare_wgrad = False
+        try:
+            gwt = wgrad(xin, g)                                   # (Cx + 3, Cout) = the [x | xyz] block of dW^T
+        finally:
+            if sf is not None:
+                sf.bare_wgrad = held
+        gW[:, Cg:] = gwt.t()
+        return g_fg, gx, None, gW, (gt.sum(0) if ctx.has_bias else None)
+
+
+def cloud_cat_linear_ok(fg, x, xyz, W):
+    B, Cg = fg.shape
+    R, Cx = x.shape
+    return (GEMM_MODE == "own" and GEMM_X3 and fg.dtype == torch.float32 and x.dtype == torch.float32 and x.is_cuda and R % B == 0
+            and R // B >= 128 and W.shape[1] == Cg + Cx + 3 and W.shape[0] % 128 == 0 and Cx % 4 == 0 and Cg % 4 == 0
+            and os.environ.get("HSP_CLOUD_CAT_LINEAR", "1") != "0")
+
+
+def cloud_cat_linear(fg, x, xyz, W, b):
+    """F.linear(cat[fg expanded over each cloud's rows (R, Cg), x (R, Cx), xyz (B, N, 3)], W (Cout, Cg + Cx + 3), b) as a K = Cx + 3
+    product with a per-cloud bias (``_CloudCatLinear``)"""
+    return _CloudCatLinear.apply(fg, x, xyz, W, b)
 
 
 class _FaceSplit(torch.autograd.Function):

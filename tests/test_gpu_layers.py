@@ -419,6 +419,31 @@ def test_linear_rows_leaves_the_batchnorm_first_pass(dev, ref, R, Cin, Cout):
         assert (a - c).abs().max().item() <= 2e-5 * sc
 
 
+@pytest.mark.parametrize("B,N", [(16, 1028), (5, 300)])
+def test_cloud_cat_linear(dev, ref, B, N):
+    """the face head's first Conv1d on cat[f_global over the cloud, h, xyz] (FaceRecon.py:113-117) as a K = 259 product with a
+    per-cloud bias: output and the gradients of f_global, h, the (512, 771) weight and the bias vs the fp64 composition"""
+    from hs_pose_amd import ops
+    R, Cg, Cx, Cout = B * N, 512, 256, 512
+    fg = ref.hash_tensor((B, Cg), 81, 1.0).to(dev).requires_grad_(True)
+    x = ref.hash_tensor((R, Cx), 82, 1.0).to(dev).requires_grad_(True)
+    xyz = (ref.hash_tensor((B, N, 3), 83, 1.0) * 0.3).to(dev)
+    W = (ref.hash_tensor((Cout, Cg + Cx + 3), 84, 1.0) * 0.04).to(dev).requires_grad_(True)
+    b = ref.hash_tensor((Cout,), 85, 1.0).to(dev).requires_grad_(True)
+    up = ref.hash_tensor((R, Cout), 86, 1.0).to(dev)
+    assert ops.cloud_cat_linear_ok(fg, x, xyz, W)
+    y = ops.cloud_cat_linear(fg, x, xyz, W, b)
+    got = torch.autograd.grad(y, (fg, x, W, b), up)
+    fd, xd, Wd, bd = (t.detach().double().requires_grad_(True) for t in (fg, x, W, b))
+    full = torch.cat([fd.unsqueeze(1).expand(-1, N, -1).reshape(R, Cg), xd, xyz.reshape(R, 3).double()], dim=1)
+    want_y = full @ Wd.t() + bd
+    want = torch.autograd.grad(want_y, (fd, xd, Wd, bd), up.double())
+    assert (y.double() - want_y).abs().max().item() <= 1e-5 * want_y.abs().max().item()
+    for a, c, name in zip(got, want, ("f_global", "x", "W", "b")):
+        assert a.shape == c.shape, name
+        assert (a.double() - c).abs().max().item() <= 2e-5 * c.abs().max().item(), name
+
+
 @pytest.mark.parametrize("B,N", [(16, 1028), (3, 700)])
 def test_fan_linear_rows(dev, ref, B, N):
     """the first layers of every consumer of feat's rows as one node (PoseR.py:27 x2, PoseTs.py:32 on cat[feat, xyz],
