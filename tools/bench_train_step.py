@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly (CPU-bound) instead of replaying a hipGraph")
     ap.add_argument("--graph-net", action="store_true", help="eager step with posenet forward/backward replayed from two hipGraphs")
     args = ap.parse_args()
-    from hs_pose_amd import gemm_tuning
+    from tools import gemm_tuning                # (library-GEMM tuning table: only matters under HSP_GEMM=library)
     from hs_pose_amd.config import FLAGS
     from hs_pose_amd.HSPose import HSPose
     from hs_pose_amd.train import TrainDriver
