@@ -442,8 +442,10 @@ __global__ __launch_bounds__(256) void split_params_x3_kernel(const HspSplitDesc
 }
 
 static int x3_pick_split(long long tiles, int TT) {
+    // workgroups aimed at: 2 per CU (HSP_X3_SPLIT_TARGET: measured 3 and 4 per CU -- more, shorter K slices and a deeper fold)
+    static const int per_cu = [] { const char* e = getenv("HSP_X3_SPLIT_TARGET"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 8 ? v : 2; }();
     if (tiles >= 2 * HSP_NUM_CU || TT < 16) return 1;
-    int ns = (int)((2 * HSP_NUM_CU + tiles - 1) / tiles);
+    int ns = (int)((per_cu * HSP_NUM_CU + tiles - 1) / tiles);
     if (ns > TT / 8) ns = TT / 8;
     if (ns > 16) ns = 16;
     if (ns < 2) return 1;
