@@ -1503,8 +1503,8 @@ class _FanMember(torch.autograd.Function):
     sum (three 250 MB element-wise passes at B=16, N=1028), and every member still runs when ITS upstream gradient arrives,
     while that gradient is still cache-resident (one node for all four was measured 0.2 ms SLOWER per step: it runs when the
     last gradient arrives, after 270 MB of them have gone through a 256 MB cache).  Stream order makes the buffer complete
-    before x's producer reads it; x must have NO consumer outside the group (a foreign gradient arriving between two members
-    would be summed out of place and the later members' terms lost).  The layer on cat[x, xyz] (``xw``: the pitched concatenation) contributes through the first K
+    before x's producer reads it (the members share an alias of x -- ``fan_linear_rows`` -- so a gradient from a consumer
+    outside the group is only added once the group's buffer is final).  The layer on cat[x, xyz] (``xw``: the pitched concatenation) contributes through the first K
     columns of its weight; the coordinates carry no gradient.  One backward pass per forward (no retain_graph)."""
 
     @staticmethod
@@ -1559,6 +1559,10 @@ def fan_linear_rows(x, xyz, layers):
     epilogues instead of in autograd's element-wise adds (``_FanMember``).  Each entry of the result is (y, part): part = the
     first pass of the train-mode BatchNorm behind the layer (``bn_relu(y, bn, partial=part)``), possibly empty."""
     R, K = x.shape
+    # the members read x through ONE alias: autograd then delivers their (single, in-place accumulated) gradient to the alias node
+    # only after every member has run, and adds a gradient x may receive from a consumer OUTSIDE the group after that -- the
+    # buffer is complete before anything else touches it
+    x = x.view_as(x)
     group, xw, outs = _FanGroup(), None, []
     for w, b in layers:
         if w.shape[1] != K and xw is None:

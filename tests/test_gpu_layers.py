@@ -487,6 +487,11 @@ def test_fan_linear_rows(dev, ref, B, N):
         assert gw.shape == w.shape
         assert (gw.double() - want_w).abs().max().item() <= 1e-5 * want_w.abs().max().item()
         assert (gb.double() - up.double().sum(0)).abs().max().item() <= 1e-5 * up.double().sum(0).abs().max().item() + 1e-4
+    # a consumer of x OUTSIDE the group: its gradient is added to the group's once that is complete
+    ys = [y for y, _ in ops.fan_linear_rows(x, xyz, list(zip(ws, bs)))]
+    other = x * 2.0
+    (gx3,) = torch.autograd.grad(ys + [other], [x], ups + [torch.ones_like(other)])
+    assert (gx3.double() - (want_gx + 2.0)).abs().max().item() <= 1e-5 * want_gx.abs().max().item()
     # one consumer without a gradient (its head's loss switched off): the chain skips it
     ys = [y for y, _ in ops.fan_linear_rows(x, xyz, list(zip(ws, bs)))]
     (gx2,) = torch.autograd.grad([ys[0], ys[2], ys[3]], [x], [ups[0], ups[2], ups[3]])
