@@ -103,7 +103,9 @@ class FaceRecon(nn.Module):
         k = self.neighbor_num
         if self._x3 is None:
             self._x3 = ops.X3Planes()
-        with ops.x3_scope(self._x3):
+        # eval mode: the forward in the reference's own operation order, so that the feature-space neighbour search sees the
+        # reference's bits (ops.exact_scope); train mode: the faster products
+        with ops.x3_scope(self._x3), ops.exact_scope(not self.training and self.feature_dtype == torch.float32):
             return self._forward(vertices, cat_id)
 
     def _forward(self, vertices, cat_id):

@@ -49,11 +49,16 @@ __device__ __forceinline__ float dot3_chain(float ax, float ay, float az, float 
     return __fmaf_rn(az, bz, __fmaf_rn(ay, by, mul_rn(ax, bx)));
 }
 
+// sum of the squares of three numbers the way ATen's vector_norm accumulates them on the CPU: acc = fma(x, x, acc) in element
+// order (its norm kernels are compiled with fma contraction) -- F.normalize over a dimension of size 3, contiguous (dim = -1:
+// the neighbour directions) or strided (dim = 0: the support directions), bit for bit (oracle/gen_golden_exact.py)
+__device__ __forceinline__ float norm2_chain(float x, float y, float z) { return __fmaf_rn(z, z, __fmaf_rn(y, y, mul_rn(x, x))); }
+
 // unit vector from p to q the way F.normalize does it: v / max(|v|, 1e-12), |v| = sqrt(sum of squares)
 __device__ __forceinline__ float3 unit_dir(float px, float py, float pz, float qx, float qy, float qz) {
     float dx = sub_rn(qx, px), dy = sub_rn(qy, py), dz = sub_rn(qz, pz);
-    float n2 = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
-    float nrm = fmaxf(__fsqrt_rn(n2), 1e-12f);
+    float n2 = norm2_chain(dx, dy, dz);
+    float nrm = fmaxf(sqrtf(n2), 1e-12f);              // (sqrtf: correctly rounded; __fsqrt_rn is the 1-ulp native one)
     return make_float3(__fdiv_rn(dx, nrm), __fdiv_rn(dy, nrm), __fdiv_rn(dz, nrm));
 }
 

@@ -1,0 +1,135 @@
+// exact.hip -- the reductions and element-wise formulas of the reference's forward whose ROUNDING ORDER decides which
+// neighbours the next layer's feature-space KNN picks (gcn3d.py:19-23 ranks rows that differ in the last bits), restated in the
+// exact order the reference's CPU path (ATen, torch 2.x) evaluates them.  Together with the k-ordered products of gemm_wave.hip
+// they make the eval-mode forward of the HS stack reproduce the reference's feature rows bit for bit, so a free-running forward
+// selects the reference's neighbour lists instead of lists that agree "up to near ties" (DESIGN.md section 2.2).
+// Pinned by tests/golden/exact_*.npz (oracle/gen_golden_exact.py imports the reference and records its outputs).
+#include "common.h"
+
+namespace hsp {
+
+// ---- get_ORL_global (gcn3d.py:211-218): torch.mean(max_n feature[idx], dim=1) ------------------------------------------------
+// ATen sums an outer (strided) dimension with cascade_sum / multi_row_sum: rows are added one by one into a level-0 accumulator
+// that is dumped into level 1 every 16 rows, level 1 into level 2 every 256, level 2 into level 3 every 4096 (level_step = 16 for
+// every N < 2^20), the remainder rows go into level 0 last, and the levels are added 0 <- 1 <- 2 <- 3; the mean divides by N.
+// Level 0 is 16-row chunks summed from zero: one thread per (chunk, 4 channels).
+#define ORLX_ROWS 16
+__global__ __launch_bounds__(256) void orl_exact_l0_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx, int N,
+                                                           int k, int kstride, int C, uint8_t* __restrict__ argmax,
+                                                           float* __restrict__ part, int nchunk) {
+    const int cq = C >> 2;
+    const int b = blockIdx.y;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)nchunk * cq) return;
+    const int chunk = (int)(e / cq), g = (int)(e - (long long)chunk * cq);
+    const int r0 = chunk * ORLX_ROWS, r1 = min(N, r0 + ORLX_ROWS);
+    const float* fb = feat + (size_t)b * N * C + (g << 2);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = r0; i < r1; ++i) {
+        const int32_t* nb = idx + ((size_t)b * N + i) * kstride;
+        float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int n = 0; n < k; ++n) {                      // ascending n, strict >: the first maximum wins, as torch.max
+            const float4 f = *reinterpret_cast<const float4*>(fb + (size_t)nb[n] * C);
+            if (f.x > best.x) { best.x = f.x; a0 = n; }
+            if (f.y > best.y) { best.y = f.y; a1 = n; }
+            if (f.z > best.z) { best.z = f.z; a2 = n; }
+            if (f.w > best.w) { best.w = f.w; a3 = n; }
+        }
+        *reinterpret_cast<uchar4*>(argmax + ((size_t)b * N + i) * C + (g << 2)) =
+            make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
+        s.x = add_rn(s.x, best.x); s.y = add_rn(s.y, best.y); s.z = add_rn(s.z, best.z); s.w = add_rn(s.w, best.w);
+    }
+    *reinterpret_cast<float4*>(part + ((size_t)b * nchunk + chunk) * C + (g << 2)) = s;
+}
+
+// levels 1..3 and the division: one thread per (cloud, channel)
+__global__ __launch_bounds__(256) void orl_exact_fold_kernel(const float* __restrict__ part, int B, int N, int nchunk, int C,
+                                                             float* __restrict__ fg) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= B * C) return;
+    const int b = e / C, c = e - b * C;
+    const float* p = part + (size_t)b * nchunk * C + c;
+    const int nfull = N / ORLX_ROWS;
+    float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int j = 0; j < nfull; ++j) {
+        const int i = (j + 1) * ORLX_ROWS;                 // rows consumed so far
+        a1 = add_rn(a1, p[(size_t)j * C]);
+        if ((i & 0xf0) == 0) {
+            a2 = add_rn(a2, a1); a1 = 0.f;
+            if ((i & 0xf00) == 0) { a3 = add_rn(a3, a2); a2 = 0.f; }
+        }
+    }
+    float s = nfull < nchunk ? p[(size_t)nfull * C] : 0.f; // the remainder rows (level 0 after the last dump)
+    s = add_rn(s, a1); s = add_rn(s, a2); s = add_rn(s, a3);
+    fg[e] = __fdiv_rn(s, (float)N);
+}
+
+// ---- eval-mode BatchNorm1d on the reference's transposed (B,C,N) view (FaceRecon.py:90-95) ------------------------------------
+// ATen's generic path (batch_norm_cpu_transform_input_template): invstd = 1 / at::sqrt(running_var + eps), then
+// ((x - mean) * invstd) * weight + bias, each operation rounded (no fma).  at::sqrt on the CPU is MKL VML's vsSqrt: within an ulp
+// but NOT correctly rounded (one channel in ~180 differs from the IEEE value: oracle/gen_golden_exact.py), so the caller may
+// hand in the invstd the host's ATen computed (``invstd`` != NULL); without it the correctly rounded value is used.
+__global__ __launch_bounds__(256) void bn_eval_exact_kernel(const float* __restrict__ x, long long n4, int C,
+                                                            const float* __restrict__ rm, const float* __restrict__ rv,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ w, const float* __restrict__ bia, float eps,
+                                                            int relu, float* __restrict__ y) {
+    const int cq = C >> 2;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e % cq) << 2;
+        const float4 v = *reinterpret_cast<const float4*>(x + e * 4);
+        const float4 m = *reinterpret_cast<const float4*>(rm + c);
+        float4 var = make_float4(1.f, 1.f, 1.f, 1.f), iv = var;
+        if (invstd) iv = *reinterpret_cast<const float4*>(invstd + c);
+        else var = *reinterpret_cast<const float4*>(rv + c);
+        const float4 ww = *reinterpret_cast<const float4*>(w + c), bb = *reinterpret_cast<const float4*>(bia + c);
+        float4 o;
+#define BNX(X)                                                                       \
+        {                                                                            \
+            const float inv = invstd ? iv.X : __fdiv_rn(1.0f, sqrtf(add_rn(var.X, eps)));   \
+            o.X = add_rn(mul_rn(mul_rn(sub_rn(v.X, m.X), inv), ww.X), bb.X);         \
+            if (relu) o.X = fmaxf(o.X, 0.f);                                         \
+        }
+        BNX(x) BNX(y) BNX(z) BNX(w)
+#undef BNX
+        *reinterpret_cast<float4*>(y + e * 4) = o;
+    }
+}
+
+}  // namespace hsp
+
+using namespace hsp;
+
+extern "C" size_t hsp_orl_exact_workspace_bytes(int B, int N, int C) {
+    if (B <= 0 || N <= 0 || C <= 0) return 0;
+    return (size_t)B * ((N + ORLX_ROWS - 1) / ORLX_ROWS) * C * sizeof(float);
+}
+
+extern "C" int hsp_orl_global_exact_f32(const float* feat, const int32_t* idx, int B, int N, int k, int kstride, int C, float* fg,
+                                        uint8_t* argmax, void* ws, size_t ws_bytes, hspStream_t stream) {
+    if (!feat || !idx || !fg || !argmax || B <= 0 || N <= 0 || k <= 0 || kstride < k || C <= 0) return HSP_ERR_BAD_ARG;
+    if ((C & 3) || k > 255 || N >= (1 << 20)) return HSP_ERR_UNSUPPORTED;        // (level_step = 16 holds below 2^20 rows)
+    if (!ws || ws_bytes < hsp_orl_exact_workspace_bytes(B, N, C)) return HSP_ERR_WORKSPACE;
+    hipStream_t st = as_stream(stream);
+    const int nchunk = (N + ORLX_ROWS - 1) / ORLX_ROWS;
+    float* part = reinterpret_cast<float*>(ws);
+    const long long work = (long long)nchunk * (C >> 2);
+    hipLaunchKernelGGL(orl_exact_l0_kernel, dim3((unsigned)((work + 255) / 256), B), dim3(256), 0, st, feat, idx, N, k, kstride, C,
+                       argmax, part, nchunk);
+    hipLaunchKernelGGL(orl_exact_fold_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, B, N, nchunk, C, fg);
+    return check_launch();
+}
+
+extern "C" int hsp_bn_eval_f32(const float* x, long long R, int C, const float* running_mean, const float* running_var,
+                               const float* invstd, const float* weight, const float* bias, float eps, int relu, float* y,
+                               hspStream_t stream) {
+    if (!x || !y || !running_mean || (!running_var && !invstd) || !weight || !bias || R <= 0 || C <= 0) return HSP_ERR_BAD_ARG;
+    if (C & 3) return HSP_ERR_UNSUPPORTED;
+    const long long n4 = R * (C >> 2);
+    long long blocks = (n4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bn_eval_exact_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, n4, C, running_mean,
+                       running_var, invstd, weight, bias, eps, relu, y);
+    return check_launch();
+}

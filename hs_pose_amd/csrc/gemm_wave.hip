@@ -16,7 +16,10 @@
 //       A:  RB  x 16 bytes  A[row0 + 32 rb + li][k8 + 4 lh .. +3]                    (one row per lane: the MFMA A layout)
 //       B:  "nn" (K,N): 4 x (4 NCB) bytes  B[k8 + 4 lh + j][col0 + NCB li .. + NCB-1]   j = 0..3
 //           "nt" (N,K): NCB x 16 bytes     B[col0 + NCB li + cb][k8 + 4 lh .. +3]
-//     MFMA j of a step multiplies the k pair (k8 + j, k8 + 4 + j); the column a lane stands for in column block cb is
+//     The two half-waves then trade registers (v_permlane32_swap: (t0,t1) -> (k8+0|k8+1), (k8+4|k8+5); (t2,t3) -> (k8+2|k8+3),
+//     (k8+6|k8+7)) so that the four MFMAs of a step multiply the k pairs (0,1), (2,3), (4,5), (6,7) IN ASCENDING ORDER: a
+//     product is then bit for bit the k-ordered fp32 fma chain from 0 that the reference's CPU GEMM runs for K <= 256
+//     (oracle/gen_golden_exact.py pins that) -- 10 VALU swaps per 16 MFMAs.  The column a lane stands for in column block cb is
 //     col0 + NCB li + cb -- the NCB accumulators of a row are NCB CONSECUTIVE columns, so "nn" operands load with one wide
 //     access per k and the tile is written with 16-byte stores (NCB = 4);
 //   * the loads run a ring of 4 steps ahead of the MFMAs (buffer loads: scalar step offsets, rows past M read 0) and the ring
@@ -45,6 +48,7 @@ struct GwArgs {
     float* C; int ldc; int M, N;
     const float* bias;
     const float* resid; int ldr;
+    const float* resid2; int ldr2;         // exact forms: a second residual, added LAST
     const float* cbias; int rpc;
     const float* xyz3; const float* w3;
     float alpha;
@@ -91,14 +95,31 @@ __device__ __forceinline__ void gw_issue(u32x4 (&a)[4][RB], u32x4 (&b)[4][4], co
     }
 }
 
+// lanes (li, 0) / (li, 1) hold k8 + 0..3 / k8 + 4..7 in (t0,t1,t2,t3): after the two swaps t0 = (k8+0 | k8+1), t2 = (k8+2 | k8+3),
+// t1 = (k8+4 | k8+5), t3 = (k8+6 | k8+7) in (lower | upper) half-wave: ascending k pairs in the order 0, 2, 1, 3
+#define GW_PAIR_UP(T0, T1, T2, T3)                                                       \
+    {                                                                                    \
+        const u32x2 p_ = __builtin_amdgcn_permlane32_swap((T0), (T1), false, false);     \
+        const u32x2 q_ = __builtin_amdgcn_permlane32_swap((T2), (T3), false, false);     \
+        (T0) = p_[0]; (T1) = p_[1]; (T2) = q_[0]; (T3) = q_[1];                           \
+    }
+
 template <int RB, int NCB, int LB, int Q>
-__device__ __forceinline__ void gw_compute(f32x16 (&acc)[RB][NCB], const u32x4 (&a)[4][RB], const u32x4 (&b)[4][4]) {
+__device__ __forceinline__ void gw_compute(f32x16 (&acc)[RB][NCB], u32x4 (&a)[4][RB], u32x4 (&b)[4][4]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int x = 0; x < RB; ++x) GW_PAIR_UP(a[Q][x][0], a[Q][x][1], a[Q][x][2], a[Q][x][3])
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+        if constexpr (LB == 1) GW_PAIR_UP(b[Q][0][c], b[Q][1][c], b[Q][2][c], b[Q][3][c])
+        else GW_PAIR_UP(b[Q][c][0], b[Q][c][1], b[Q][c][2], b[Q][c][3])
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
         for (int x = 0; x < RB; ++x)
 #pragma unroll
             for (int c = 0; c < NCB; ++c) {
+                const int j = (jj == 1) ? 2 : (jj == 2) ? 1 : jj;      // registers in ascending-k order: 0, 2, 1, 3
                 const float bv = LB == 1 ? u2f(b[Q][j][c]) : u2f(b[Q][c][j]);
                 const float av = u2f(a[Q][x][j]);
 #if GW_ABLATE == 1
@@ -150,18 +171,23 @@ __device__ __forceinline__ void gw_segment(f32x16 (&acc)[RB][NCB], u32x4 (&a)[4]
     __builtin_amdgcn_sched_barrier(0);
 }
 
-struct GwRsrc { __amdgpu_buffer_rsrc_t A0, B0, A1, B1, C, R; };
+struct GwRsrc { __amdgpu_buffer_rsrc_t A0, B0, A1, B1, C, R, R2; };
 
 // `count` tiles of (32 RB) x (32 NCB): tile i has its first row at row0(i) and lane li its first column at col0(i) + cs li
 // (bulk tiles: cs = NCB; a 32 x 32 block cut out of a wider tile keeps that tile's column stride)
-// EPI: what the epilogue adds -- bit 0 bias, bit 1 residual + per-cloud bias, bit 2 the K = 3 coordinate product.  (Template
+// EPI: what the epilogue adds -- bit 0 bias, bit 1 residual + per-cloud bias, bit 2 the K = 3 coordinate product, bit 3 relu;
+// the EXACT forms (the reference's own order of additions, gcn3d.py:112,156,186): bit 5 residual alone, bit 6 per-cloud bias THEN
+// residual, bit 4 a second residual added last.  A2C: the second source's rows are per-CLOUD rows (row r reads A2[r / rpc]):
+// conv2 over cat[F, f_global] (gcn3d.py:111,185) as ONE chain that runs on from F's channels into f_global's.  (Template
 // parameters, not run-time tests: a load inside a run-time branch makes hipcc wait vmcnt(0) at the join -- measured: a drained
 // prefetch ring and a full memory round trip per tile.)
-template <int RB, int NCB, int LB0, int LB1, bool TWO, int EPI, typename TileFn>
+template <int RB, int NCB, int LB0, int LB1, bool TWO, int EPI, bool A2C, typename TileFn>
 __device__ __forceinline__ void gw_tiles(const GwArgs& g, const GwRsrc& rs, int count, int cs, TileFn tile_of) {
     const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     constexpr bool two = TWO;
-    constexpr bool HAS_BIAS = EPI & 1, HAS_RES = EPI & 2, HAS_XYZ = EPI & 4, HAS_RELU = EPI & 8;
+    constexpr bool HAS_BIAS = EPI & 1, HAS_XYZ = EPI & 4, HAS_RELU = EPI & 8;
+    constexpr bool EXACT = (EPI & (16 | 32 | 64)) != 0;               // the reference's order of additions
+    constexpr bool HAS_RES = (EPI & (2 | 32 | 64)) != 0, HAS_CB = (EPI & (2 | 64)) != 0, HAS_RES2 = (EPI & 16) != 0;
     auto seg_of = [&](int i, int src) {
         GwSeg<RB> sg;
         int row0, col0;
@@ -173,7 +199,11 @@ __device__ __forceinline__ void gw_tiles(const GwArgs& g, const GwRsrc& rs, int 
         sg.nsteps = src ? g.T1 : g.T0;
         sg.ldb_bytes = ldb * 4u;
 #pragma unroll
-        for (int x = 0; x < RB; ++x) sg.voffA[x] = ((unsigned)(row0 + 32 * x + li) * lda + 4u * lh) * 4u;
+        for (int x = 0; x < RB; ++x) {
+            unsigned row = (unsigned)(row0 + 32 * x + li);
+            if (A2C && src) row = min(row, (unsigned)g.M - 1u) / (unsigned)g.rpc;      // a per-cloud row
+            sg.voffA[x] = (row * lda + 4u * lh) * 4u;
+        }
         sg.voffB = sg.lb == 1 ? (4u * lh * ldb + col0 + cs * li) * 4u : ((unsigned)(col0 + cs * li) * ldb + 4u * lh) * 4u;
         return sg;
     };
@@ -203,7 +233,7 @@ __device__ __forceinline__ void gw_tiles(const GwArgs& g, const GwRsrc& rs, int 
             bv[c] = 0.f;
             if constexpr (HAS_BIAS) bv[c] = g.bias[colb + c];
             if constexpr (HAS_XYZ) { w3v[c][0] = g.w3[(colb + c) * 3]; w3v[c][1] = g.w3[(colb + c) * 3 + 1]; w3v[c][2] = g.w3[(colb + c) * 3 + 2]; }
-            if constexpr (HAS_RES) {
+            if constexpr (HAS_CB) {
                 cbv[0][c] = g.cbias[(size_t)c0 * g.N + colb + c];
                 cbv[1][c] = g.cbias[(size_t)c1 * g.N + colb + c];
             }
@@ -224,7 +254,7 @@ __device__ __forceinline__ void gw_tiles(const GwArgs& g, const GwRsrc& rs, int 
         for (int x = 0; x < RB; ++x) {
 #pragma unroll
             for (int r4 = 0; r4 < 16; r4 += 4) {
-            u32x4 rq[4];                                      // four residual rows requested together
+            u32x4 rq[4], rq2[4];                              // four residual rows requested together
             if constexpr (HAS_RES) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -236,6 +266,14 @@ __device__ __forceinline__ void gw_tiles(const GwArgs& g, const GwRsrc& rs, int 
                         const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs.R, off, 0, 0);
                         rq[q][0] = t[0]; rq[q][1] = t[1];
                     } else rq[q][0] = __builtin_amdgcn_raw_buffer_load_b32(rs.R, off, 0, 0);
+                    if constexpr (HAS_RES2) {
+                        const unsigned off2 = ((unsigned)row * g.ldr2 + colb) * 4u;
+                        if constexpr (NCB == 4) rq2[q] = __builtin_amdgcn_raw_buffer_load_b128(rs.R2, off2, 0, 0);
+                        else if constexpr (NCB == 2) {
+                            const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs.R2, off2, 0, 0);
+                            rq2[q][0] = t[0]; rq2[q][1] = t[1];
+                        } else rq2[q][0] = __builtin_amdgcn_raw_buffer_load_b32(rs.R2, off2, 0, 0);
+                    }
                 }
             }
 #pragma unroll
@@ -244,6 +282,27 @@ __device__ __forceinline__ void gw_tiles(const GwArgs& g, const GwRsrc& rs, int 
                 const int row = row0 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int rowc = min(row, g.M - 1);
                 float v[NCB];
+                if constexpr (EXACT) {
+                    // ((conv2 chain [+ its f_global block]) + F) + STE: gcn3d.py:112 / :186 then :90 / :156, each sum rounded once
+#pragma unroll
+                    for (int c = 0; c < NCB; ++c) v[c] = acc[x][c][r];
+                    if constexpr (HAS_CB) {
+#pragma unroll
+                        for (int c = 0; c < NCB; ++c) v[c] += rowc >= nb ? cbv[1][c] : cbv[0][c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < NCB; ++c) v[c] += u2f(rq[q][c]);
+                    if constexpr (HAS_RES2) {
+#pragma unroll
+                        for (int c = 0; c < NCB; ++c) v[c] += u2f(rq2[q][c]);
+                    }
+                    if constexpr (HAS_XYZ) {
+                        const float* p3 = g.xyz3 + (size_t)rowc * 3;
+                        const float px = p3[0], py = p3[1], pz = p3[2];
+#pragma unroll
+                        for (int c = 0; c < NCB; ++c) v[c] += __fmaf_rn(pz, w3v[c][2], __fmaf_rn(py, w3v[c][1], px * w3v[c][0]));
+                    }
+                } else {
 #pragma unroll
                 for (int c = 0; c < NCB; ++c) v[c] = g.alpha * acc[x][c][r] + bv[c];
                 if constexpr (HAS_RES) {
@@ -256,9 +315,10 @@ __device__ __forceinline__ void gw_tiles(const GwArgs& g, const GwRsrc& rs, int 
 #pragma unroll
                     for (int c = 0; c < NCB; ++c) v[c] += __fmaf_rn(pz, w3v[c][2], __fmaf_rn(py, w3v[c][1], px * w3v[c][0]));
                 }
-                if constexpr (HAS_RES) {          // (the host sends tiles that could span three clouds to gemm_rows)
+                if constexpr (HAS_CB) {          // (the host sends tiles that could span three clouds to gemm_rows)
 #pragma unroll
                     for (int c = 0; c < NCB; ++c) v[c] += rowc >= nb ? cbv[1][c] : cbv[0][c];
+                }
                 }
                 if constexpr (HAS_RELU) {         // FaceRecon.py:88: relu(conv_0(...)) in the producing kernel
 #pragma unroll
@@ -291,7 +351,7 @@ __device__ __forceinline__ void gw_tiles(const GwArgs& g, const GwRsrc& rs, int 
 }
 
 // LB0 / LB1: layout of B1 / B2 (0 "nt", 1 "nn"; a single-source product is instantiated with LB1 == LB0)
-template <int RB, int NCB, int WPS, int LB0, int LB1, bool TWO, int EPI>
+template <int RB, int NCB, int WPS, int LB0, int LB1, bool TWO, int EPI, bool A2C = false>
 __global__ __launch_bounds__(256, WPS) void gemm_wave_kernel(const GwArgs g) {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int w = blockIdx.x * 4 + wv;
@@ -301,13 +361,16 @@ __global__ __launch_bounds__(256, WPS) void gemm_wave_kernel(const GwArgs g) {
     const size_t b0_elems = g.lb[0] == 1 ? ((size_t)g.K[0] - 1) * g.ldb[0] + g.N : ((size_t)g.N - 1) * g.ldb[0] + g.K[0];
     rs.B0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B[0]), 0, (int)(b0_elems * 4), 0x00020000);
     constexpr bool two = TWO;
-    const size_t a1_elems = two ? ((size_t)g.M - 1) * g.lda[1] + g.K[1] : 1;
+    const size_t a1_elems = two ? ((size_t)(A2C ? (g.M - 1) / g.rpc : g.M - 1)) * g.lda[1] + g.K[1] : 1;
     const size_t b1_elems = two ? (g.lb[1] == 1 ? ((size_t)g.K[1] - 1) * g.ldb[1] + g.N : ((size_t)g.N - 1) * g.ldb[1] + g.K[1]) : 1;
     rs.A1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(two ? g.A[1] : g.A[0]), 0, (int)(a1_elems * 4), 0x00020000);
     rs.B1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(two ? g.B[1] : g.B[0]), 0, (int)(b1_elems * 4), 0x00020000);
     rs.C = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)((((size_t)g.M - 1) * g.ldc + g.N) * 4), 0x00020000);
-    rs.R = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((EPI & 2) ? g.resid : g.C), 0,
-                                             (int)((((size_t)g.M - 1) * ((EPI & 2) ? g.ldr : g.ldc) + g.N) * 4), 0x00020000);
+    constexpr bool has_res = (EPI & (2 | 32 | 64)) != 0;
+    rs.R = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_res ? g.resid : g.C), 0,
+                                             (int)((((size_t)g.M - 1) * (has_res ? g.ldr : g.ldc) + g.N) * 4), 0x00020000);
+    rs.R2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((EPI & 16) ? g.resid2 : g.C), 0,
+                                              (int)((((size_t)g.M - 1) * ((EPI & 16) ? g.ldr2 : g.ldc) + g.N) * 4), 0x00020000);
 
     // tile order: row panels fastest (the waves of a CU work on ONE column panel at a time and share its B lines in L1) or
     // column panels fastest (they share the A rows)
@@ -318,14 +381,14 @@ __global__ __launch_bounds__(256, WPS) void gemm_wave_kernel(const GwArgs g) {
     };
     // whole tiles [w base, (w+1) base)
     const int first = w * g.base;
-    gw_tiles<RB, NCB, LB0, LB1, TWO, EPI>(g, rs, g.base, NCB, [&](int i, int& row0, int& col0) { tile_rc(first + i, row0, col0); });
+    gw_tiles<RB, NCB, LB0, LB1, TWO, EPI, A2C>(g, rs, g.base, NCB, [&](int i, int& row0, int& col0) { tile_rc(first + i, row0, col0); });
     // the 32 x 32 blocks of the leftover tiles, dealt round-robin (usually at most one per wave): block (xb, cb) of tile u_rem + w / (RB NCB) -- rows 32 xb .., columns cb + NCB li
     for (int pc = w; pc < g.npieces; pc += g.nwaves) {
         const int u = g.u_rem + pc / (RB * NCB), sub = pc % (RB * NCB);
         int row0, col0;
         tile_rc(u, row0, col0);
         row0 += 32 * (sub / NCB); col0 += sub % NCB;
-        gw_tiles<1, 1, LB0, LB1, TWO, EPI>(g, rs, 1, NCB, [&](int, int& r0, int& c0) { r0 = row0; c0 = col0; });
+        gw_tiles<1, 1, LB0, LB1, TWO, EPI, A2C>(g, rs, 1, NCB, [&](int, int& r0, int& c0) { r0 = row0; c0 = col0; });
     }
 }
 
@@ -388,6 +451,60 @@ extern "C" int hsp_gemm_wave_plan_info(int M, int N, int K1, int K2, int cfg, in
 extern "C" int hsp_gemm_wave_supported(int M, int N, int K1, int K2, int cfg) {
     GwPlan p;
     return gw_plan(M, N, K1, K2, cfg, &p) ? 1 : 0;
+}
+
+/* The HS layer's out product in the REFERENCE's order of operations (gcn3d.py:111-112,185-186 then :90,:156), every product a
+ * k-ordered fp32 fma chain from 0 -- what the reference's CPU GEMM runs for K <= 256 -- so that the rows handed to the next
+ * layer's feature-space neighbour search carry the reference's bits:
+ *   two_chain == 0 (2 C <= 256: conv2 over cat[F, f_global] is ONE chain):
+ *       out = ((chain_k F[r][k] Wa[n][k]  ->continued->  chain_k fg[r / rows_per_cloud][k] Wb[n][k]) + F[r][n]) + tail
+ *   two_chain == 1 (2 C = 512: the CPU GEMM sums two K = 256 block chains):  t = chain(fg Wb^T) comes in as cloud_t (B, N):
+ *       out = (((chain_k F[r][k] Wa[n][k]) + cloud_t[r / rows_per_cloud][n]) + F[r][n]) + tail
+ *   tail = ste[r][n] (the STE product, its own chain: a plain hsp_gemm_wave_f32 "nt" call) or, for the surface layer (xyz3 != NULL),
+ *   the K = 3 chain xyz3[r] . w3[n]; relu != 0 applies FaceRecon.py:88's relu.
+ * Shapes: C a multiple of 32, 16-byte aligned rows; rows_per_cloud >= 32. */
+extern "C" int hsp_layer_out_exact_f32(const float* F, int ldf, const float* Wa, int ldwa, const float* fg, int ldfg,
+                                       const float* Wb, int ldwb, const float* cloud_t, int two_chain, const float* ste, int ldste,
+                                       const float* xyz3, const float* w3, int relu, int M, int C, int rows_per_cloud, float* out,
+                                       int ldo, hspStream_t stream) {
+    if (!F || !Wa || !out || M <= 0 || C <= 0 || rows_per_cloud <= 0) return HSP_ERR_BAD_ARG;
+    if (two_chain ? !cloud_t : (!fg || !Wb)) return HSP_ERR_BAD_ARG;
+    if ((ste == nullptr) == (xyz3 == nullptr) || (xyz3 && !w3)) return HSP_ERR_BAD_ARG;
+    if (relu && !xyz3) return HSP_ERR_UNSUPPORTED;
+    GwPlan p;
+    if (!gw_plan(M, C, C, two_chain ? 0 : C, 0, &p)) return HSP_ERR_UNSUPPORTED;
+    if (rows_per_cloud < 32 * p.RB) return HSP_ERR_UNSUPPORTED;
+    auto al16 = [](const void* q, int ld) { return ((reinterpret_cast<size_t>(q) | ((size_t)ld * 4)) & 15) == 0; };
+    if (!al16(F, ldf) || !al16(Wa, ldwa) || !al16(out, ldo) || (!two_chain && (!al16(fg, ldfg) || !al16(Wb, ldwb))) ||
+        (ste && !al16(ste, ldste)))
+        return HSP_ERR_UNSUPPORTED;
+    GwArgs g{};
+    g.A[0] = F; g.B[0] = Wa; g.lda[0] = ldf; g.ldb[0] = ldwa; g.K[0] = C; g.lb[0] = 0;
+    g.A[1] = two_chain ? nullptr : fg; g.B[1] = two_chain ? nullptr : Wb; g.lda[1] = ldfg; g.ldb[1] = ldwb;
+    g.K[1] = two_chain ? 0 : C; g.lb[1] = 0;
+    g.C = out; g.ldc = ldo; g.M = M; g.N = C; g.resid = F; g.ldr = ldf; g.resid2 = ste; g.ldr2 = ldste;
+    g.cbias = cloud_t; g.rpc = rows_per_cloud; g.xyz3 = xyz3; g.w3 = w3; g.alpha = 1.f;
+    g.TM = p.TM; g.TN = p.TN; g.T0 = C / 8; g.T1 = two_chain ? 0 : C / 8;
+    g.base = p.base; g.nwaves = p.nwaves; g.u_rem = p.u_rem; g.npieces = p.npieces; g.order = 0;
+    const dim3 grid((unsigned)((p.nwaves + 3) / 4)), block(256);
+    hipStream_t st = as_stream(stream);
+    // forms: A one chain + F + ste (32|16, A2C)   B one chain + F + xyz (32|4 [|8], A2C)   C chain + t + F + ste (64|16)
+    //        D chain + t + F + xyz (64|4 [|8])
+#define GWX_K(R, C_, W_) \
+    do { \
+        if (!two_chain && ste) hipLaunchKernelGGL((gemm_wave_kernel<R, C_, W_, 0, 0, true, 32 | 16, true>), grid, block, 0, st, g); \
+        else if (!two_chain && relu) hipLaunchKernelGGL((gemm_wave_kernel<R, C_, W_, 0, 0, true, 32 | 4 | 8, true>), grid, block, 0, st, g); \
+        else if (!two_chain) hipLaunchKernelGGL((gemm_wave_kernel<R, C_, W_, 0, 0, true, 32 | 4, true>), grid, block, 0, st, g); \
+        else if (ste) hipLaunchKernelGGL((gemm_wave_kernel<R, C_, W_, 0, 0, false, 64 | 16>), grid, block, 0, st, g); \
+        else if (relu) hipLaunchKernelGGL((gemm_wave_kernel<R, C_, W_, 0, 0, false, 64 | 4 | 8>), grid, block, 0, st, g); \
+        else hipLaunchKernelGGL((gemm_wave_kernel<R, C_, W_, 0, 0, false, 64 | 4>), grid, block, 0, st, g); \
+    } while (0)
+    if (p.RB == 1 && p.NCB == 4) GWX_K(1, 4, 2);
+    else if (p.RB == 1 && p.NCB == 2) GWX_K(1, 2, 2);
+    else if (p.RB == 1 && p.NCB == 1) GWX_K(1, 1, 2);
+    else return HSP_ERR_UNSUPPORTED;
+#undef GWX_K
+    return check_launch();
 }
 
 extern "C" int hsp_gemm_wave_f32(const float* A1, int lda1, const float* B1, int ldb1, int b1_layout, int K1,

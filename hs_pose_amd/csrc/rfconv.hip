@@ -28,8 +28,8 @@ __device__ __forceinline__ void load_dirs_normed(const float* __restrict__ dirs,
     d2 = *reinterpret_cast<const float4*>(dirs + 2 * SC + j);
 #define RF_NRM(X)                                                                                    \
     {                                                                                                \
-        const float n2 = add_rn(add_rn(mul_rn(d0.X, d0.X), mul_rn(d1.X, d1.X)), mul_rn(d2.X, d2.X)); \
-        const float nr = fmaxf(__fsqrt_rn(n2), 1e-12f);                                              \
+        const float n2 = norm2_chain(d0.X, d1.X, d2.X);                                              \
+        const float nr = fmaxf(sqrtf(n2), 1e-12f);           /* correctly rounded, as ATen's */          \
         d0.X = __fdiv_rn(d0.X, nr); d1.X = __fdiv_rn(d1.X, nr); d2.X = __fdiv_rn(d2.X, nr);          \
     }
     RF_NRM(x) RF_NRM(y) RF_NRM(z) RF_NRM(w)

@@ -1261,6 +1261,77 @@ def _scaled_mm(a, b, alpha):
     return torch.addmm(out, a, b, beta=0.0, alpha=alpha, out=out)
 
 
+# ------------------------------------------------------------------------------------------------
+# eval-mode forward in the reference's arithmetic
+# The feature-space neighbour search ranks rows by distances that cancel catastrophically: two forwards that differ in the
+# last bit of a feature row pick different neighbours for a few rows per thousand, and the outputs then differ by 1e-3, not
+# 1e-7.  The reference's CPU forward is reproducible operation by operation (oracle/gen_golden_exact.py pins each statement
+# against the imported reference): its GEMMs for K <= 256 are k-ordered fp32 fma chains from 0 (K = 512: two such chains added),
+# mean over the supports is a sequential sum / S, mean over the points is ATen's 16-row cascade / N, eval-mode BatchNorm is
+# ((x - m) * invstd) * w + b.  With ``exact_scope(True)`` (FaceRecon sets it whenever the module is in eval mode) the HS layers
+# run exactly those orders: csrc/gemm_wave.hip's products ARE that chain (v_mfma_f32_32x32x2_f32, ascending k),
+# hsp_layer_out_exact_f32 adds in the reference's order, hsp_orl_global_exact_f32 is the cascade, hsp_bn_eval_f32 the BatchNorm.
+# The training forward keeps the faster forms (fp32 from bf16 splits): its BatchNorm batch statistics, dropout and
+# device-side augmentation draws rule bit-level agreement out anyway.
+# ------------------------------------------------------------------------------------------------
+_exact = False
+
+
+class exact_scope:
+    """within the scope the HS layers' forward runs in the reference's operation order (see above)"""
+
+    def __init__(self, on=True):
+        self.on = bool(on) and os.environ.get("HSP_EXACT", "1") != "0"
+
+    def __enter__(self):
+        global _exact
+        self.prev, _exact = _exact, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _exact
+        _exact = self.prev
+        return False
+
+
+def exact_forward():
+    return _exact
+
+
+def _exact_layer_ok(N, Cin, C, tensors):
+    """shapes the exact forms cover: channel counts that are multiples of 32, conv2 over at most 512 input channels (one chain
+    or two; conv_4's 1024 are four blocks and its rows rank nothing), clouds of at least 32 points, 16-byte aligned rows"""
+    return (C % 32 == 0 and (Cin == 3 or Cin % 32 == 0) and 2 * C <= 512 and N >= 32
+            and all(t is None or (t.dtype == torch.float32 and _al16(t)) for t in tensors))
+
+
+def _orl_fwd_exact(F3, idx_x, k):
+    """_orl_fwd_raw with the reference's summation order: (fg (B,C), argmax (B,N,C) uint8)"""
+    B, N, C = F3.shape
+    fg = torch.empty(B, C, dtype=torch.float32, device=F3.device)
+    arg = torch.empty(B, N, C, dtype=torch.uint8, device=F3.device)
+    wsb = lib().hsp_orl_exact_workspace_bytes(B, N, C)
+    ws = _ws(wsb, F3.device)
+    _run("hsp_orl_global_exact_f32", (_p(F3), _p(idx_x), B, N, k, idx_x.shape[2], C, _p(fg), _p(arg), _p(ws), wsb, _stream()),
+         key=f"B{B}N{N}k{k}C{C}", abytes=B * N * (4 * C + 4 * k + C))
+    return fg, arg
+
+
+def _layer_out_exact(F2, w_conv2, fg, N, out3, ste=None, xyz3=None, w3=None, relu=False):
+    """out = ((conv2(cat[F, f_global])) + F) + STE in the reference's order (hsp_layer_out_exact_f32)"""
+    R, C = F2.shape
+    Wa, Wb = w_conv2[:, :C], w_conv2[:, C:]
+    out = out3.view(R, C)
+    two = 2 * C > 256
+    t2 = gemm_wave(fg, Wb, False) if two else None             # K = 512: the f_global block is its own chain
+    _run("hsp_layer_out_exact_f32", (_p(F2), _ld(F2), _p(Wa), _ld(Wa), _p(None if two else fg), 0 if two else _ld(fg),
+                                     _p(None if two else Wb), 0 if two else _ld(Wb), _p(t2), 1 if two else 0,
+                                     _p(ste), _ld(ste) if ste is not None else 0, _p(xyz3), _p(w3), 1 if relu else 0, R, C, N,
+                                     _p(out), _ld(out), _stream()),
+         key=f"R{R}C{C}{'x' if xyz3 is not None else ''}", abytes=4 * R * C * 4, aflops=2 * R * C * C * (1 if two else 2))
+    return out3
+
+
 class _HSLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste3, w_conv23, bn_shift=None):
@@ -1276,17 +1347,24 @@ class _HSLayer(torch.autograd.Function):
         SC = directions.shape[1]
         C = SC // S
         X2 = X.view(B * N, Cin)
-        fm = _fm_rows(X2, weights, bias)                                       # (BN, (S+1)C)
+        exact = _exact and bn_shift is None and _exact_layer_ok(N, Cin, C, (X2, weights, w_ste, w_conv2))
+        # exact: fm = (X W, a k-ordered chain) + b -- gcn3d.py:171 as the reference's CPU GEMM rounds it
+        fm = gemm_wave(X2, weights, True, bias=bias) if exact else _fm_rows(X2, weights, bias)      # (BN, (S+1)C)
         need_bwd = any(ctx.needs_input_grad)
         F3, arg, fwin = _rf_conv_fwd_raw(xyz, idx_f, directions, fm.view(B, N, -1), S, need_bwd)
         if fwin is not None:
             fm = fwin                                                          # fm itself is no longer needed
         fm = fm.view(B, N, -1)
-        fg, arg_o = _orl_fwd_raw(F3, idx_x, k)                                 # (B,C)
         F2 = F3.view(B * N, C)
         out3 = torch.empty(B, N, C, dtype=torch.float32, device=X.device)      # (returned as is: not a view)
-        t2 = _mm_nt(fg, w_conv2[:, C:])                                        # (B,C): the per-cloud half of conv2
-        part = _layer_out_rows(X2, w_ste, F2, w_conv2[:, :C], t2, out3, bn_shift=bn_shift)   # X Wste^T + F Wa^T + F + t[b]
+        if exact:
+            fg, arg_o = _orl_fwd_exact(F3, idx_x, k)
+            _layer_out_exact(F2, w_conv2, fg, N, out3, ste=gemm_wave(X2, w_ste, False))
+            part = None
+        else:
+            fg, arg_o = _orl_fwd_raw(F3, idx_x, k)                             # (B,C)
+            t2 = _mm_nt(fg, w_conv2[:, C:])                                    # (B,C): the per-cloud half of conv2
+            part = _layer_out_rows(X2, w_ste, F2, w_conv2[:, :C], t2, out3, bn_shift=bn_shift)   # X Wste^T + F Wa^T + F + t[b]
         ctx.save_for_backward(xyz, X, idx_f, idx_x, fm, arg, F3, arg_o, fg, weights, directions, w_ste3, w_conv23)
         ctx.k, ctx.S, ctx.x3 = k, S, x3_planes
         ctx.with_part = bn_shift is not None
@@ -1345,11 +1423,15 @@ class _SurfaceLayer(torch.autograd.Function):
         arg = torch.empty(B, N, SC, dtype=torch.uint16, device=xyz.device)
         _run("hsp_rf_surface_fwd", (_p(xyz), _p(idx_x), _p(directions), B, N, k, S, C, _p(F3), _p(arg), _stream()),
              key=f"B{B}N{N}k{k}S{S}C{C}", abytes=B * N * (12 + 4 * k + 4 * C + SC) + 12 * SC)
-        fg, arg_o = _orl_fwd_raw(F3, idx_x, k)
         F2, x2 = F3.view(B * N, C), xyz.view(B * N, 3)
         out3 = torch.empty(B, N, C, dtype=torch.float32, device=xyz.device)
-        t2 = _mm_nt(fg, w_conv2[:, C:])
-        _layer_out_rows(x2, w_ste, F2, w_conv2[:, :C], t2, out3, relu=relu)
+        if _exact and _exact_layer_ok(N, 3, C, (w_conv2,)):
+            fg, arg_o = _orl_fwd_exact(F3, idx_x, k)
+            _layer_out_exact(F2, w_conv2, fg, N, out3, xyz3=x2, w3=w_ste.contiguous(), relu=relu)
+        else:
+            fg, arg_o = _orl_fwd_raw(F3, idx_x, k)
+            t2 = _mm_nt(fg, w_conv2[:, C:])
+            _layer_out_rows(x2, w_ste, F2, w_conv2[:, :C], t2, out3, relu=relu)
         ctx.k, ctx.S, ctx.relu, ctx.x3 = k, S, relu, x3_planes
         if relu:
             # relu(conv_0(...)) (FaceRecon.py:88) inside the node: the relu rides in the product's epilogue, the result is handed
@@ -1804,6 +1886,49 @@ class _BNRelu(torch.autograd.Function):
         return dx, dg, db, None, None, None, None, None, None, None, None, None
 
 
+def _eval_invstd(bn):
+    """1 / sqrt(running_var + eps) exactly as the reference's eval-mode BatchNorm gets it: from the HOST's ATen
+    (batch_norm_cpu_transform_input_template evaluates ``1 / at::sqrt(running_var + eps)``; at::sqrt is MKL VML's vsSqrt, which
+    is within an ulp but not correctly rounded, so no device formula reproduces it).  C floats, cached on the module until the
+    running variance changes; None inside a stream capture that finds no cached value (the kernel then uses the correctly
+    rounded value)."""
+    rv = bn.running_var
+    key = (rv.data_ptr(), rv._version, float(bn.eps), rv.device)
+    hit = getattr(bn, "_hsp_invstd", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    inv = (1 / torch.sqrt(rv.detach().cpu() + bn.eps)).to(rv.device)
+    bn._hsp_invstd = (key, inv)
+    return inv
+
+
+class _BNEval(torch.autograd.Function):
+    """eval-mode BatchNorm (+ ReLU) on point rows, hsp_bn_eval_f32; the backward (rare: an eval-mode network being
+    differentiated) is the textbook affine one in torch ops"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, invstd, eps, relu):
+        C = x.shape[-1]
+        y = torch.empty_like(x)
+        _run("hsp_bn_eval_f32", (_p(x), x.numel() // C, C, _p(running_mean), _p(running_var), _p(invstd), _p(weight), _p(bias),
+                                 float(eps), 1 if relu else 0, _p(y), _stream()), key=f"R{x.numel() // C}C{C}", abytes=8 * x.numel())
+        ctx.save_for_backward(x, weight, running_mean, invstd if invstd is not None else torch.rsqrt(running_var + eps), y)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, mean, invstd, y = ctx.saved_tensors
+        if ctx.relu:
+            dy = dy * (y > 0)
+        C = x.shape[-1]
+        xh = ((x - mean) * invstd).reshape(-1, C)
+        d2 = dy.reshape(-1, C)
+        return dy * (invstd * weight), (d2 * xh).sum(0), d2.sum(0), None, None, None, None, None
+
+
 def bn_relu(x, bn, relu=True, out_dtype=None, fork=False, partial=None):
     """relu(bn(x)) for point rows x (..., C) with an nn.BatchNorm1d module ``bn`` (its parameters, running
     statistics and train/eval state are honoured exactly like calling the module on the (R,C) view, which
@@ -1824,6 +1949,11 @@ def bn_relu(x, bn, relu=True, out_dtype=None, fork=False, partial=None):
              (_p(xc), xc.numel() // C, C, _p(bn.running_mean), _p(invstd), _p(bn.weight), _p(bn.bias), 1 if relu else 0, _p(y),
               _stream()), key=f"R{xc.numel() // C}C{C}", abytes=(_es(xc) + 2) * xc.numel())
         return (y, y) if fork else y
+    if (not fused and not bn.training and bn.affine and bn.track_running_stats and x.is_cuda and x.dtype == torch.float32
+            and C % 4 == 0 and x.is_contiguous()):
+        # eval mode: ((x - m) * invstd) * w + b in ATen's own operation order (hsp_bn_eval_f32), relu fused
+        y = _BNEval.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, _eval_invstd(bn), bn.eps, relu)
+        return (y, y.view_as(y)) if fork else y
     if not fused:                                   # eval mode / exotic configurations: not on the training hot path
         y = bn(x.reshape(-1, C)).view_as(x)
         y = torch.relu_(y) if relu else y

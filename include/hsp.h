@@ -166,6 +166,30 @@ int hsp_points_max_bwd(const float *grad_out, const int32_t *argrow, int B, int 
 size_t hsp_orl_workspace_bytes(int B, int N, int C);
 int hsp_orl_global_fwd(const float *feat, const int32_t *idx, int B, int N, int k, int kstride, int C,
                        float *fg, uint8_t *argmax, void *ws, size_t ws_bytes, hspStream_t stream);
+/* The same feature with the REFERENCE's summation order: ATen's cascade sum over the points (16-row level-0 chunks, levels dumped
+ * every 16 / 256 / 4096 rows, remainder last) then a division by N -- torch.mean(dim=1) of gcn3d.py:217 bit for bit
+ * (tests/golden/exact_*.npz).  ws: hsp_orl_exact_workspace_bytes(B,N,C).  argmax as above. */
+size_t hsp_orl_exact_workspace_bytes(int B, int N, int C);
+int hsp_orl_global_exact_f32(const float *feat, const int32_t *idx, int B, int N, int k, int kstride, int C, float *fg,
+                             uint8_t *argmax, void *ws, size_t ws_bytes, hspStream_t stream);
+/* eval-mode BatchNorm1d of FaceRecon.py:90-95 on point rows x (R,C) in ATen's own operation order (the reference applies it to
+ * a transposed view: the generic TensorIterator path): y = ((x - running_mean) * invstd) * weight + bias, every operation
+ * rounded to fp32, optionally followed by relu.  invstd (C) = 1 / sqrt(running_var + eps) as the HOST's ATen evaluates it
+ * (its sqrt is MKL VML's, not correctly rounded: one channel in ~180 differs), or NULL: the correctly rounded value from
+ * running_var.  C % 4 == 0. */
+int hsp_bn_eval_f32(const float *x, long long R, int C, const float *running_mean, const float *running_var,
+                    const float *invstd, const float *weight, const float *bias, float eps, int relu, float *y,
+                    hspStream_t stream);
+/* The HS layer's out product in the reference's order of operations (gcn3d.py:111-112 / :185-186 then :90 / :156): every product a
+ * k-ordered fp32 fma chain from 0 (what the reference's CPU GEMM runs for K <= 256; K = 512 is two such chains added), additions
+ * in the reference's order.  two_chain == 0 (2C <= 256): out = ((chain(F Wa^T) continued by chain(fg[cloud] Wb^T)) + F) + tail;
+ * two_chain == 1: out = (((chain(F Wa^T)) + cloud_t[cloud]) + F) + tail with cloud_t (B,C) = chain(fg Wb^T) from
+ * hsp_gemm_wave_f32.  tail = ste (M,C) (the STE product) or the K = 3 chain xyz3 . w3 (surface layer; relu allowed).
+ * C % 32 == 0, 16-byte aligned rows, rows_per_cloud >= 32. */
+int hsp_layer_out_exact_f32(const float *F, int ldf, const float *Wa, int ldwa, const float *fg, int ldfg, const float *Wb,
+                            int ldwb, const float *cloud_t, int two_chain, const float *ste, int ldste, const float *xyz3,
+                            const float *w3, int relu, int M, int C, int rows_per_cloud, float *out, int ldo,
+                            hspStream_t stream);
 /* out (B,C) = sum_i x[b,i,:]  (the per-cloud column sum autograd takes of a gradient that was
  * broadcast over the points, e.g. d/d(fg Wb^T)); deterministic two-stage.  ws as above. */
 int hsp_colsum_rows(const float *x, int B, int N, int C, float *out, void *ws, size_t ws_bytes,
