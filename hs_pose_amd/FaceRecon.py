@@ -135,6 +135,10 @@ class FaceRecon(nn.Module):
                         and os.environ.get("HSP_BN_EPILOGUE", "1") != "0"):
                     out, part = conv(*a, bn_shift=True)
                     return ops.bn_relu(out, bn, fork=fork, partial=part)
+                if conv is self.conv_3 and ops.exact_forward():
+                    # (the reference hands conv_3 relu(bn2(...)).transpose(1, 2) WITHOUT making it contiguous, FaceRecon.py:92-95:
+                    # the |x|^2 of its feature-space neighbour search then rounds as a strided sum)
+                    return ops.bn_relu(conv(*a, transposed_view=True), bn, out_dtype=od, fork=fork)
                 return ops.bn_relu(conv(*a), bn, out_dtype=od, fork=fork)
             if fork:
                 fm_1, a_1 = layer_bn(self.conv_1, self.bn1, vertices, fm_0, k)

@@ -34,6 +34,11 @@ SIGNATURES = {
     "hsp_points_max_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "hsp_points_max_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "hsp_orl_workspace_bytes": (_sz, [_i, _i, _i]),
+    "hsp_knn_exact_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "hsp_knn_exact_f32": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp]),
+    "hsp_knn_quadmode_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp]),
+    "hsp_quad_outer_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "hsp_center_cloud_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "hsp_orl_exact_workspace_bytes": (_sz, [_i, _i, _i]),
     "hsp_orl_global_exact_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "hsp_bn_eval_f32": (_i, [_vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _i, _vp, _vp]),

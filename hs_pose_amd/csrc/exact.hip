@@ -97,6 +97,72 @@ __global__ __launch_bounds__(256) void bn_eval_exact_kernel(const float* __restr
     }
 }
 
+// ---- ATen's sums over a STRIDED dimension (sum_kernel_impl -> vectorized_outer_sum) ----------------------------------------------
+// Reducing a dimension of stride != 1 while another dimension is contiguous walks the contiguous one in columns: the first
+// 32 * floor(cols / 32) columns (4 vectors of 8 lanes) are summed by multi_row_sum = the plain cascade (level-0 accumulator
+// dumped every 16 elements, level 1 every 256, level 2 every 4096, levels added 0 <- 1 <- 2 <- 3); the REMAINING columns by
+// row_sum: four interleaved partial sums (elements e = 4 i + p, each partial a cascade over floor(size / 4) elements), the
+// size % 4 leftover elements into partial 0, then partial 0 += 1, += 2, += 3.
+__device__ __forceinline__ int ceil_log2_int(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
+
+template <typename F>   // F(e) -> element e of the reduced dimension
+__device__ float aten_cascade(F elem, int first, int step, int size) {
+    const int lp = max(4, ceil_log2_int(size) / 4), ls = 1 << lp, lm = ls - 1;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = 0;
+    for (; i + ls <= size;) {
+        for (int j = 0; j < ls; ++j, ++i) a0 = add_rn(a0, elem(first + i * step));
+        a1 = add_rn(a1, a0); a0 = 0.f;
+        if ((i & (lm << lp)) == 0) {
+            a2 = add_rn(a2, a1); a1 = 0.f;
+            if ((i & (lm << (2 * lp))) == 0) { a3 = add_rn(a3, a2); a2 = 0.f; }
+        }
+    }
+    for (; i < size; ++i) a0 = add_rn(a0, elem(first + i * step));
+    a0 = add_rn(a0, a1); a0 = add_rn(a0, a2); a0 = add_rn(a0, a3);
+    return a0;
+}
+template <typename F>
+__device__ float aten_row_sum_ilp4(F elem, int size) {
+    const int si = size / 4;
+    float p[4];
+    for (int kk = 0; kk < 4; ++kk) p[kk] = aten_cascade(elem, kk, 4, si);
+    for (int i = si * 4; i < size; ++i) p[0] = add_rn(p[0], elem(i));
+    p[0] = add_rn(p[0], p[1]); p[0] = add_rn(p[0], p[2]); p[0] = add_rn(p[0], p[3]);
+    return p[0];
+}
+template <typename F>
+__device__ float aten_outer_sum(F elem, int size, int col, int cols) {
+    return col < (cols / 32) * 32 ? aten_cascade(elem, 0, 1, size) : aten_row_sum_ilp4(elem, size);
+}
+
+// |x|^2 per row of x (B,N,C) as torch.sum(v ** 2, dim=2) evaluates it when v is the TRANSPOSED VIEW of a (B,C,N) tensor --
+// what FaceRecon.py:94-95 hands conv_3: relu(bn(...)).transpose(1, 2) is never made contiguous, so the channel sum is an
+// outer sum over columns n (gcn3d.py:20)
+__global__ __launch_bounds__(256) void quad_outer_kernel(const float* __restrict__ x, int N, int C, float* __restrict__ quad) {
+    const int n = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (n >= N) return;
+    const float* row = x + ((size_t)b * N + n) * C;
+    quad[(size_t)b * N + n] = aten_outer_sum([&](int c) { const float v = row[c]; return mul_rn(v, v); }, C, n, N);
+}
+
+// PoseNet9D.py:25: points - points.mean(dim=1, keepdim=True): the mean over the N points of a contiguous (B,N,3) tensor is an
+// outer sum over 3 columns (all of them "remaining" columns: the interleaved form), divided by N
+__global__ __launch_bounds__(256) void center_cloud_kernel(const float* __restrict__ pts, int N, float* __restrict__ out,
+                                                           float* __restrict__ mean) {
+    __shared__ float sm[3];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* p = pts + (size_t)b * N * 3;
+    if (tid < 3) {
+        const float s = aten_outer_sum([&](int i) { return p[(size_t)i * 3 + tid]; }, N, tid, 3);
+        const float m = __fdiv_rn(s, (float)N);
+        sm[tid] = m;
+        mean[b * 3 + tid] = m;
+    }
+    __syncthreads();
+    for (int e = tid; e < N * 3; e += 256) out[(size_t)b * N * 3 + e] = sub_rn(p[e], sm[e % 3]);
+}
+
 }  // namespace hsp
 
 using namespace hsp;
@@ -131,5 +197,17 @@ extern "C" int hsp_bn_eval_f32(const float* x, long long R, int C, const float* 
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(bn_eval_exact_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, n4, C, running_mean,
                        running_var, invstd, weight, bias, eps, relu, y);
+    return check_launch();
+}
+
+extern "C" int hsp_quad_outer_f32(const float* x, int B, int N, int C, float* quad, hspStream_t stream) {
+    if (!x || !quad || B <= 0 || N <= 0 || C <= 0) return HSP_ERR_BAD_ARG;
+    hipLaunchKernelGGL(quad_outer_kernel, dim3((N + 255) / 256, B), dim3(256), 0, as_stream(stream), x, N, C, quad);
+    return check_launch();
+}
+
+extern "C" int hsp_center_cloud_f32(const float* pts, int B, int N, float* centred, float* mean, hspStream_t stream) {
+    if (!pts || !centred || !mean || B <= 0 || N <= 0) return HSP_ERR_BAD_ARG;
+    hipLaunchKernelGGL(center_cloud_kernel, dim3(B), dim3(256), 0, as_stream(stream), pts, N, centred, mean);
     return check_launch();
 }

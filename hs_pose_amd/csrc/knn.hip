@@ -1130,8 +1130,11 @@ extern "C" size_t hsp_knn_workspace_bytes(int B, int N, int C, int k) {
     return (size_t)B * N * sizeof(float) * (size_t)(1 + rows_extra);
 }
 
-extern "C" int hsp_knn_f32(const float* x, int B, int N, int C, int k, int drop_first, int32_t* idx, void* ws,
-                           size_t ws_bytes, hspStream_t stream) {
+extern "C" int hsp_quad_outer_f32(const float* x, int B, int N, int C, float* quad, hspStream_t stream);
+
+// quad_mode 0: |x|^2 in ATen's order for a CONTIGUOUS (B,N,C) tensor; 1: for the transposed view of a (B,C,N) tensor (exact.hip)
+static int knn_f32_impl(const float* x, int B, int N, int C, int k, int drop_first, int32_t* idx, void* ws,
+                        size_t ws_bytes, int quad_mode, hspStream_t stream) {
     if (!x || !idx || B <= 0 || N <= 0 || C <= 0 || k <= 0) return HSP_ERR_BAD_ARG;
     const int drop = drop_first ? 1 : 0;
     const int m = k + drop;
@@ -1156,16 +1159,29 @@ extern "C" int hsp_knn_f32(const float* x, int B, int N, int C, int k, int drop_
     if (hsp_knn_workspace_bytes(B, N, C, k) > ws_bytes || !ws) return HSP_ERR_WORKSPACE;
     float* quad = reinterpret_cast<float*>(ws);
     const long long rows = (long long)B * N;
-    if (C >= 8 && C < 512 && (C & 7) == 0)
-        hipLaunchKernelGGL(quad32_kernel, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, st, x, rows, C, quad);
-    else
-        hipLaunchKernelGGL(quad_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, x, rows, C, quad);
-    int rc = check_launch();
+    int rc;
+    if (quad_mode == 1) rc = hsp_quad_outer_f32(x, B, N, C, quad, stream);
+    else {
+        if (C >= 8 && C < 512 && (C & 7) == 0)
+            hipLaunchKernelGGL(quad32_kernel, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, st, x, rows, C, quad);
+        else
+            hipLaunchKernelGGL(quad_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, x, rows, C, quad);
+        rc = check_launch();
+    }
     if (rc) return rc;
 #define CALLF(K) launch_knn_feat<K>(x, quad, quad + rows, B, N, C, k, drop, idx, st)
     HSP_K1_SWITCH(CALLF)
 #undef CALLF
 #undef HSP_K1_SWITCH
+}
+
+extern "C" int hsp_knn_f32(const float* x, int B, int N, int C, int k, int drop_first, int32_t* idx, void* ws,
+                           size_t ws_bytes, hspStream_t stream) {
+    return knn_f32_impl(x, B, N, C, k, drop_first, idx, ws, ws_bytes, 0, stream);
+}
+extern "C" int hsp_knn_quadmode_f32(const float* x, int B, int N, int C, int k, int drop_first, int32_t* idx, void* ws,
+                                    size_t ws_bytes, int quad_mode, hspStream_t stream) {
+    return knn_f32_impl(x, B, N, C, k, drop_first, idx, ws, ws_bytes, quad_mode, stream);
 }
 
 extern "C" int hsp_knn_bf16(const hsp_bf16_t* x, int B, int N, int C, int k, int drop_first, int32_t* idx, void* ws,

@@ -206,10 +206,11 @@ class HS_layer(nn.Module):
         self.directions.data.uniform_(-stdv, stdv)
 
     def forward(self, vertices: "(bs, vertice_num, 3)", feature_map: "(bs, vertice_num, in_channel)",
-                neighbor_num: int, bn_shift=None):
+                neighbor_num: int, bn_shift=None, transposed_view=False):
         """(bs, vertice_num, out_channel) -- STE + fm GEMM + RF-F graph conv + ORL as one fused autograd node.  ``bn_shift``
         (fp32 rows): see ops.hs_layer -- returns (out, BatchNorm partial sums)."""
-        neighbor_index = ops.knn(feature_map, neighbor_num)          # RF-F: neighbours in feature space
+        # RF-F: neighbours in feature space (``transposed_view``: see ops.knn -- FaceRecon sets it for conv_3)
+        neighbor_index = ops.knn(feature_map, neighbor_num, **({"transposed_view": True} if transposed_view else {}))
         if feature_map.dtype == torch.bfloat16:                      # bf16 feature rows in -> out (fp32 out ahead of a BatchNorm)
             return ops_bf16.hs_layer(vertices, feature_map, neighbor_index, _xyz_knn(vertices, neighbor_num), neighbor_num,
                                      self.support_num, self.weights, self.bias, self.directions, self.STE_layer.weight,

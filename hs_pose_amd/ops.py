@@ -121,8 +121,9 @@ def _run(name, args, key="", abytes=0, aflops=0):
 # neighbour search (no gradient: indices)
 # ------------------------------------------------------------------------------------------------
 
-def knn(x, k, drop_first=True):
-    """int32 (B,N,k) nearest rows of x (B,N,C) per row; semantics of gcn3d.get_neighbor_index."""
+def knn(x, k, drop_first=True, transposed_view=False):
+    """int32 (B,N,k) nearest rows of x (B,N,C) per row; semantics of gcn3d.get_neighbor_index.  ``transposed_view`` (exact scope
+    only): the reference holds these rows as the transposed view of a (B,C,N) tensor, which changes how its |x|^2 rounds."""
     x = _reqf(x.detach(), "knn.x")
     B, N, C = x.shape
     idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
@@ -135,12 +136,31 @@ def knn(x, k, drop_first=True):
         _run("hsp_knn_bf16", (_p(x), B, N, C, k, 1 if drop_first else 0, _p(idx), _p(ws), wsb, _stream()),
              key=f"B{B}N{N}C{C}k{k}", abytes=B * N * (2 * C + 4 * k + 8), aflops=2 * B * N * N * C)
         return idx
+    if _exact and k + (1 if drop_first else 0) + 1 <= 33 and os.environ.get("HSP_EXACT_TIES", "1") != "0":
+        # eval-mode forward (exact_scope): torch.topk's own order among exactly equal distances (csrc/knn_exact.hip)
+        wsb = L.hsp_knn_exact_workspace_bytes(B, N, C, k, 1 if drop_first else 0)
+        ws = _ws(wsb, x.device)
+        _run("hsp_knn_exact_f32", (_p(x), B, N, C, k, 1 if drop_first else 0, 1 if transposed_view else 0, _p(idx), _p(ws), wsb, None,
+                                   _stream()),
+             key=f"B{B}N{N}C{C}k{k}", abytes=B * N * (4 * C + 4 * k + (8 if C != 3 else 0)),
+             aflops=(2 * B * N * N * C if C != 3 else 0))
+        return idx
     wsb = L.hsp_knn_workspace_bytes(B, N, C, k)
     ws = _ws(wsb, x.device)
     _run("hsp_knn_f32", (_p(x), B, N, C, k, 1 if drop_first else 0, _p(idx), _p(ws), wsb, _stream()),
          key=f"B{B}N{N}C{C}k{k}", abytes=B * N * (4 * C + 4 * k + (8 if C != 3 else 0)),
          aflops=(2 * B * N * N * C if C != 3 else 0))       # feature path: the distance GEMM on the fp32 matrix cores
     return idx
+
+
+def center_cloud(points):
+    """(points - mean over the points, mean (B,1,3)) with the mean in the reference's summation order (PoseNet9D.py:25)"""
+    pts = _req(points.detach(), torch.float32, "center_cloud.points")
+    B, N, _ = pts.shape
+    out = torch.empty_like(pts)
+    mean = torch.empty(B, 1, 3, dtype=torch.float32, device=pts.device)
+    _run("hsp_center_cloud_f32", (_p(pts), B, N, _p(out), _p(mean), _stream()), key=f"B{B}N{N}", abytes=24 * B * N)
+    return out, mean
 
 
 def nn1(target, source):

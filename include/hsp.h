@@ -56,6 +56,25 @@ const char *hsp_last_hip_error(void);
 size_t hsp_knn_workspace_bytes(int B, int N, int C, int k);
 int hsp_knn_f32(const float *x, int B, int N, int C, int k, int drop_first, int32_t *idx,
                 void *ws, size_t ws_bytes, hspStream_t stream);
+/* get_neighbor_index with torch.topk's OWN order among exactly equal distances (ATen's CPU topk = libstdc++'s
+ * nth_element + sort, or partial_sort for (k + drop_first) * 64 <= N, under a comparator that only sees the value: restated in
+ * csrc/knn_exact.hip and oracle/hsp_oracle.c, pinned against torch.topk on tie-rich rows).  hsp_knn_f32 breaks ties by the lowest
+ * index; on tie-free rows the two agree.  Used by the eval-mode forward (exact scope).  k + drop_first + 1 <= 33.
+ * quad_mode (C != 3): how torch.sum(x ** 2, dim=2) of gcn3d.py:20 rounds -- 0: x is a contiguous (B,N,C) tensor (ATen's
+ * vectorised row sum), 1: x is the transposed VIEW of a (B,C,N) tensor, which is what FaceRecon.py:94-95 hands conv_3 (ATen then
+ * sums the channels as an outer reduction: cascade for the first 32 floor(N/32) points, four interleaved cascades for the rest).
+ * ws: hsp_knn_exact_workspace_bytes; tie_rows (may be NULL): a device int that is incremented once per row that held a tie. */
+size_t hsp_knn_exact_workspace_bytes(int B, int N, int C, int k, int drop_first);
+int hsp_knn_exact_f32(const float *x, int B, int N, int C, int k, int drop_first, int quad_mode, int32_t *idx, void *ws,
+                      size_t ws_bytes, int *tie_rows, hspStream_t stream);
+/* hsp_knn_f32 with the |x|^2 order chosen as above */
+int hsp_knn_quadmode_f32(const float *x, int B, int N, int C, int k, int drop_first, int32_t *idx, void *ws, size_t ws_bytes,
+                         int quad_mode, hspStream_t stream);
+/* |x|^2 per row in the transposed-view order (quad_mode 1) */
+int hsp_quad_outer_f32(const float *x, int B, int N, int C, float *quad, hspStream_t stream);
+/* PoseNet9D.py:25: centred = pts - mean over the N points, mean (B,3) in ATen's summation order for a contiguous (B,N,3) tensor
+ * (an outer sum over 3 columns: four interleaved 16-element cascades per column) divided by N */
+int hsp_center_cloud_f32(const float *pts, int B, int N, float *centred, float *mean, hspStream_t stream);
 
 /* replaces get_nearest_index(target, source)          network/fs_net_repo/gcn3d.py:27-36
  * tgt (B,Nt,3), src (B,Ns,3) -> idx (B,Nt): top-1 source row, d = (s2[j]+t2[i]) - 2*inner. */

@@ -114,6 +114,14 @@ def statements():
         x = oc.hash_tensor((2, N, 32), 7300 + N, 1.0)
         assert np.array_equal(x.mean(dim=1).numpy(), cascade_mean(x.numpy())), N
         out[f"mean_n{N}"] = x.mean(dim=1).numpy()
+    # --- |x|^2 of a transposed view (what conv_3 gets, FaceRecon.py:94-95) and the cloud's mean (PoseNet9D.py:25): outer sums
+    for (N, C) in ((257, 256), (100, 64), (1028, 32)):
+        t = torch.relu(oc.hash_tensor((2, C, N), 7350 + N, 1.0))               # (B,C,N) as BatchNorm1d leaves it
+        out[f"quad_outer_n{N}"] = torch.sum(t.transpose(1, 2) ** 2, dim=2).numpy()
+    for N in (1028, 100):
+        pts = oc.hash_tensor((2, N, 3), 7360 + N, 0.05); pts[:, :, 2] += 0.8
+        m = pts.mean(dim=1, keepdim=True)
+        out[f"centre_mean_n{N}"] = m.numpy(); out[f"centre_local_n{N}"] = (pts - m).numpy()
     # --- F.normalize ------------------------------------------------------------------------------------------------------------
     v = oc.hash_tensor((500, 3), 7400, 0.05)
     a, b_, c = v.numpy().T
@@ -138,6 +146,21 @@ def statements():
     np.savez_compressed(os.path.join(GOLD, "exact_statements.npz"), **out)
     print("exact_statements: every statement equals the reference's op; invstd differs from the IEEE value in",
           out["bn_invstd_differs_from_ieee"].tolist(), "channels")
+
+
+def topk_ties():
+    """torch.topk(largest=False) on rows full of exactly equal values: the order libstdc++ leaves them in (both branches of
+    ATen's TopKImpl.h: nth_element + sort for m * 64 > N, partial_sort otherwise)"""
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    for tag, (R, N, m, q) in {"n1028_m21": (24, 1028, 21, 64), "n257_m21": (24, 257, 21, 32), "n64_m9": (24, 64, 9, 16),
+                              "n1028_m5": (24, 1028, 5, 64), "n4096_m21": (8, 4096, 21, 128)}.items():
+        d = torch.randint(0, q * 8, (R, N), generator=g).float() / q
+        out["d_" + tag] = (d * q).to(torch.int16).numpy()                   # (stored as the integer numerators)
+        out["q_" + tag] = np.array([q, m], np.int32)
+        out["i_" + tag] = torch.topk(d, m, dim=-1, largest=False, sorted=True)[1].numpy().astype(np.int16)
+    np.savez_compressed(os.path.join(GOLD, "exact_topk_ties.npz"), **out)
+    print("exact_topk_ties:", [k_ for k_ in out if k_.startswith("i_")])
 
 
 def layers():
@@ -193,6 +216,7 @@ def stack(debug_dump=None):
 
 if __name__ == "__main__":
     statements()
+    topk_ties()
     layers()
     dd = sys.argv[sys.argv.index("--debug-dump") + 1] if "--debug-dump" in sys.argv else None
     stack(dd)

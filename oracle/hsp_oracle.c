@@ -137,6 +137,160 @@ static void select_smallest(const float *d, int N, int m, int32_t *sel) {
     free(bd);
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * torch.topk(dist, m, largest=False) on the CPU, INCLUDING its order among exactly equal distances.
+ * ATen (aten/src/ATen/native/cpu/TopKImpl.h) fills a queue of (value, index) pairs and, for m * 64 > N, calls
+ *   std::nth_element(q, q + m - 1, q + N, cmp);  std::sort(q, q + m - 1, cmp);      cmp(x, y) = x.value < y.value  (no NaNs here)
+ * and for m * 64 <= N  std::partial_sort(q, q + m, q + N, cmp).  The comparator never looks at the index, so which of several
+ * equal distances lands where is decided by libstdc++'s algorithms -- deterministic, restated below line by line
+ * (bits/stl_algo.h, bits/stl_heap.h: introselect / introsort with median-of-three to first, unguarded partition, insertion
+ * sorts with threshold 16, heap select).  Pinned against torch.topk itself on tie-rich rows (oracle/gen_golden_exact.py,
+ * tests/golden/exact_topk_ties.npz).
+ * ------------------------------------------------------------------------------------------------------------------- */
+typedef struct { float v; int32_t i; } tk_t;
+#define TK_LT(a, b) ((a).v < (b).v)
+static inline void tk_swap(tk_t *a, tk_t *b) { tk_t t = *a; *a = *b; *b = t; }
+static int tk_lg(long n) { int k = 0; while (n > 1) { n >>= 1; k++; } return k; }
+
+static void tk_move_median_to_first(tk_t *result, tk_t *a, tk_t *b, tk_t *c) {
+    if (TK_LT(*a, *b)) {
+        if (TK_LT(*b, *c)) tk_swap(result, b);
+        else if (TK_LT(*a, *c)) tk_swap(result, c);
+        else tk_swap(result, a);
+    } else if (TK_LT(*a, *c)) tk_swap(result, a);
+    else if (TK_LT(*b, *c)) tk_swap(result, c);
+    else tk_swap(result, b);
+}
+static tk_t *tk_unguarded_partition(tk_t *first, tk_t *last, tk_t *pivot) {
+    for (;;) {
+        while (TK_LT(*first, *pivot)) ++first;
+        --last;
+        while (TK_LT(*pivot, *last)) --last;
+        if (!(first < last)) return first;
+        tk_swap(first, last);
+        ++first;
+    }
+}
+static tk_t *tk_partition_pivot(tk_t *first, tk_t *last) {
+    tk_t *mid = first + (last - first) / 2;
+    tk_move_median_to_first(first, first + 1, mid, last - 1);
+    return tk_unguarded_partition(first + 1, last, first);
+}
+static void tk_unguarded_linear_insert(tk_t *last) {
+    tk_t val = *last;
+    tk_t *next = last - 1;
+    while (TK_LT(val, *next)) { *last = *next; last = next; --next; }
+    *last = val;
+}
+static void tk_insertion_sort(tk_t *first, tk_t *last) {
+    if (first == last) return;
+    for (tk_t *i = first + 1; i != last; ++i) {
+        if (TK_LT(*i, *first)) {
+            tk_t val = *i;
+            memmove(first + 1, first, (size_t)(i - first) * sizeof(tk_t));
+            *first = val;
+        } else tk_unguarded_linear_insert(i);
+    }
+}
+/* heap primitives (max-heap under TK_LT), as bits/stl_heap.h */
+static void tk_push_heap(tk_t *first, long hole, long top, tk_t value) {
+    long parent = (hole - 1) / 2;
+    while (hole > top && TK_LT(first[parent], value)) { first[hole] = first[parent]; hole = parent; parent = (hole - 1) / 2; }
+    first[hole] = value;
+}
+static void tk_adjust_heap(tk_t *first, long hole, long len, tk_t value) {
+    const long top = hole;
+    long child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (TK_LT(first[child], first[child - 1])) child--;
+        first[hole] = first[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        first[hole] = first[child - 1];
+        hole = child - 1;
+    }
+    tk_push_heap(first, hole, top, value);
+}
+static void tk_make_heap(tk_t *first, tk_t *last) {
+    const long len = last - first;
+    if (len < 2) return;
+    long parent = (len - 2) / 2;
+    for (;;) {
+        tk_t value = first[parent];
+        tk_adjust_heap(first, parent, len, value);
+        if (parent == 0) return;
+        parent--;
+    }
+}
+static void tk_pop_heap(tk_t *first, tk_t *last, tk_t *result) {
+    tk_t value = *result;
+    *result = *first;
+    tk_adjust_heap(first, 0, last - first, value);
+}
+static void tk_heap_select(tk_t *first, tk_t *middle, tk_t *last) {
+    tk_make_heap(first, middle);
+    for (tk_t *i = middle; i < last; ++i)
+        if (TK_LT(*i, *first)) tk_pop_heap(first, middle, i);
+}
+static void tk_sort_heap(tk_t *first, tk_t *last) {
+    while (last - first > 1) { --last; tk_pop_heap(first, last, last); }
+}
+static void tk_introselect(tk_t *first, tk_t *nth, tk_t *last, int depth_limit) {
+    while (last - first > 3) {
+        if (depth_limit == 0) {
+            tk_heap_select(first, nth + 1, last);
+            tk_swap(first, nth);
+            return;
+        }
+        --depth_limit;
+        tk_t *cut = tk_partition_pivot(first, last);
+        if (cut <= nth) first = cut; else last = cut;
+    }
+    tk_insertion_sort(first, last);
+}
+static void tk_introsort_loop(tk_t *first, tk_t *last, int depth_limit) {
+    while (last - first > 16) {
+        if (depth_limit == 0) {                        /* std::__partial_sort(first, last, last) */
+            tk_heap_select(first, last, last);
+            tk_sort_heap(first, last);
+            return;
+        }
+        --depth_limit;
+        tk_t *cut = tk_partition_pivot(first, last);
+        tk_introsort_loop(cut, last, depth_limit);
+        last = cut;
+    }
+}
+static void tk_sort(tk_t *first, tk_t *last) {
+    if (first == last) return;
+    tk_introsort_loop(first, last, tk_lg(last - first) * 2);
+    if (last - first > 16) {
+        tk_insertion_sort(first, first + 16);
+        for (tk_t *i = first + 16; i != last; ++i) tk_unguarded_linear_insert(i);
+    } else tk_insertion_sort(first, last);
+}
+/* sel[0..m) = indices torch.topk(d, m, largest=False, sorted=True) returns on the CPU */
+static void topk_smallest_aten(const float *d, int N, int m, int32_t *sel, tk_t *q) {
+    for (int j = 0; j < N; j++) { q[j].v = d[j]; q[j].i = j; }
+    if ((long)m * 64 <= N) {                           /* std::partial_sort */
+        tk_heap_select(q, q + m, q + N);
+        tk_sort_heap(q, q + m);
+    } else {
+        if (q + (m - 1) != q + N) tk_introselect(q, q + (m - 1), q + N, tk_lg(N) * 2);
+        tk_sort(q, q + (m - 1));
+    }
+    for (int j = 0; j < m; j++) sel[j] = q[j].i;
+}
+/* stand-alone form for the fixture generator / tests: rows (R,N) of distances -> (R,m) indices */
+void hsp_oracle_topk_smallest(const float *d, int R, int N, int m, int32_t *sel) {
+    tk_t *q = (tk_t *)malloc(sizeof(tk_t) * (size_t)N);
+    for (int r = 0; r < R; r++) topk_smallest_aten(d + (size_t)r * N, N, m, sel + (size_t)r * m, q);
+    free(q);
+}
+
 /* get_neighbor_index (gcn3d.py:15-24).  x (B,N,C) fp32 row-major -> idx (B,N,k) int32.
  * drop_first=1 reproduces the reference ([:, :, 1:] after topk(k+1)). Also returns (optional,
  * may be NULL) the selected distances dsel (B,N,k) for near-tie diagnostics. */

@@ -52,6 +52,14 @@ class OracleC:
         assert rc == 0
         return (out, ds) if with_dist else out
 
+    def topk_smallest(self, d, m):
+        """indices torch.topk(d, m, largest=False) returns on the CPU, ties included (libstdc++'s order, restated in C)"""
+        dn = np.ascontiguousarray(d, dtype=np.float32)
+        R, N = dn.shape
+        out = np.empty((R, m), np.int32)
+        self.lib.hsp_oracle_topk_smallest(_P(dn), R, N, m, _P(out))
+        return out
+
     def nn1(self, t, s):
         tn = np.ascontiguousarray(t, dtype=np.float32)
         sn = np.ascontiguousarray(s, dtype=np.float32)

@@ -46,6 +46,18 @@ def test_exact_statements(dev, ref):
         idx = torch.arange(N, dtype=torch.int32, device=dev).view(1, N, 1).repeat(2, 1, 1).contiguous()   # "neighbourhood" = the row
         fg, _ = ops._orl_fwd_exact(x, idx, 1)
         _same(fg, g[f"mean_n{N}"], f"mean over {N} points")
+    from hs_pose_amd._lib import lib
+    from hs_pose_amd.ops import _p, _run, _stream
+    for (N, C) in ((257, 256), (100, 64), (1028, 32)):
+        x = torch.relu(ref.hash_tensor((2, C, N), 7350 + N, 1.0)).transpose(1, 2).contiguous().to(dev)      # our layout: (B,N,C)
+        q = torch.empty(2, N, device=dev)
+        _run("hsp_quad_outer_f32", (_p(x), 2, N, C, _p(q), _stream()))
+        _same(q, g[f"quad_outer_n{N}"], f"|x|^2 of a transposed view, N = {N}")
+    for N in (1028, 100):
+        pts = ref.hash_tensor((2, N, 3), 7360 + N, 0.05); pts[:, :, 2] += 0.8
+        local, mean = ops.center_cloud(pts.to(dev))
+        _same(mean, g[f"centre_mean_n{N}"], f"cloud mean, N = {N}")
+        _same(local, g[f"centre_local_n{N}"], f"centred cloud, N = {N}")
     C = 256
     bn = torch.nn.BatchNorm1d(C).eval()
     with torch.no_grad():
@@ -97,14 +109,15 @@ def test_exact_stack_refinit(dev, ref, flags):
     pts = ref.hash_tensor((B, N, 3), seed, 0.05)
     pts[:, :, 2] += 0.8
     obj = torch.from_numpy((ref.hash_unit(B, seed + 1) * 6).astype(np.int64)).float().view(B, 1)
-    pts = pts - pts.mean(dim=1, keepdim=True)                    # (on the CPU, as the fixture's input was formed: PoseNet9D.py:25)
     grabbed, hooks = {}, []
     for nm in ("conv_0", "conv_1", "conv_2", "conv_3", "conv_4"):
         hooks.append(getattr(fr, nm).register_forward_hook(
             lambda mod, i, o, nm=nm: grabbed.__setitem__(nm, (o[0] if isinstance(o, tuple) else o).detach().clone())))
+    from hs_pose_amd import ops
     torch.manual_seed(1)
     with torch.no_grad():
-        _, _, feat = fr(pts.to(dev), obj.to(dev))
+        local, _ = ops.center_cloud(pts.to(dev))                 # PoseNet9D.py:25, the mean in the reference's order
+        _, _, feat = fr(local, obj.to(dev))
     for h_ in hooks:
         h_.remove()
     report = []
@@ -118,3 +131,54 @@ def test_exact_stack_refinit(dev, ref, flags):
     assert np.abs(got4 - g["conv_4"]).max() <= 2e-6 * max(1.0, np.abs(g["conv_4"]).max())
     gotf = feat[..., :1286].reshape(-1)[::211].cpu().numpy() if feat.shape[-1] != 1286 else feat.reshape(-1)[::211].cpu().numpy()
     assert np.abs(gotf - g["feat"]).max() <= 2e-6 * max(1.0, np.abs(g["feat"]).max())
+    # the whole PoseNet9D, free-running, against the reference's pose / size outputs and neighbour lists (the refinit fixture)
+    g2 = golden("stack_refinit_eval_1028")
+    lists = []
+    real_knn = ops.knn
+
+    def rec(x, k, *a, **kw):
+        o = real_knn(x, k, *a, **kw)
+        if x.shape[-1] != 3:
+            lists.append(o.cpu().numpy())
+        return o
+    ops.knn = rec
+    try:
+        torch.manual_seed(1)
+        with torch.no_grad():
+            outs = net(pts.to(dev), obj.to(dev))
+    finally:
+        ops.knn = real_knn
+    agree = [float((l_ == g2[f"featknn{i + 1}"]).all(-1).mean()) for i, l_ in enumerate(lists[:4])]
+    names = ["p_green_R", "p_red_R", "f_green_R", "f_red_R", "Pred_T", "Pred_s"]
+    errs = {n_: float(np.abs(o.cpu().numpy() - g2["out." + n_]).max()) for n_, o in zip(names, outs[4:])}
+    print(f"EXACT FREE-RUNNING PoseNet9D (eval, N = 1028): rows with the reference's ordered neighbour list per HS layer {agree}; "
+          f"max abs error of the pose / size outputs {errs}")
+    assert agree == [1.0, 1.0, 1.0, 1.0], agree
+    assert max(errs.values()) <= 1e-5, errs
+
+
+@pytest.mark.parametrize("B,N,C,k", [(2, 1028, 128, 20), (3, 257, 256, 20), (2, 64, 256, 8), (2, 1028, 3, 20), (2, 1028, 3, 4),
+                                     (1, 300, 32, 12), (2, 4096, 64, 20)])
+def test_knn_exact_tie_order(dev, ref, B, N, C, k):
+    """rows on a small integer lattice: every distance is an exact integer in fp32 whatever the summation order, and nearly every
+    row holds ties among its nearest and at the boundary -- the exact-scope neighbour search returns torch.topk's CPU order
+    (ref.knn_index runs the torch ops of gcn3d.py:15-24 on the host), the default search its own lowest-index order"""
+    from hs_pose_amd import ops
+    g = torch.Generator().manual_seed(N + C + k)
+    x = torch.randint(0, 3 if C > 3 else 6, (B, N, C), generator=g).float()
+    want = ref.knn_index(x, k)
+    with ops.exact_scope(True):
+        got = ops.knn(x.to(dev), k)
+    rows = (got.cpu().long() == want).all(-1).float().mean().item()
+    plain = (ops.knn(x.to(dev), k).cpu().long() == want).all(-1).float().mean().item()
+    print(f"tie-rich lattice B{B} N{N} C{C} k{k}: rows equal to torch.topk's order {rows:.4f} (lowest-index rule: {plain:.4f})")
+    assert rows == 1.0
+
+
+def test_knn_exact_equals_default_without_ties(dev, ref):
+    """on tie-free rows the two searches agree (and the exact one costs one more list entry plus a check per row)"""
+    from hs_pose_amd import ops
+    x = ref.hash_tensor((2, 1028, 128), 9100, 1.0).to(dev)
+    with ops.exact_scope(True):
+        a = ops.knn(x, 20)
+    assert torch.equal(a, ops.knn(x, 20))

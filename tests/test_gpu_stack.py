@@ -68,8 +68,8 @@ class ForcedFeatKnn:
         self.agree_set = []                # rows whose neighbour SET does
         monkeypatch.setattr(ops, "knn", self)
 
-    def __call__(self, x, k, drop_first=True):
-        own = self.real(x, k, drop_first)
+    def __call__(self, x, k, drop_first=True, **kw):
+        own = self.real(x, k, drop_first, **kw)
         if x.shape[-1] == 3:
             return own
         want = self.lists[self.calls % 4]
@@ -274,8 +274,12 @@ def test_posenet9d_free_running_1028(dev, ref, flags, monkeypatch, name):
 # hand-written kernels (HSP_GEMM=own, the default: csrc/gemm_x3.hip sums each product row in another order) 0.91 / 0.70 / 0.54 /
 # 0.57 and 1.3e-3 (p_red_R) in eval mode, 0.91 / 0.74 / 0.57 / 0.80 and 7.0e-2 under train-mode BatchNorm -- neighbour SETS
 # 0.99 / 0.94 / 0.87-0.89 / 0.83-0.95, above the reference's self-agreement in every layer.  The test runs in both modes.
-REFINIT_BOUND = {"stack_refinit_eval_1028": 2e-3, "stack_refinit_trainbn_1028": 1.5e-1}
-REFINIT_AGREE = {"stack_refinit_eval_1028": (0.85, 0.65, 0.5, 0.5), "stack_refinit_trainbn_1028": (0.85, 0.65, 0.5, 0.7)}
+# Round 4: in EVAL mode the forward now runs in the reference's own rounding order (ops.exact_scope: k-ordered products, ATen's
+# summation orders, torch.topk's tie order -- tests/test_gpu_exact.py pins each statement): every ordered neighbour list equals
+# the reference's and the pose / size outputs agree to 2e-6 (1.3e-3 in round 3).  The train-mode case keeps the bounds above:
+# BatchNorm batch statistics are a reduction over B*N rows whose order is the library's, not ATen's.
+REFINIT_BOUND = {"stack_refinit_eval_1028": 1e-5, "stack_refinit_trainbn_1028": 1.5e-1}
+REFINIT_AGREE = {"stack_refinit_eval_1028": (1.0, 1.0, 1.0, 1.0), "stack_refinit_trainbn_1028": (0.85, 0.65, 0.5, 0.7)}
 
 
 @pytest.mark.parametrize("name", ["stack_refinit_eval_1028", "stack_refinit_trainbn_1028"])

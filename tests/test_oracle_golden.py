@@ -194,3 +194,16 @@ def test_chamfer_oracle_vs_bruteforce(ref, oc):
     ((w1 * u1).sum() + (w2 * u2).sum()).backward()
     gx1, gx2 = oc.chamfer_bwd(x1.detach().numpy(), x2.detach().numpy(), i1, i2, u1.numpy(), u2.numpy())
     assert np.allclose(gx1, x1.grad.numpy(), atol=1e-5) and np.allclose(gx2, x2.grad.numpy(), atol=1e-5)
+
+
+def test_topk_tie_order_matches_torch(oc):
+    """torch.topk's order among exactly equal distances = libstdc++'s nth_element + sort / partial_sort under a value-only
+    comparator: the C restatement (oracle/hsp_oracle.c, the checker of csrc/knn_exact.hip) against the indices the imported
+    reference's torch.topk returned on tie-rich rows (oracle/gen_golden_exact.py), and against this host's torch.topk"""
+    g = golden("exact_topk_ties")
+    for tag in ("n1028_m21", "n257_m21", "n64_m9", "n1028_m5", "n4096_m21"):
+        q, m = (int(v) for v in g["q_" + tag])
+        d = g["d_" + tag].astype(np.float32) / np.float32(q)
+        got = oc.topk_smallest(d, m)
+        assert np.array_equal(got, g["i_" + tag].astype(np.int32)), tag
+        assert np.array_equal(got, torch.topk(torch.from_numpy(d), m, dim=-1, largest=False)[1].numpy()), tag

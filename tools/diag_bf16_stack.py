@@ -17,7 +17,7 @@ B, N = 2, int(sys.argv[1]) if len(sys.argv) > 1 else 1028
 pts = oc.hash_tensor((B, N, 3), 61, 0.05).to(dev); pts = pts - pts.mean(dim=1, keepdim=True)
 obj = torch.tensor([[1.0], [4.0]]).to(dev)
 real = ops.knn; lists = []; mode = ["rec"]; pos = [0]
-def knn(x, k, drop_first=True):
+def knn(x, k, drop_first=True, **kw):
     own = real(x, k, drop_first)
     if x.shape[-1] == 3: return own
     if mode[0] == "rec": lists.append(own); return own

@@ -47,3 +47,43 @@ with torch.no_grad(), ops.exact_scope(True), gcn3d.knn_scope():
                        fr.conv_1.STE_layer.weight, fr.conv_1.conv2.weight)
 a = out.cpu().numpy()
 print("   ... with the reference's neighbour lists: equal", float((a == b).mean()), "max abs diff", float(np.abs(a - b).max()))
+# --- eval BatchNorm on the reference's conv outputs
+for cn, bnm in (("conv_1", "bn1"), ("conv_2", "bn2"), ("conv_3", "bn3")):
+    bn = getattr(fr, bnm)
+    xin = torch.from_numpy(d[cn]).to(dev)
+    with torch.no_grad():
+        y = ops.bn_relu(xin, bn, relu=False)
+    want = np.transpose(d[bnm], (0, 2, 1)) if d[bnm].shape[1] == bn.num_features and d[bnm].shape[2] != bn.num_features else d[bnm]
+    a = y.cpu().numpy()
+    badc = np.nonzero((a != want).any(axis=(0, 1)))[0]
+    inv_host = ops._eval_invstd(bn).cpu().numpy()
+    rv = bn.running_var.cpu().numpy()
+    inv_ieee = (np.float32(1) / np.sqrt((rv + np.float32(1e-5)).astype(np.float32))).astype(np.float32)
+    print(bnm, "equal", float((a == want).mean()), "channels that differ", badc.tolist()[:10], " host invstd != IEEE in", int((inv_host != inv_ieee).sum()), "channels",
+          " running_var all ones:", bool((rv == 1).all()))
+# --- conv_3 in isolation on the reference's fm_2
+bn2 = d["bn2"]
+fm2 = torch.relu(torch.from_numpy(np.transpose(bn2, (0, 2, 1)) if bn2.shape[1] == 256 and bn2.shape[2] != 256 else bn2)).contiguous().to(dev)
+print("fm2 shape", tuple(fm2.shape))
+# v_pool_1: the pooled coordinates: recompute the pool draw as the forward did
+torch.manual_seed(1)
+perm = torch.randperm(1028)[:257]
+v1 = pts[:, perm, :].contiguous().to(dev)
+with ops.exact_scope(True):
+    idx3 = ops.knn(fm2, 20)
+want3 = torch.from_numpy(g["featknn3"].astype(np.int64))
+print("conv_3 feature KNN (exact ties) vs reference lists:", float((idx3.cpu().long() == want3).all(-1).float().mean()),
+      " default rule:", float((ops.knn(fm2, 20).cpu().long() == want3).all(-1).float().mean()))
+o3 = ref.knn_index(fm2.cpu(), 20)
+print("   CPU oracle (this host) vs fixture:", float((o3 == want3).all(-1).float().mean()))
+for lists, nm in ((idx3, "own lists"), (want3.int().to(dev), "reference lists")):
+    with torch.no_grad(), ops.exact_scope(True), gcn3d.knn_scope():
+        out = ops.hs_layer(v1, fm2, lists, ops.knn(v1, 20), 20, 7, fr.conv_3.weights, fr.conv_3.bias, fr.conv_3.directions,
+                           fr.conv_3.STE_layer.weight, fr.conv_3.conv2.weight)
+    a, b = out.cpu().numpy(), d["conv_3"]
+    print(f"conv_3 with {nm}: equal", float((a == b).mean()), "max abs diff", float(np.abs(a - b).max()))
+# pieces: fm product and STE against the container's values are not in the dump; compare the graph conv + ORL chain by parts
+X2 = fm2.view(-1, 256)
+fmm = ops.gemm_wave(X2, fr.conv_3.weights, True, bias=fr.conv_3.bias)
+fm_cpu = (fm2.cpu() @ fr.conv_3.weights.cpu() + fr.conv_3.bias.cpu()).view(-1, 2048)
+print("fm product vs this host's CPU:", float((fmm.cpu() == fm_cpu).float().mean()))
