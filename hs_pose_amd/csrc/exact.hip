@@ -6,6 +6,9 @@
 // Pinned by tests/golden/exact_*.npz (oracle/gen_golden_exact.py imports the reference and records its outputs).
 #include "common.h"
 
+extern "C" int hsp_gather_max_fwd(const float* feat, const int32_t* idx, const int32_t* qsel, int B, int Nsrc, int Nidx, int Nq, int k,
+                                  int kstride, int C, float* out, uint8_t* argmax, hspStream_t stream);
+
 namespace hsp {
 
 // ---- get_ORL_global (gcn3d.py:211-218): torch.mean(max_n feature[idx], dim=1) ------------------------------------------------
@@ -14,32 +17,23 @@ namespace hsp {
 // every N < 2^20), the remainder rows go into level 0 last, and the levels are added 0 <- 1 <- 2 <- 3; the mean divides by N.
 // Level 0 is 16-row chunks summed from zero: one thread per (chunk, 4 channels).
 #define ORLX_ROWS 16
-__global__ __launch_bounds__(256) void orl_exact_l0_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx, int N,
-                                                           int k, int kstride, int C, uint8_t* __restrict__ argmax,
-                                                           float* __restrict__ part, int nchunk) {
+// (the neighbourhood max G (B,N,C) comes from hsp_gather_max_fwd -- a thread per (point, 4 channels) --, then:)
+__global__ __launch_bounds__(256) void orl_exact_l0_kernel(const float* __restrict__ G, int N, int C, float* __restrict__ part,
+                                                           int nchunk) {
     const int cq = C >> 2;
     const int b = blockIdx.y;
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= (long long)nchunk * cq) return;
     const int chunk = (int)(e / cq), g = (int)(e - (long long)chunk * cq);
     const int r0 = chunk * ORLX_ROWS, r1 = min(N, r0 + ORLX_ROWS);
-    const float* fb = feat + (size_t)b * N * C + (g << 2);
+    const float* gb = G + (size_t)b * N * C + (g << 2);
+    float4 v[ORLX_ROWS];
+#pragma unroll
+    for (int t = 0; t < ORLX_ROWS; ++t) v[t] = *reinterpret_cast<const float4*>(gb + (size_t)min(r0 + t, N - 1) * C);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = r0; i < r1; ++i) {
-        const int32_t* nb = idx + ((size_t)b * N + i) * kstride;
-        float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        for (int n = 0; n < k; ++n) {                      // ascending n, strict >: the first maximum wins, as torch.max
-            const float4 f = *reinterpret_cast<const float4*>(fb + (size_t)nb[n] * C);
-            if (f.x > best.x) { best.x = f.x; a0 = n; }
-            if (f.y > best.y) { best.y = f.y; a1 = n; }
-            if (f.z > best.z) { best.z = f.z; a2 = n; }
-            if (f.w > best.w) { best.w = f.w; a3 = n; }
-        }
-        *reinterpret_cast<uchar4*>(argmax + ((size_t)b * N + i) * C + (g << 2)) =
-            make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
-        s.x = add_rn(s.x, best.x); s.y = add_rn(s.y, best.y); s.z = add_rn(s.z, best.z); s.w = add_rn(s.w, best.w);
-    }
+#pragma unroll
+    for (int t = 0; t < ORLX_ROWS; ++t)
+        if (r0 + t < r1) { s.x = add_rn(s.x, v[t].x); s.y = add_rn(s.y, v[t].y); s.z = add_rn(s.z, v[t].z); s.w = add_rn(s.w, v[t].w); }
     *reinterpret_cast<float4*>(part + ((size_t)b * nchunk + chunk) * C + (g << 2)) = s;
 }
 
@@ -143,24 +137,57 @@ __global__ __launch_bounds__(256) void quad_outer_kernel(const float* __restrict
     const int n = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
     if (n >= N) return;
     const float* row = x + ((size_t)b * N + n) * C;
-    quad[(size_t)b * N + n] = aten_outer_sum([&](int c) { const float v = row[c]; return mul_rn(v, v); }, C, n, N);
+    quad[(size_t)b * N + n] = aten_outer_sum([&](int c) { const float v = __ldg(row + c); return mul_rn(v, v); }, C, n, N);
 }
 
 // PoseNet9D.py:25: points - points.mean(dim=1, keepdim=True): the mean over the N points of a contiguous (B,N,3) tensor is an
 // outer sum over 3 columns (all of them "remaining" columns: the interleaved form), divided by N
 __global__ __launch_bounds__(256) void center_cloud_kernel(const float* __restrict__ pts, int N, float* __restrict__ out,
                                                            float* __restrict__ mean) {
-    __shared__ float sm[3];
+    // column c (0..2), partial p (0..3): elements e = 4 i + p, i < si = N / 4, summed as a cascade -> 12 cascades whose 16-element
+    // level-0 chunks are independent: one thread per (cascade, chunk), then one thread per cascade folds the levels
+    extern __shared__ float sc[];                      // 12 x nchunk chunk sums, then 12 cascade results, then 3 means
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* p = pts + (size_t)b * N * 3;
+    const int si = N / 4;
+    const int lp = max(4, ceil_log2_int(si) / 4), ls = 1 << lp;
+    const int nfull = si / ls, nchunk = nfull + 1;     // (the last chunk: the si % ls remainder elements, maybe none)
+    for (int w = tid; w < 12 * nchunk; w += 256) {
+        const int cas = w / nchunk, ch = w - cas * nchunk, c = cas >> 2, pp = cas & 3;
+        const int i0 = ch * ls, i1 = min(si, i0 + ls);
+        float a = 0.f;
+        for (int i = i0; i < i1; ++i) a = add_rn(a, p[(size_t)(4 * i + pp) * 3 + c]);
+        sc[w] = a;
+    }
+    __syncthreads();
+    float* res = sc + 12 * nchunk;
+    if (tid < 12) {
+        const float* cs = sc + tid * nchunk;
+        const int lm = ls - 1;
+        float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int j = 0; j < nfull; ++j) {
+            const int i = (j + 1) * ls;
+            a1 = add_rn(a1, cs[j]);
+            if ((i & (lm << lp)) == 0) {
+                a2 = add_rn(a2, a1); a1 = 0.f;
+                if ((i & (lm << (2 * lp))) == 0) { a3 = add_rn(a3, a2); a2 = 0.f; }
+            }
+        }
+        float a0 = cs[nfull];
+        a0 = add_rn(a0, a1); a0 = add_rn(a0, a2); a0 = add_rn(a0, a3);
+        res[tid] = a0;
+    }
+    __syncthreads();
     if (tid < 3) {
-        const float s = aten_outer_sum([&](int i) { return p[(size_t)i * 3 + tid]; }, N, tid, 3);
-        const float m = __fdiv_rn(s, (float)N);
-        sm[tid] = m;
+        float s0 = res[tid * 4];
+        for (int i = si * 4; i < N; ++i) s0 = add_rn(s0, p[(size_t)i * 3 + tid]);     // the N % 4 leftover elements into partial 0
+        s0 = add_rn(s0, res[tid * 4 + 1]); s0 = add_rn(s0, res[tid * 4 + 2]); s0 = add_rn(s0, res[tid * 4 + 3]);
+        const float m = __fdiv_rn(s0, (float)N);
+        res[12 + tid] = m;
         mean[b * 3 + tid] = m;
     }
     __syncthreads();
-    for (int e = tid; e < N * 3; e += 256) out[(size_t)b * N * 3 + e] = sub_rn(p[e], sm[e % 3]);
+    for (int e = tid; e < N * 3; e += 256) out[(size_t)b * N * 3 + e] = sub_rn(p[e], res[12 + e % 3]);
 }
 
 }  // namespace hsp
@@ -169,7 +196,7 @@ using namespace hsp;
 
 extern "C" size_t hsp_orl_exact_workspace_bytes(int B, int N, int C) {
     if (B <= 0 || N <= 0 || C <= 0) return 0;
-    return (size_t)B * ((N + ORLX_ROWS - 1) / ORLX_ROWS) * C * sizeof(float);
+    return (size_t)B * ((N + ORLX_ROWS - 1) / ORLX_ROWS) * C * sizeof(float) + (size_t)B * N * C * sizeof(float);   // chunk sums + G
 }
 
 extern "C" int hsp_orl_global_exact_f32(const float* feat, const int32_t* idx, int B, int N, int k, int kstride, int C, float* fg,
@@ -180,9 +207,11 @@ extern "C" int hsp_orl_global_exact_f32(const float* feat, const int32_t* idx, i
     hipStream_t st = as_stream(stream);
     const int nchunk = (N + ORLX_ROWS - 1) / ORLX_ROWS;
     float* part = reinterpret_cast<float*>(ws);
+    float* G = part + (size_t)B * nchunk * C;
+    const int rc = hsp_gather_max_fwd(feat, idx, nullptr, B, N, N, N, k, kstride, C, G, argmax, stream);
+    if (rc) return rc;
     const long long work = (long long)nchunk * (C >> 2);
-    hipLaunchKernelGGL(orl_exact_l0_kernel, dim3((unsigned)((work + 255) / 256), B), dim3(256), 0, st, feat, idx, N, k, kstride, C,
-                       argmax, part, nchunk);
+    hipLaunchKernelGGL(orl_exact_l0_kernel, dim3((unsigned)((work + 255) / 256), B), dim3(256), 0, st, G, N, C, part, nchunk);
     hipLaunchKernelGGL(orl_exact_fold_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, B, N, nchunk, C, fg);
     return check_launch();
 }
@@ -208,6 +237,10 @@ extern "C" int hsp_quad_outer_f32(const float* x, int B, int N, int C, float* qu
 
 extern "C" int hsp_center_cloud_f32(const float* pts, int B, int N, float* centred, float* mean, hspStream_t stream) {
     if (!pts || !centred || !mean || B <= 0 || N <= 0) return HSP_ERR_BAD_ARG;
-    hipLaunchKernelGGL(center_cloud_kernel, dim3(B), dim3(256), 0, as_stream(stream), pts, N, centred, mean);
+    int lp = 4, si = N / 4, l2 = 0;
+    while ((1 << l2) < si) ++l2;
+    if (l2 / 4 > lp) lp = l2 / 4;
+    const size_t lds = (size_t)(12 * (si / (1 << lp) + 1) + 16) * sizeof(float);
+    hipLaunchKernelGGL(center_cloud_kernel, dim3(B), dim3(256), lds, as_stream(stream), pts, N, centred, mean);
     return check_launch();
 }

@@ -837,9 +837,12 @@ __global__ __launch_bounds__(256) void nn1_kernel(const float* __restrict__ tgt,
 static int pick_k1(int m) {
     if (m <= 3) return 3;
     if (m <= 5) return 5;
+    if (m <= 6) return 6;               // (6, 10, 22: one entry past the network's 5 / 9 / 21 -- the exact search's boundary check)
     if (m <= 9) return 9;
+    if (m <= 10) return 10;
     if (m <= 17) return 17;
     if (m <= 21) return 21;
+    if (m <= 22) return 22;
     if (m <= 33) return 33;
     return 0;
 }
@@ -1146,9 +1149,12 @@ static int knn_f32_impl(const float* x, int B, int N, int C, int k, int drop_fir
     switch (K1) {                                            \
         case 3: return CALL(3);                              \
         case 5: return CALL(5);                              \
+        case 6: return CALL(6);                              \
         case 9: return CALL(9);                              \
+        case 10: return CALL(10);                            \
         case 17: return CALL(17);                            \
         case 21: return CALL(21);                            \
+        case 22: return CALL(22);                            \
         default: return CALL(33);                            \
     }
     if (C == 3) {
@@ -1200,7 +1206,7 @@ extern "C" int hsp_knn_bf16(const hsp_bf16_t* x, int B, int N, int C, int k, int
     hipLaunchKernelGGL(quad_bf16_kernel, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, st, x, rows, C, quad);
     int rc = check_launch();
     if (rc) return rc;
-    switch (K1) {
+    switch (K1 == 6 ? 9 : K1 == 10 ? 17 : K1 == 22 ? 33 : K1) {
         case 3: return launch_knn_feat_bf16<3>(x, quad, B, N, C, k, drop, idx, st);
         case 5: return launch_knn_feat_bf16<5>(x, quad, B, N, C, k, drop, idx, st);
         case 9: return launch_knn_feat_bf16<9>(x, quad, B, N, C, k, drop, idx, st);

@@ -12,8 +12,9 @@
 //   1. hsp_knn_f32 selects the m + 1 nearest by (distance, index)                         (m = k + drop_first)
 //   2. knn_ties_kernel, one wave per query: the m + 1 candidates' distances again (same arithmetic: k-ordered fma chain,
 //      ((inner * -2) + |c|^2) + |q|^2); no two equal neighbours in that sorted list -> the selection is unique, copy it;
-//      otherwise all N distances of the row go to LDS and ONE lane runs libstdc++'s algorithm on them (~3 N dependent LDS
-//      steps: ~0.15 ms for N = 1028, on the few rows that need it, in parallel across the chip).
+//      otherwise all N distances of the row go to LDS and the wave runs libstdc++'s algorithm on them: the partition passes
+//      of nth_element as ballot sweeps (tkw_partition_pivot), the short tails (median of three, insertion sort, the final
+//      std::sort of m - 1 entries, the heap forms) by one lane.
 #include "common.h"
 #include <stdlib.h>
 
@@ -141,12 +142,74 @@ __device__ void tkd_sort(TkE* first, TkE* last) {
     } else tkd_insertion_sort(first, last);
 }
 
+// ---- the same partition step by a whole wave -------------------------------------------------------------------------------------
+// libstdc++'s __unguarded_partition walks two pointers towards each other over elements the other pointer has not touched yet, so
+// its swaps are exactly: the t-th element from the LEFT that is not below the pivot <-> the t-th element from the RIGHT that is not
+// above it, for as long as the former lies left of the latter (T pairs); it returns min(position of the (T+1)-th left element,
+// position of the T-th right element) -- checked against the sequential form on 20 000 tie-rich arrays.  Both lists come out of one
+// ballot / popcount sweep, the swaps are independent: N / 64 wave steps per pass instead of ~N dependent LDS round trips (a row of
+// 1028 distances: ~0.15 ms sequentially, the pace of the whole kernel).
+__device__ int tkw_partition_pivot(TkE* q, int* LA, int* LB, int first, int last, int lane) {
+    if (lane == 0) tkd_move_median_to_first(q + first, q + first + 1, q + first + (last - first) / 2, q + last - 1);
+    __syncthreads();
+    const float pv = q[first].v;
+    const int lo = first + 1, hi = last;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int nA = 0, nB = 0;
+    for (int base = lo; base < hi; base += 64) {
+        const int p = base + lane;
+        const bool valid = p < hi;
+        const float v = valid ? q[p].v : 0.f;
+        const bool a = valid && !(v < pv), b = valid && !(pv < v);
+        const unsigned long long ba = __ballot(a), bb = __ballot(b);
+        if (a) LA[nA + __popcll(ba & below)] = p;
+        if (b) LB[nB + __popcll(bb & below)] = p;
+        nA += __popcll(ba); nB += __popcll(bb);
+    }
+    __syncthreads();
+    const int nmin = nA < nB ? nA : nB;
+    int T = 0;
+    for (int base = 0; base < nmin; base += 64) {
+        const int t = base + lane;
+        const bool ok = t < nmin && LA[t] < LB[nB - 1 - t];
+        const int c = __popcll(__ballot(ok));
+        T += c;
+        if (c < 64) break;                                  // (the pairs that swap are a prefix)
+    }
+    for (int t = lane; t < T; t += 64) {
+        const int a = LA[t], b = LB[nB - 1 - t];
+        const TkE x = q[a], y = q[b];
+        q[a] = y; q[b] = x;
+    }
+    const int aT = T < nA ? LA[T] : 0x7fffffff, bp = T > 0 ? LB[nB - T] : hi;
+    __syncthreads();
+    return aT < bp ? aT : bp;
+}
+// std::nth_element(q, q + nth, q + n): __introselect, the partition steps by the wave, the rest by lane 0
+__device__ void tkw_nth_element(TkE* q, int* LA, int* LB, int nth, int n, int lane) {
+    int first = 0, last = n, depth = 2 * tkd_lg(n);
+    while (last - first > 3) {
+        if (depth == 0) {
+            if (lane == 0) { tkd_heap_select(q + first, q + nth + 1, q + last); tkd_swap(q + first, q + nth); }
+            __syncthreads();
+            return;
+        }
+        --depth;
+        const int cut = tkw_partition_pivot(q, LA, LB, first, last, lane);
+        if (cut <= nth) first = cut; else last = cut;
+    }
+    if (lane == 0) tkd_insertion_sort(q + first, q + last);
+    __syncthreads();
+}
+
 // one wave per query row.  cand (B,N,mc): the mc = min(m + 1, N) nearest by (distance, index) from hsp_knn_f32 (no drop).
 __global__ __launch_bounds__(64) void knn_ties_kernel(const float* __restrict__ x, const float* __restrict__ quad,
                                                       const int32_t* __restrict__ cand, int N, int C, int k, int drop, int mc,
                                                       int32_t* __restrict__ idx, int* __restrict__ nties) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     TkE* q = reinterpret_cast<TkE*>(smem);                     // N entries (tie rows only)
+    int* LA = reinterpret_cast<int*>(q + N);                   // N: partition scratch
+    int* LB = LA + N;
     const int lane = threadIdx.x;
     const int b = blockIdx.y, i = blockIdx.x;
     const int m = k + drop;
@@ -161,7 +224,15 @@ __global__ __launch_bounds__(64) void knn_ties_kernel(const float* __restrict__ 
     auto dist_to = [&](int j, float qi) {
         const float* xj = xb + (size_t)j * C;
         float acc = 0.f;
-        for (int c = 0; c < C; ++c) acc = __fmaf_rn(xi[c], xj[c], acc);      // torch.bmm: k-ordered chain from 0
+        if ((C & 3) == 0) {
+            for (int c = 0; c < C; c += 4) {                                 // torch.bmm: k-ordered chain from 0
+                const float4 a = *reinterpret_cast<const float4*>(xi + c), bq = *reinterpret_cast<const float4*>(xj + c);
+                acc = __fmaf_rn(a.x, bq.x, acc); acc = __fmaf_rn(a.y, bq.y, acc);
+                acc = __fmaf_rn(a.z, bq.z, acc); acc = __fmaf_rn(a.w, bq.w, acc);
+            }
+        } else {
+            for (int c = 0; c < C; ++c) acc = __fmaf_rn(xi[c], xj[c], acc);
+        }
         return add_rn(add_rn(mul_rn(acc, -2.0f), quad_of(j)), qi);           // gcn3d.py:21, left to right
     };
     const float qi = quad_of(i);
@@ -177,15 +248,12 @@ __global__ __launch_bounds__(64) void knn_ties_kernel(const float* __restrict__ 
     }
     for (int j = lane; j < N; j += 64) { q[j].v = dist_to(j, qi); q[j].i = j; }
     __syncthreads();
-    if (lane == 0) {
-        if (nties) atomicAdd(nties, 1);
-        if ((long long)m * 64 <= N) {                          // std::partial_sort
-            tkd_heap_select(q, q + m, q + N);
-            tkd_sort_heap(q, q + m);
-        } else {
-            if (m - 1 != N) tkd_introselect(q, q + (m - 1), q + N, 2 * tkd_lg(N));
-            tkd_sort(q, q + (m - 1));
-        }
+    if (lane == 0 && nties) atomicAdd(nties, 1);
+    if ((long long)m * 64 <= N) {                              // std::partial_sort
+        if (lane == 0) { tkd_heap_select(q, q + m, q + N); tkd_sort_heap(q, q + m); }
+    } else {
+        if (m - 1 != N) tkw_nth_element(q, LA, LB, m - 1, N, lane);
+        if (lane == 0) tkd_sort(q, q + (m - 1));
     }
     __syncthreads();
     if (lane >= drop && lane < m) out[lane - drop] = q[lane].i;
@@ -219,7 +287,7 @@ extern "C" int hsp_knn_exact_f32(const float* x, int B, int N, int C, int k, int
     int32_t* cand = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + inner);
     int rc = hsp_knn_quadmode_f32(x, B, N, C, mc, 0, cand, ws, inner, C == 3 ? 0 : quad_mode, stream);
     if (rc) return rc;
-    const size_t lds = (size_t)N * sizeof(TkE);
+    const size_t lds = (size_t)N * (sizeof(TkE) + 2 * sizeof(int));
     if (lds > 160 * 1024) return HSP_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_ties_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
