@@ -194,6 +194,74 @@ def relaunch_multi_gpu(n):
     os.execv(sys.executable, cmd)
 
 
+def dry_run(args, rank, world, device, result_out):
+    """the launch / timing / reporting skeleton of main() with a stub step (tests/test_bench_contract.py runs it with two gloo
+    ranks on the CPU): WORLD_SIZE == --gpus, warm-up, barrier + K timed steps + barrier, MAX over ranks, one JSON line from
+    rank 0 with the weak-scaled global batch.  The stub step is one all-reduce of a gradient-sized buffer (3.1 M fp32: the HS
+    stack's parameters); its rate means nothing and the line says so."""
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}: launch one rank per GPU (or plain `python bench.py --gpus N`)"
+    B, N = args.batch, args.points
+    grad = torch.ones(3_100_288, dtype=torch.float32, device=device)
+
+    def step():
+        if dist.is_initialized():
+            dist.all_reduce(grad)
+            grad.div_(world)
+
+    def fence():
+        if dist.is_initialized():
+            dist.barrier()
+        if device.type == "cuda":
+            torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    if dist.is_initialized():
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+    if rank == 0:
+        assert abs(grad[0].item() - 1.0) < 1e-6               # the mean of identical replicas is the replica
+        line = {"metric": f"point-clouds/sec (N={N}) HS-layer fwd+bwd", "value": round(world * B * args.steps / dt, 2),
+                "unit": "point-clouds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": args.dtype, "data": "synthetic", "dry_run": True,
+                "config": {"workload": "DRY RUN (no kernels): stub step = one gradient-sized all-reduce; launcher / contract check only",
+                           "global_batch": world * B, "points": N, "parallelism": f"dp{world}",
+                           "backend": dist.get_backend() if dist.is_initialized() else "none"},
+                "roofline": None, "cpu_baseline": None}
+        print(json.dumps(line), file=result_out, flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def roofline_of(kname, kkey, kd, bf16, traffic):
+    """the roofline object of one C-ABI call: algorithmic flops (GEMM-shaped calls) or bytes per launch / its HIP-event average"""
+    from hs_pose_amd import ops
+    if kd.get("aflops", 0) > 0:           # GEMM-shaped kernel (feature-space distance tiles / weight gradient): MFMA roofline
+        peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
+        achieved = kd["aflops"] / (kd["avg_us"] * 1e-6) / 1e12
+        roof = {"bound": "mfma", "kernel": f"{kname}[{kkey}]", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 5), "avg_us": round(kd["avg_us"], 2), "algorithmic_flops_per_launch": kd["aflops"],
+                "algorithmic_bytes_per_launch": kd["abytes"], "traffic": None}
+    else:
+        achieved = kd["abytes"] / (kd["avg_us"] * 1e-6) / 1e9
+        roof = {"bound": "hbm", "kernel": f"{kname}[{kkey}]", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "avg_us": round(kd["avg_us"], 2),
+                "algorithmic_bytes_per_launch": kd["abytes"], "traffic": None}
+    roof["traffic"] = traffic.get(f"{kname}[{kkey}]", {}).get("hbm_bytes_per_launch")
+    sb = ops.design_stream_bytes.get((kname, kkey))
+    if sb:                                 # the bytes the kernel streams by design (uint16 winning-row slots, winners' support values)
+        roof["kernel_stream_bytes_per_launch"] = sb
+        roof["kernel_stream_frac"] = round(sb / (kd["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+    return roof
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,6 +278,9 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="leave hipBLASLt/rocBLAS on their default heuristics")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / contract check without a GPU: the ranks rendezvous (gloo on CPU), run K stub steps with one "
+                         "gradient-sized all-reduce each, and rank 0 prints the line with \"dry_run\": true -- no throughput claim")
     ap.add_argument("--no-side", action="store_true",
                     help="skip the secondary figures appended to config (bf16 dense clouds, the no-BLAS-library step)")
     args = ap.parse_args()
@@ -228,6 +299,8 @@ def main():
     from hs_pose_amd.parallel import GradReducer, graphed_step_with_exchange, init_distributed
 
     rank, world, device = init_distributed()
+    if args.dry_run:
+        return dry_run(args, rank, world, device, result_out)
     assert device.type == "cuda", "bench.py measures the HIP path; it needs a GPU"
     if not args.no_gemm_tuning and ops.GEMM_MODE != "own":
         from tools import gemm_tuning                   # only the HSP_GEMM=library comparison figure calls the BLAS library
@@ -340,28 +413,19 @@ def main():
         # two layers that share a shape are two launches)
         (kname, kkey), kd = max(summ.items(), key=lambda kv: kv[1]["avg_us"])
         hsp_ms = sum(d["total_ms"] for d in summ.values()) / args.steps
-        if kd.get("aflops", 0) > 0:       # GEMM-shaped kernel (feature-space distance tiles / weight gradient): MFMA roofline
-            achieved = kd["aflops"] / (kd["avg_us"] * 1e-6) / 1e12
-            roof = {"bound": "mfma", "kernel": f"{kname}[{kkey}]", "achieved": round(achieved, 3),
-                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 5),
-                    "avg_us": round(kd["avg_us"], 2), "algorithmic_flops_per_launch": kd["aflops"],
-                    "algorithmic_bytes_per_launch": kd["abytes"], "traffic": None}
-        else:
-            achieved = kd["abytes"] / (kd["avg_us"] * 1e-6) / 1e9
-            roof = {"bound": "hbm", "kernel": f"{kname}[{kkey}]", "achieved": round(achieved, 2),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "avg_us": round(kd["avg_us"], 2), "algorithmic_bytes_per_launch": kd["abytes"], "traffic": None}
+        traffic = {}
         try:                               # HBM bytes per launch measured with rocprofv3 PMC passes (committed with the profile)
             with open(TRAFFIC_JSON) as f:
-                tj = json.load(f)
-            roof["traffic"] = tj.get(f"{kname}[{kkey}]", {}).get("hbm_bytes_per_launch")
-            roof["traffic_source"] = (os.path.relpath(TRAFFIC_JSON, ROOT) + " (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE passes of this command)")
+                traffic = json.load(f)
         except Exception:
             pass
-        sb = ops.design_stream_bytes.get((kname, kkey))
-        if sb:                             # the bytes the kernel streams by design (uint16 winning-row slots, winners' support values)
-            roof["kernel_stream_bytes_per_launch"] = sb
-            roof["kernel_stream_frac"] = round(sb / (kd["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+        roof = roofline_of(kname, kkey, kd, bf16, traffic)
+        roof["traffic_source"] = (os.path.relpath(TRAFFIC_JSON, ROOT) + " (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE passes of this command; "
+                                  "committed with the round's profile, not re-measured by this run)")
+        # the same object for the five longest calls of the step (the "dominant" one above can change between runs when two
+        # calls are within noise of each other: hsp_knn_f32[C128] and hsp_rf_conv_fwd[N1028] both sit near 85-100 us)
+        top = sorted(summ.items(), key=lambda kv: -kv[1]["avg_us"])[:5]
+        roof_all = [roofline_of(n_, k_, d_, bf16, traffic) for (n_, k_), d_ in top]
         roof["avg_us_source"] = ("HIP events around the call, in the timed region" if graphed is None else
                                  "HIP events around the call, the same K steps re-issued eagerly right after the timed "
                                  "graph replays (events cannot be recorded inside a replay)")
@@ -369,9 +433,6 @@ def main():
         if bf16:
             ubytes *= 0.5                                      # every feature tensor of the byte model is stored in 2 bytes
         mfma_peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
-        if roof["bound"] == "mfma" and bf16:
-            roof["peak"] = mfma_peak
-            roof["frac"] = round(roof["achieved"] / mfma_peak, 5)
         step_s = median_ms * 1e-3
         step_roof = {"algorithmic_bytes_per_cloud": round(ubytes), "gemm_flops_per_cloud": round(uflops),
                      "step_hbm_frac": round(B * ubytes / step_s / 1e9 / HBM_PEAK_GBS, 5),
@@ -404,10 +465,16 @@ def main():
                        "global_batch": world * B, "points": N, "parallelism": f"dp{world}", "hipgraph": graphed is not None, "split_graph": bool(graphed is not None and graphed.split), "grad_exchange": ("none" if world == 1 else "2 all-reduces, first overlapped with backward" if graphed is not None and graphed.split else "1 all-reduce after backward" if graphed is not None else "bucketed, hook-driven"),
                        "libhsp_ms_per_step": round(hsp_ms, 4),
                        # dense per-point products: hand-written csrc/gemm_rows.hip vs the BLAS library, per composite shape
+                       "dense_products": ("fp32 in / out / accumulation; products on the bf16 matrix cores from exact three-way bf16 "
+                                          "splits of both operands, 6 of the 9 slice products (csrc/gemm_x3.hip: error vs fp64 at or "
+                                          "below an fp32 GEMM's, tests/test_gpu_gemm_x3.py); feature-space distance tiles, K = 3 "
+                                          "products and the eval-mode forward on the fp32 matrix cores" if not bf16 else
+                                          "bf16 operands on the bf16 matrix cores, fp32 accumulation"),
                        "gemm": {"mode": ops.GEMM_MODE,
                                 "own": sorted(k_ for k_, v_ in ops.gemm_choices().items() if v_ == "own"),
                                 "library": sorted(k_ for k_, v_ in ops.gemm_choices().items() if v_ == "library")}},
             "roofline": roof,
+            "roofline_longest_calls": roof_all,
             "step_roofline": step_roof,
         }
         if world == 1 and not args.no_u3 and not bf16:
@@ -424,7 +491,8 @@ def main():
                 torch.cuda.empty_cache()
                 d = side_run(["--dtype", "bf16", "--points", "4096", "--batch", "64", "--steps", "10", "--warmup", "3"])
                 line["config"].update({"bf16_b64_n4096_ms_per_step": d["ms_per_step"], "bf16_b64_n4096_clouds_per_s": d["value"],
-                                       "bf16_b64_n4096_step_hbm_frac": d["step_roofline"]["step_hbm_frac"]})
+                                       "bf16_b64_n4096_step_hbm_frac": d["step_roofline"]["step_hbm_frac"],
+                                       "bf16_b64_n4096_roofline": d["roofline"]})
             except Exception as exc:
                 line["config"]["bf16_b64_n4096_error"] = f"{type(exc).__name__}: {exc}"[:200]
             try:
