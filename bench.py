@@ -302,9 +302,9 @@ def main():
     if args.dry_run:
         return dry_run(args, rank, world, device, result_out)
     assert device.type == "cuda", "bench.py measures the HIP path; it needs a GPU"
-    if not args.no_gemm_tuning and ops.GEMM_MODE != "own":
-        from tools import gemm_tuning                   # only the HSP_GEMM=library comparison figure calls the BLAS library
-        gemm_tuning.enable()                            # (solution selection during the warm-up steps)
+    if os.environ.get("HSP_GEMM") == "library":         # the comparison figure (a child process of the default run): BLAS-library
+        from tools import library_gemm                  # composites through tools/library_gemm.py, TunableOp solution selection
+        library_gemm.enable(tune=not args.no_gemm_tuning)
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}: launch one rank per GPU (or plain `python bench.py --gpus N`)"
     B, N = args.batch, args.points
 
@@ -470,9 +470,7 @@ def main():
                                           "below an fp32 GEMM's, tests/test_gpu_gemm_x3.py); feature-space distance tiles, K = 3 "
                                           "products and the eval-mode forward on the fp32 matrix cores" if not bf16 else
                                           "bf16 operands on the bf16 matrix cores, fp32 accumulation"),
-                       "gemm": {"mode": ops.GEMM_MODE,
-                                "own": sorted(k_ for k_, v_ in ops.gemm_choices().items() if v_ == "own"),
-                                "library": sorted(k_ for k_, v_ in ops.gemm_choices().items() if v_ == "library")}},
+                       "gemm": {"mode": ops.GEMM_MODE}},
             "roofline": roof,
             "roofline_longest_calls": roof_all,
             "step_roofline": step_roof,

@@ -117,8 +117,7 @@ class FaceRecon(nn.Module):
             ops.x3_refresh()                          # fp32 weights -> the three bf16 slices of the x3 products (one launch)
         with gcn3d.knn_scope():
             od = self.feature_dtype if self.feature_dtype == torch.bfloat16 else None
-            fork0 = (od is None and not self.keep_backward_cut and os.environ.get("HSP_BN_FORK", "1") != "0"
-                     and torch.is_grad_enabled())
+            fork0 = od is None and not self.keep_backward_cut and torch.is_grad_enabled()
             if fork0:
                 fm_0, a_0 = self.conv_0(vertices, k, relu_fork=True)          # relu in the node, one tensor per consumer
             else:
@@ -126,13 +125,12 @@ class FaceRecon(nn.Module):
             # fm_1 .. fm_3 have two consumers each (the next level and the concat): the BatchNorm node hands out one tensor per
             # consumer (``fork``), so their gradients meet inside its backward kernels instead of in an element-wise add.  The
             # two-graph split (keep_backward_cut) cuts at single aliases and keeps the plain form.
-            fork = od is None and not self.keep_backward_cut and os.environ.get("HSP_BN_FORK", "1") != "0"
+            fork = od is None and not self.keep_backward_cut
 
             def layer_bn(conv, bn, *a):
                 """bn_relu(conv(...)); fp32 rows in train mode: the layer's out product also leaves the first pass of the
                 BatchNorm statistics (ops.hs_layer bn_shift), whatever the fork mode -- graph and eager twins stay bit-equal"""
-                if (od is None and bn.training and bn.track_running_stats and torch.is_grad_enabled()
-                        and os.environ.get("HSP_BN_EPILOGUE", "1") != "0"):
+                if od is None and bn.training and bn.track_running_stats and torch.is_grad_enabled():
                     out, part = conv(*a, bn_shift=True)
                     return ops.bn_relu(out, bn, fork=fork, partial=part)
                 if conv is self.conv_3 and ops.exact_forward():

@@ -111,8 +111,8 @@ class HSPose(nn.Module):
         return total_loss(loss_dict)
 
     graphed_posenet = None
-    # device batches take the fused loss kernels; HSP_FUSED_LOSSES=0 keeps the torch-op composition of losses.py (A/B runs)
-    fused_losses = os.environ.get("HSP_FUSED_LOSSES", "1") != "0"
+    # device batches take the fused loss kernels; False keeps the torch-op composition of losses.py (the readable statement: tests)
+    fused_losses = True
 
     def enable_graphed_posenet(self, PC, obj_id):
         """capture ``posenet`` forward / backward for training batches of this shape (hs_pose_amd.graph.GraphedNetwork);

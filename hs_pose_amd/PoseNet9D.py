@@ -12,11 +12,14 @@ from .PoseR import Rot_green, Rot_red
 from .PoseTs import Pose_Ts
 
 
+FUSED_FACE_SPLIT = True      # (tests flip it to compare the one-launch forms with the torch compositions below)
+
+
 def _axis_and_confidence(head_out):
     """(B,4) head output -> (unit axis (B,3) from columns 1:4 with the reference's 1e-6 guard, sigmoid of column 0)
     (PoseNet9D.py:40-46)"""
     if (head_out.is_cuda and head_out.dtype == torch.float32 and head_out.dim() == 2 and head_out.shape[1] == 4
-            and os.environ.get("HSP_FUSED_FACE_SPLIT", "1") != "0"):
+            and FUSED_FACE_SPLIT):
         return ops.axis_conf(head_out)                  # one launch each way instead of 4 forward + ~14 in autograd's backward
     v = head_out[:, 1:]
     return v / (v.norm(dim=1, keepdim=True) + 1e-6), head_out[:, 0].sigmoid()
@@ -26,7 +29,7 @@ def _split_face_head(face, n_faces=6):
     """(B,N,30) face-head output -> per-face unit normals (B,N,6,3), distances (B,N,6), confidences (B,N,6)
     (PoseNet9D.py:31-35)"""
     b, n, c = face.shape
-    if face.is_cuda and face.dtype == torch.float32 and n_faces == 6 and c == 30 and os.environ.get("HSP_FUSED_FACE_SPLIT", "1") != "0":
+    if face.is_cuda and face.dtype == torch.float32 and n_faces == 6 and c == 30 and FUSED_FACE_SPLIT:
         return ops.face_split(face)                     # one launch each way instead of ~8 forward + ~20 in autograd's backward
     normals = face[..., :3 * n_faces].view(b, n, n_faces, 3)
     return (normals / normals.norm(dim=-1, keepdim=True), face[..., 3 * n_faces:4 * n_faces],
@@ -61,7 +64,7 @@ class PoseNet9D(nn.Module):
         blk = self.face_recon.conv1d_block[0] if FLAGS.train else None
         if blk is not None:
             layers.append((blk.weight.squeeze(-1), blk.bias))
-        if os.environ.get("HSP_FAN_HEADS", "1") == "0" or not ops.fan_linear_rows_ok(rows, xyz, [w for w, _ in layers]):
+        if not ops.fan_linear_rows_ok(rows, xyz, [w for w, _ in layers]):
             self._first = None
             return None
         outs = ops.fan_linear_rows(rows, xyz, layers)

@@ -46,7 +46,6 @@ SIGNATURES = {
     "hsp_orl_global_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "hsp_colsum_rows": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "hsp_add_relu_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp]),
-    "hsp_set_ticket_buffer": (_i, [_vp, _i]),
     "hsp_residual_bias": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "hsp_concat_rows": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "hsp_gather_rows_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),

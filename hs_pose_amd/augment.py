@@ -89,7 +89,7 @@ def defor_3D_pc(pc, gt_t, r=0.2, points_defor=None, return_defor=False):
     return (new_pc, points_defor) if return_defor else new_pc
 
 
-FUSED = os.environ.get("HSP_FUSED_AUGMENT", "1") != "0"      # device batches: one libhsp launch (hsp_pose_augment)
+FUSED = True      # device batches: one libhsp launch (hsp_pose_augment); False: the torch composition above (tests)
 
 
 def _data_augment_fused(PC, gt_R, gt_t, gt_s, mean_shape, sym, aug_bb, aug_rt_t, aug_rt_r, model_point, nocs_scale, obj_ids):

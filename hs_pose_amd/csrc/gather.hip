@@ -81,63 +81,15 @@ __global__ __launch_bounds__(256) void gather_max_fwd_kernel(const FT* __restric
 // over the k gathered rows, the chunk's column sums are folded through LDS in a fixed order and written
 // to part[b][chunk][C]; orl_finalize_kernel folds the chunks (deterministic).  The (B,N,C) max tensor of
 // the reference is never written.
-// ---- last-arriving-workgroup fold (the guide's split-K seam: release -> ticket -> acquire) -----------------------------------------
-// The two-stage per-cloud reductions (ORL mean, column sums) wrote per-chunk partials and folded them with a second, tiny launch
-// (chunk_fold_kernel: ~4.5 us of launch latency for ~1 us of work).  With a zero-initialised ticket word per cloud the LAST
-// workgroup of a cloud to finish folds that cloud's partials itself, in exactly chunk_fold_kernel's order (bit-identical).
-// Protocol (placement-independent, NO fences -- measured: an agent-scope release per workgroup writes back the XCD's whole dirty
-// L2 and cost the step +60 us): the partials are stored WRITE-THROUGH (relaxed agent-scope atomic stores lower to sc1 stores) ->
-// every wave s_waitcnt vmcnt(0) -> barrier -> lane 0: relaxed agent fetch_add on the cloud's ticket; the workgroup that draws
-// nchunk - 1 resets the word (the next launch on the stream finds it zero) and folds, reading the partials with relaxed
-// agent-scope atomic loads (sc1: past the reader's L1).
-static int* g_tickets = nullptr;
-static int g_ntickets = 0;
-
-__device__ __forceinline__ void store_wt4(float* p, float4 v, bool wt) {
-    if (wt) {
-        __hip_atomic_store(p, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(p + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(p + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(p + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        *reinterpret_cast<float4*>(p) = v;
-    }
-}
-
-// returns true in EVERY thread of the last-arriving workgroup of group `grp` (`flag`: one LDS word no longer in use)
-__device__ __forceinline__ bool last_arriver(int* tickets, int grp, int members, int* flag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int t = __hip_atomic_fetch_add(tickets + grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = t == members - 1;
-        if (last) __hip_atomic_store(tickets + grp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *flag = last;
-    }
-    __syncthreads();
-    return *flag != 0;
-}
-
-// chunk_fold_kernel's sum for one (cloud, column), same order; the partials are read past L1
-__device__ __forceinline__ float fold_chunks(const float* __restrict__ p, int nchunk, int C) {
-    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int ch = 0;
-    for (; ch + 7 < nchunk; ch += 8) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s[u] += __hip_atomic_load(p + (size_t)(ch + u) * C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    for (; ch < nchunk; ++ch) s[ch & 7] += __hip_atomic_load(p + (size_t)ch * C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-}
-
+// (Round 3 also built last-arriving-workgroup folds -- a ticket per cloud, write-through partials, the last workgroup folds -- to
+// save the ~4.5 us fold launches: bit-identical, +20 us per step fence-free and +60 us with agent-scope fences: the in-kernel fold
+// is the same dependent-load chain run by one workgroup per cloud at the kernel's tail.  Removed in round 4.)
 #define ORL_ROWS 128         // upper bound of points per chunk
 template <typename FT>
 __global__ __launch_bounds__(256) void orl_partial_kernel(const FT* __restrict__ feat,
                                                           const int32_t* __restrict__ idx, int N, int k,
                                                           int kstride, int C, uint8_t* __restrict__ argmax,
-                                                          float* __restrict__ part, int nchunk, int rows,
-                                                          int* __restrict__ tickets = nullptr, float* __restrict__ out = nullptr,
-                                                          float scale = 1.f) {
+                                                          float* __restrict__ part, int nchunk, int rows) {
     __shared__ float4 red[256];
     const int cq = C >> 2;
     const int tid = threadIdx.x;
@@ -159,12 +111,7 @@ __global__ __launch_bounds__(256) void orl_partial_kernel(const FT* __restrict__
     __syncthreads();
     if (rl == 0) {
         for (int l = 1; l < RL; ++l) { const float4 v = red[l * cq + g]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
-        store_wt4(part + ((size_t)b * nchunk + chunk) * C + (g << 2), s, tickets != nullptr);
-    }
-    if (tickets) {
-        __syncthreads();                                       // red is free
-        if (last_arriver(tickets, b, nchunk, reinterpret_cast<int*>(red)))
-            for (int c = tid; c < C; c += 256) out[(size_t)b * C + c] = fold_chunks(part + (size_t)b * nchunk * C + c, nchunk, C) * scale;
+        *reinterpret_cast<float4*>(part + ((size_t)b * nchunk + chunk) * C + (g << 2)) = s;
     }
 }
 
@@ -189,8 +136,7 @@ __global__ __launch_bounds__(256) void chunk_fold_kernel(const float* __restrict
 // part[b][chunk][c] = sum of x[b][i][c] over the chunk's rows (first stage of a per-cloud column sum)
 template <typename FT>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const FT* __restrict__ x, int N, int C,
-                                                             float* __restrict__ part, int nchunk, int rows,
-                                                             int* __restrict__ tickets = nullptr, float* __restrict__ out = nullptr) {
+                                                             float* __restrict__ part, int nchunk, int rows) {
     __shared__ float4 red[256];
     const int cq = C >> 2;
     const int tid = threadIdx.x;
@@ -206,12 +152,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const FT* __restric
     __syncthreads();
     if (rl == 0) {
         for (int l = 1; l < RL; ++l) { const float4 v = red[l * cq + g]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
-        store_wt4(part + ((size_t)b * nchunk + chunk) * C + (g << 2), s, tickets != nullptr);
-    }
-    if (tickets) {
-        __syncthreads();
-        if (last_arriver(tickets, b, nchunk, reinterpret_cast<int*>(red)))
-            for (int c = tid; c < C; c += 256) out[(size_t)b * C + c] = fold_chunks(part + (size_t)b * nchunk * C + c, nchunk, C);
+        *reinterpret_cast<float4*>(part + ((size_t)b * nchunk + chunk) * C + (g << 2)) = s;
     }
 }
 
@@ -219,8 +160,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const FT* __restric
 // gradient g^T xyz, gcn3d.py:85): part[b][chunk][slot][c], slot 0 = sum g, slot 1..3 = sum g * (x, y, z)
 template <typename FT>
 __global__ __launch_bounds__(256) void colsum_xyz_partial_kernel(const FT* __restrict__ x, const float* __restrict__ xyz, int N, int C,
-                                                                 float* __restrict__ part, int nchunk, int rows,
-                                                                 int* __restrict__ tickets = nullptr, float* __restrict__ out = nullptr) {
+                                                                 float* __restrict__ part, int nchunk, int rows) {
     __shared__ float4 red[4][256];
     const int cq = C >> 2;
     const int tid = threadIdx.x;
@@ -249,14 +189,8 @@ __global__ __launch_bounds__(256) void colsum_xyz_partial_kernel(const FT* __res
         for (int q = 0; q < 4; ++q) {
             float4 a = s[q];
             for (int l = 1; l < RL; ++l) { const float4 v = red[q][l * cq + g]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
-            store_wt4(part + (((size_t)b * nchunk + chunk) * 4 + q) * C + (g << 2), a, tickets != nullptr);
+            *reinterpret_cast<float4*>(part + (((size_t)b * nchunk + chunk) * 4 + q) * C + (g << 2)) = a;
         }
-    }
-    if (tickets) {
-        __syncthreads();
-        if (last_arriver(tickets, b, nchunk, reinterpret_cast<int*>(&red[0][0])))
-            for (int c = tid; c < 4 * C; c += 256)
-                out[(size_t)b * 4 * C + c] = fold_chunks(part + (size_t)b * nchunk * 4 * C + c, nchunk, 4 * C);
     }
 }
 
@@ -539,8 +473,7 @@ __global__ __launch_bounds__(256) void add_relu_bwd_kernel(const float* __restri
 }
 
 static int pick_scatter_cols(int Nsrc, int C) {
-    static const int cap = [] { const char* e = getenv("HSP_SCATTER_TC"); return e ? atoi(e) : 16; }();
-    for (int tc = cap; tc >= 4; tc >>= 1)
+    for (int tc = 16; tc >= 4; tc >>= 1)
         if (C % tc == 0 && (size_t)Nsrc * tc * 4 <= 144 * 1024) return tc;
     return 0;
 }
@@ -980,13 +913,7 @@ static int orl_global_fwd_impl(const FT* feat, const int32_t* idx, int B, int N,
     const int rows = chunk_rows(B, N, C);
     const int nchunk = (N + rows - 1) / rows;
     float* part = reinterpret_cast<float*>(ws);
-    if (g_tickets && B <= g_ntickets) {          // one launch: the last workgroup of a cloud folds it
-        hipLaunchKernelGGL(orl_partial_kernel<FT>, dim3(nchunk, B), dim3(256), 0, st, feat, idx, N, k, kstride, C, argmax, part, nchunk,
-                           rows, g_tickets, fg, 1.0f / (float)N);
-        return check_launch();
-    }
-    hipLaunchKernelGGL(orl_partial_kernel<FT>, dim3(nchunk, B), dim3(256), 0, st, feat, idx, N, k, kstride, C, argmax, part, nchunk, rows,
-                       (int*)nullptr, (float*)nullptr, 1.f);
+    hipLaunchKernelGGL(orl_partial_kernel<FT>, dim3(nchunk, B), dim3(256), 0, st, feat, idx, N, k, kstride, C, argmax, part, nchunk, rows);
     hipLaunchKernelGGL(chunk_fold_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, B, nchunk, C, 1.0f / (float)N, fg);
     return check_launch();
 }
@@ -1008,26 +935,12 @@ extern "C" int hsp_colsum_rows(const float* x, int B, int N, int C, float* out, 
     const int rows = chunk_rows(B, N, C);
     const int nchunk = (N + rows - 1) / rows;
     float* part = reinterpret_cast<float*>(ws);
-    if (colsum_vec4(C) && g_tickets && B <= g_ntickets) {
-        hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(nchunk, B), dim3(256), 0, st, x, N, C, part, nchunk, rows, g_tickets, out);
-        return check_launch();
-    }
     if (colsum_vec4(C))
-        hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(nchunk, B), dim3(256), 0, st, x, N, C, part, nchunk, rows, (int*)nullptr,
-                           (float*)nullptr);
+        hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(nchunk, B), dim3(256), 0, st, x, N, C, part, nchunk, rows);
     else
         hipLaunchKernelGGL(colsum_partial_scalar_kernel, dim3(nchunk, B), dim3(256), 0, st, x, N, C, part, nchunk, rows);
     hipLaunchKernelGGL(chunk_fold_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, B, nchunk, C, 1.0f, out);
     return check_launch();
-}
-
-/* the zero-initialised ticket words (one per cloud, n >= the largest batch) that let the two-stage per-cloud reductions fold in
- * their first launch (the last workgroup of a cloud folds it); device memory owned by the caller, zeroed ONCE -- every launch
- * leaves the words at zero.  Not set (or n smaller than the batch): the reductions keep their second launch. */
-extern "C" int hsp_set_ticket_buffer(int* tickets, int n) {
-    g_tickets = (tickets && n > 0) ? tickets : nullptr;
-    g_ntickets = g_tickets ? n : 0;
-    return HSP_OK;
 }
 
 /* out4 (B, 4, C): slot 0 = sum_i x[b][i][:] (the colsum of hsp_colsum_rows), slots 1..3 = sum_i x[b][i][:] * xyz[b][i][0..2]
@@ -1043,13 +956,7 @@ static int colsum_rows_xyz_impl(const FT* x, const float* xyz, int B, int N, int
     const int rows = chunk_rows(B, N, C);
     const int nchunk = (N + rows - 1) / rows;
     float* part = reinterpret_cast<float*>(ws);
-    if (g_tickets && B <= g_ntickets) {
-        hipLaunchKernelGGL(colsum_xyz_partial_kernel<FT>, dim3(nchunk, B), dim3(256), 0, st, x, xyz, N, C, part, nchunk, rows, g_tickets,
-                           out4);
-        return check_launch();
-    }
-    hipLaunchKernelGGL(colsum_xyz_partial_kernel<FT>, dim3(nchunk, B), dim3(256), 0, st, x, xyz, N, C, part, nchunk, rows, (int*)nullptr,
-                       (float*)nullptr);
+    hipLaunchKernelGGL(colsum_xyz_partial_kernel<FT>, dim3(nchunk, B), dim3(256), 0, st, x, xyz, N, C, part, nchunk, rows);
     hipLaunchKernelGGL(chunk_fold_kernel, dim3((B * 4 * C + 255) / 256), dim3(256), 0, st, part, B, nchunk, 4 * C, 1.0f, out4);
     return check_launch();
 }
@@ -1071,8 +978,7 @@ extern "C" int hsp_colsum_rows_bf16(const hsp_bf16_t* x, int B, int N, int C, fl
     const int rows = chunk_rows(B, N, C);
     const int nchunk = (N + rows - 1) / rows;
     float* part = reinterpret_cast<float*>(ws);
-    hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, dim3(nchunk, B), dim3(256), 0, st, x, N, C, part, nchunk, rows, (int*)nullptr,
-                       (float*)nullptr);
+    hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, dim3(nchunk, B), dim3(256), 0, st, x, N, C, part, nchunk, rows);
     hipLaunchKernelGGL(chunk_fold_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, B, nchunk, C, 1.0f, out);
     return check_launch();
 }

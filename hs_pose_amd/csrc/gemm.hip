@@ -586,11 +586,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const float* __restric
 }
 
 static bool wgrad_x3_ok(const void* A, int lda, const void* B, int ldb, int M, int N) {
-    static const bool off = [] { const char* e = getenv("HSP_WGRAD_X3"); return e && e[0] == '0'; }();
     // (>= 4 output tiles: a single 128 x 128 tile leaves the K slices as the only parallelism -- 65 workgroups at K = 16448 --
     // and the fp32 kernel's 4-slices-per-workgroup form is faster there: 9.8 vs 18.3 us)
     // (ragged M: the last column quad of A is read whole, so its rows must reach ceil4(M))
-    return !off && (N & 127) == 0 && ((M + 127) >> 7) * (N >> 7) >= 4 && (lda & 3) == 0 && (ldb & 3) == 0 && lda >= ((M + 3) & ~3) &&
+    return (N & 127) == 0 && ((M + 127) >> 7) * (N >> 7) >= 4 && (lda & 3) == 0 && (ldb & 3) == 0 && lda >= ((M + 3) & ~3) &&
            ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(B)) & 15) == 0;
 }
 // shapes only the x3 form takes: M not a multiple of 64 (the heads' K = 1286 / 1289 / 771 first layers)
@@ -618,8 +617,7 @@ static int wgrad_bf16_pick(int M, int N, int K, int* kslice) {
     return (K + ks - 1) / ks;
 }
 static bool wgrad_bf16_mfma_ok(const void* A, int lda, const void* B, int ldb, int M, int N) {
-    static const bool off = [] { const char* e = getenv("HSP_WGRAD_BF16"); return e && e[0] == 'f'; }();   // "fp32": the widening form
-    return !off && (M & 127) == 0 && (N & 127) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 &&
+    return (M & 127) == 0 && (N & 127) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 &&
            ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(B)) & 15) == 0;
 }
 
@@ -808,9 +806,8 @@ extern "C" int hsp_wgrad_partial_pair_f32(const float* A0, int lda0, const float
             // workspace rule is unchanged: fewer partials than it allows for).
             constexpr int G = 4 * WG_UNROLL;
             const int t0 = (M0 >> 6) * (N0 >> 6), t1 = (M1 >> 6) * (N1 >> 6);
-            static const bool fit_off = [] { const char* e = getenv("HSP_WGRAD_PAIR_FIT"); return e && e[0] == '0'; }();
             int total = t0 * (sk0 / 4) + t1 * (sk1 / 4);
-            for (int it = 0; it < 8 && !fit_off && total > 2 * HSP_NUM_CU && sk0 > 8 && sk1 > 8; ++it) {
+            for (int it = 0; it < 8 && total > 2 * HSP_NUM_CU && sk0 > 8 && sk1 > 8; ++it) {
                 const double f = (double)(2 * HSP_NUM_CU) / total;
                 auto shrink = [&](int K, int& sk, int& ks) {
                     int want = (int)(sk * f) & ~3;

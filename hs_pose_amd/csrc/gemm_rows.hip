@@ -477,7 +477,6 @@ static int launch_cfg(const GemmRowsArgs& a, int lb1, int lb2, float* a_ws, size
     const int per_cu = (int)((160 * 1024) / lds) > 4 ? 4 : (int)((160 * 1024) / lds);
     long long nb = (long long)HSP_NUM_CU * per_cu;
     const long long tiles = (long long)g.tiles_m * g.tiles_n * g.nsplit;
-    if (const char* e = getenv("HSP_GEMM_PERSIST")) { if (e[0] == '0') nb = tiles; }        // profiling override: one tile per workgroup
     if (nb > tiles) nb = tiles;
     nb = (nb + 7) / 8 * 8;
     const dim3 grid((unsigned)nb), block(256);
@@ -582,7 +581,6 @@ static int gemm_rows_dispatch(const void* A1, int lda1, const void* B1, int ldb1
     hipStream_t st = as_stream(stream);
     const int TTall = (K1 + 128 / ES - 1) / (128 / ES) + (two ? (K2 + 128 / ES - 1) / (128 / ES) : 0);
     bool small = prefer_small_tile(M, N, TTall);
-    if (const char* e = getenv("HSP_GEMM_TILE")) small = e[0] == 's' ? true : e[0] == 'l' ? false : small;   // profiling override
     const int mode = al == 16 ? 1 : al == 8 ? 2 : 0;           // staging load width
     g.nsplit = 1;
     if (small) return launch_mode<T, 1, 1>(g, lb1, lb2, mode, reinterpret_cast<float*>(ws), ws ? ws_bytes : 0, st);

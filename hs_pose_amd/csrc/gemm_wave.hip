@@ -224,7 +224,6 @@ __device__ __forceinline__ void gw_tiles(const GwArgs& g, const GwRsrc& rs, int 
         int row0, col0;
         tile_of(i, row0, col0);
         const int colb = col0 + cs * li;
-        constexpr int TR = 32 * RB;
         const int c0 = row0 / g.rpc, nb = (c0 + 1) * g.rpc;
         float bv[NCB], w3v[NCB][3], cbv[2][NCB];
         const int c1 = min(c0 + 1, (g.M - 1) / g.rpc);

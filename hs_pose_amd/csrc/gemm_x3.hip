@@ -73,7 +73,8 @@ __device__ __forceinline__ void x3_split8(const float (&x)[8], u32x4& hi, u32x4&
 
 // WM: 32-row blocks per wave along M (tile = 64 WM x 128).  TWO: second source.  EPI: bit 0 bias, bit 1 residual, bit 2
 // per-cloud bias (template parameters: a load inside a run-time branch costs a drained queue at the join)
-// PA > 0: short-K form, all activation blocks (<= PA) fetched up front.
+// (measured and removed in round 3: a short-K form that fetched every activation block of a tile up front -- 1.93 vs 1.92 ms per
+// step: the tile's time is the weight planes' round trips as much as the activations')
 template <int WM, bool TWO, int EPI, int PA = 0>
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
     constexpr int BM = 64 * WM;
@@ -229,28 +230,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
                                                                             __builtin_bit_cast(bf16x8, fb[y][SB[q]]), acc[x][y], 0, 0, 0);
         }
     };
-    if constexpr (PA > 0) {
-        // SHORT K (at most PA blocks, e.g. the layer's out / gF products: K = 128 ... 256 on 257 workgroups -- about one per CU,
-        // nothing to overlap with): every activation load of the tile is issued before the first block, so the tile pays ONE
-        // HBM round trip instead of one per block; the weight planes (L2) stay one block ahead.  Loads past the last block
-        // re-read it (no branch around a load).
-        float ava[PA][NAU][8];
-#pragma unroll
-        for (int tt = 0; tt < PA; ++tt) fetchA(ava[tt], min(t_begin + tt, t_end - 1));
-        fetchB(t_begin);
-#pragma unroll
-        for (int tt = 0; tt < PA; ++tt) {
-            const int t = t_begin + tt;
-            if (t < t_end) {
-                __syncthreads();
-                stashA(ava[tt], t);
-                stashB();
-                __syncthreads();
-            }
-            fetchB(min(t + 1, t_end - 1));
-            if (t < t_end) mma();
-        }
-    } else {
+    {
         float av[NAU][8];
         if (t_begin < t_end) { fetchA(av, t_begin); fetchB(t_begin); }
         for (int t = t_begin; t < t_end; ++t) {
@@ -442,8 +422,8 @@ __global__ __launch_bounds__(256) void split_params_x3_kernel(const HspSplitDesc
 }
 
 static int x3_pick_split(long long tiles, int TT) {
-    // workgroups aimed at: 2 per CU (HSP_X3_SPLIT_TARGET: measured 3 and 4 per CU -- more, shorter K slices and a deeper fold)
-    static const int per_cu = [] { const char* e = getenv("HSP_X3_SPLIT_TARGET"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 8 ? v : 2; }();
+    // workgroups aimed at: 2 per CU (measured 3 and 4 per CU -- more, shorter K slices and a deeper fold: no faster)
+    constexpr int per_cu = 2;
     if (tiles >= 2 * HSP_NUM_CU || TT < 16) return 1;
     int ns = (int)((per_cu * HSP_NUM_CU + tiles - 1) / tiles);
     if (ns > TT / 8) ns = TT / 8;
@@ -455,8 +435,6 @@ static int x3_pick_split(long long tiles, int TT) {
 
 // tile height: 128 rows when that still gives every CU a tile (or K is short and the tile count is what fills the chip)
 static int x3_pick_wm(int M, int N) {
-    static const int force = [] { const char* e = getenv("HSP_X3_WM"); return e ? atoi(e) : 0; }();
-    if (force == 1 || force == 2) return force;
     const long long t128 = (long long)((M + 127) / 128) * ((N + X3_BN - 1) / X3_BN);
     return t128 >= 2 * HSP_NUM_CU ? 2 : 1;
 }
@@ -542,10 +520,6 @@ static int gemm_x3_impl(const float* A1, int lda1, const hsp_bf16_t* P1, int ldp
         else hipLaunchKernelGGL((gemm_x3_kernel<1, false, 9, 0>), grid, block, 3 * (size_t)(64 + X3_BN) * 64, st, g);
         return check_launch();
     }
-    // (measured, B=16 N=1028: 1.93 ms/step with the short-K form against 1.92 without -- the tile's time is the weight planes'
-    // round trips as much as the activations' -- so it is opt-in: HSP_X3_PA=1)
-    static const bool pa_on = [] { const char* e = getenv("HSP_X3_PA"); return e && e[0] == '1'; }();
-    const bool short_k = pa_on && wm == 1 && ns == 1 && TT <= 8;
 #define X3_K(WM_, TWO_, EPI_, PA_)                                                                                 \
     do {                                                                                                           \
         auto kern = gemm_x3_kernel<WM_, TWO_, EPI_, PA_>;                                                          \
@@ -567,7 +541,6 @@ static int gemm_x3_impl(const float* A1, int lda1, const hsp_bf16_t* P1, int ldp
         }                                                          \
     } while (0)
     if (wm == 2) X3_LAUNCH(2, 0);
-    else if (short_k) X3_LAUNCH(1, 8);
     else X3_LAUNCH(1, 0);
 #undef X3_LAUNCH
 #undef X3_K

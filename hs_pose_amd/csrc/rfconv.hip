@@ -339,115 +339,6 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_pipe_kernel(const float* __
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward, CHANNEL-SPLIT schedule (HS_layer only) for clouds whose fm does not fit an XCD's 4 MiB L2 (N = 1028, C = 128:
-// 4.2 MB fp32; N = 4096 bf16: 8.4 MB).  The neighbour gather re-reads every support row ~k times; when the cloud's fm
-// overflows L2 those re-reads go to MALL / HBM (measured 449 MB per launch against 166 MB algorithmic at N = 1028).
-// Here the C channels are walked in NSPLIT passes of C / NSPLIT channels x all S supports (a channel's S supports stay
-// together, so the mean over supports completes inside a pass): the gather working set of a pass is
-// N * S * (C / NSPLIT) elements (1.8 MB for both shapes above), L2-resident.  A pass has GH = S * C / (4 NSPLIT) float4
-// column groups, so a 256-thread workgroup takes PP = 256 / GH points at a time (2 at C = 128 fp32, 4 at bf16 / 4 passes).
-// Same arithmetic, same results bit for bit as rf_fwd_kernel (tests compare them).
-// dynamic LDS: PP * (S * C / NSPLIT + 5 k) floats
-// ------------------------------------------------------------------------------------------------
-template <bool WF, typename FT>
-__global__ __launch_bounds__(RF_THREADS) void rf_fwd_split_kernel(const float* __restrict__ xyz,
-                                                                  const int32_t* __restrict__ idx,
-                                                                  const float* __restrict__ dirs,
-                                                                  const FT* __restrict__ fm, int B, int N, int k,
-                                                                  int S, int C, int nsplit, FT* __restrict__ out,
-                                                                  uint16_t* __restrict__ argrow,
-                                                                  FT* __restrict__ fwin) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int SC = S * C;
-    const int CH = C / nsplit;                                 // channels per pass
-    const int G4 = CH >> 2;                                    // float4 groups per support in a pass
-    const int GH = S * G4;                                     // float4 groups per point in a pass
-    const int PP = RF_THREADS / GH;                            // points per iteration
-    float* smax = reinterpret_cast<float*>(smem);              // PP x (S*CH)
-    float4* sR = reinterpret_cast<float4*>(smax + PP * S * CH);   // PP x k
-    int* sIdx = reinterpret_cast<int*>(sR + PP * k);           // PP x k
-    const int tid = threadIdx.x;
-    const int slot = tid / GH, g = tid - slot * GH;            // point slot, group inside the pass
-    const bool active = slot < PP;
-    const int sp = g / G4, c4 = g - sp * G4;                   // support, float4 group inside the pass's channels
-    const int fstride = (S + 1) * C;
-    const float invS_div = (float)S;
-    const PointIter it(B);
-    for (int b = it.b0; b < B; b += it.bstep) {
-        const float* xb = xyz + (size_t)b * N * 3;
-        for (int pass = 0; pass < nsplit; ++pass) {
-            const int j = sp * C + pass * CH + c4 * 4;             // column of the S*C axis
-            float4 d0, d1, d2;
-            load_dirs_normed(dirs, SC, active ? j : 0, d0, d1, d2);
-            const FT* fsup = fm + (size_t)b * N * fstride + C + j;
-            for (int i0 = it.i0 * PP; i0 < N; i0 += it.istep * PP) {
-                __syncthreads();                                   // previous iteration's LDS reads are done
-                if (tid < PP * k) {
-                    const int ps = tid / k, n = tid - ps * k;
-                    const int i = min(i0 + ps, N - 1);
-                    const int m = idx[((size_t)b * N + i) * k + n];
-                    sIdx[tid] = m;
-                    const float3 r = unit_dir(xb[i * 3], xb[i * 3 + 1], xb[i * 3 + 2], xb[m * 3], xb[m * 3 + 1], xb[m * 3 + 2]);
-                    sR[tid] = make_float4(r.x, r.y, r.z, 0.f);
-                }
-                __syncthreads();
-                const int i = i0 + slot;
-                if (active && i < N) {
-                    const size_t pt = (size_t)b * N + i;
-                    const float4* rr = sR + slot * k;
-                    const int* ii = sIdx + slot * k;
-                    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-                    int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-                    float4 wf = make_float4(1.f, 1.f, 1.f, 1.f);
-#pragma unroll 4
-                    for (int n = 0; n < k; ++n) {
-                        const float4 r = rr[n];
-                        float4 th;
-                        th.x = RF_RELU(__fmaf_rn(r.z, d2.x, __fmaf_rn(r.y, d1.x, mul_rn(r.x, d0.x))));
-                        th.y = RF_RELU(__fmaf_rn(r.z, d2.y, __fmaf_rn(r.y, d1.y, mul_rn(r.x, d0.y))));
-                        th.z = RF_RELU(__fmaf_rn(r.z, d2.z, __fmaf_rn(r.y, d1.z, mul_rn(r.x, d0.z))));
-                        th.w = RF_RELU(__fmaf_rn(r.z, d2.w, __fmaf_rn(r.y, d1.w, mul_rn(r.x, d0.w))));
-                        const float4 f = Feat<FT>::ld4(fsup + (size_t)ii[n] * fstride);
-                        th.x = mul_rn(th.x, f.x); th.y = mul_rn(th.y, f.y);
-                        th.z = mul_rn(th.z, f.z); th.w = mul_rn(th.w, f.w);
-                        if (WF) {
-                            if (th.x > best.x) wf.x = f.x;
-                            if (th.y > best.y) wf.y = f.y;
-                            if (th.z > best.z) wf.z = f.z;
-                            if (th.w > best.w) wf.w = f.w;
-                        }
-                        if (th.x > best.x) { best.x = th.x; a0 = n; }
-                        if (th.y > best.y) { best.y = th.y; a1 = n; }
-                        if (th.z > best.z) { best.z = th.z; a2 = n; }
-                        if (th.w > best.w) { best.w = th.w; a3 = n; }
-                    }
-                    if (WF) Feat<FT>::st4_nt(fwin + pt * SC + j, wf);
-                    *reinterpret_cast<float4*>(smax + (slot * S + sp) * CH + c4 * 4) = best;
-                    const unsigned lo = (unsigned)ii[a0] | ((unsigned)ii[a1] << 16);
-                    const unsigned hi = (unsigned)ii[a2] | ((unsigned)ii[a3] << 16);
-                    unsigned* ap = reinterpret_cast<unsigned*>(argrow + pt * SC + j);
-                    __builtin_nontemporal_store(lo, ap); __builtin_nontemporal_store(hi, ap + 1);
-                }
-                __syncthreads();
-                for (int e = tid; e < PP * CH; e += RF_THREADS) {
-                    const int ps = e / CH, c = e - ps * CH;
-                    const int ip = i0 + ps;
-                    if (ip < N) {
-                        const size_t pt = (size_t)b * N + ip;
-                        const float* sm = smax + ps * S * CH + c;
-                        float acc = sm[0];
-                        for (int q = 1; q < S; ++q) acc = add_rn(acc, sm[q * CH]);
-                        float v = __fdiv_rn(acc, invS_div);
-                        v = add_rn(Feat<FT>::ld(fm + pt * fstride + pass * CH + c), v);
-                        Feat<FT>::st_nt(out + pt * C + pass * CH + c, v);
-                    }
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // backward of HS_layer.graph_conv, GATHER form (no atomics, fixed summation order).
 // A workgroup owns one SOURCE row m at a time and walks the reverse-edge list of m (csr.hip):
 // for every edge e = i*k + n with idx[b,i,n] == m and every column j
@@ -806,46 +697,22 @@ static int rf_fwd(const float* xyz, const int32_t* idx, const float* dirs, const
     int rc = rf_check(xyz, idx, dirs, B, N, k, S, C);
     if (rc) return rc;
     if (!out || !argrow || (!SURFACE && !fm)) return HSP_ERR_BAD_ARG;
-    if constexpr (!SURFACE) {
-        // channel-split schedule once a cloud's fm outgrows an XCD's L2 (rf_fwd_split_kernel); HSP_RF_SPLIT=0/1 overrides
-        const size_t cloud = (size_t)N * (S + 1) * C * sizeof(FT);
-        int nsplit = 1;
-        while (nsplit < 8 && cloud / nsplit > ((size_t)5 << 19) && C % (8 * nsplit) == 0 && S * (C / (4 * 2 * nsplit)) >= 32)
-            nsplit *= 2;
-        // measured (round 2): the split schedule is bit-identical but SLOWER (121 vs 101 us at B=16 N=1028 fp32, 2.12 vs 1.81 ms
-        // at B=64 N=4096 bf16) -- the forward is bound by VALU work per gathered element (~45 instructions per float4 and
-        // neighbour), not by L2 misses -- so it stays opt-in (HSP_RF_SPLIT=1) and the one-pass kernel is the default.
-        // (Also measured and reverted: the theta chain on v_pk_mul_f32 / v_pk_fma_f32 with the winner's support value fetched
-        // after the loop: 111 vs 101 us -- packed fp32 issues slower than the two scalar ops it replaces here.)
-        { const char* e = getenv("HSP_RF_SPLIT"); if (!e || e[0] != '1') nsplit = 1; }
-        if (nsplit > 1 && B >= HSP_NUM_XCD) {
-            const int GH = S * (C / (4 * nsplit)), PP = RF_THREADS / GH;
-            const size_t lds2 = (size_t)PP * (S * (C / nsplit) + 5 * k) * 4;
-            const int grid2 = persistent_blocks(((long long)B * N + PP - 1) / PP, 8);
-            if (fwin)
-                hipLaunchKernelGGL((rf_fwd_split_kernel<true, FT>), dim3(grid2), dim3(RF_THREADS), lds2, as_stream(stream), xyz,
-                                   idx, dirs, fm, B, N, k, S, C, nsplit, out, argrow, fwin);
-            else
-                hipLaunchKernelGGL((rf_fwd_split_kernel<false, FT>), dim3(grid2), dim3(RF_THREADS), lds2, as_stream(stream), xyz,
-                                   idx, dirs, fm, B, N, k, S, C, nsplit, out, argrow, fwin);
-            return check_launch();
-        }
-    }
+    // (A channel-split schedule -- C / 2 channels per pass so that a cloud's fm slice stays in the XCD's L2 -- halves the fabric
+    // reads (FETCH_SIZE 252 -> 121 MB at B=16 N=1028) but the kernel is VALU-issue-bound: 121 vs 101 us in round 2, and again
+    // slower inside the matrix-core form of round 4, tools/experiments/.  Removed.)
     const size_t lds = (size_t)(S * C + 5 * k) * 4;
     if (lds > 64 * 1024) return HSP_ERR_UNSUPPORTED;
-    static const int bpc_env = [] { const char* e = getenv("HSP_RF_BPC"); return e ? atoi(e) : 0; }();
     // workgroups per CU: 8 for the large layers; small clouds amortise a workgroup's prologue (direction loads + normalisation)
     // over more points with 6 / 4 (measured at B = 16: N = 257 55.3 -> 52.4 us, N = 64 24.3 -> 23.6 us)
     const long long npts = (long long)B * N;
-    const int grid = persistent_blocks(npts, bpc_env > 0 ? bpc_env : npts < 2048 ? 4 : npts < 8192 ? 6 : 8);
+    const int grid = persistent_blocks(npts, npts < 2048 ? 4 : npts < 8192 ? 6 : 8);
     const int nch = ((S * C >> 2) + RF_THREADS - 1) / RF_THREADS;
     if (nch > 4) return HSP_ERR_UNSUPPORTED;              // S*C <= 4096
     {
         // the pipelined schedule (three points' phases per barrier interval) wherever the last slot leaves k threads free
-        static const bool pipe_off = [] { const char* e = getenv("HSP_RF_PIPE"); return e && e[0] == '0'; }();
         const int spare0 = (S * C >> 2) - (nch - 1) * RF_THREADS;
         const size_t lds_pipe = 2 * (size_t)(S * C + 6 * k) * 4;
-        if (!pipe_off && spare0 + k <= RF_THREADS && lds_pipe <= 64 * 1024) {
+        if (spare0 + k <= RF_THREADS && lds_pipe <= 64 * 1024) {
 #define RF_PIPE_LAUNCH(NCH)                                                                                        \
     if (!SURFACE && fwin)                                                                                          \
         hipLaunchKernelGGL((rf_fwd_pipe_kernel<SURFACE, NCH, !SURFACE, FT>), dim3(grid), dim3(RF_THREADS), lds_pipe, \
@@ -891,14 +758,10 @@ extern "C" int hsp_rf_surface_fwd_bf16(const float* xyz, const int32_t* idx, con
 
 // the forward's fwin stream pays off once a cloud's fm no longer stays in its XCD's L2 next to the other streams
 // (round 3: always.  With the tile kernel's adds in fixed point the 4-byte gathers of the winners' support values were what
-// the small clouds' backward waited on: 52.7 -> 28.1 us at N = 257, C = 256 for +5 us in the forward.  HSP_RF_FWIN_MIN=<bytes
-// of a cloud's fm> restores a threshold.)
-static size_t rf_fwin_min_bytes() {
-    static const size_t v = [] { const char* e = getenv("HSP_RF_FWIN_MIN"); return e ? (size_t)atoll(e) : (size_t)0; }();
-    return v;
-}
+// the small clouds' backward waited on: 52.7 -> 28.1 us at N = 257, C = 256 for +5 us in the forward.)
 extern "C" int hsp_rf_conv_wants_fwin(int N, int S, int C) {
-    return (size_t)N * (S + 1) * C * sizeof(float) >= rf_fwin_min_bytes() ? 1 : 0;
+    (void)N; (void)S; (void)C;
+    return 1;
 }
 
 extern "C" int hsp_rf_conv_fwd(const float* xyz, const int32_t* idx, const float* dirs_n, const float* fm, int B,
@@ -973,8 +836,7 @@ extern "C" size_t hsp_rf_bwd_scatter_workspace_bytes(int B, int SC) {
 
 // dense clouds: two half-cloud tiles of 16 columns instead of one whole-cloud tile of <= 8 (see rf_bwd_tile_kernel)
 static bool rf_use_row_split(int N, int C, bool surface, int tc_whole) {
-    static const bool off = [] { const char* e = getenv("HSP_RF_ROWSPLIT"); return e && e[0] == '0'; }();
-    if (off || surface || tc_whole >= 16 || C % 16) return false;
+    if (surface || tc_whole >= 16 || C % 16) return false;
     const int nr = (N + 1) / 2;
     return ((size_t)nr * 16 + 3 * (size_t)nr) * 4 <= 156u * 1024;
 }

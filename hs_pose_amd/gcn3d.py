@@ -126,7 +126,9 @@ def _orl_fused(feature, vertices, neighbor_num, conv2_weight):
     C = feature.shape[-1]
     w = conv2_weight.squeeze(-1)                       # (C, 2C)
     fg = ops.orl_global(feature, _xyz_knn(vertices, neighbor_num), neighbor_num)   # (B,C)
-    return feature + F.linear(feature, w[:, :C]) + F.linear(fg, w[:, C:]).unsqueeze(1)
+    b, n, _ = feature.shape
+    lin = ops.linear_rows(feature.reshape(b * n, C), w[:, :C]).view(b, n, C)
+    return feature + lin + ops.linear_rows(fg, w[:, C:]).unsqueeze(1)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -222,7 +224,7 @@ class HS_layer(nn.Module):
     def graph_conv(self, neighbor_index, feature_map, vertices, neighbor_num):
         """reference :158-181 with the gather, theta product, max and mean fused into one kernel."""
         bs, n, cin = feature_map.shape
-        fm = torch.addmm(self.bias, feature_map.reshape(bs * n, cin), self.weights).view(bs, n, -1)
+        fm = ops.linear_rows(feature_map.reshape(bs * n, cin), self.weights.t().contiguous(), self.bias).view(bs, n, -1)
         return ops.rf_conv(vertices, neighbor_index.to(torch.int32), self.directions, fm, self.support_num)
 
     def ORL_forward(self, feature_fuse, vertices, neighbor_num):

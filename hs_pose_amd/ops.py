@@ -17,7 +17,6 @@ _vp = ctypes.c_void_p
 # reverse-edge index (fixed summation order, bit-reproducible gradients) instead of the faster
 # column-tile LDS scatter, whose fp32 LDS adds are order-dependent in the last bits.
 DETERMINISTIC = os.environ.get("HSP_DETERMINISTIC", "0") == "1"
-STEP_FOLDS = os.environ.get("HSP_STEP_FOLDS", "1") != "0"     # ops.StepFolds: one fold launch per backward pass (0: a launch per fold)
 
 
 def _p(t):
@@ -439,18 +438,11 @@ def orl_global(feat, idx, k):
 #             gX = g Wste + gfm W^T ; gWste = g^T X
 # ------------------------------------------------------------------------------------------------
 
-_wgrad_choice = {}          # (M, N, K, colsum) -> "custom" | "library", measured at first use
-# custom (default) | auto | library.  "auto" times both forms once per shape at first use; its verdicts vary from run to run for
-# the small shapes (a first-use timing of a 10 us kernel) and the library form it then sometimes keeps -- a split-K GEMM, its
-# reduce kernel and a strided copy -- measured 29 us in the step where the hand-written kernel takes 10-12 us
-WGRAD_MODE = os.environ.get("HSP_WGRAD", "custom")
-
-
-def _wgrad_library(A2, B2, out, colsum):
-    if out.is_contiguous():
-        torch.mm(A2.t(), B2, out=out)
-    else:
-        out.copy_(A2.t() @ B2)
+def _wgrad_fallback(A2, B2, out, colsum):
+    """A2^T B2 for the shapes the split-K kernels do not take (an output dimension that is no multiple of 64 and too small for
+    the ragged form, e.g. a 3-wide coordinate block): the general tile kernel on a transposed copy of A2"""
+    res = gemm_rows(A2.t().contiguous(), B2 if B2.stride(1) == 1 else B2.contiguous(), nn1=True)
+    out.copy_(res)
     if not colsum:
         return out
     if B2.is_contiguous():                                   # two-stage kernel: no ATen multi-block reduction
@@ -516,8 +508,7 @@ class StepFolds:
     def __enter__(self):
         if StepFolds.current is not None:
             raise HspError("StepFolds: scopes do not nest")
-        if STEP_FOLDS:                    # (HSP_STEP_FOLDS=0: the scope is inert, every fold stays its own launch -- the A/B knob)
-            StepFolds.current = self
+        StepFolds.current = self
         return self
 
     def __exit__(self, *exc):
@@ -586,52 +577,17 @@ def _wgrad_custom(A2, B2, out, colsum):
     return (out, cs) if colsum else out
 
 
-def _time_us(fn, reps=5):
-    fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return 1e3 * e0.elapsed_time(e1) / reps
-
-
 def wgrad(A2, B2, out=None, colsum=False):
     """A2^T @ B2 for point-row matrices A2 (K,M), B2 (K,N) (rows may be strided views of wider tensors)
-    -> (M,N) [+ column sums of B2 = the bias gradient]: the parameter-gradient GEMM.  Two implementations:
-    the split-K fp32-MFMA kernel of csrc/gemm.hip (column sum fused, strided output, bit-reproducible) and
-    the BLAS library through torch.  ``HSP_WGRAD=auto`` (default) times both once per shape, outside any
-    graph capture, and keeps the faster; shapes the kernel does not cover (M or N not a multiple of 64,
-    e.g. the 3-wide xyz STE) always go to the library."""
+    -> (M,N) [+ column sums of B2 = the bias gradient]: the parameter-gradient GEMM on the split-K kernels of csrc/gemm.hip
+    (column sum fused, strided output, bit-reproducible); shapes they do not cover go to the general tile kernel."""
     K, M = A2.shape
     N = B2.shape[1]
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=A2.device)
-    if _wgrad_ragged_ok(A2, B2, out) and WGRAD_MODE != "library":
-        return _wgrad_custom(A2, B2, out, colsum)               # (only the x3 kernel takes a ragged M; no library twin is timed)
-    ok = (M % 64 == 0 and N % 64 == 0 and A2.stride(1) == 1 and B2.stride(1) == 1 and out.stride(1) == 1
-          and A2.stride(0) % 2 == 0 and B2.stride(0) % 2 == 0 and A2.dtype == torch.float32 and A2.is_cuda)
-    if not ok or WGRAD_MODE == "library":
-        return _wgrad_library(A2, B2, out, colsum)
-    if WGRAD_MODE == "custom" or GEMM_MODE == "own":
+    if _wgrad_ragged_ok(A2, B2, out) or _wgrad_ok(A2, B2, out):
         return _wgrad_custom(A2, B2, out, colsum)
-    key = (M, N, K, bool(colsum))
-    choice = _wgrad_choice.get(key)
-    if choice is None:
-        if torch.cuda.is_current_stream_capturing() or _timer is not None:
-            choice = "custom"                       # cannot time here; decided on a later eager call
-        else:
-            held, WgradBatch.current = WgradBatch.current, None      # time the complete op, not the batched half
-            held_sf, StepFolds.current = StepFolds.current, None
-            try:
-                t_c = _time_us(lambda: _wgrad_custom(A2, B2, out, colsum))
-                t_l = _time_us(lambda: _wgrad_library(A2, B2, out, colsum))
-            finally:
-                WgradBatch.current, StepFolds.current = held, held_sf
-            choice = _wgrad_choice[key] = "custom" if t_c <= t_l else "library"
-    return _wgrad_custom(A2, B2, out, colsum) if choice == "custom" else _wgrad_library(A2, B2, out, colsum)
+    return _wgrad_fallback(A2, B2, out, colsum)
 
 
 def _wgrad_ragged_ok(A2, B2, out):
@@ -640,7 +596,7 @@ def _wgrad_ragged_ok(A2, B2, out):
     (``assemble_feat`` / ``cat_rows_pitched`` lay them out so), N a multiple of 128, own-GEMM mode"""
     K, M = A2.shape
     N = B2.shape[1]
-    return (GEMM_MODE == "own" and os.environ.get("HSP_WGRAD_X3", "1") != "0" and M % 64 != 0 and M >= 128 and N % 128 == 0
+    return (GEMM_MODE == "own" and M % 64 != 0 and M >= 128 and N % 128 == 0
             and -(-M // 128) * (N // 128) >= 4 and A2.dtype == torch.float32 and B2.dtype == torch.float32 and A2.is_cuda
             and A2.stride(1) == 1 and B2.stride(1) == 1 and out.stride(1) == 1 and A2.stride(0) % 4 == 0 and B2.stride(0) % 4 == 0
             and A2.stride(0) >= (M + 3) // 4 * 4 and A2.data_ptr() % 16 == 0 and B2.data_ptr() % 16 == 0)
@@ -658,12 +614,7 @@ def wgrad_pair(A0, B0, out0, A1, B1, out1):
     hand-written kernel takes (the two parameter gradients of an HS layer that depend only on the incoming gradient: g^T F and
     g^T X -- each alone leaves most of the chip idle); otherwise two ``wgrad`` calls."""
     batch = WgradBatch.current
-
-    def custom(A2, B2):
-        K, M = A2.shape
-        return WGRAD_MODE == "custom" or GEMM_MODE == "own" or _wgrad_choice.get((M, B2.shape[1], K, False)) == "custom"
-    if (batch is None or WGRAD_MODE == "library" or not _wgrad_ok(A0, B0, out0) or not _wgrad_ok(A1, B1, out1)
-            or not custom(A0, B0) or not custom(A1, B1)):
+    if batch is None or not _wgrad_ok(A0, B0, out0) or not _wgrad_ok(A1, B1, out1):
         wgrad(A0, B0, out=out0)
         wgrad(A1, B1, out=out1)
         return
@@ -783,11 +734,12 @@ class X3Planes:
     another matrix while its entry lives; the registry -- tables, planes and references -- goes away with the network.  A table
     that was replaced (a matrix registered later) is parked, not freed: a captured hipGraph may still point to it."""
 
-    def __init__(self):
-        self.entries = {}            # key -> dict(src (kept alive), planes, N, K, kp, transpose)
+    def __init__(self, max_entries=0):
+        self.entries = {}            # key -> dict(src (kept alive), planes, N, K, kp, transpose, ver: src._version at the split)
         self.table = None            # device table of every entry (rebuilt when an entry is added)
         self.total_tiles = 0
         self._old_tables = []
+        self.max_entries = max_entries
 
     @staticmethod
     def _key(W, transpose):
@@ -805,12 +757,19 @@ class X3Planes:
             N, K = (W.shape[1], W.shape[0]) if transpose else (W.shape[0], W.shape[1])
             kp = (K + 31) // 32 * 32
             e = dict(src=W.detach(), planes=torch.zeros(3, N, kp, dtype=torch.bfloat16, device=W.device), N=N, K=K, kp=kp,
-                     transpose=bool(transpose))
+                     transpose=bool(transpose), ver=W._version)
+            if self.max_entries and len(self.entries) >= self.max_entries:      # the process-wide registry of ad-hoc callers:
+                self.entries.pop(next(iter(self.entries)))                      # oldest out (a network's own registry is unbounded)
             self.entries[k_] = e
             self._split([e])                                   # this matrix now ...
             if self.table is not None:
                 self._old_tables.append(self.table)
             self.table, self.total_tiles = self._table_of(list(self.entries.values()))   # ... and the table of all for refresh()
+        elif e["ver"] != e["src"]._version and not torch.cuda.is_current_stream_capturing():
+            # the weights moved in place (optimizer.step, load_state_dict) since these planes were cut and nobody called
+            # refresh(): a stand-alone module / a direct ops.linear_rows caller.  Re-split this matrix now.
+            self._split([e])
+            e["ver"] = e["src"]._version
         return e["planes"], e["kp"], e["N"] * e["kp"]
 
     def _table_of(self, ents):
@@ -837,9 +796,11 @@ class X3Planes:
         ents = list(self.entries.values())
         _run("hsp_split_params_x3", (_p(self.table), len(ents), self.total_tiles, _stream()), key=f"n{len(ents)}",
              abytes=sum(10 * e["N"] * e["K"] for e in ents))
+        for e in ents:
+            e["ver"] = e["src"]._version
 
 
-x3_planes = X3Planes()               # the CURRENT registry (a process-wide one until a network installs its own: x3_scope)
+x3_planes = X3Planes(max_entries=256)   # the CURRENT registry (a process-wide one until a network installs its own: x3_scope)
 
 
 class x3_scope:
@@ -859,8 +820,7 @@ class x3_scope:
         return False
 
 
-# HSP_GEMM_X3=0: the hand-written path stays on the fp32 matrix cores (gemm_wave / gemm_rows) everywhere
-GEMM_X3 = os.environ.get("HSP_GEMM_X3", "1") != "0"
+GEMM_X3 = True         # False (tools/gemm_gap.py, profiling): the products stay on the fp32 matrix cores (gemm_wave / gemm_rows)
 
 
 def x3_refresh():
@@ -909,7 +869,6 @@ def linear_bn_part_ok(x2, W, bias):
     (``hsp_gemm_x3_bias_bn_f32``)"""
     R, N = x2.shape[0], W.shape[0]
     return (GEMM_MODE == "own" and bias is not None and R >= 256 and x2.dtype == torch.float32 and N % 4 == 0 and 256 % (N // 4) == 0
-            and os.environ.get("HSP_BN_EPILOGUE", "1") != "0"
             and gemm_x3_ok(x2, W, None, None, bias, None, None, None, None, R, N) and lib().hsp_gemm_x3_bn_tiles(R, N) <= 512)
 
 
@@ -954,43 +913,15 @@ def gemm_x3(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=Non
 
 
 # ------------------------------------------------------------------------------------------------
-# dense per-point products of a layer.  HSP_GEMM = own (default) | library | auto.
-#   own:     hand-written kernels only -- csrc/gemm_x3.hip (fp32 products from exact three-way bf16 splits on the bf16 matrix
-#            cores) for every product it covers, csrc/gemm_wave.hip / gemm_rows.hip (fp32 matrix cores) for the rest, the
-#            small per-cloud kernels for the 16-row ORL products, csrc/gemm.hip for the parameter gradients.  No BLAS call.
-#   library: the BLAS library through torch (kept as the comparison figure of bench.py; round 3, B=16 N=1028: 1.93 ms / step
-#            with the TunableOp-selected Tensile kernels against 1.95 ms own)
-#   auto:    times both forms of a composite once per shape (outside any graph capture) and keeps the faster
-# bf16 rows always run on the hand-written kernels (ops_bf16.py).  ``gemm_choices()`` reports what "auto" picked.
+# dense per-point products of a layer: hand-written kernels only -- csrc/gemm_x3.hip (fp32 products from exact three-way bf16
+# splits on the bf16 matrix cores) for every product it covers, csrc/gemm_wave.hip / gemm_rows.hip (fp32 matrix cores) for the
+# rest and for the eval-mode forward, the small per-cloud kernels for the 16-row ORL products, csrc/gemm.hip for the parameter
+# gradients.  No BLAS-library call.  (The comparison against the tuned BLAS library that bench.py reports lives in
+# tools/library_gemm.py.)
 # ------------------------------------------------------------------------------------------------
-GEMM_MODE = os.environ.get("HSP_GEMM", "own")
-_gemm_choice = {}
-
-
-def gemm_choices():
-    """{composite[shape]: "own" | "library"} decided so far (bench.py prints the tally)"""
-    return dict(_gemm_choice)
-
-
-# composite families ("fm", "out", "gx", "nn", "nt": the key prefixes below) that take the own kernel even in library mode
-GEMM_OWN_FAMILIES = set(f for f in os.environ.get("HSP_GEMM_OWN", "").split(",") if f)
-
-
-def _pick(key, own_fn, lib_fn):
-    if GEMM_MODE == "own":
-        return own_fn()
-    if GEMM_MODE == "library":
-        return own_fn() if key.split("[")[0] in GEMM_OWN_FAMILIES else lib_fn()
-    choice = _gemm_choice.get(key)
-    if choice is None:
-        if torch.cuda.is_current_stream_capturing() or _timer is not None:
-            return own_fn()                                   # cannot time here; decided on a later eager call
-        t_own = _time_us(own_fn)
-        t_lib = _time_us(lib_fn)
-        # (isolated timings flatter the fused form slightly -- inside the step's graph the library's picks are warm -- so it
-        # has to win by a margin)
-        choice = _gemm_choice[key] = "own" if t_own <= 0.9 * t_lib else "library"
-    return own_fn() if choice == "own" else lib_fn()
+GEMM_MODE = "own"      # a constant of the product.  tools/library_gemm.py (bench.py's comparison figure, the tests' second
+                       # mode) swaps the composites below for BLAS-library calls and sets this to "library", which also
+                       # switches off the fusions that only the hand-written kernels offer.
 
 
 def _al16(t):
@@ -1036,11 +967,7 @@ def gemm_own(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=No
 
 def _fm_rows(X2, weights, bias, out=None):
     """fm = X W + b   (gcn3d.py:171)"""
-    R, Cin = X2.shape
-    # (the library form allocates its own result: addmm with out= and a broadcast bias takes a slower path in ATen)
-    return _pick(f"fm[R{R}K{Cin}N{weights.shape[1]}]",
-                 lambda: gemm_own(X2, weights, True, bias=bias, out=out),
-                 lambda: torch.addmm(bias, X2, weights) if out is None else torch.addmm(bias, X2, weights, out=out))
+    return gemm_own(X2, weights, True, bias=bias, out=out)
 
 
 def _layer_out_rows(x2, w_ste, F2, Wa, t2, out3, relu=False, bn_shift=None):
@@ -1055,63 +982,32 @@ def _layer_out_rows(x2, w_ste, F2, Wa, t2, out3, relu=False, bn_shift=None):
 
 
 def _layer_out_rows_plain(x2, w_ste, F2, Wa, t2, out3, relu=False):
-    """out = x Wste^T + F Wa^T + F + t[cloud]   (gcn3d.py:149,186,156): one fused launch, or GEMM + GEMM + residual pass"""
+    """out = x Wste^T + F Wa^T + F + t[cloud]   (gcn3d.py:149,186,156): one fused launch"""
     B, N, C = out3.shape
     out = out3.view(B * N, C)
-
-    def lib():
-        torch.mm(x2, w_ste.t(), out=out)
-        out.addmm_(F2, Wa.t())
-        _residual_bias(out3, F2.view(B, N, C), t2)
-        return torch.relu_(out3) if relu else out3
-    def own():
-        if x2.shape[1] == 3:                                  # HSlayer_surface: the K = 3 STE on raw coordinates rides in the epilogue
-            gemm_own(F2, Wa, False, resid=F2, cloud_bias=t2.contiguous(), rows_per_cloud=N, out=out, xyz3=x2,
-                     w3=w_ste.contiguous(), relu=relu)       # (... and so does the relu that follows conv_0)
-        else:
-            gemm_own(x2, w_ste, False, F2, Wa, False, resid=F2, cloud_bias=t2.contiguous(), rows_per_cloud=N, out=out)
-            if relu:
-                torch.relu_(out3)
-        return out3
-    return _pick(f"out[R{B * N}K{x2.shape[1]}+{C}N{C}]", own, lib)
+    if x2.shape[1] == 3:                                  # HSlayer_surface: the K = 3 STE on raw coordinates rides in the epilogue
+        gemm_own(F2, Wa, False, resid=F2, cloud_bias=t2.contiguous(), rows_per_cloud=N, out=out, xyz3=x2,
+                 w3=w_ste.contiguous(), relu=relu)       # (... and so does the relu that follows conv_0)
+    else:
+        gemm_own(x2, w_ste, False, F2, Wa, False, resid=F2, cloud_bias=t2.contiguous(), rows_per_cloud=N, out=out)
+        if relu:
+            torch.relu_(out3)
+    return out3
 
 
 def _mm_nn(g2, W, out=None, alpha=1.0):
     """alpha * (g @ W) for a row-strided (K,N) matrix W"""
-    R, K = g2.shape
-
-    def lib():
-        if out is None:
-            return torch.mm(g2, W) if alpha == 1.0 else _scaled_mm(g2, W, alpha)
-        if alpha == 1.0:
-            return torch.mm(g2, W, out=out)
-        return torch.addmm(out, g2, W, beta=0.0, alpha=alpha, out=out)
-    return _pick(f"nn[R{R}K{K}N{W.shape[1]}]", lambda: gemm_own(g2, W, True, out=out, alpha=alpha), lib)
+    return gemm_own(g2, W, True, out=out, alpha=alpha)
 
 
 def _mm_nt(x2, W, bias=None, out=None):
     """x @ W^T (+ bias) for a (N,K) weight"""
-    R, K = x2.shape
-
-    def lib():
-        if out is None:
-            return torch.addmm(bias, x2, W.t()) if bias is not None else torch.mm(x2, W.t())
-        if bias is not None:
-            return torch.addmm(bias, x2, W.t(), out=out)
-        return torch.mm(x2, W.t(), out=out)
-    return _pick(f"nt[R{R}K{K}N{W.shape[0]}{'b' if bias is not None else ''}]",
-                 lambda: gemm_own(x2, W, False, bias=bias, out=out), lib)
+    return gemm_own(x2, W, False, bias=bias, out=out)
 
 
 def _grad_in_rows(g2, w_ste, gfm2, weights, out):
     """gX = g Wste + gfm W^T   (input gradient of gcn3d.py:149 and :171)"""
-    R = g2.shape[0]
-
-    def lib():
-        torch.mm(g2, w_ste, out=out)
-        return out.addmm_(gfm2, weights.t())
-    return _pick(f"gx[R{R}K{g2.shape[1]}+{gfm2.shape[1]}N{out.shape[1]}]",
-                 lambda: gemm_own(g2, w_ste, True, gfm2, weights, False, out=out), lib)
+    return gemm_own(g2, w_ste, True, gfm2, weights, False, out=out)
 
 
 def small_rows(A, W, nn=False, out=None, alpha=1.0):
@@ -1126,37 +1022,22 @@ def small_rows(A, W, nn=False, out=None, alpha=1.0):
 
 
 def _tiny_tn(a, b, out, mom=None, gste=None):
-    """out = a^T b for per-cloud rows a (B,M), b (B,N) (B = 16): one library launch, or one small hand-written launch when no
-    library GEMM may run (HSP_GEMM=own)"""
-    if GEMM_MODE == "own":
-        B, Ma = a.shape
-        Cm = mom.shape[1] // 4 if mom is not None else 0
-        _run("hsp_small_outer_f32", (_p(a), _ld(a), _p(b), _ld(b), B, Ma, b.shape[1], _p(out), _ld(out),
-                                     _p(mom[:, Cm:]) if mom is not None else None, _ld(mom) if mom is not None else 0, Cm,
-                                     _p(gste), _stream()),
-             key=f"B{B}M{Ma}N{b.shape[1]}", abytes=4 * (B * (Ma + b.shape[1]) + Ma * b.shape[1]))
+    """out = a^T b for per-cloud rows a (B,M), b (B,N) (B = 16): one small launch (hsp_small_outer_f32); ``mom`` / ``gste``: the
+    surface layer's (C,3) STE gradient as a rider (the sum over the clouds of the coordinate moments of g)"""
+    B, Ma = a.shape
+    Cm = mom.shape[1] // 4 if mom is not None else 0
+    if B > 64:
+        # hsp_small_outer_f32 holds one row per lane (B <= 64 clouds).  Larger per-GPU batches: the general weight-gradient
+        # path for a^T b (any row count), the (C, 3) coordinate-moment rider as a plain column sum over the clouds
+        wgrad(a.contiguous(), b.contiguous(), out=out)
+        if mom is not None:
+            gste.copy_(mom[:, Cm:].sum(dim=0).view(3, Cm).t())
         return out
-    return torch.mm(a.t(), b, out=out)
-
-
-_tickets = None            # zeroed ticket words handed to libhsp (hsp_set_ticket_buffer): one buffer, one device, per process
-
-
-def _ensure_tickets(device):
-    """HSP_TICKET_FOLD=1 (opt-in): give libhsp its zero-initialised ticket words (once, outside any graph capture); the per-cloud
-    two-stage reductions then fold inside their first launch (the last workgroup of a cloud folds it).  Measured (round 3,
-    B=16 N=1028, ten folds per step): with agent-scope release / acquire fences +60 us per step (a release writes back the XCD's
-    whole dirty L2), fence-free with write-through partials + a ticket +20 us -- the in-kernel fold is the same dependent-load
-    chain as the 4.5 us fold launch, run by ONE workgroup per cloud at the kernel's tail, plus a drained queue in every
-    workgroup.  The separate launch stays the default."""
-    global _tickets
-    if _tickets is None:
-        if os.environ.get("HSP_TICKET_FOLD", "0") != "1" or torch.cuda.is_current_stream_capturing():
-            return
-        _tickets = torch.zeros(256, dtype=torch.int32, device=device)
-        lib().hsp_set_ticket_buffer(_tickets.data_ptr(), _tickets.numel())
-    elif _tickets.device != device:                        # a second device in this process: back to the two-launch form
-        lib().hsp_set_ticket_buffer(None, 0)
+    _run("hsp_small_outer_f32", (_p(a), _ld(a), _p(b), _ld(b), B, Ma, b.shape[1], _p(out), _ld(out),
+                                 _p(mom[:, Cm:]) if mom is not None else None, _ld(mom) if mom is not None else 0, Cm,
+                                 _p(gste), _stream()),
+         key=f"B{B}M{Ma}N{b.shape[1]}", abytes=4 * (B * (Ma + b.shape[1]) + Ma * b.shape[1]))
+    return out
 
 
 def _orl_fwd_raw(F3, idx_x, k):
@@ -1167,7 +1048,6 @@ def _orl_fwd_raw(F3, idx_x, k):
     L = lib()
     wsb = L.hsp_orl_workspace_bytes(B, N, C)
     ws = _ws(wsb, F3.device)
-    _ensure_tickets(F3.device)
     _run("hsp_orl_global_fwd", (_p(F3), _p(idx_x), B, N, k, idx_x.shape[2], C, _p(fg), _p(arg), _p(ws), wsb, _stream()),
          key=f"B{B}N{N}k{k}C{C}", abytes=B * N * (4 * C + 4 * k + C))
     return fg, arg
@@ -1189,7 +1069,6 @@ def colsum_rows(x3):
     L = lib()
     wsb = L.hsp_orl_workspace_bytes(B, N, C)
     ws = _ws(wsb, x3.device)
-    _ensure_tickets(x3.device)
     _run("hsp_colsum_rows", (_p(x3), B, N, C, _p(out), _p(ws), wsb, _stream()), key=f"B{B}N{N}C{C}", abytes=4 * B * N * C)
     return out
 
@@ -1201,7 +1080,6 @@ def colsum_rows_xyz(g, xyz):
     mom = torch.empty(B, 4 * C, dtype=torch.float32, device=g.device)
     wsb = 4 * lib().hsp_orl_workspace_bytes(B, N, C)
     ws = _ws(wsb, g.device)
-    _ensure_tickets(g.device)
     _run("hsp_colsum_rows_xyz" + _sfx(g), (_p(g), _p(xyz), B, N, C, _p(mom), _p(ws), wsb, _stream()), key=f"B{B}N{N}C{C}",
          abytes=B * N * (_es(g) * C + 12))
     return mom
@@ -1273,12 +1151,6 @@ def _rf_conv_bwd_raw(xyz, idx, directions, fm, arg, gF3, S):
                                                       _p(arg), _p(gF3), B, N, S, C, _p(gfm), _p(gd)), ws, wsb, (directions, gd),
                           key=f"B{B}N{N}S{S}C{C}", abytes=B * N * (12 + 5 * SC + 4 * C + 4 * (S + 1) * C) + 24 * SC)
     return gfm, gd
-
-
-def _scaled_mm(a, b, alpha):
-    """alpha * (a @ b) with the scale in the GEMM epilogue (no separate element-wise kernel)"""
-    out = torch.empty(a.shape[0], b.shape[1], dtype=a.dtype, device=a.device)
-    return torch.addmm(out, a, b, beta=0.0, alpha=alpha, out=out)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1512,7 +1384,7 @@ class _SurfaceLayer(torch.autograd.Function):
         _rf_bwd_dirs_call("hsp_rf_surface_bwd", (_p(xyz), _p(directions), _p(arg), _p(gF3), B, N, S, C, _p(gD)), ws, wsb,
                           (directions, gD), key=f"B{B}N{N}S{S}C{C}", abytes=B * N * (12 + 4 * C + SC) + 24 * SC)
         if not own_ste:
-            g_ste = g2.t() @ x2
+            g_ste = wgrad(g2, x2)
         return None, None, None, None, gD, g_ste.unsqueeze_(-1), g_conv2.unsqueeze_(-1), None
 
 
@@ -1580,10 +1452,10 @@ class _LinearRows(torch.autograd.Function):
             gwt, gbp = wgrad(x2, gp, colsum=True)
             gw, gb = gwt[:, :Cout].t(), gbp[:Cout]
         else:
-            if GEMM_MODE == "own" and R <= 64 and g.stride(1) == 1 and x2.stride(1) == 1:
+            if R <= 64 and g.stride(1) == 1 and x2.stride(1) == 1:
                 gw = _tiny_tn(g, x2, torch.empty(Cout, Cin, dtype=torch.float32, device=g.device))   # per-cloud rows (the towers' conv4)
             else:
-                gw = torch.mm(g.t(), x2)
+                gw = wgrad(g, x2)
             if ctx.has_bias:
                 gb = colsum_rows(g.view(1, R, Cout)).view(Cout)
         return gx, gw, (gb if ctx.has_bias else None), None
@@ -1594,6 +1466,8 @@ class _FanGroup:
 
     def __init__(self):
         self.gx = None
+        self.members = 0             # set by fan_linear_rows
+        self.seen = 0                # members whose backward has run in the current pass
 
 
 class _FanMember(torch.autograd.Function):
@@ -1637,6 +1511,9 @@ class _FanMember(torch.autograd.Function):
                 else:
                     gemm_own(g, wk, True, resid=grp.gx, out=grp.gx)
         gwt, gb = wgrad(x if xw is None else xw, g, colsum=True)                     # (Cin, Cout) = dW^T, column sums of g = db
+        grp.seen += 1
+        if grp.members and grp.seen >= grp.members:          # last member of this pass: a second backward over the same graph
+            grp.gx, grp.seen = None, 0                       # (retain_graph, gradient checks) starts a fresh buffer
         return ret, None, None, gwt.t(), (gb if ctx.has_bias else None)
 
 
@@ -1666,6 +1543,7 @@ def fan_linear_rows(x, xyz, layers):
     # buffer is complete before anything else touches it
     x = x.view_as(x)
     group, xw, outs = _FanGroup(), None, []
+    group.members = len(layers)
     for w, b in layers:
         if w.shape[1] != K and xw is None:
             with torch.no_grad():                                 # (its gradient is routed by the member, not through the cat)
@@ -1727,7 +1605,7 @@ def cloud_cat_linear_ok(fg, x, xyz, W):
     R, Cx = x.shape
     return (GEMM_MODE == "own" and GEMM_X3 and fg.dtype == torch.float32 and x.dtype == torch.float32 and x.is_cuda and R % B == 0
             and R // B >= 128 and W.shape[1] == Cg + Cx + 3 and W.shape[0] % 128 == 0 and Cx % 4 == 0 and Cg % 4 == 0
-            and os.environ.get("HSP_CLOUD_CAT_LINEAR", "1") != "0")
+)
 
 
 def cloud_cat_linear(fg, x, xyz, W, b):
@@ -2031,7 +1909,7 @@ def gather_rows(feat, idx):
 ONE_HOT_WIDTH = 6          # categories of a kind-3 (one-hot) segment; FaceRecon sets it from FLAGS.obj_c
 
 # feat row pitch: columns padded to a multiple of this many elements (8 = 16 bytes of bf16, 32 of fp32); 1 = no padding
-FEAT_PITCH_ALIGN = int(os.environ.get("HSP_FEAT_PITCH_ALIGN", "8"))
+FEAT_PITCH_ALIGN = 8
 
 
 class _AssembleFeat(torch.autograd.Function):

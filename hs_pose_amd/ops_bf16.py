@@ -94,7 +94,6 @@ def _orl_fwd(F3, idx_x, k):
     arg = torch.empty(B, N, C, dtype=torch.uint8, device=F3.device)
     wsb = lib().hsp_orl_workspace_bytes(B, N, C)
     ws = _ws(wsb, F3.device)
-    ops._ensure_tickets(F3.device)
     _run("hsp_orl_global_fwd_bf16", (_p(F3), _p(idx_x), B, N, k, idx_x.shape[2], C, _p(fg), _p(arg), _p(ws), wsb, _stream()),
          key=f"B{B}N{N}k{k}C{C}", abytes=B * N * (2 * C + 4 * k + C))
     return fg, arg

@@ -220,12 +220,6 @@ int hsp_colsum_rows(const float *x, int B, int N, int C, float *out, void *ws, s
  * that reach fm_0 (conv_1 and the concat); ga / gb rows of an even pitch lda / ldb (8-byte aligned), gb may be NULL; C even */
 int hsp_add_relu_bwd(const float *ga, int lda, const float *gb, int ldb, const float *y, int R, int C, float *out,
                      hspStream_t stream);
-/* hand libhsp n zero-initialised int words of device memory (n >= the largest batch; zeroed ONCE by the caller -- every launch
- * leaves them at zero): the two-stage per-cloud reductions (hsp_orl_global_fwd, hsp_colsum_rows, hsp_colsum_rows_xyz) then fold
- * in their first launch -- the last workgroup of a cloud to finish folds that cloud's partials, same order, same bits (agent-scope
- * release / ticket / acquire).  NULL: back to the separate fold launch.  One buffer per process; launches that use it must be
- * ordered on one stream. */
-int hsp_set_ticket_buffer(int *tickets, int n);
 int hsp_residual_bias(float *out, const float *f, const float *t, int B, int N, int C, hspStream_t stream);
 
 /* ---- feature assembly ---------------------------------------------------------------------------

@@ -148,6 +148,8 @@ def dev():
 def gemm_mode(request, monkeypatch):
     """the fp32 dense products of the layer / head nodes on the BLAS library through torch, or on the hand-written kernels only
     (csrc/gemm_wave.hip, gemm_rows.hip, gemm.hip): the stack goldens hold for both"""
-    from hs_pose_amd import ops
-    monkeypatch.setattr(ops, "GEMM_MODE", request.param)
+    if request.param == "library":
+        sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+        from tools import library_gemm
+        library_gemm.enable(monkeypatch)          # the comparison shim: BLAS-library composites, own-only fusions off
     return request.param

@@ -149,7 +149,7 @@ def test_face_split_matches_torch_composition(dev, ref, monkeypatch, B, N):
     ups = [ref.hash_tensor(sh, 902 + i, 1.0).to(dev) for i, sh in enumerate(((B, N, 6, 3), (B, N, 6), (B, N, 6)))]
     res = []
     for fused in ("1", "0"):
-        monkeypatch.setenv("HSP_FUSED_FACE_SPLIT", fused)
+        monkeypatch.setattr(P9, "FUSED_FACE_SPLIT", fused == "1")
         face = face0.clone().requires_grad_(True)
         outs = P9._split_face_head(face)
         assert [tuple(o.shape) for o in outs] == [(B, N, 6, 3), (B, N, 6), (B, N, 6)]
@@ -170,7 +170,7 @@ def test_axis_conf_matches_torch_composition(dev, ref, monkeypatch):
     ups = [ref.hash_tensor((16, 3), 912, 1.0).to(dev), ref.hash_tensor((16,), 913, 1.0).to(dev)]
     res = []
     for fused in ("1", "0"):
-        monkeypatch.setenv("HSP_FUSED_FACE_SPLIT", fused)
+        monkeypatch.setattr(P9, "FUSED_FACE_SPLIT", fused == "1")
         h = h0.clone().requires_grad_(True)
         outs = P9._axis_and_confidence(h)
         (g,) = torch.autograd.grad(outs, [h], ups)
