@@ -6,7 +6,7 @@
 # Second half: the bf16 dense-cloud configuration (BASELINE configs[3]).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-RD=${1:-r02}
+RD=${1:-r04}
 O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O $R/profiles/$RD
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -22,9 +22,8 @@ cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/k_graph_kernel_stats.
 T=$(find $O/stats -name '*kernel_trace.csv' | head -1)
 python $R/tools/trace_by_shape.py $T auto > $O/k_per_shape_kernel_us.txt
 python $R/bench.py --steps 20 --warmup 5 --breakdown --no-cpu-baseline --no-u3 --no-side > $O/k_breakdown_eager_events.txt 2>&1
-# comparison figures: the BLAS library for the dense products; the hand-written path on the fp32 matrix cores only
+# comparison figure: the BLAS library for the dense products (tools/library_gemm.py)
 HSP_GEMM=library python $R/bench.py --no-cpu-baseline --no-u3 --no-side > $O/k_bench_gemm_library.json 2>/dev/null
-HSP_GEMM=own HSP_GEMM_X3=0 python $R/bench.py --no-cpu-baseline --no-u3 --no-side > $O/k_bench_gemm_own_f32mfma.json 2>/dev/null
 # ---- bf16, B=64, N=4096
 BF="--dtype bf16 --points 4096 --batch 64 --no-cpu-baseline"
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -49,7 +48,7 @@ python $R/bench.py --points 4096 --batch 64 --steps 10 --warmup 3 --no-cpu-basel
 bash $R/tools/prof_train_step.sh > $O/u3_prof.log 2>&1
 head -120 $R/gpurun_out/prof_u3/u3_per_shape_kernel_us.txt > $R/profiles/$RD/u3_per_shape_kernel_us_top120.txt
 # the judged copies (trimmed: the library tuning runs of the first steps fill the long tail of the bf16 tables)
-for f in k_bench.json k_bench_gemm_own_f32mfma.json k_bench_gemm_library.json k_graph_kernel_stats.csv k_per_shape_kernel_us.txt k_breakdown_eager_events.txt b_bench_bf16.json b_bench_f32_same_shape.json b_breakdown_eager_events_bf16.txt; do cp $O/$f $R/profiles/$RD/$f; done
+for f in k_bench.json k_pmc_FETCH_SIZE.csv k_pmc_WRITE_SIZE.csv k_bench_gemm_library.json k_graph_kernel_stats.csv k_per_shape_kernel_us.txt k_breakdown_eager_events.txt b_bench_bf16.json b_bench_f32_same_shape.json b_breakdown_eager_events_bf16.txt; do cp $O/$f $R/profiles/$RD/$f; done
 head -61 $O/b_per_shape_kernel_us_bf16.txt > $R/profiles/$RD/b_per_shape_kernel_us_bf16_top60.txt
 head -81 $O/b_graph_kernel_stats_bf16.csv > $R/profiles/$RD/b_graph_kernel_stats_bf16_top80.csv
 mkdir -p $R/gpurun_out/profiles_$RD && cp $R/profiles/$RD/* $R/gpurun_out/profiles_$RD/
