@@ -1,16 +1,50 @@
-"""Drop-in mirror of the reference's ``tools/pyTorchChamferDistance/chamfer_distance.py``."""
+"""Drop-in mirror of the reference's ``tools/pyTorchChamferDistance/chamfer_distance.py``.
+
+``cd`` is the compiled extension the reference JIT-builds at :8-10 -- here the prebuilt in-tree binding over libhsp.so
+(csrc/hsp_torch.cpp), with the same four entry points and argument roles (caller-allocated outputs, int32 indices).
+GPU tensors only: the reference's CPU branch (``cd.forward``) has no counterpart and the binding raises on a CPU tensor."""
 import torch
 
-from . import ops
+from ._ext import ext
 
 
-class ChamferDistanceFunction:
-    """reference chamfer_distance.py:12-55: ``apply(xyz1, xyz2) -> (dist1, dist2)`` (differentiable)."""
+class _LazyCd:
+    """``cd.forward_cuda(...)`` etc.; the module is loaded on first use (importing this file needs no built extension)"""
+
+    def __getattr__(self, name):
+        return getattr(ext(), name)
+
+
+cd = _LazyCd()
+
+
+class ChamferDistanceFunction(torch.autograd.Function):
+    """reference chamfer_distance.py:12-55: ``apply(xyz1, xyz2) -> (dist1, dist2)`` -- squared nearest-neighbour distances
+    both ways, differentiable with respect to both clouds."""
 
     @staticmethod
-    def apply(xyz1, xyz2):
-        d1, d2, _, _ = ops.chamfer(xyz1, xyz2)
-        return d1, d2
+    def forward(ctx, xyz1, xyz2):
+        batchsize, n, _ = xyz1.size()
+        m = xyz2.size(1)
+        xyz1, xyz2 = xyz1.contiguous().float(), xyz2.contiguous().float()
+        dev = xyz1.device
+        dist1 = torch.empty(batchsize, n, device=dev)
+        dist2 = torch.empty(batchsize, m, device=dev)
+        idx1 = torch.empty(batchsize, n, dtype=torch.int32, device=dev)
+        idx2 = torch.empty(batchsize, m, dtype=torch.int32, device=dev)
+        cd.forward_cuda(xyz1, xyz2, dist1, dist2, idx1, idx2)
+        ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
+        return dist1, dist2
+
+    @staticmethod
+    def backward(ctx, graddist1, graddist2):
+        xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
+        graddist1 = (graddist1 if graddist1 is not None else torch.zeros_like(xyz1[..., 0])).contiguous().float()
+        graddist2 = (graddist2 if graddist2 is not None else torch.zeros_like(xyz2[..., 0])).contiguous().float()
+        gradxyz1 = torch.empty_like(xyz1)
+        gradxyz2 = torch.empty_like(xyz2)
+        cd.backward_cuda(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2)
+        return gradxyz1, gradxyz2
 
 
 class ChamferDistance(torch.nn.Module):

@@ -155,6 +155,9 @@ def knn(x, k, drop_first=True, transposed_view=False):
 def center_cloud(points):
     """(points - mean over the points, mean (B,1,3)) with the mean in the reference's summation order (PoseNet9D.py:25)"""
     pts = _req(points.detach(), torch.float32, "center_cloud.points")
+    if _timer is None:
+        from ._ext import ext
+        return ext().center_cloud(pts)
     B, N, _ = pts.shape
     out = torch.empty_like(pts)
     mean = torch.empty(B, 1, 3, dtype=torch.float32, device=pts.device)
@@ -406,6 +409,12 @@ class _PoolLayer(torch.autograd.Function):
 
 def pool_layer(feat, xyz, idx, qsel, k):
     """(feature_map_pool (B,Nq,C), vertices_pool (B,Nq,3)) of Pool_layer for fp32 rows; xyz carries no gradient."""
+    if (_timer is None and not torch.is_grad_enabled() and feat.is_cuda and feat.dtype == torch.float32 and feat.is_contiguous()
+            and xyz.dtype == torch.float32 and xyz.is_contiguous() and idx.dtype == torch.int32 and idx.is_contiguous()
+            and qsel.dtype == torch.int32 and qsel.dim() == 1 and qsel.is_contiguous()):
+        from ._ext import ext
+        v, out = ext().pool_forward(xyz, feat, idx, qsel, k)
+        return out, v
     return _PoolLayer.apply(feat, xyz, idx, qsel, k)
 
 
@@ -1190,6 +1199,16 @@ def exact_forward():
     return _exact
 
 
+def _ext_inference():
+    """True when an eval-mode forward may take the C++ binding's one-call forms (csrc/hsp_torch.cpp): exact scope, no autograd
+    graph to record, no per-call event timer attached (bench.py --breakdown times the ctypes calls)"""
+    return _exact and _timer is None and not torch.is_grad_enabled()
+
+
+def _f32c(*ts):
+    return all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts)
+
+
 def _exact_layer_ok(N, Cin, C, tensors):
     """shapes the exact forms cover: channel counts that are multiples of 32, conv2 over at most 512 input channels (one chain
     or two; conv_4's 1024 are four blocks and its rows rank nothing), clouds of at least 32 points, 16-byte aligned rows"""
@@ -1395,6 +1414,11 @@ def hs_layer(xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste, w_con
     BatchNorm's statistics, left by the out product's epilogue (empty when that product did not run on the kernel that does
     it); pass both to ``bn_relu(out, bn, partial=partial)``."""
     if bn_shift is None:
+        if (_ext_inference() and _f32c(xyz, X, weights, bias, directions, w_ste, w_conv2) and idx_f.dtype == torch.int32
+                and idx_x.dtype == torch.int32 and idx_f.is_contiguous() and idx_x.is_contiguous()
+                and _exact_layer_ok(X.shape[1], X.shape[2], directions.shape[1] // S, (X, weights))):
+            from ._ext import ext                      # inference: the layer's launch sequence issued from C++ in one call
+            return ext().hs_layer_forward(xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste, w_conv2)
         return _HSLayer.apply(xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste, w_conv2)
     return _HSLayer.apply(xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste, w_conv2, bn_shift)
 
@@ -1402,6 +1426,11 @@ def hs_layer(xyz, X, idx_f, idx_x, k, S, weights, bias, directions, w_ste, w_con
 def surface_layer(xyz, idx_x, k, S, directions, w_ste, w_conv2, relu=False):
     """HSlayer_surface.forward (gcn3d.py:79-90) given the xyz neighbour index (exactly k columns).  ``relu``: apply the relu
     that follows the layer (FaceRecon.py:88) inside the node and return the result TWICE (one tensor per consumer)."""
+    if (_ext_inference() and _f32c(xyz, directions, w_ste, w_conv2) and idx_x.dtype == torch.int32 and idx_x.is_contiguous()
+            and idx_x.shape[2] == k and _exact_layer_ok(xyz.shape[1], 3, directions.shape[1] // S, (w_conv2.squeeze(-1),))):
+        from ._ext import ext
+        y = ext().surface_layer_forward(xyz, idx_x, k, S, directions, w_ste, w_conv2, relu)
+        return (y, y.view_as(y)) if relu else y
     return _SurfaceLayer.apply(xyz, idx_x, k, S, directions, w_ste, w_conv2, relu)
 
 
@@ -1850,6 +1879,10 @@ def bn_relu(x, bn, relu=True, out_dtype=None, fork=False, partial=None):
     if (not fused and not bn.training and bn.affine and bn.track_running_stats and x.is_cuda and x.dtype == torch.float32
             and C % 4 == 0 and x.is_contiguous()):
         # eval mode: ((x - m) * invstd) * w + b in ATen's own operation order (hsp_bn_eval_f32), relu fused
+        if _timer is None and not torch.is_grad_enabled():
+            from ._ext import ext
+            y = ext().bn_eval(x, bn.running_mean, bn.running_var, _eval_invstd(bn), bn.weight, bn.bias, bn.eps, relu)
+            return (y, y.view_as(y)) if fork else y
         y = _BNEval.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, _eval_invstd(bn), bn.eps, relu)
         return (y, y.view_as(y)) if fork else y
     if not fused:                                   # eval mode / exotic configurations: not on the training hot path

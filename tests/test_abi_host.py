@@ -102,6 +102,29 @@ def test_no_cpu_fallback(flags):
         FaceRecon()(torch.zeros(1, 64, 3), torch.zeros(1, 1))
 
 
+def test_torch_binding_loads_and_rejects_cpu_tensors():
+    """hs_pose_amd/_hsp_torch.so (csrc/hsp_torch.cpp): the reference extension's four entry points (chamfer_distance.cpp:180-185)
+    and the inference calls are exported, resolve against the same libhsp.so, and refuse CPU tensors before any launch"""
+    from hs_pose_amd._ext import available, ext
+    assert available(), "run `make -C hs_pose_amd/csrc` (or __graft_entry__.build())"
+    m = ext()
+    for name in ("forward", "forward_cuda", "backward", "backward_cuda", "get_neighbor_index", "get_nearest_index", "knn_exact",
+                 "hs_layer_forward", "surface_layer_forward", "pool_forward", "bn_eval", "center_cloud"):
+        assert callable(getattr(m, name)), name
+    x = torch.zeros(1, 8, 3)
+    d = torch.zeros(1, 8)
+    i = torch.zeros(1, 8, dtype=torch.int)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        m.forward_cuda(x, x, d, d, i, i)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        m.forward(x, x, d, d, i, i)                      # (the reference's CPU entry point has no counterpart: no CPU path)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        m.center_cloud(x)
+    from hs_pose_amd.chamfer import ChamferDistance
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        ChamferDistance()(x, x)
+
+
 def test_missing_library_is_an_error(monkeypatch, tmp_path):
     from hs_pose_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
