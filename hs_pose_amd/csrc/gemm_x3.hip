@@ -338,6 +338,170 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
     }
 }
 
+// ================================================================================================================================
+// The PANEL form for the K = 128, wide-N products (fm = X W + b of conv_1 / conv_2, gcn3d.py:171: N = 1024 / 2048 columns).
+// The tile kernel above spends a K = 128 tile as a four-block pipeline with an exposed memory round trip per block (matrix pipe 17 %
+// busy); here the weight operand never moves again after the prologue:
+//   * a 256-thread workgroup owns a 128-column PANEL for its whole life; each of its 4 waves holds the three bf16 planes of ITS 32
+//     columns as MFMA B operands IN REGISTERS (8 ksteps x 3 planes x 4 VGPRs = 96) -- staged once through LDS with whole-line loads
+//     (fragment-shaped loads straight from the (N, K) planes touch 64 lines for 1 KB: the prologue then cost 4-8 us per workgroup);
+//   * the workgroup walks the 32-row tiles of the activations: a tile is fetched as fp32 two tiles ahead (registers), split into
+//     its three planes on the way into a double-buffered LDS tile, ONE barrier per tile;
+//   * the walk is a per-wave software pipeline: while the 48 MFMAs of tile i run (one accumulator chain: 8 x (3 ds_read_b128 +
+//     6 MFMA 32x32x16)), the same wave stages tile i + 1 (ksteps 0-1), refills its prefetch registers (kstep 2) and stores tile
+//     i - 1 from the other accumulator (ksteps 4-7) -- staging, multiplying and storing in separate phases left the matrix pipe
+//     idle through two of the three (measured: every phase's time simply added up);
+//   * two workgroups per CU, each with its own barrier;
+//   * LDS rows are 256 bytes with the 16-byte chunks XOR-swizzled by (row & 15): the fragment reads (ds_read_b128 lane groups
+//     = 16 distinct rows mod 16) and the staging writes (one row x 16 chunks) both touch all 64 banks (SQ_LDS_BANK_CONFLICT = 0);
+//   * every memory operation of the walk is UNCONDITIONAL -- a tile past the end fetches rows past M, which the buffer descriptor
+//     answers with zeros, and stores beyond the descriptor, which drops them: with branches around them hipcc can no longer count
+//     the operations in flight and waits for ALL of them, prefetches included, inside every tile;
+//   * workgroup -> (panel, row-tile slot) so that the workgroups of one XCD (blockIdx % 8) take ALL panels of their row slots: a
+//     row tile is fetched from HBM once and found in that XCD's L2 by the other panels.
+// ================================================================================================================================
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_x3_panel_kernel(const X3Args g) {
+    constexpr int KS = 8, K = 128, D = 2;
+    constexpr int ROWB = K * 2, PLANE = 32 * ROWB, BUF = 3 * PLANE;        // bytes: a row of one plane, a plane, a tile (24 KB)
+    constexpr int UPR = K / 8, NAU = (32 * UPR) / 256;                     // 8-float units per row (16) / per thread (2)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                                                       // [2][3][32][K] bf16 (prologue: [3][64][K], a half panel)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int P = g.tiles_n, R = gridDim.x / P;
+    const int xq = blockIdx.x / HSP_NUM_XCD, xcd = blockIdx.x % HSP_NUM_XCD;
+    const int panel = xq % P, slot = (xq / P) * HSP_NUM_XCD + xcd;
+    const int col = panel * 128 + 32 * wave + li;                          // (N is a multiple of 128: every column exists)
+    const int ntiles = g.tiles_m;
+
+    const __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.A[0]), 0, (int)((((size_t)g.M - 1) * g.lda[0] + g.K[0]) * 4), 0x00020000);
+    auto fetchA = [&](float (&dst)[NAU][8], int tile) {
+#pragma unroll
+        for (int i = 0; i < NAU; ++i) {
+            const int u = tid + 256 * i, row = u / UPR, k0 = 8 * (u % UPR);
+            const int gr = tile * 32 + row;
+            const unsigned off = gr < g.M ? ((unsigned)gr * (unsigned)g.lda[0] + (unsigned)k0) * 4u : 0xfffffff0u;
+            const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rsA0, off, 0, 0);
+            const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rsA0, off, 16, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { dst[i][e] = __uint_as_float(v0[e]); dst[i][4 + e] = __uint_as_float(v1[e]); }
+        }
+    };
+    auto stashA = [&](float (&srcv)[8], int unit, int buf) {
+        const int u = tid + 256 * unit, row = u / UPR, c8 = u % UPR;
+        u32x4 h, m, l;
+        x3_split8(srcv, h, m, l);
+        char* d = sA + buf * BUF + row * ROWB + ((c8 ^ (row & 15)) << 4);
+        *reinterpret_cast<u32x4*>(d) = h;
+        *reinterpret_cast<u32x4*>(d + PLANE) = m;
+        *reinterpret_cast<u32x4*>(d + 2 * PLANE) = l;
+    };
+
+    // ---- activation tiles two ahead in registers (set j holds tile j mod 2); in flight under the weight staging
+    float av[D][NAU][8];
+    int t = slot;
+#pragma unroll
+    for (int j = 0; j < D; ++j) fetchA(av[j], t + j * R);
+
+    // ---- this wave's weight fragments (column `col`, k = 16 s + 8 lh ... + 8, three planes) through LDS, half a panel (64 columns)
+    // at a time: 16 consecutive threads read one 256-byte row of a plane, the waves that own those columns pick their fragments up
+    u32x4 br[KS][3];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();                                         // the first half's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int q = tid + 256 * i, p = q >> 10, n = (q >> 4) & 63, c = q & 15;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(g.P[0] + p * g.ps[0] + (size_t)(panel * 128 + 64 * half + n) * g.ldp[0] + 8 * c);
+            *reinterpret_cast<u32x4*>(sA + (p * 64 + n) * ROWB + ((c ^ (n & 15)) << 4)) = v;
+        }
+        __syncthreads();
+        if ((wave >> 1) == half) {
+            const int n = 32 * (wave & 1) + li;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    br[s][p] = *reinterpret_cast<const u32x4*>(sA + (p * 64 + n) * ROWB + (((2 * s + lh) ^ (n & 15)) << 4));
+        }
+    }
+    float bvv = 0.f;
+    if constexpr (EPI & 1) bvv = g.bias[col];
+    __syncthreads();                                                       // the staging area becomes the activation tiles
+    // nothing of the prologue is pending inside the walk (a pending prologue load would put a conservative vmcnt wait in front of
+    // every MFMA that reads a fragment register)
+    __builtin_amdgcn_s_waitcnt(0x0070);                                    // vmcnt(0) lgkmcnt(0)
+    stashA(av[0][0], 0, 0);
+    stashA(av[0][1], 1, 0);
+    fetchA(av[0], t + D * R);
+    __syncthreads();
+
+    // (stores: the row part of the address sits in the range-checked vector offset, so rows past M -- and a whole tile sent to offset
+    // 2^31: the descriptor ends below that, nothing wraps -- are dropped; two VALU per store)
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)((((size_t)g.M - 1) * g.ldc + g.N) * 4), 0x00020000);
+    const unsigned ldc4 = (unsigned)g.ldc * 4u;
+    auto store4 = [&](const f32x16& acc, int tile, bool valid, int r0) {                   // rows r0 .. r0 + 3 of the tile
+        const unsigned base = valid ? (unsigned)(tile * 32 + 4 * lh) * ldc4 + (unsigned)col * 4u : 0x80000000u;
+#pragma unroll
+        for (int r = r0; r < r0 + 4; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(g.alpha * acc[r] + bvv), rsC, base + (unsigned)dr * ldc4, 0, 0);
+        }
+    };
+    f32x16 acc2[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[a][r] = 0.f;
+    int it = 0;
+    auto step = [&](auto SJ, auto SP) {                                    // SJ: the register set that holds the NEXT tile; SP: accumulator
+        constexpr int J = decltype(SJ)::value, PAR = decltype(SP)::value;
+        const int buf = it & 1;
+        const char* ab = sA + buf * BUF + li * ROWB;
+        constexpr int SA[6] = {0, 2, 1, 0, 1, 0}, SB[6] = {2, 0, 1, 1, 0, 0};             // small terms first (as the tile kernel)
+        u32x4 fa[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) fa[0][p] = *reinterpret_cast<const u32x4*>(ab + p * PLANE + ((lh ^ (li & 15)) << 4));
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s + 1 < KS) {
+                const int off = ((2 * (s + 1) + lh) ^ (li & 15)) << 4;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) fa[(s + 1) & 1][p] = *reinterpret_cast<const u32x4*>(ab + p * PLANE + off);
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc2[PAR] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][SA[q]]),
+                                                                    __builtin_bit_cast(bf16x8, br[s][SB[q]]),
+                                                                    (s == 0 && q == 0) ? zero : acc2[PAR], 0, 0, 0);   // (C = 0: an inline constant)
+            }
+            // side work of this kstep, under its MFMAs
+            if (s < NAU) stashA(av[J][s], s, buf ^ 1);                     // next tile -> the other LDS tile
+            else if (s == NAU) fetchA(av[J], t + (D + 1) * R);             // refill two tiles ahead
+            else if (s >= 4) store4(acc2[PAR ^ 1], t - R, it > 0, 4 * (s - 4));            // the previous tile
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        t += R;
+        ++it;
+    };
+    while (t < ntiles) {                                                   // iteration `it` stages set (it + 1) mod 2 into tile (it + 1) & 1
+        step(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        if (t >= ntiles) break;
+        step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    }
+#pragma unroll
+    for (int r0 = 0; r0 < 16; r0 += 4) {                                   // the last tile (tile t - R)
+        if (it & 1) store4(acc2[0], t - R, it > 0, r0);
+        else store4(acc2[1], t - R, it > 0, r0);
+    }
+}
+
 // sum of the split-K partial tiles (fixed order), scaled; the products that split carry no other epilogue
 __global__ __launch_bounds__(256) void gemm_x3_reduce_kernel(const float* __restrict__ ws, int nsplit, long long total, int N,
                                                              float alpha, float* __restrict__ C, int ldc) {
@@ -493,6 +657,36 @@ static int gemm_x3_impl(const float* A1, int lda1, const hsp_bf16_t* P1, int ldp
     // BatchNorm partials: the layer's out product (residual + per-cloud bias; 64-row tiles) or a Linear with bias (one source)
     const bool bn_out = bn && resid && cloud_bias && !bias, bn_lin = bn && bias && !resid && !cloud_bias && !two;
     if (bn && (!bn_part || !(bn_out || bn_lin))) return HSP_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    {   // the panel form: K = 128, columns in whole 128-wide panels, enough row tiles per panel slot to amortise the weight fragments
+        const int epi0 = (bias ? 1 : 0) | (resid ? 2 : 0) | (cloud_bias ? 4 : 0);
+        if (!bn && !two && epi0 <= 1 && K1 == 128 && N % 128 == 0 && (long long)(M + 32) * ldc * 4 < (1ll << 31)) {
+            const int P = N / 128;
+            const int R = (2 * HSP_NUM_CU / P) / HSP_NUM_XCD * HSP_NUM_XCD;  // two workgroups per CU; a multiple of the XCD count
+            const int nt = (M + 31) / 32;
+            const int rounds = R ? (nt + R - 1) / R : 0;
+            if (R && rounds >= 3 && (double)nt / ((double)rounds * R) >= 0.75) {
+                g.tiles_m = nt; g.tiles_n = P; g.nsplit = 1; g.ws = nullptr;
+                const dim3 pgrid((unsigned)(P * R)), pblock(256);
+                const size_t lds = (size_t)2 * 3 * 32 * 128 * 2;             // 48 KB
+#define X3_PANEL(EPI_)                                                                                                    \
+    do {                                                                                                                  \
+        auto kern = gemm_x3_panel_kernel<EPI_>;                                                                           \
+        static bool attr_set = false;                                                                                     \
+        if (!attr_set) {                                                                                                  \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }                                        \
+            attr_set = true;                                                                                              \
+        }                                                                                                                 \
+        hipLaunchKernelGGL(kern, pgrid, pblock, lds, st, g);                                                              \
+    } while (0)
+                if (epi0) X3_PANEL(1);
+                else X3_PANEL(0);
+#undef X3_PANEL
+                return check_launch();
+            }
+        }
+    }
     const int wm = bn_out ? 1 : x3_pick_wm(M, N), bm = 64 * wm;
     g.tiles_m = (M + bm - 1) / bm; g.tiles_n = (N + X3_BN - 1) / X3_BN;
     const int TT = (K1 + X3_BK - 1) / X3_BK + (two ? (K2 + X3_BK - 1) / X3_BK : 0);
@@ -502,7 +696,6 @@ static int gemm_x3_impl(const float* A1, int lda1, const hsp_bf16_t* P1, int ldp
     g.nsplit = ns; g.ws = ns > 1 ? reinterpret_cast<float*>(ws) : nullptr;
     const long long items = (long long)g.tiles_m * g.tiles_n * ns;
     if (items > (1ll << 30)) return HSP_ERR_UNSUPPORTED;
-    hipStream_t st = as_stream(stream);
     const dim3 grid((unsigned)items), block(256);
     // instantiated epilogues: 0 none, 1 bias, 2 residual (one source: the input-gradient chain of layers that share their input
     // rows -- C may BE resid: an element is read and written by the same thread), 6 residual + per-cloud bias (the layer's out

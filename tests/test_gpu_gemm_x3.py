@@ -36,6 +36,13 @@ CASES = [  # M, N, K1, nn1, K2, nn2, epilogue, rows per cloud
     (16448, 256, 1024, False, 0, False, "bias", 0),
     (16448, 1286, 1024, True, 0, False, "none", 0),           # its input gradient: N = 1286 (ragged last column tile)
     (4112, 200, 2048, False, 0, False, "none", 0),            # ragged N with split-K
+    # the panel form (K = 128, weight fragments resident in registers: gemm_x3_panel_kernel) and its neighbours on the tile kernel
+    (4112, 2048, 128, True, 0, False, "bias", 0),             # fm (conv_2): panel
+    (4099, 1024, 128, False, 0, False, "none", 0),            # panel, ragged last row tile, alpha
+    (49152, 1024, 128, True, 0, False, "bias", 0),            # panel, 24 tiles per workgroup
+    (1024, 4096, 256, True, 0, False, "bias", 0),             # fm (conv_4): K = 256, tile kernel
+    (8000, 1024, 128, False, 128, False, "none", 0),          # two sources: tile kernel
+    (5001, 1024, 64, True, 64, False, "bias", 0),
 ]
 
 
