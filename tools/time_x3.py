@@ -12,7 +12,7 @@ if len(sys.argv) > 1:
     a = sys.argv[1:]
     SHAPES = [(int(a[i]), int(a[i + 1]), int(a[i + 2]), int(a[i + 3]), a[i + 4]) for i in range(0, len(a), 5)]
 for (M, N, K1, K2, epi) in SHAPES:
-    A1 = torch.randn(M, K1, device=dev)
+    A1 = torch.randn(M, (K1 + 7) // 8 * 8, device=dev)[:, :K1]          # rows on a 16-byte pitch
     B1 = torch.randn(K1, N, device=dev) * 0.05
     A2 = torch.randn(M, K2, device=dev) if K2 else None
     B2 = torch.randn(N, K2, device=dev) * 0.05 if K2 else None
