@@ -88,8 +88,9 @@ def test_gemm_x3_matches_fp64(dev, M, N, K1, nn1, K2, nn2, epi, rpc):
     rms = (got.double() - want).pow(2).mean().sqrt().item() / scale
     rms_lib = (lib32 - want).pow(2).mean().sqrt().item() / scale
     print(f"x3 M{M} N{N} K{K1}+{K2}: max err {err:.2e} of scale (fp32 library {err_lib:.2e}); rms {rms:.2e} (library {rms_lib:.2e})")
-    assert err <= max(4.0 * err_lib, 2e-6), (err, err_lib)
-    assert rms <= max(4.0 * rms_lib, 5e-7), (rms, rms_lib)
+    # measured worst ratios (profiles/r04/x3_error.txt): 2.8x (max) and 1.7x (rms), both on the two-source out products
+    assert err <= max(3.5 * err_lib, 2e-6), (err, err_lib)
+    assert rms <= max(2.0 * rms_lib, 5e-7), (rms, rms_lib)
 
 
 def test_gemm_x3_split_is_exact(dev):
