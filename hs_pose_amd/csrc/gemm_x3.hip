@@ -275,7 +275,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3Args g) {
             // the shift of the shifted sums: any per-column value every tile agrees on and that sits near the column's mean --
             // the residual + per-cloud-bias part of ROW 0 of the result (data of this step only: a replayed graph and an eager
             // step compute identical bits; a running statistic would not give that); the heads' Linear + BatchNorm form
-            // (EPI 9) shifts by the layer's bias
+            // (EPI 9) shifts by the layer's bias: what is left in the sums is x W^T of post-ReLU rows, whose column mean can be a
+            // few standard deviations -- the variance then carries (mean / std)^2 * 2^-24 of relative error (1.5e-6 at 5 sigma),
+            // two orders below the tolerance the BatchNorm outputs are held to; a per-tile data shift would need a third row
+            // in bn_part and a Chan merge in bn_finalize
             if constexpr (HAS_RES) bsh = g.resid[colc] + g.cbias[colc];
             else bsh = bvv;
             if (tm == 0 && wm0 == 0 && lh == 0 && cok) g.bn_shift[col] = bsh;

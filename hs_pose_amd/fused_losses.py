@@ -49,8 +49,26 @@ def _f32(t, shape, name):
 
 
 class LossDict(dict):
-    """the reference's loss_dict (four sub-dictionaries of 0-dim terms) that also carries their sum (``total``)"""
+    """the reference's loss_dict (four sub-dictionaries of 0-dim terms) that also carries their sum (``total``) and the identity of
+    the 19 term tensors it was built with (``terms``): the sum is only valid for exactly those"""
     total = None
+    terms = None
+
+    def untouched(self):
+        """True while every group still holds exactly the tensors the loss kernels returned (no term dropped, replaced,
+        re-weighted or added)"""
+        if self.terms is None or set(self.keys()) != {g for g, _ in TERMS}:
+            return False
+        k = 0
+        for group, keys in TERMS:
+            d = self[group]
+            if len(d) != len(keys):
+                return False
+            for key in keys:
+                if d.get(key) is not self.terms[k]:
+                    return False
+                k += 1
+        return True
 
 
 def total_loss(loss_dict):
@@ -58,7 +76,7 @@ def total_loss(loss_dict):
     ``sum(fsnet_loss.values()) + sum(recon_loss.values()) + sum(geo_loss.values()) + sum(prop_loss.values())`` -- taken from the
     fused loss kernels' own reduction when the dict came from them (one launch forward, one in backward, instead of ~28)."""
     t = getattr(loss_dict, "total", None)
-    if t is not None:
+    if t is not None and loss_dict.untouched():          # an edited dict (an ablation's dropped / re-weighted / extra term): sum it as is
         return t
     return sum(sum(d.values()) for d in (loss_dict['fsnet_loss'], loss_dict['recon_loss'], loss_dict['geo_loss'],
                                          loss_dict['prop_loss']))
@@ -128,6 +146,7 @@ def pose_losses(net_out, PC, gt_R, gt_t, gt_s, mean_shape, sym, obj_id):
     vals = _PoseLosses.apply(*[net_out[k] for k in _NET], PC, gt_R, gt_t, gt_s, mean_shape, sym, obj_id.reshape(-1).float())
     out, k = LossDict(), 0
     out.total = vals[N_TERMS]
+    out.terms = tuple(vals[:N_TERMS])
     for group, keys in TERMS:
         out[group] = {}
         for key in keys:

@@ -138,6 +138,22 @@ def test_fused_total_equals_the_term_by_term_sum(dev, ref, flags):
             assert (a - b).abs().max().item() <= 2e-6 * max(b.abs().max().item(), 1e-6)
     plain = {k: dict(v) for k, v in ld.items()}
     assert abs(float(total_loss(plain)) - float(res[0][0])) <= 2e-6 * abs(float(res[0][0]))
+    # an EDITED dict (an ablation drops, re-weights or adds a term) must be summed as it stands, not answered from the cached total
+    full = float(res[0][0])
+    gt, pred = case(ref, dev, n_points=128, seed=4100, repeat=2)
+    ld = fused(gt, pred)
+    dropped = float(ld['geo_loss'].pop(next(iter(ld['geo_loss']))))
+    assert abs(float(total_loss(ld)) - (full - dropped)) <= 2e-6 * abs(full)
+    ld = fused(gt, pred)
+    key = next(iter(ld['fsnet_loss']))
+    old = float(ld['fsnet_loss'][key])
+    ld['fsnet_loss'][key] = 3.0 * ld['fsnet_loss'][key]
+    assert abs(float(total_loss(ld)) - (full + 2.0 * old)) <= 2e-6 * abs(full)
+    ld = fused(gt, pred)
+    ld['extra'] = {'reg': torch.tensor(1.5, device=dev)}
+    assert abs(float(total_loss(ld)) - full) <= 2e-6 * abs(full)        # (the reference's sum names its four groups: 'extra' is not in it)
+    ld = fused(gt, pred)
+    assert total_loss(ld) is ld.total                                      # untouched: the kernels' own reduction
 
 
 @pytest.mark.parametrize("B,N", [(16, 1028), (3, 77)])
