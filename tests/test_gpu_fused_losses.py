@@ -198,7 +198,7 @@ def test_axis_conf_matches_torch_composition(dev, ref, monkeypatch):
 
 def test_hspose_forward_uses_fused_losses(dev, flags):
     """HSPose.forward(do_loss=True) on a device batch returns the fused terms (same keys; finite; backward reaches the
-    network) and HSP_FUSED_LOSSES-off instances agree with it"""
+    network) and instances with ``fused_losses = False`` agree with it"""
     from hs_pose_amd.HSPose import HSPose
     import bench
     flags.train = 1

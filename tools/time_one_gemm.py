@@ -37,5 +37,5 @@ if "lib" in sys.argv:
     for _ in range(20): fn()
     e1.record(); torch.cuda.synchronize()
     print(f"   library: {1e3 * e0.elapsed_time(e1) / 20:8.1f} us")
-print(f"M{M} N{N} K{K} {'nn' if nn else 'nt'} {str(dt)[6:]} tile={os.environ.get('HSP_GEMM_TILE','auto')} lib={os.path.basename(os.environ.get('HSP_LIB','libhsp.so'))}: "
+print(f"M{M} N{N} K{K} {'nn' if nn else 'nt'} {str(dt)[6:]} lib={os.path.basename(os.environ.get('HSP_LIB','libhsp.so'))}: "
       f"{best:8.1f} us  {2.0 * M * N * K / best / 1e6:7.1f} TF")
