@@ -583,7 +583,7 @@ template <int K1, bool FULLK>
 __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restrict__ x,
                                                        const float* __restrict__ quad, int N, int C, int k,
                                                        int drop, int32_t* __restrict__ idx, int full_tiles,
-                                                       int ntail, float* __restrict__ dtail, int vrem) {
+                                                       int ntail, float* __restrict__ dtail) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // remainder queries: one workgroup each.  They take the LOWEST block ids so that they are dispatched
     // first and run alongside the MFMA tiles instead of after them.
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
     float* pub = qtile + 32 * QS + 4 * 32 * KF_CT_STRIDE + 4 * 32;     // [32 queries][8 lists]
     constexpr bool SHARE_OK = K1 >= 8;
     constexpr int A_HI = SHARE_OK ? K1 / 8 : 0, A_LO = SHARE_OK ? K1 / 8 - 1 : 0;   // a_l - 1 for l < K1 % 8, else
-    const bool SHARE = SHARE_OK && (vrem ? full_tiles : (N + 31) >> 5) >= 4;    // all four waves own a tile
+    const bool SHARE = SHARE_OK && ((N + 31) >> 5) >= 4;    // all four waves own a tile
     pub[tid] = INFINITY;
     const int b = blockIdx.y;
     const int q0 = ((int)blockIdx.x - ntail) * 32;
@@ -635,10 +635,7 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
     TopList<K1> top;
     top.init();
 
-    // candidate tiles of the MFMA walk.  vrem > 0: the last vrem (<= 8) candidates of the cloud -- N = 1028 = 32 * 32 + 4, 257 = 8 * 32
-    // + 1 -- do NOT get a tile of their own (a 33rd / 9th tile made one wave's walk 9 / 3 tiles long against 8 / 2 for the others,
-    // and the workgroup waits for it): they are met after the walk, one k-ordered fma chain per (query, candidate) pair
-    const int ntiles = vrem ? full_tiles : (N + 31) >> 5;
+    const int ntiles = (N + 31) >> 5;
     const int nchunks = Cp >> 6;
     // register prefetch of one candidate chunk: 32 rows x 32 float2 = 16 float2 per lane; lane (h, pair)
     // takes rows h, h+2, ... of the tile, so every half-wave reads 256 contiguous bytes of one row.
@@ -729,6 +726,20 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
             // max-over-lanes(#survivors) times instead of once per candidate.
             qsm[col] = tile * 32 + col < N ? __uint_as_float(qraw) : INFINITY;   // both halves: same value
             __builtin_amdgcn_wave_barrier();
+            if (dtail && tile == ntiles - 1) {
+                // symmetric remainder path (knn_feat_sym_tail_kernel): the rows of this partial tile are the
+                // remainder QUERIES t; their distance to this lane's query j, in the association of query t
+                const int nfull = full_tiles * 32, rem = N - nfull;
+                if (h * 4 < rem) {
+                    const float4 qc = *reinterpret_cast<const float4*>(qsm + 4 * h);
+                    const float qcv[4] = {qc.x, qc.y, qc.z, qc.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (h * 4 + u < rem)
+                            dtail[((size_t)b * rem + h * 4 + u) * nfull + q] =
+                                add_rn(add_rn(mul_rn(acc[u], -2.0f), qq), qcv[u]);
+                }
+            }
             float thr = top.d[K1 - 1];
             if (SHARE) {
                 const float4 t0 = *reinterpret_cast<const float4*>(pub + col * 8);
@@ -774,29 +785,6 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
         }
         tile = ntile;
         chunk = nchunk;
-    }
-
-    // ---- the remainder candidates: lane (query col, half h) of wave w takes candidate nfull + 2 w + h.  The chain multiplies the
-    // same pairs in the same order as the MFMA tile would (v_mfma_f32_32x32x2_f32 is a k-ordered fma chain from 0): identical bits.
-    // In the symmetric-remainder mode the same distance, in the association of the remainder row as QUERY, goes to dtail
-    // (knn_feat_sym_tail_kernel selects for those queries).
-    if (vrem) {
-        const int nfull = full_tiles * 32, u = 2 * wave + h;
-        if (u < vrem) {
-            const float* rc = xb + (size_t)(nfull + u) * C;
-            const float* qrow = qtile + col * QS;               // element k of the query: [k >> 6][k & 1][(k >> 1) & 31]
-            float a = 0.f;
-            int c = 0;
-            for (; (C & 3) == 0 && c + 3 < C; c += 4) {         // 16-byte row segments where the rows are aligned
-                const float4 v = *reinterpret_cast<const float4*>(rc + c);
-                const float* qb = qrow + (c >> 6) * 64 + ((c & 63) >> 1);
-                a = __fmaf_rn(v.w, qb[33], __fmaf_rn(v.z, qb[1], __fmaf_rn(v.y, qb[32], __fmaf_rn(v.x, qb[0], a))));
-            }
-            for (; c < C; ++c) a = __fmaf_rn(rc[c], qrow[(c >> 6) * 64 + (c & 1) * 32 + ((c & 63) >> 1)], a);
-            const float qc = quadb[nfull + u];
-            top.insert_always(add_rn(add_rn(mul_rn(a, -2.0f), qc), qq), nfull + u);
-            if (dtail) dtail[((size_t)b * vrem + u) * nfull + q] = add_rn(add_rn(mul_rn(a, -2.0f), qq), qc);
-        }
     }
 
     // ---- merge the 8 lists of every query
@@ -944,7 +932,7 @@ static int launch_knn_feat(const float* x, const float* quad, float* dtail, int 
     }
     const int ntail = mode == KF_REM_WG ? rem : 0;
     hipLaunchKernelGGL(kern, dim3(full_tiles + ntail, B), dim3(256), lds, st, x, quad, N, C, k, drop, idx, full_tiles,
-                       ntail, mode == KF_REM_SYM ? dtail : nullptr, rem);
+                       ntail, mode == KF_REM_SYM ? dtail : nullptr);
     int rc = check_launch();
     if (rc || mode != KF_REM_SYM) return rc;
     const size_t lds_s = (size_t)4 * (12 * ((size_t)N + 3) + (size_t)(1 + rem) * C * 4);
