@@ -72,9 +72,10 @@ class PoseNet9D(nn.Module):
         return outs[3] if blk is not None else None
 
     def _forward(self, points, obj_id):
-        if (not self.training and points.is_cuda and points.dtype == torch.float32 and not points.requires_grad
-                and os.environ.get("HSP_EXACT", "1") != "0"):
-            local, centre = ops.center_cloud(points)             # eval: the mean in the reference's summation order
+        if points.is_cuda and points.dtype == torch.float32 and not points.requires_grad:
+            # the mean in the reference's summation order (one launch), training included: the coordinate searches then see the
+            # reference's bits, so their tie-ridden rows (tiled clouds) come out as the reference's lists in both modes
+            local, centre = ops.center_cloud(points)
         else:
             centre = points.mean(dim=1, keepdim=True)
             local = points - centre                              # the network sees clouds centred on their mean

@@ -71,17 +71,24 @@ struct TopList {
 // holds the sentinel index INT_MAX; it is replaced by `fallback` (a valid row, the query itself) before it is written,
 // so a NaN / Inf input row can never turn into an out-of-range neighbour index downstream (the reference's topk also
 // returns valid indices there; the NaN shows up in the loss and engine/train.py:91-95 skips the batch).
+// ``msel`` > k + drop with ``tie_row``: the walk continues to rank msel - 1 (K1 >= msel) and *tie_row is set to 1 when two
+// neighbouring ranks below msel hold EQUAL distances -- the only rows on which torch.topk's answer is not the
+// (distance, index) order (csrc/knn_exact.hip) --, else to 0.
 template <int K1, int T, bool PAIRS = false>
 __device__ __forceinline__ void merge_write(const int2* __restrict__ lists, int my_list, int sub, int k,
                                             int drop, bool valid, int32_t* __restrict__ out_row,
-                                            int nrows, int fallback, int2* __restrict__ out_pairs = nullptr) {
+                                            int nrows, int fallback, int2* __restrict__ out_pairs = nullptr,
+                                            int msel = 0, uint8_t* __restrict__ tie_row = nullptr) {
     const int2* mine = lists + (size_t)my_list * K1;
     int ptr = 0;
     int2 h = mine[0];
     float hd = __int_as_float(h.x);
     int hi = h.y;
     const int m = k + drop;
-    for (int r = 0; r < m; ++r) {
+    const int mm = tie_row && msel > m ? msel : m;
+    float prev = 0.f;
+    bool tie = false;
+    for (int r = 0; r < mm; ++r) {
         float bd = hd;
         int bi = hi;
 #pragma unroll
@@ -103,12 +110,15 @@ __device__ __forceinline__ void merge_write(const int2* __restrict__ lists, int 
                 hi = INT_MAX;
             }
         }
+        tie = tie || (r > 0 && bd == prev);
+        prev = bd;
         if (PAIRS) {
             if (sub == 0) out_pairs[r] = make_int2(__float_as_int(bd), bi);
-        } else if (valid && sub == 0 && r >= drop) {
+        } else if (valid && sub == 0 && r >= drop && r < m) {
             out_row[r - drop] = (unsigned)bi < (unsigned)nrows ? bi : fallback;
         }
     }
+    if (tie_row && valid && sub == 0) *tie_row = tie ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -118,7 +128,8 @@ __device__ __forceinline__ void merge_write(const int2* __restrict__ lists, int 
 // ------------------------------------------------------------------------------------------------
 template <int K1, int T>
 __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ x, int N, int k, int drop,
-                                                   int32_t* __restrict__ idx, int chunk) {
+                                                   int32_t* __restrict__ idx, int chunk, int msel,
+                                                   uint8_t* __restrict__ tie) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* pts = reinterpret_cast<float4*>(smem);
     int2* lists = reinterpret_cast<int2*>(smem);          // aliases pts once the scan is over
@@ -156,7 +167,8 @@ __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ x, 
     }
     __syncthreads();                       // every lane is done with pts: reuse the LDS for the lists
     top.store(lists + (size_t)tid * K1);   // each lane re-reads only its own list: no further barrier
-    merge_write<K1, T>(lists, tid, t, k, drop, valid, idx + ((size_t)b * N + (valid ? q : 0)) * k, N, valid ? q : 0);
+    merge_write<K1, T>(lists, tid, t, k, drop, valid, idx + ((size_t)b * N + (valid ? q : 0)) * k, N, valid ? q : 0, nullptr,
+                       msel, tie ? tie + (size_t)b * N + (valid ? q : 0) : nullptr);
 }
 
 __device__ __forceinline__ unsigned sortable_key(float f) {
@@ -175,9 +187,11 @@ __device__ __forceinline__ unsigned sortable_key(float f) {
 #define KNN3W_QW 4
 #define KNN3W_CAP 128   // survivor scratch entries per wave (typically ~k + 4 are used)
 
+// ``tie`` (may be null) with ``msel`` = k + drop + 1: the selection runs one rank past the answer and tie[row] says whether two of
+// those msel nearest hold EQUAL distances (see merge_write).
 template <int S>
 __global__ __launch_bounds__(256) void knn3_wave_kernel(const float* __restrict__ x, int N, int k, int drop,
-                                                        int32_t* __restrict__ idx) {
+                                                        int32_t* __restrict__ idx, int msel, uint8_t* __restrict__ tie) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* pts = reinterpret_cast<float4*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -191,6 +205,7 @@ __global__ __launch_bounds__(256) void knn3_wave_kernel(const float* __restrict_
     }
     __syncthreads();
     const int m = k + drop;
+    const int ms = tie && msel > m ? msel : m;                       // ranks looked at
     for (int qi = 0; qi < KNN3W_QW; ++qi) {
         const int q = (blockIdx.x * 4 + wave) * KNN3W_QW + qi;       // wave-uniform
         if (q >= N) break;
@@ -206,10 +221,10 @@ __global__ __launch_bounds__(256) void knn3_wave_kernel(const float* __restrict_
             d[s] = j < N ? fminf(dv, FLT_MAX) : INFINITY;       // NaN / +inf of a real row -> FLT_MAX: still selectable, so
             lmin = fminf(lmin, d[s]);                           // every output slot is written with a valid index
         }
-        // the m-th smallest of the 64 lane minima: m distinct candidates are <= tau
+        // the ms-th smallest of the 64 lane minima: ms distinct candidates are <= tau
         const unsigned key = sortable_key(lmin);
         unsigned prefix = 0;
-        int need = m;
+        int need = ms;
         for (int bit = 31; bit >= 0; --bit) {
             const unsigned hi = bit == 31 ? 0u : (0xffffffffu << (bit + 1));
             const bool zero = ((key ^ prefix) & hi) == 0 && ((key >> bit) & 1u) == 0;
@@ -228,17 +243,25 @@ __global__ __launch_bounds__(256) void knn3_wave_kernel(const float* __restrict_
         }
         __builtin_amdgcn_wave_barrier();
         int32_t* out = idx + ((size_t)b * N + q) * k;
+        bool tied = false;
         if (n <= KNN3W_CAP) {
             for (int e = lane; e < n; e += 64) {
                 const int2 me = sv[e];
                 const float de = __int_as_float(me.x);
                 int rank = 0;
+                bool eq_lo = false, eq_hi = false;            // an equal distance at a lower / a higher index
                 for (int f = 0; f < n; ++f) {
                     const int2 o = sv[f];
                     const float df = __int_as_float(o.x);
-                    rank += (df < de || (df == de && o.y < me.y)) ? 1 : 0;
+                    const bool eq = df == de;
+                    rank += (df < de || (eq && o.y < me.y)) ? 1 : 0;
+                    eq_lo = eq_lo || (eq && o.y < me.y);
+                    eq_hi = eq_hi || (eq && o.y > me.y);
                 }
                 if (rank >= drop && rank < m) out[rank - drop] = me.y;
+                // equal distances occupy neighbouring ranks: the pair lies below ms when this entry does and its partner is the
+                // previous rank, or the next one and that is still below ms
+                tied = tied || (rank < ms && (eq_lo || (eq_hi && rank + 1 < ms)));
             }
         } else {
             // more survivors than scratch (heavily duplicated points): extract the m smallest (distance, index)
@@ -246,7 +269,7 @@ __global__ __launch_bounds__(256) void knn3_wave_kernel(const float* __restrict_
             // ballots for the wave minimum.  Slow (~150 ballots per pick) but exact and scratch-free.
             unsigned pk = 0;                                  // previous pick: sortable distance key, index
             int pj = -1;
-            for (int r = 0; r < m; ++r) {
+            for (int r = 0; r < ms; ++r) {
                 unsigned bk = 0xffffffffu;
                 int bj = 0x7fffffff;
 #pragma unroll
@@ -268,9 +291,14 @@ __global__ __launch_bounds__(256) void knn3_wave_kernel(const float* __restrict_
                     const unsigned long long z = __ballot(((bj >> bit) & 1) == 0) & live;
                     if (z) live = z; else wj |= 1 << bit;
                 }
-                if (lane == 0 && r >= drop) out[r - drop] = wj;
+                if (lane == 0 && r >= drop && r < m) out[r - drop] = wj;
+                tied = tied || (r > 0 && wk == pk);
                 pk = wk; pj = wj;
             }
+        }
+        if (tie) {
+            const bool any_tied = __ballot(tied) != 0ull;
+            if (lane == 0) tie[(size_t)b * N + q] = any_tied ? 1 : 0;
         }
         __builtin_amdgcn_wave_barrier();                      // sv is reused by the next query
     }
@@ -848,7 +876,7 @@ static int pick_k1(int m) {
 }
 
 template <int K1, int T>
-static int launch_knn3(const float* x, int B, int N, int k, int drop, int32_t* idx, hipStream_t st) {
+static int launch_knn3(const float* x, int B, int N, int k, int drop, int32_t* idx, hipStream_t st, int msel, uint8_t* tie) {
     const int chunk = N < 4096 ? N : 4096;
     size_t lds = (size_t)chunk * 16;
     if (lds < (size_t)256 * K1 * 8) lds = (size_t)256 * K1 * 8;
@@ -859,37 +887,38 @@ static int launch_knn3(const float* x, int B, int N, int k, int drop, int32_t* i
     }
     constexpr int Q = 256 / T;
     dim3 grid((N + Q - 1) / Q, B);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, N, k, drop, idx, chunk);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, N, k, drop, idx, chunk, msel, tie);
     return check_launch();
 }
 
 template <int S>
-static int launch_knn3_wave(const float* x, int B, int N, int k, int drop, int32_t* idx, hipStream_t st) {
+static int launch_knn3_wave(const float* x, int B, int N, int k, int drop, int32_t* idx, hipStream_t st, int msel, uint8_t* tie) {
     const size_t lds = (size_t)N * 16 + (size_t)4 * KNN3W_CAP * 8;
     auto kern = knn3_wave_kernel<S>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
     }
-    hipLaunchKernelGGL(kern, dim3((N + 4 * KNN3W_QW - 1) / (4 * KNN3W_QW), B), dim3(256), lds, st, x, N, k, drop, idx);
+    hipLaunchKernelGGL(kern, dim3((N + 4 * KNN3W_QW - 1) / (4 * KNN3W_QW), B), dim3(256), lds, st, x, N, k, drop, idx, msel, tie);
     return check_launch();
 }
 
 template <int K1>
-static int launch_knn3_t(const float* x, int B, int N, int k, int drop, int32_t* idx, hipStream_t st) {
+static int launch_knn3_t(const float* x, int B, int N, int k, int drop, int32_t* idx, hipStream_t st, int msel = 0,
+                         uint8_t* tie = nullptr) {
     const long long nq = (long long)B * N;
     // one wave per query while the per-lane distances fit in registers (<= 65 per lane: N <= 4160, the dense clouds of
     // BASELINE configs[3]; 1.8 ms with the per-lane-list kernel below at B=64 N=4096)
     if (N >= 64 && (nq < 131072 || N > 64 * 17)) {
-        if (N <= 64 * 5) return launch_knn3_wave<5>(x, B, N, k, drop, idx, st);
-        if (N <= 64 * 9) return launch_knn3_wave<9>(x, B, N, k, drop, idx, st);
-        if (N <= 64 * 17) return launch_knn3_wave<17>(x, B, N, k, drop, idx, st);
-        if (N <= 64 * 33) return launch_knn3_wave<33>(x, B, N, k, drop, idx, st);
-        if (N <= 64 * 65) return launch_knn3_wave<65>(x, B, N, k, drop, idx, st);
+        if (N <= 64 * 5) return launch_knn3_wave<5>(x, B, N, k, drop, idx, st, msel, tie);
+        if (N <= 64 * 9) return launch_knn3_wave<9>(x, B, N, k, drop, idx, st, msel, tie);
+        if (N <= 64 * 17) return launch_knn3_wave<17>(x, B, N, k, drop, idx, st, msel, tie);
+        if (N <= 64 * 33) return launch_knn3_wave<33>(x, B, N, k, drop, idx, st, msel, tie);
+        if (N <= 64 * 65) return launch_knn3_wave<65>(x, B, N, k, drop, idx, st, msel, tie);
     }
-    if (nq >= 131072) return launch_knn3<K1, 1>(x, B, N, k, drop, idx, st);
-    if (nq >= 32768) return launch_knn3<K1, 4>(x, B, N, k, drop, idx, st);
-    return launch_knn3<K1, 16>(x, B, N, k, drop, idx, st);
+    if (nq >= 131072) return launch_knn3<K1, 1>(x, B, N, k, drop, idx, st, msel, tie);
+    if (nq >= 32768) return launch_knn3<K1, 4>(x, B, N, k, drop, idx, st, msel, tie);
+    return launch_knn3<K1, 16>(x, B, N, k, drop, idx, st, msel, tie);
 }
 
 // how the N % 32 remainder queries of the feature path are handled
@@ -1119,6 +1148,25 @@ static int launch_knn_feat_bf16(const bf16_t* x, const float* quad, int B, int N
     }
     hipLaunchKernelGGL(kern, dim3((N + 127) / 128, B), dim3(256), lds, st, x, quad, N, C, k, drop, idx);
     return check_launch();
+}
+
+// xyz search of csrc/knn_exact.hip: ranks [drop, k + drop) by (distance, index) into idx (B,N,k) and, per row, whether two of the
+// k + drop + 1 nearest hold equal distances (tie, B*N bytes)
+int knn3_select_flags(const float* x, int B, int N, int k, int drop, int32_t* idx, uint8_t* tie, hipStream_t st) {
+    const int m = k + drop;
+    const int msel = m + 1 < N ? m + 1 : N;
+    switch (pick_k1(msel)) {
+        case 3: return launch_knn3_t<3>(x, B, N, k, drop, idx, st, msel, tie);
+        case 5: return launch_knn3_t<5>(x, B, N, k, drop, idx, st, msel, tie);
+        case 6: return launch_knn3_t<6>(x, B, N, k, drop, idx, st, msel, tie);
+        case 9: return launch_knn3_t<9>(x, B, N, k, drop, idx, st, msel, tie);
+        case 10: return launch_knn3_t<10>(x, B, N, k, drop, idx, st, msel, tie);
+        case 17: return launch_knn3_t<17>(x, B, N, k, drop, idx, st, msel, tie);
+        case 21: return launch_knn3_t<21>(x, B, N, k, drop, idx, st, msel, tie);
+        case 22: return launch_knn3_t<22>(x, B, N, k, drop, idx, st, msel, tie);
+        case 33: return launch_knn3_t<33>(x, B, N, k, drop, idx, st, msel, tie);
+        default: return HSP_ERR_UNSUPPORTED;
+    }
 }
 
 }  // namespace hsp

@@ -21,125 +21,173 @@
 namespace hsp {
 
 struct TkE { float v; int i; };
-#define TKD_LT(a, b) ((a).v < (b).v)
 
-__device__ __forceinline__ void tkd_swap(TkE* a, TkE* b) { const TkE t = *a; *a = *b; *b = t; }
+#ifdef HSP_TIE_PROF
+// stamps of ONE flagged row (tools/prof_tie_pass.py builds a private copy of the library with this switch): core clocks
+__device__ long long* g_tie_prof = nullptr;
+#define TIE_STAMP(slot) do { if (g_tie_prof && (threadIdx.x & 63) == 0) g_tie_prof[slot] = clock64(); } while (0)
+#else
+#define TIE_STAMP(slot) do { } while (0)
+#endif
+
+// The libstdc++ routines below are written once, in INDEX form, over an accessor: LdsAcc keeps the array in LDS (the full row of
+// N distances), LaneAcc keeps a short array (<= 64 entries) with element p in LANE p of two registers and runs the sequential
+// algorithm as wave-uniform scalar code over v_readlane / v_writelane -- a dependent step costs ~10 clocks instead of an LDS round
+// trip (~120): the final std::sort of the 20 nearest took ~10 us per row by one lane on LDS, and Pool_layer's partial_sort
+// (heap_select over all N entries, one dependent LDS read each) ~40 us; on lanes ~1 us and ~2 us.
+struct LdsAcc {
+    TkE* q;
+    __device__ __forceinline__ TkE get(int p) const { return q[p]; }
+    __device__ __forceinline__ void set(int p, TkE e) const { q[p] = e; }
+};
+struct LaneAcc {
+    float v;
+    int i;
+    __device__ __forceinline__ TkE get(int p) const {
+        p = __builtin_amdgcn_readfirstlane(p);
+        TkE e;
+        e.v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), p));
+        e.i = __builtin_amdgcn_readlane(i, p);
+        return e;
+    }
+    __device__ __forceinline__ void set(int p, TkE e) {
+        const bool me = (int)(threadIdx.x & 63) == p;          // (a compare + two selects: no v_writelane builtin in this hipcc)
+        v = me ? e.v : v;
+        i = me ? e.i : i;
+    }
+};
+
 __device__ __forceinline__ int tkd_lg(int n) { int k = 0; while (n > 1) { n >>= 1; ++k; } return k; }
 
-__device__ void tkd_move_median_to_first(TkE* result, TkE* a, TkE* b, TkE* c) {
-    if (TKD_LT(*a, *b)) {
-        if (TKD_LT(*b, *c)) tkd_swap(result, b);
-        else if (TKD_LT(*a, *c)) tkd_swap(result, c);
-        else tkd_swap(result, a);
-    } else if (TKD_LT(*a, *c)) tkd_swap(result, a);
-    else if (TKD_LT(*b, *c)) tkd_swap(result, c);
-    else tkd_swap(result, b);
+template <class A> __device__ __forceinline__ void tk_swap(A& a, int x, int y) {
+    const TkE t = a.get(x);
+    a.set(x, a.get(y));
+    a.set(y, t);
 }
-__device__ TkE* tkd_partition_pivot(TkE* first, TkE* last) {
-    TkE* mid = first + (last - first) / 2;
-    tkd_move_median_to_first(first, first + 1, mid, last - 1);
-    TkE* pivot = first;
+template <class A> __device__ void tk_move_median_to_first(A& a, int result, int x, int y, int z) {
+    const float va = a.get(x).v, vb = a.get(y).v, vc = a.get(z).v;
+    if (va < vb) {
+        if (vb < vc) tk_swap(a, result, y);
+        else if (va < vc) tk_swap(a, result, z);
+        else tk_swap(a, result, x);
+    } else if (va < vc) tk_swap(a, result, x);
+    else if (vb < vc) tk_swap(a, result, z);
+    else tk_swap(a, result, y);
+}
+template <class A> __device__ int tk_partition_pivot(A& a, int first, int last) {
+    const int mid = first + (last - first) / 2;
+    tk_move_median_to_first(a, first, first + 1, mid, last - 1);
+    const float pv = a.get(first).v;              // (the pivot slot is never swapped inside the loop)
     ++first;
-    const float pv = pivot->v;                    // (the pivot slot is never swapped inside the loop)
     for (;;) {
-        while (first->v < pv) ++first;
+        while (a.get(first).v < pv) ++first;
         --last;
-        while (pv < last->v) --last;
+        while (pv < a.get(last).v) --last;
         if (!(first < last)) return first;
-        tkd_swap(first, last);
+        tk_swap(a, first, last);
         ++first;
     }
 }
-__device__ void tkd_unguarded_linear_insert(TkE* last) {
-    const TkE val = *last;
-    TkE* next = last - 1;
-    while (TKD_LT(val, *next)) { *last = *next; last = next; --next; }
-    *last = val;
+template <class A> __device__ void tk_unguarded_linear_insert(A& a, int last) {
+    const TkE val = a.get(last);
+    int next = last - 1;
+    for (;;) {
+        const TkE nx = a.get(next);
+        if (!(val.v < nx.v)) break;
+        a.set(last, nx);
+        last = next;
+        --next;
+    }
+    a.set(last, val);
 }
-__device__ void tkd_insertion_sort(TkE* first, TkE* last) {
+template <class A> __device__ void tk_insertion_sort(A& a, int first, int last) {
     if (first == last) return;
-    for (TkE* i = first + 1; i != last; ++i) {
-        if (TKD_LT(*i, *first)) {
-            const TkE val = *i;
-            for (TkE* p = i; p != first; --p) *p = *(p - 1);          // move_backward(first, i, i + 1)
-            *first = val;
-        } else tkd_unguarded_linear_insert(i);
+    for (int i = first + 1; i != last; ++i) {
+        const TkE val = a.get(i);
+        if (val.v < a.get(first).v) {
+            for (int p = i; p != first; --p) a.set(p, a.get(p - 1));          // move_backward(first, i, i + 1)
+            a.set(first, val);
+        } else tk_unguarded_linear_insert(a, i);
     }
 }
-__device__ void tkd_push_heap(TkE* first, int hole, int top, TkE value) {
+template <class A> __device__ void tk_push_heap(A& a, int first, int hole, int top, TkE value) {
     int parent = (hole - 1) / 2;
-    while (hole > top && TKD_LT(first[parent], value)) { first[hole] = first[parent]; hole = parent; parent = (hole - 1) / 2; }
-    first[hole] = value;
+    while (hole > top) {
+        const TkE pe = a.get(first + parent);
+        if (!(pe.v < value.v)) break;
+        a.set(first + hole, pe);
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    a.set(first + hole, value);
 }
-__device__ void tkd_adjust_heap(TkE* first, int hole, int len, TkE value) {
+template <class A> __device__ void tk_adjust_heap(A& a, int first, int hole, int len, TkE value) {
     const int top = hole;
     int child = hole;
     while (child < (len - 1) / 2) {
         child = 2 * (child + 1);
-        if (TKD_LT(first[child], first[child - 1])) --child;
-        first[hole] = first[child];
+        const TkE c1 = a.get(first + child), c0 = a.get(first + child - 1);
+        TkE take = c1;
+        if (c1.v < c0.v) { --child; take = c0; }
+        a.set(first + hole, take);
         hole = child;
     }
     if ((len & 1) == 0 && child == (len - 2) / 2) {
         child = 2 * (child + 1);
-        first[hole] = first[child - 1];
+        a.set(first + hole, a.get(first + child - 1));
         hole = child - 1;
     }
-    tkd_push_heap(first, hole, top, value);
+    tk_push_heap(a, first, hole, top, value);
 }
-__device__ void tkd_make_heap(TkE* first, TkE* last) {
-    const int len = (int)(last - first);
+template <class A> __device__ void tk_make_heap(A& a, int first, int last) {
+    const int len = last - first;
     if (len < 2) return;
     for (int parent = (len - 2) / 2;; --parent) {
-        tkd_adjust_heap(first, parent, len, first[parent]);
+        tk_adjust_heap(a, first, parent, len, a.get(first + parent));
         if (parent == 0) return;
     }
 }
-__device__ void tkd_pop_heap(TkE* first, TkE* last, TkE* result) {
-    const TkE value = *result;
-    *result = *first;
-    tkd_adjust_heap(first, 0, (int)(last - first), value);
+template <class A> __device__ void tk_pop_heap(A& a, int first, int last, int result) {
+    const TkE value = a.get(result);
+    a.set(result, a.get(first));
+    tk_adjust_heap(a, first, 0, last - first, value);
 }
-__device__ void tkd_heap_select(TkE* first, TkE* middle, TkE* last) {
-    tkd_make_heap(first, middle);
-    for (TkE* i = middle; i < last; ++i)
-        if (TKD_LT(*i, *first)) tkd_pop_heap(first, middle, i);
+template <class A> __device__ void tk_heap_select(A& a, int first, int middle, int last) {
+    tk_make_heap(a, first, middle);
+    for (int i = middle; i < last; ++i)
+        if (a.get(i).v < a.get(first).v) tk_pop_heap(a, first, middle, i);
 }
-__device__ void tkd_sort_heap(TkE* first, TkE* last) {
-    while (last - first > 1) { --last; tkd_pop_heap(first, last, last); }
-}
-__device__ void tkd_introselect(TkE* first, TkE* nth, TkE* last, int depth_limit) {
-    while (last - first > 3) {
-        if (depth_limit == 0) { tkd_heap_select(first, nth + 1, last); tkd_swap(first, nth); return; }
-        --depth_limit;
-        TkE* cut = tkd_partition_pivot(first, last);
-        if (cut <= nth) first = cut; else last = cut;
-    }
-    tkd_insertion_sort(first, last);
+template <class A> __device__ void tk_sort_heap(A& a, int first, int last) {
+    while (last - first > 1) { --last; tk_pop_heap(a, first, last, last); }
 }
 // std::sort of a short range: __introsort_loop (recursion on the upper part turned into a small explicit stack) + final insertion sort
-__device__ void tkd_sort(TkE* first, TkE* last) {
+template <class A> __device__ void tk_sort(A& a, int first, int last) {
     if (first == last) return;
-    struct { TkE* f; TkE* l; int d; } st[40];
+    int sf[40], sl[40], sd[40];
     int sp = 0;
-    st[sp].f = first; st[sp].l = last; st[sp].d = 2 * tkd_lg((int)(last - first)); ++sp;
+    sf[0] = first; sl[0] = last; sd[0] = 2 * tkd_lg(last - first); sp = 1;
     while (sp) {
         --sp;
-        TkE* f = st[sp].f; TkE* l = st[sp].l; int d = st[sp].d;
+        int f = sf[sp], l = sl[sp], d = sd[sp];
         while (l - f > 16) {
-            if (d == 0) { tkd_heap_select(f, l, l); tkd_sort_heap(f, l); break; }
+            if (d == 0) { tk_heap_select(a, f, l, l); tk_sort_heap(a, f, l); break; }
             --d;
-            TkE* cut = tkd_partition_pivot(f, l);
+            const int cut = tk_partition_pivot(a, f, l);
             // the reference recurses into [cut, l) FIRST and then continues with [f, cut): the two ranges are disjoint, so the
             // order in which they are finished does not change the result
-            if (sp < 40) { st[sp].f = cut; st[sp].l = l; st[sp].d = d; ++sp; }
+            if (sp < 40) { sf[sp] = cut; sl[sp] = l; sd[sp] = d; ++sp; }
             l = cut;
         }
     }
     if (last - first > 16) {
-        tkd_insertion_sort(first, first + 16);
-        for (TkE* i = first + 16; i != last; ++i) tkd_unguarded_linear_insert(i);
-    } else tkd_insertion_sort(first, last);
+        tk_insertion_sort(a, first, first + 16);
+        for (int i = first + 16; i != last; ++i) tk_unguarded_linear_insert(a, i);
+    } else tk_insertion_sort(a, first, last);
+}
+// a range of at most 32 entries needs at most 16 pending sub-ranges; ranges <= 16 skip the loop entirely
+template <class A> __device__ void tk_sort_short(A& a, int first, int last) {
+    if (last - first <= 16) { tk_insertion_sort(a, first, last); return; }
+    tk_sort(a, first, last);
 }
 
 // ---- the same partition step by a whole wave -------------------------------------------------------------------------------------
@@ -149,57 +197,140 @@ __device__ void tkd_sort(TkE* first, TkE* last) {
 // position of the T-th right element) -- checked against the sequential form on 20 000 tie-rich arrays.  Both lists come out of one
 // ballot / popcount sweep, the swaps are independent: N / 64 wave steps per pass instead of ~N dependent LDS round trips (a row of
 // 1028 distances: ~0.15 ms sequentially, the pace of the whole kernel).
+// (The workgroup is ONE wave: its LDS operations execute in program order, so a store by one lane is seen by a later load of
+// another without a barrier; wave_barrier only pins the compiler's order.)
 __device__ int tkw_partition_pivot(TkE* q, int* LA, int* LB, int first, int last, int lane) {
-    if (lane == 0) tkd_move_median_to_first(q + first, q + first + 1, q + first + (last - first) / 2, q + last - 1);
-    __syncthreads();
-    const float pv = q[first].v;
+    // __move_median_to_first(first, first + 1, mid, last - 1): every lane reads the three candidates (broadcast loads, one round
+    // trip) and picks; lane 0 swaps.  The scan below substitutes the swapped-in value at the donor slot instead of waiting for it.
+    const int x = first + 1, y = first + (last - first) / 2, z = last - 1;
+    const TkE ef = q[first];
+    const float va = q[x].v, vb = q[y].v, vc = q[z].v;
+    int sel;
+    if (va < vb) sel = vb < vc ? y : (va < vc ? z : x);
+    else sel = va < vc ? x : (vb < vc ? z : y);
+    const float pv = sel == x ? va : (sel == y ? vb : vc);
+    if (lane == 0) { const TkE es = q[sel]; q[sel] = ef; q[first] = es; }
     const int lo = first + 1, hi = last;
     const unsigned long long below = (1ull << lane) - 1ull;
     int nA = 0, nB = 0;
-    for (int base = lo; base < hi; base += 64) {
-        const int p = base + lane;
-        const bool valid = p < hi;
-        const float v = valid ? q[p].v : 0.f;
-        const bool a = valid && !(v < pv), b = valid && !(pv < v);
-        const unsigned long long ba = __ballot(a), bb = __ballot(b);
-        if (a) LA[nA + __popcll(ba & below)] = p;
-        if (b) LB[nB + __popcll(bb & below)] = p;
-        nA += __popcll(ba); nB += __popcll(bb);
+    for (int base = lo; base < hi; base += 256) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = base + 64 * u + lane;
+            v[u] = q[p < hi ? p : hi - 1].v;
+            if (p == sel) v[u] = ef.v;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = base + 64 * u + lane;
+            const bool valid = p < hi;
+            const bool a = valid && !(v[u] < pv), b = valid && !(pv < v[u]);
+            const unsigned long long ba = __ballot(a), bb = __ballot(b);
+            if (a) LA[nA + __popcll(ba & below)] = p;
+            if (b) LB[nB + __popcll(bb & below)] = p;
+            nA += __popcll(ba); nB += __popcll(bb);
+        }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     const int nmin = nA < nB ? nA : nB;
     int T = 0;
     for (int base = 0; base < nmin; base += 64) {
         const int t = base + lane;
-        const bool ok = t < nmin && LA[t] < LB[nB - 1 - t];
+        const bool ok = t < nmin && LA[t < nmin ? t : 0] < LB[t < nmin ? nB - 1 - t : 0];
         const int c = __popcll(__ballot(ok));
         T += c;
         if (c < 64) break;                                  // (the pairs that swap are a prefix)
     }
     for (int t = lane; t < T; t += 64) {
         const int a = LA[t], b = LB[nB - 1 - t];
-        const TkE x = q[a], y = q[b];
-        q[a] = y; q[b] = x;
+        const TkE ex = q[a], ey = q[b];
+        q[a] = ey; q[b] = ex;
     }
     const int aT = T < nA ? LA[T] : 0x7fffffff, bp = T > 0 ? LB[nB - T] : hi;
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     return aT < bp ? aT : bp;
 }
-// std::nth_element(q, q + nth, q + n): __introselect, the partition steps by the wave, the rest by lane 0
+template <class A> __device__ void tk_introselect(A& a, int first, int nth, int last, int depth) {
+    while (last - first > 3) {
+        if (depth == 0) { tk_heap_select(a, first, nth + 1, last); tk_swap(a, first, nth); return; }
+        --depth;
+        const int cut = tk_partition_pivot(a, first, last);
+        if (cut <= nth) first = cut; else last = cut;
+    }
+    tk_insertion_sort(a, first, last);
+}
+// std::nth_element(q, q + nth, q + n): __introselect.  Ranges above 64 entries: partition steps by the wave on LDS (~1 us each:
+// a handful of dependent LDS round trips); once the range fits the wave it moves onto the lanes and the sequential algorithm
+// finishes there (~20 clocks per step), then goes back.
 __device__ void tkw_nth_element(TkE* q, int* LA, int* LB, int nth, int n, int lane) {
     int first = 0, last = n, depth = 2 * tkd_lg(n);
-    while (last - first > 3) {
+    while (last - first > 64) {
         if (depth == 0) {
-            if (lane == 0) { tkd_heap_select(q + first, q + nth + 1, q + last); tkd_swap(q + first, q + nth); }
-            __syncthreads();
+            LdsAcc a{q};
+            if (lane == 0) { tk_heap_select(a, first, nth + 1, last); tk_swap(a, first, nth); }
+            __builtin_amdgcn_wave_barrier();
             return;
         }
         --depth;
         const int cut = tkw_partition_pivot(q, LA, LB, first, last, lane);
         if (cut <= nth) first = cut; else last = cut;
     }
-    if (lane == 0) tkd_insertion_sort(q + first, q + last);
-    __syncthreads();
+    const int len = last - first;
+    LaneAcc R;
+    const TkE e = q[first + (lane < len ? lane : 0)];
+    R.v = e.v; R.i = e.i;
+    tk_introselect(R, 0, nth - first, len, depth);
+    if (lane < len) { TkE o; o.v = R.v; o.i = R.i; q[first + lane] = o; }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// torch.topk(d, m, largest=False, sorted=True) of the N (value, index) entries of q (LDS, index order): rank r ends up in LANE r of
+// the result (r < m <= 64).  ATen's TopKImpl.h: std::partial_sort for m * 64 <= N -- here the heap lives on the lanes and the scan
+// over the other N - m entries is one ballot per 64 of them (an entry enters the heap only if it is below the CURRENT top, so the
+// entries of a chunk are taken in order, the ballot refreshed after each pop) and q is left UNTOUCHED; otherwise std::nth_element
+// (in place, wave-parallel partitions) + std::sort of the first m - 1 (on the lanes).  ``destroys`` tells the caller whether q
+// was permuted.
+__device__ __forceinline__ bool tkw_topk_destroys(int m, int N) { return !((long long)m * 64 <= N); }
+
+__device__ LaneAcc tkw_topk(TkE* q, int* LA, int* LB, int m, int N, int lane) {
+    LaneAcc H;
+    if ((long long)m * 64 <= N) {                              // std::partial_sort(q, q + m, q + N)
+        const TkE e0 = q[lane < m ? lane : 0];
+        H.v = e0.v; H.i = e0.i;
+        TIE_STAMP(1);
+        tk_make_heap(H, 0, m);
+        float top = H.get(0).v;
+        TIE_STAMP(2);
+        for (int base = m; base < N; base += 64) {
+            const int p = base + lane;
+            const bool valid = p < N;
+            const TkE e = q[valid ? p : 0];
+            unsigned long long mask = __ballot(valid && e.v < top);
+            while (mask) {
+                const int l = __builtin_ctzll(mask);
+                TkE val;
+                val.v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e.v), l));
+                val.i = __builtin_amdgcn_readlane(e.i, l);
+                tk_adjust_heap(H, 0, 0, m, val);               // __pop_heap(first, middle, i) minus the store to *i (never read again)
+                top = H.get(0).v;
+                const unsigned long long later = l == 63 ? 0ull : ~((2ull << l) - 1ull);
+                mask = __ballot(valid && e.v < top) & later;
+            }
+        }
+        TIE_STAMP(3);
+        tk_sort_heap(H, 0, m);
+        TIE_STAMP(4);
+    } else {
+        TIE_STAMP(5);
+        if (m - 1 != N) tkw_nth_element(q, LA, LB, m - 1, N, lane);
+        TIE_STAMP(6);
+        const TkE e0 = q[lane < m ? lane : 0];
+        H.v = e0.v; H.i = e0.i;
+        tk_sort_short(H, 0, m - 1);
+        TIE_STAMP(7);
+    }
+    return H;
 }
 
 // one wave per query row.  cand (B,N,mc): the mc = min(m + 1, N) nearest by (distance, index) from hsp_knn_f32 (no drop).
@@ -249,19 +380,118 @@ __global__ __launch_bounds__(64) void knn_ties_kernel(const float* __restrict__ 
     for (int j = lane; j < N; j += 64) { q[j].v = dist_to(j, qi); q[j].i = j; }
     __syncthreads();
     if (lane == 0 && nties) atomicAdd(nties, 1);
-    if ((long long)m * 64 <= N) {                              // std::partial_sort
-        if (lane == 0) { tkd_heap_select(q, q + m, q + N); tkd_sort_heap(q, q + m); }
-    } else {
-        if (m - 1 != N) tkw_nth_element(q, LA, LB, m - 1, N, lane);
-        if (lane == 0) tkd_sort(q, q + (m - 1));
+    const LaneAcc H = tkw_topk(q, LA, LB, m, N, lane);
+    if (lane >= drop && lane < m) out[lane - drop] = H.i;
+}
+
+// ---- coordinates (C == 3): the tie pass over FLAGGED rows only -------------------------------------------------------------------
+// knn3_select_flags has written every row's (distance, index)-ordered list and a flag per row; rows whose k + drop + 1 nearest are
+// pairwise different are final (torch.topk's answer is unique there, and the k2-list is the prefix of the k-list).  A fixed grid of
+// single-wave workgroups walks the rows (hipGraph-friendly: the launch does not depend on how many rows are flagged; a tie-free
+// batch costs one byte read per row) and replays flagged rows through libstdc++'s algorithm, once per requested list length --
+// on a tiled cloud (datasets/load_data.py:314-316) that is every row, and the k = 4 list of Pool_layer (gcn3d.py:236: partial_sort
+// at N = 1028) is NOT the prefix of the layers' k = 20 list (nth_element + sort).
+__global__ __launch_bounds__(64) void knn_xyz_ties_kernel(const float* __restrict__ x, const uint8_t* __restrict__ tie, int B, int N,
+                                                          int k, int k2, int drop, int32_t* __restrict__ idx,
+                                                          int32_t* __restrict__ idx2, int* __restrict__ nties) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    TkE* q = reinterpret_cast<TkE*>(smem);
+    int* LA = reinterpret_cast<int*>(q + N);
+    int* LB = LA + N;
+    const int lane = threadIdx.x;
+    const int rows = B * N;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        int32_t* out = idx + (size_t)row * k;
+        int32_t* out2 = idx2 ? idx2 + (size_t)row * k2 : nullptr;
+        if (!tie[row]) {                                       // (wave-uniform)
+            if (out2 && lane < k2) out2[lane] = out[lane];
+            continue;
+        }
+        const int b = row / N, i = row - b * N;
+        const float* xb = x + (size_t)b * N * 3;
+        const float qx = xb[i * 3], qy = xb[i * 3 + 1], qz = xb[i * 3 + 2];
+        const float qq = quad3(qx, qy, qz);
+        if (lane == 0 && nties) atomicAdd(nties, 1);
+        TIE_STAMP(0);
+        // the list whose search leaves q untouched (partial_sort) goes first: one fill serves both
+        const int m1 = k + drop, m2 = k2 + drop;
+        const bool second_first = out2 && !tkw_topk_destroys(m2, N) && tkw_topk_destroys(m1, N);
+        bool filled = false;
+        for (int pass = 0; pass < (out2 ? 2 : 1); ++pass) {
+            const bool short_list = (pass == 0) == second_first && out2;
+            if (!filled) {
+                for (int j0 = lane; j0 < N; j0 += 8 * 64) {                 // eight rows' loads in flight per lane
+                    float px[8], py[8], pz[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = j0 + 64 * u < N ? j0 + 64 * u : N - 1;
+                        px[u] = xb[j * 3]; py[u] = xb[j * 3 + 1]; pz[u] = xb[j * 3 + 2];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = j0 + 64 * u;
+                        const float inner = dot3_chain(qx, qy, qz, px[u], py[u], pz[u]);
+                        // (NaN / +inf -> FLT_MAX as in the selection kernels: the partition loops need a total order)
+                        TkE e;
+                        e.v = fminf(add_rn(add_rn(mul_rn(inner, -2.0f), quad3(px[u], py[u], pz[u])), qq), 3.402823466e+38f);
+                        e.i = j;
+                        if (j < N) q[j] = e;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                TIE_STAMP(8);
+            }
+            const int m = short_list ? m2 : m1;
+            const LaneAcc H = tkw_topk(q, LA, LB, m, N, lane);
+            filled = !tkw_topk_destroys(m, N);
+            int32_t* o = short_list ? out2 : out;
+            if (lane >= drop && lane < m) o[lane - drop] = H.i;
+            __builtin_amdgcn_wave_barrier();
+        }
     }
-    __syncthreads();
-    if (lane >= drop && lane < m) out[lane - drop] = q[lane].i;
 }
 
 }  // namespace hsp
 
 using namespace hsp;
+
+#ifdef HSP_TIE_PROF
+extern "C" int hsp_debug_set_tie_prof(void* dev_buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tie_prof), &dev_buf, sizeof(void*)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+extern "C" size_t hsp_knn_xyz_workspace_bytes(int B, int N) {
+    if (B <= 0 || N <= 0) return 0;
+    return ((size_t)B * N + 255) & ~(size_t)255;
+}
+
+extern "C" int hsp_knn_xyz_f32(const float* xyz, int B, int N, int k, int k2, int drop_first, int32_t* idx, int32_t* idx2, void* ws,
+                               size_t ws_bytes, int* tie_rows, hspStream_t stream) {
+    if (!xyz || !idx || B <= 0 || N <= 0 || k <= 0 || k2 < 0 || k2 > k || (k2 > 0) != (idx2 != nullptr)) return HSP_ERR_BAD_ARG;
+    const int drop = drop_first ? 1 : 0;
+    const int m = k + drop;
+    if (m > N || k > HSP_MAX_K) return HSP_ERR_BAD_ARG;
+    if (m + 1 > 33) return HSP_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < hsp_knn_xyz_workspace_bytes(B, N)) return HSP_ERR_WORKSPACE;
+    uint8_t* tie = reinterpret_cast<uint8_t*>(ws);
+    int rc = knn3_select_flags(xyz, B, N, k, drop, idx, tie, as_stream(stream));
+    if (rc) return rc;
+    const size_t lds = (size_t)N * (sizeof(TkE) + 2 * sizeof(int));
+    if (lds > 160 * 1024) return HSP_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_xyz_ties_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
+    }
+    const long long rows = (long long)B * N;
+    const int per_cu = (int)(160 * 1024 / (lds > 16 * 1024 ? lds : 16 * 1024));      // resident single-wave workgroups per CU
+    const long long cap = (long long)HSP_NUM_CU * (per_cu < 1 ? 1 : per_cu);
+    const int grid = (int)(rows < cap ? rows : cap);
+    hipLaunchKernelGGL(knn_xyz_ties_kernel, dim3(grid), dim3(64), lds, as_stream(stream), xyz, tie, B, N, k, k2, drop, idx, idx2,
+                       tie_rows);
+    return check_launch();
+}
 
 extern "C" size_t hsp_knn_exact_workspace_bytes(int B, int N, int C, int k, int drop_first) {
     if (B <= 0 || N <= 0 || C <= 0 || k <= 0) return 0;
@@ -283,6 +513,7 @@ extern "C" int hsp_knn_exact_f32(const float* x, int B, int N, int C, int k, int
     const int mc = m + 1 < N ? m + 1 : N;
     if (mc > 33 || mc > 64) return HSP_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < hsp_knn_exact_workspace_bytes(B, N, C, k, drop_first)) return HSP_ERR_WORKSPACE;
+    if (C == 3) return hsp_knn_xyz_f32(x, B, N, k, 0, drop_first, idx, nullptr, ws, ws_bytes, tie_rows, stream);   // flags + flagged rows
     const size_t inner = (hsp_knn_workspace_bytes(B, N, C, mc) + 255) & ~(size_t)255;
     int32_t* cand = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + inner);
     int rc = hsp_knn_quadmode_f32(x, B, N, C, mc, 0, cand, ws, inner, C == 3 ? 0 : quad_mode, stream);

@@ -9,7 +9,9 @@ unchanged.  What differs is the execution plan:
   * graph_conv is one fused kernel per layer -- no (B,N,k,S*C) tensors;
   * the xyz-space KNN of one resolution is computed ONCE per forward and shared by the RF-P branch,
     every ORL branch and the pool of that resolution (the reference recomputes it 4x at N0, 3x at
-    N1; with the lowest-index-first tie rule the k=4 list is exactly the prefix of the k=20 list);
+    N1).  One search yields BOTH lists a resolution needs -- the layers' k = 20 and Pool_layer's k = 4
+    (reference :236) -- each in torch.topk's own order among equal distances: on a tiled cloud
+    (datasets/load_data.py:314-316) the short list is not the prefix of the long one (ops.knn_xyz);
   * conv2(cat[feature, f_global]) is evaluated as feature @ Wa^T + (f_global @ Wb^T) broadcast --
     f_global is constant over the points of a cloud, so half of that GEMM is a per-cloud bias.
 """
@@ -28,9 +30,13 @@ from . import ops, ops_bf16
 _knn_memo = None
 
 
+POOL_K = 4                                 # Pool_layer's list length in FaceRecon (reference FaceRecon.py:21,24)
+
+
 @contextlib.contextmanager
 def knn_scope():
-    """Within the scope, xyz-space KNN results are memoised per vertices tensor (by identity)."""
+    """Within the scope, xyz-space KNN results are memoised per (vertices tensor -- by identity --, list length); the first
+    search of a resolution also produces the POOL_K-list of the Pool_layer that follows (ops.knn_xyz: one search, two lists)."""
     global _knn_memo
     prev, _knn_memo = _knn_memo, {}
     try:
@@ -40,16 +46,21 @@ def knn_scope():
 
 
 def _xyz_knn(vertices, k):
-    """int32 (B,N,k') with k' >= k: the k nearest are the first k columns."""
-    if _knn_memo is None:
+    """int32 (B,N,k): get_neighbor_index(vertices, k) of the reference, ties as torch.topk leaves them."""
+    if _knn_memo is None or vertices.dtype != torch.float32:
         return ops.knn(vertices, k)
     key = id(vertices)
     hit = _knn_memo.get(key)
-    if hit is not None and hit[0] is vertices and hit[1].shape[2] >= k:
-        return hit[1]
-    idx = ops.knn(vertices, k)
-    _knn_memo[key] = (vertices, idx)      # holding the tensor keeps id() unique for the scope
-    return idx
+    if hit is None or hit[0] is not vertices:
+        hit = (vertices, {})               # holding the tensor keeps id() unique for the scope
+        _knn_memo[key] = hit
+    lists = hit[1]
+    if k not in lists:
+        if k > POOL_K and POOL_K not in lists:
+            lists[k], lists[POOL_K] = ops.knn_xyz(vertices, k, POOL_K)
+        else:
+            lists[k] = ops.knn(vertices, k)
+    return lists[k]
 
 
 # ------------------------------------------------------------------------------------------------

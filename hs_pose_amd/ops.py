@@ -120,11 +120,36 @@ def _run(name, args, key="", abytes=0, aflops=0):
 # neighbour search (no gradient: indices)
 # ------------------------------------------------------------------------------------------------
 
-def knn(x, k, drop_first=True, transposed_view=False):
+def knn_xyz(xyz, k, k2=0, drop_first=True):
+    """(idx (B,N,k), idx2 (B,N,k2) or None): get_neighbor_index on COORDINATES, torch.topk's order among equal distances included
+    (a tiled cloud, datasets/load_data.py:314-316, is full of them), for the two list lengths one resolution needs -- the layers'
+    k and Pool_layer's k2 = 4 (gcn3d.py:236), which is not the prefix of the k-list on such a cloud.  Training and eval alike:
+    a tie-free batch pays one small extra launch (csrc/knn_exact.hip)."""
+    x = _req(xyz.detach(), torch.float32, "knn_xyz.xyz")
+    B, N, C = x.shape
+    if C != 3:
+        raise HspError("knn_xyz: expects (B,N,3) coordinates")
+    k2 = int(k2) if k2 and k2 < k else 0
+    m = k + (1 if drop_first else 0)
+    if m + 1 > 33 or N < 2:                                 # beyond the tie pass's list length: the (distance, index) order
+        idx = knn(x, k, drop_first, _plain_xyz=True)
+        return idx, (idx[:, :, :k2].contiguous() if k2 else None)
+    idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
+    idx2 = torch.empty(B, N, k2, dtype=torch.int32, device=x.device) if k2 else None
+    wsb = lib().hsp_knn_xyz_workspace_bytes(B, N)
+    ws = _ws(wsb, x.device)
+    _run("hsp_knn_xyz_f32", (_p(x), B, N, k, k2, 1 if drop_first else 0, _p(idx), _p(idx2), _p(ws), wsb, None, _stream()),
+         key=f"B{B}N{N}k{k}", abytes=B * N * (12 + 4 * (k + k2)))
+    return idx, idx2
+
+
+def knn(x, k, drop_first=True, transposed_view=False, _plain_xyz=False):
     """int32 (B,N,k) nearest rows of x (B,N,C) per row; semantics of gcn3d.get_neighbor_index.  ``transposed_view`` (exact scope
     only): the reference holds these rows as the transposed view of a (B,C,N) tensor, which changes how its |x|^2 rounds."""
     x = _reqf(x.detach(), "knn.x")
     B, N, C = x.shape
+    if C == 3 and x.dtype == torch.float32 and not _plain_xyz:
+        return knn_xyz(x, k, 0, drop_first)[0]
     idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
     L = lib()
     if x.dtype == torch.bfloat16:                           # feature rows stored in bf16: bf16 MFMA distance tiles

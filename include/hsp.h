@@ -67,6 +67,17 @@ int hsp_knn_f32(const float *x, int B, int N, int C, int k, int drop_first, int3
 size_t hsp_knn_exact_workspace_bytes(int B, int N, int C, int k, int drop_first);
 int hsp_knn_exact_f32(const float *x, int B, int N, int C, int k, int drop_first, int quad_mode, int32_t *idx, void *ws,
                       size_t ws_bytes, int *tie_rows, hspStream_t stream);
+/* get_neighbor_index on COORDINATES (C == 3), torch.topk's order among equal distances included, for up to two list lengths of
+ * the same search: idx (B,N,k) and, when k2 > 0, idx2 (B,N,k2), k2 <= k -- the layers' k-list and Pool_layer's 4-list of one
+ * resolution (gcn3d.py:236; on a tiled cloud, datasets/load_data.py:314-316, the short list is NOT the prefix of the long one:
+ * ATen takes std::partial_sort for (k2 + drop) * 64 <= N and nth_element + sort otherwise).  The search itself is hsp_knn_f32's
+ * xyz kernel run one rank past the answer; it flags the rows that hold two equal distances among those k + drop + 1 nearest, and
+ * a fixed-grid pass replays only the flagged rows through libstdc++'s routines (csrc/knn_exact.hip).  A tie-free batch pays one
+ * small launch.  This is what every xyz search of the package goes through, training included.
+ * ws: hsp_knn_xyz_workspace_bytes (the row flags); tie_rows (may be NULL): device int, += number of flagged rows. */
+size_t hsp_knn_xyz_workspace_bytes(int B, int N);
+int hsp_knn_xyz_f32(const float *xyz, int B, int N, int k, int k2, int drop_first, int32_t *idx, int32_t *idx2, void *ws,
+                    size_t ws_bytes, int *tie_rows, hspStream_t stream);
 /* hsp_knn_f32 with the |x|^2 order chosen as above */
 int hsp_knn_quadmode_f32(const float *x, int B, int N, int C, int k, int drop_first, int32_t *idx, void *ws, size_t ws_bytes,
                          int quad_mode, hspStream_t stream);

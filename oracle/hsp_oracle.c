@@ -317,6 +317,29 @@ int hsp_oracle_knn(const float *x, int B, int N, int C, int k, int drop_first, i
     return 0;
 }
 
+/* the same search with torch.topk's OWN order among exactly equal distances (ATen TopKImpl.h -> libstdc++, restated above):
+ * what the reference returns on tiled clouds (datasets/load_data.py:314-316), where duplicates make ties the normal case.
+ * Pinned against the imported reference by tests/golden/exact_stack_tiled_1028.npz (tests/test_oracle_golden.py). */
+int hsp_oracle_knn_topk(const float *x, int B, int N, int C, int k, int drop_first, int32_t *idx) {
+    int m = k + (drop_first ? 1 : 0);
+    if (m > N || k <= 0) return -1;
+    float *quad = (float *)malloc(sizeof(float) * (size_t)N);
+    float *d = (float *)malloc(sizeof(float) * (size_t)N);
+    int32_t *sel = (int32_t *)malloc(sizeof(int32_t) * (size_t)m);
+    tk_t *q = (tk_t *)malloc(sizeof(tk_t) * (size_t)N);
+    for (int b = 0; b < B; b++) {
+        const float *xb = x + (size_t)b * N * C;
+        hsp_oracle_quad(xb, N, C, quad);
+        for (int i = 0; i < N; i++) {
+            knn_dist_row(xb, quad, N, C, i, d);
+            topk_smallest_aten(d, N, m, sel, q);
+            for (int r = 0; r < k; r++) idx[((size_t)b * N + i) * k + r] = sel[r + (drop_first ? 1 : 0)];
+        }
+    }
+    free(quad); free(d); free(sel); free(q);
+    return 0;
+}
+
 /* get_nearest_index (gcn3d.py:27-36). tgt (B,Nt,C), src (B,Ns,C) -> idx (B,Nt) int32 */
 int hsp_oracle_nn1(const float *tgt, int Nt, const float *src, int Ns, int B, int C, int32_t *idx) {
     float *sq = (float *)malloc(sizeof(float) * (size_t)Ns);

@@ -23,6 +23,20 @@ def golden(name):
     return np.load(os.path.join(GOLD, name + ".npz"))
 
 
+def tiled_batch(ref, bases, seed, n_pts=1028):
+    """(B, n_pts, 3) float32: cloud b = bases[b] closed-form points at ~0.8 m, brought to n_pts the way the reference's loader
+    pads a short crop (datasets/load_data.py:314-316: whole repetitions, then the leading remainder) -- the inputs of
+    oracle/gen_golden_tiled.py, rebuilt here so the fixtures carry outputs only"""
+    clouds = []
+    for b, L in enumerate(bases):
+        pcl = ref.hash_tensor((L, 3), seed + 17 * b, 0.05).numpy()
+        pcl[:, 2] += np.float32(0.8)
+        if L < n_pts:
+            pcl = np.concatenate([np.tile(pcl, (n_pts // L, 1)), pcl[:n_pts % L]], axis=0)
+        clouds.append(pcl)
+    return torch.from_numpy(np.stack(clouds, 0).astype(np.float32))
+
+
 @pytest.fixture(scope="session")
 def oracle_lib():
     """oracle/libhsp_oracle.so (C index oracle), built on demand with gcc."""
@@ -51,6 +65,14 @@ class OracleC:
         rc = self.lib.hsp_oracle_knn(_P(xn), B, N, C, k, drop_first, _P(out), _P(ds) if with_dist else None)
         assert rc == 0
         return (out, ds) if with_dist else out
+
+    def knn_topk(self, x, k, drop_first=1):
+        """get_neighbor_index with torch.topk's own order among exactly equal distances (what the reference returns)"""
+        xn = np.ascontiguousarray(x, dtype=np.float32)
+        B, N, C = xn.shape
+        out = np.empty((B, N, k), np.int32)
+        assert self.lib.hsp_oracle_knn_topk(_P(xn), B, N, C, k, drop_first, _P(out)) == 0
+        return out
 
     def topk_smallest(self, d, m):
         """indices torch.topk(d, m, largest=False) returns on the CPU, ties included (libstdc++'s order, restated in C)"""

@@ -157,6 +157,73 @@ def test_exact_stack_refinit(dev, ref, flags):
     assert max(errs.values()) <= 1e-5, errs
 
 
+def test_exact_stack_tiled(dev, ref, flags, monkeypatch):
+    """TILED clouds (a 400-point and a 1000-point crop padded to 1028 by repetition, datasets/load_data.py:314-316) through the
+    reference-initialised network in eval mode, free-running, against the imported reference (oracle/gen_golden_tiled.py): every
+    ordered neighbour list -- the coordinate searches at k = 20 AND Pool_layer's own k = 4 (gcn3d.py:236), which on such a cloud
+    is not the prefix of the k = 20 list on half of the rows, and the four feature-space searches, where the duplicated points'
+    identical feature rows tie everywhere --, both Pool_layer outputs and conv_0 ... conv_3 bit for bit, the six outputs to 1e-5."""
+    from conftest import tiled_batch
+    from hs_pose_amd import ops
+    from hs_pose_amd.PoseNet9D import PoseNet9D
+    g = golden("exact_stack_tiled_1028")
+    B, N, seed = (int(v) for v in g["meta"][:3])
+    bases = [int(v) for v in g["meta"][4:]]
+    flags.train = 0
+    torch.manual_seed(0)
+    net = PoseNet9D().to(dev).eval()
+    fr = net.face_recon
+    pts = tiled_batch(ref, bases, seed, N)
+    obj = torch.from_numpy((ref.hash_unit(B, seed + 1) * 6).astype(np.int64)).float().view(B, 1)
+    grabbed, hooks = {}, []
+    for nm in ("conv_0", "conv_1", "conv_2", "conv_3", "conv_4", "pool_1", "pool_2"):
+        hooks.append(getattr(fr, nm).register_forward_hook(          # (cloned: FaceRecon applies relu to conv_0's output in place)
+            lambda mod, i, o, nm=nm: grabbed.__setitem__(nm, tuple(t.detach().clone() for t in o) if isinstance(o, tuple) else o.detach().clone())))
+    xyz_lists, feat_lists = {}, []
+    real_xyz, real_knn = ops.knn_xyz, ops.knn
+
+    def rec_xyz(x, k, k2=0, drop_first=True):
+        a, b = real_xyz(x, k, k2, drop_first)
+        xyz_lists[(x.shape[1], k)] = a
+        if b is not None:
+            xyz_lists[(x.shape[1], k2)] = b
+        return a, b
+
+    def rec_knn(x, k, *a, **kw):
+        o = real_knn(x, k, *a, **kw)
+        if x.shape[-1] != 3:
+            feat_lists.append(o)
+        return o
+    monkeypatch.setattr(ops, "knn_xyz", rec_xyz)
+    monkeypatch.setattr(ops, "knn", rec_knn)
+    torch.manual_seed(1)
+    with torch.no_grad():
+        outs = net(pts.to(dev), obj.to(dev))
+    for h_ in hooks:
+        h_.remove()
+    # every coordinate search the reference ran, list for list
+    for (n_, k_) in ((1028, 20), (1028, 4), (257, 20), (257, 4), (64, 8)):
+        got, want = xyz_lists[(n_, k_)].cpu().numpy(), g[f"xyz_n{n_}_k{k_}"]
+        rows = float((got == want).all(-1).mean())
+        assert rows == 1.0, f"xyz search N = {n_}, k = {k_}: {rows:.4f} of the rows carry the reference's ordered list"
+    agree = [float((l_.cpu().numpy() == g[f"featknn{i + 1}"]).all(-1).mean()) for i, l_ in enumerate(feat_lists[:4])]
+    print(f"EXACT TILED STACK: rows with the reference's ordered feature-space list per HS layer {agree}; "
+          f"rows whose k = 4 list differs from the k = 20 prefix {g['k4_vs_k20_prefix'].tolist()}")
+    assert agree == [1.0, 1.0, 1.0, 1.0], agree
+    for nm in ("pool_1", "pool_2"):
+        _same(grabbed[nm][0], g[nm + ".vertices"], nm + " vertices")
+        _same(grabbed[nm][1].reshape(-1)[::29], g[nm + ".feature"], nm + " feature")
+    for nm in ("conv_0", "conv_1", "conv_2", "conv_3"):
+        o = grabbed[nm]
+        _same((o[0] if isinstance(o, tuple) else o).reshape(-1)[::53], g[nm], nm)
+    got4 = grabbed["conv_4"].reshape(-1)[::53].cpu().numpy()
+    assert np.abs(got4 - g["conv_4"]).max() <= 2e-6 * max(1.0, np.abs(g["conv_4"]).max())
+    names = ["p_green_R", "p_red_R", "f_green_R", "f_red_R", "Pred_T", "Pred_s"]
+    errs = {n_: float(np.abs(o.cpu().numpy() - g["out." + n_]).max()) for n_, o in zip(names, outs[4:])}
+    print(f"EXACT TILED STACK: max abs error of the pose / size outputs {errs}")
+    assert max(errs.values()) <= 1e-5, errs
+
+
 @pytest.mark.parametrize("B,N,C,k", [(2, 1028, 128, 20), (3, 257, 256, 20), (2, 64, 256, 8), (2, 1028, 3, 20), (2, 1028, 3, 4),
                                      (1, 300, 32, 12), (2, 4096, 64, 20)])
 def test_knn_exact_tie_order(dev, ref, B, N, C, k):

@@ -43,13 +43,14 @@ def test_knn_golden_bit_exact(dev, ref, name):
 
 
 def test_knn_ties_value_equal(dev, ref, oc):
-    """uncentred cloud with exact fp32 distance ties: the kernel equals the C oracle (lowest index first)
-    bit for bit, and equals the reference's picks up to permutations inside equal-distance groups."""
+    """uncentred cloud with exact fp32 distance ties: a coordinate search returns the REFERENCE's own picks (torch.topk's order
+    among equal distances, csrc/knn_exact.hip) -- the fixture written by the imported reference, and the C oracle's restatement."""
     from hs_pose_amd import ops
     g = golden("knn_xyz_offset")
     x, k = _case_input(ref, g)
     idx = ops.knn(x.to(dev), k).cpu().numpy()
-    assert np.array_equal(idx, oc.knn(x.numpy(), k))
+    assert np.array_equal(idx, g["idx"].astype(np.int32))
+    assert np.array_equal(idx, oc.knn_topk(x.numpy(), k))
     d = ref.knn_dist(x)
     dv_ref = torch.gather(d, 2, torch.from_numpy(g["idx"].astype(np.int64))).numpy()
     dv_gpu = torch.gather(d, 2, torch.from_numpy(idx.astype(np.int64))).numpy()
@@ -77,30 +78,52 @@ def test_knn_vs_c_oracle(dev, ref, oc, B, N, C, k, drop):
     from hs_pose_amd import ops
     x = ref.hash_tensor((B, N, C), 1000 + N + C + k, 0.3)
     idx = ops.knn(x.to(dev), k, drop_first=bool(drop)).cpu().numpy()
-    want = oc.knn(x.numpy(), k, drop)
+    # coordinates: torch.topk's order among equal distances; features (outside the exact scope): lowest index first
+    want = oc.knn_topk(x.numpy(), k, drop) if C == 3 else oc.knn(x.numpy(), k, drop)
     assert np.array_equal(idx, want), f"{(idx != want).sum()} of {idx.size} differ"
 
 
 def test_knn_duplicate_points(dev, ref, oc):
-    """tiled clouds (the dataset pads short clouds by repetition, SURVEY 7 hard part 2): heavy exact ties;
-    'drop rank 0' is not 'exclude self'.  Kernel == C oracle exactly."""
+    """tiled clouds (the dataset pads short clouds by repetition, datasets/load_data.py:314-316): heavy exact ties;
+    'drop rank 0' is not 'exclude self'.  Coordinates: the kernel returns what torch.topk returns on the host (ref.knn_index runs
+    the torch ops of gcn3d.py:15-24) == the C oracle's restatement of it, for both branches of ATen's topk (nth_element + sort at
+    k = 20, partial_sort at k = 4 once N >= 320).  Feature rows: lowest index first by default, torch.topk's order in the exact scope."""
     from hs_pose_amd import ops
     base = ref.hash_tensor((2, 300, 3), 77, 0.1)
     x = torch.cat([base, base[:, :212]], dim=1).contiguous()      # 512 points, 212 duplicated
-    idx = ops.knn(x.to(dev), 20).cpu().numpy()
-    assert np.array_equal(idx, oc.knn(x.numpy(), 20))
+    for k in (20, 4):
+        idx = ops.knn(x.to(dev), k).cpu().numpy()
+        assert np.array_equal(idx, ref.knn_index(x, k).numpy().astype(np.int32)), k
+        assert np.array_equal(idx, oc.knn_topk(x.numpy(), k)), k
+    i20, i4 = ops.knn_xyz(x.to(dev), 20, 4)                       # one search, both lists
+    assert np.array_equal(i20.cpu().numpy(), oc.knn_topk(x.numpy(), 20)) and np.array_equal(i4.cpu().numpy(), oc.knn_topk(x.numpy(), 4))
+    assert not torch.equal(i20[:, :, :4], i4)                     # (the short list is not the prefix of the long one here)
     # more coincident points than the wave kernel's survivor scratch: its extraction fallback
     heavy = ref.hash_tensor((2, 400, 3), 80, 0.1)
     heavy[:, 50:250] = heavy[:, 10:11]                            # 201 identical points (all mutual distances tie)
     heavy[:, 300:340] = heavy[:, 20:21]
     idx = ops.knn(heavy.to(dev), 20).cpu().numpy()
-    assert np.array_equal(idx, oc.knn(heavy.numpy(), 20))
+    assert np.array_equal(idx, ref.knn_index(heavy, 20).numpy().astype(np.int32))
     idx = ops.knn(heavy.to(dev), 4, drop_first=False).cpu().numpy()
-    assert np.array_equal(idx, oc.knn(heavy.numpy(), 4, 0))
+    assert np.array_equal(idx, oc.knn_topk(heavy.numpy(), 4, 0))
+    # the plain (distance, index) selection underneath still equals the lowest-index oracle
+    idx = ops.knn(heavy.to(dev), 20, _plain_xyz=True).cpu().numpy()
+    assert np.array_equal(idx, oc.knn(heavy.numpy(), 20))
+    # the per-lane-list kernel (B * N >= 131072) and the small-N form take the same flags
+    big = ref.hash_tensor((130, 1028, 3), 81, 0.1)
+    big[:, 600:] = big[:, :428]
+    idx = ops.knn(big.to(dev), 4).cpu().numpy()
+    assert np.array_equal(idx[:3], oc.knn_topk(big[:3].numpy(), 4)) and np.array_equal(idx[-2:], oc.knn_topk(big[-2:].numpy(), 4))
+    small = ref.hash_tensor((3, 40, 3), 82, 0.1)
+    small[:, 25:] = small[:, :15]
+    assert np.array_equal(ops.knn(small.to(dev), 8).cpu().numpy(), oc.knn_topk(small.numpy(), 8))
     xf = torch.relu(ref.hash_tensor((1, 200, 32), 78, 1.0))
     xf = torch.cat([xf, xf[:, :56]], dim=1).contiguous()
     idx = ops.knn(xf.to(dev), 8).cpu().numpy()
     assert np.array_equal(idx, oc.knn(xf.numpy(), 8))
+    with ops.exact_scope(True):
+        idx = ops.knn(xf.to(dev), 8).cpu().numpy()
+    assert np.array_equal(idx, oc.knn_topk(xf.numpy(), 8))
     # duplicates across the remainder rows (N = 260: rows 256..259 repeat rows 0..3) and a shared bound full of ties
     xg = torch.relu(ref.hash_tensor((2, 256, 64), 79, 1.0))
     xg = torch.cat([xg, xg[:, :4]], dim=1).contiguous()
@@ -118,6 +141,25 @@ def test_nn1_golden(dev, ref, name):
     idx = gcn3d.get_nearest_index(tgt.to(dev), src.to(dev))
     assert idx.shape == (2, 1028, 1) and idx.dtype == torch.int64
     assert np.array_equal(idx.squeeze(-1).cpu().numpy(), g["idx"].astype(np.int64))
+
+
+@pytest.mark.parametrize("name", ["exact_stack_tiled_1028", "stack_tiled_trainbn_1028"])
+def test_knn_xyz_tiled_lists(dev, ref, name):
+    """the five coordinate searches of a forward on TILED clouds against the lists the imported reference computed
+    (oracle/gen_golden_tiled.py): k = 20 and Pool_layer's k = 4 at N = 1028 and 257 from one call each, k = 8 at N = 64"""
+    from conftest import tiled_batch
+    from hs_pose_amd import ops
+    g = golden(name)
+    B, N, seed = (int(v) for v in g["meta"][:3])
+    pts = tiled_batch(ref, [int(v) for v in g["meta"][4:]], seed, N)
+    centred = torch.from_numpy(g["centred"]) if "centred" in g.files else pts - pts.mean(dim=1, keepdim=True)
+    i20, i4 = ops.knn_xyz(centred.to(dev), 20, 4)
+    assert np.array_equal(i20.cpu().numpy(), g[f"xyz_n{N}_k20"]) and np.array_equal(i4.cpu().numpy(), g[f"xyz_n{N}_k4"])
+    v1 = torch.from_numpy(g["pool_1.vertices"]).to(dev)
+    i20, i4 = ops.knn_xyz(v1, 20, 4)
+    assert np.array_equal(i20.cpu().numpy(), g["xyz_n257_k20"]) and np.array_equal(i4.cpu().numpy(), g["xyz_n257_k4"])
+    v2 = torch.from_numpy(g["pool_2.vertices"]).to(dev)
+    assert np.array_equal(ops.knn(v2, 8).cpu().numpy(), g["xyz_n64_k8"])
 
 
 def test_knn_full_size_properties(dev, ref):

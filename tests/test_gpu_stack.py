@@ -323,3 +323,85 @@ def test_posenet9d_free_running_refinit(dev, ref, flags, monkeypatch, gemm_mode,
     assert all(a >= f for a, f in zip(watch.agree, REFINIT_AGREE[name])), watch.agree
     for n_, e in errs.items():
         assert e <= REFINIT_BOUND[name], f"{name} {n_}: {e:.3e} > {REFINIT_BOUND[name]}"
+
+
+def test_stack_tiled_trainbn(dev, ref, flags, monkeypatch):
+    """TRAINING-mode rule on tiled clouds (400 / 1000 / 257 / 600 base points padded to 1028 by repetition, datasets/load_data.py:
+    314-316): the coordinate searches follow torch.topk's order among equal distances in training too (ops.knn_xyz is the only
+    route), so with the reference's FEATURE-space lists replayed (train-mode BatchNorm rules out bit-equal feature rows) the
+    forward meets the reference at 1e-4 and the backward of the HS stack lands inside the bounds of the tie-free case -- the max
+    over a neighbourhood that holds a point AND its duplicate ties exactly there, and the gradient must go where torch.max's
+    first-index rule sends it.  Fixture: oracle/gen_golden_tiled.py (reference-initialised weights)."""
+    from conftest import tiled_batch
+    from hs_pose_amd import ops
+    from hs_pose_amd.PoseNet9D import PoseNet9D
+    g = golden("stack_tiled_trainbn_1028")
+    B, N, seed = (int(v) for v in g["meta"][:3])
+    bases = [int(v) for v in g["meta"][4:]]
+
+    def build():
+        flags.train = 0
+        torch.manual_seed(0)
+        net = PoseNet9D().to(dev)
+        net.train(True)
+        for m in net.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        return net
+    pts = tiled_batch(ref, bases, seed, N).to(dev)
+    obj = torch.from_numpy((ref.hash_unit(B, seed + 1) * 6).astype(np.int64)).float().view(B, 1).to(dev)
+    xyz_lists = {}
+    real_xyz = ops.knn_xyz
+
+    def rec_xyz(x, k, k2=0, drop_first=True):
+        a, b = real_xyz(x, k, k2, drop_first)
+        xyz_lists[(x.shape[1], k)] = a
+        if b is not None:
+            xyz_lists[(x.shape[1], k2)] = b
+        return a, b
+    monkeypatch.setattr(ops, "knn_xyz", rec_xyz)
+    forced = ForcedFeatKnn(monkeypatch, g, dev)
+    net = build()
+    torch.manual_seed(1)
+    with torch.no_grad():
+        outs = dict(zip(OUT_NAMES, net(pts, obj)))
+    for (n_, k_) in ((1028, 20), (1028, 4), (257, 20), (257, 4), (64, 8)):
+        rows = float((xyz_lists[(n_, k_)].cpu().numpy() == g[f"xyz_n{n_}_k{k_}"]).all(-1).mean())
+        assert rows == 1.0, f"xyz search N = {n_}, k = {k_}: {rows:.4f} of the rows carry the reference's ordered list"
+    errs = {n_: _maxerr(outs[n_], g["out." + n_]) for n_ in OUT_NAMES[4:]}
+    print(f"TILED, train-mode BatchNorm, feature lists replayed: own feature lists equal to the reference's on {forced.agree} of the "
+          f"rows per HS layer (sets {forced.agree_set}); max abs error {({k_: float(f'{v:.2e}') for k_, v in errs.items()})}")
+    for n_, e in errs.items():
+        assert e <= 1e-4, f"{n_}: {e:.3e}"
+    # unit U1 backward from the fixture's centred cloud
+    net = build()
+    torch.manual_seed(1)
+    _, _, feat = net.face_recon(torch.from_numpy(g["centred"]).to(dev), obj)
+    feat = feat[..., :1286]
+    scale = max(1.0, np.abs(g["feat"]).max())
+    assert _maxerr(feat.reshape(-1)[::211], g["feat"]) <= 1e-4 * scale
+    dfeat = ref.hash_tensor((B, N, 1286), seed + 5, 1.0).to(dev)
+    (feat * dfeat).sum().backward()
+    checked = 0
+    worst = {}
+    for pn, p in net.face_recon.named_parameters():
+        key = "gradsample." + pn
+        if key not in g.files:
+            continue
+        want = g[key]
+        norm, _ = g["gradnorm." + pn]
+        got = p.grad.reshape(-1)[::499].cpu().double().numpy()
+        last = pn.startswith("conv_4.")
+        tol = 3e-2 * max(np.abs(want).max(), norm / max(p.numel(), 1) ** 0.5, 1e-12)
+        assert np.abs(got - want).max() <= tol, f"{pn}: {np.abs(got - want).max():.3e} > {tol:.3e}"
+        gn = p.grad.double().norm().item()
+        worst[pn] = abs(gn - norm) / max(norm, 1e-12)
+        assert abs(gn - norm) <= (1e-4 if last else 3e-3) * max(norm, 1e-12), f"{pn}: grad norm {gn} vs {norm}"
+        checked += 1
+    assert checked >= 26
+    print("TILED backward: worst relative gradient-norm error", max(worst.items(), key=lambda kv: kv[1]))
+    for bn_ in ("bn1", "bn2", "bn3"):
+        for st in ("running_mean", "running_var"):
+            want = g[f"bnstat.{bn_}.{st}"]
+            got = getattr(getattr(net.face_recon, bn_), st).cpu().numpy()
+            assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max()), (bn_, st)

@@ -48,6 +48,34 @@ def test_knn_oracles_match_reference(ref, oc, name):
     assert np.array_equal(ref.knn_index(x, k).numpy(), want)         # torch restatement
 
 
+@pytest.mark.parametrize("name", ["exact_stack_tiled_1028", "stack_tiled_trainbn_1028"])
+def test_knn_oracles_match_reference_on_tiled_clouds(ref, oc, name):
+    """tiled clouds (the reference's loader pads a short crop by repetition: exact duplicates, ties everywhere): the five xyz
+    neighbour lists the reference's forward computed (oracle/gen_golden_tiled.py) against the C oracle's torch.topk restatement
+    and the torch restatement -- including Pool_layer's k = 4 list, which is NOT the prefix of the k = 20 list there"""
+    from conftest import tiled_batch
+    g = golden(name)
+    B, N, seed = (int(v) for v in g["meta"][:3])
+    bases = [int(v) for v in g["meta"][4:]]
+    pts = tiled_batch(ref, bases, seed, N)
+    centred = pts - pts.mean(dim=1, keepdim=True)                  # PoseNet9D.py:25
+    if "centred" in g.files:
+        assert np.array_equal(centred.numpy(), g["centred"])
+    for k in (20, 4):
+        want = g[f"xyz_n{N}_k{k}"].astype(np.int32)
+        assert np.array_equal(oc.knn_topk(centred.numpy(), k), want), k
+        assert np.array_equal(ref.knn_index(centred, k).numpy().astype(np.int32), want), k
+    l20, l4 = g[f"xyz_n{N}_k20"], g[f"xyz_n{N}_k4"]
+    differ = float((l20[:, :, :4] != l4).any(-1).mean())
+    assert differ > 0.3 and abs(differ - float(g["k4_vs_k20_prefix"][0])) < 1e-6
+    # the lowest-index rule (hsp_oracle_knn) is NOT the reference's rule on such a cloud
+    assert not np.array_equal(oc.knn(centred.numpy(), 4), l4.astype(np.int32))
+    # the coarser levels: the pooled vertices are rows of the fixture
+    for n1, k1 in ((257, 20), (257, 4), (64, 8)):
+        v = torch.from_numpy(g["pool_1.vertices" if n1 == 257 else "pool_2.vertices"])
+        assert np.array_equal(oc.knn_topk(v.numpy(), k1), g[f"xyz_n{n1}_k{k1}"].astype(np.int32)), (n1, k1)
+
+
 def test_knn_tie_case(ref, oc):
     """exact ties: torch.topk's order is unspecified, so only the selected distance VALUES are pinned."""
     g = golden("knn_xyz_offset")
