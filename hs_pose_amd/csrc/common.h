@@ -26,8 +26,11 @@ inline int check_launch() {
 
 inline hipStream_t as_stream(hspStream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
-// knn.hip -> knn_exact.hip: the xyz search by (distance, index) plus a per-row flag "two of the k + drop + 1 nearest are equally far"
-int knn3_select_flags(const float* x, int B, int N, int k, int drop, int32_t* idx, uint8_t* tie, hipStream_t st);
+// knn.hip -> knn_exact.hip: the xyz search by (distance, index) plus per-row flags: bit 0 "two of the k + drop + 1 nearest are equally
+// far", bit 1 the same for the k2 + drop + 1 nearest
+// (idx2 (B,N,k2), may be null: the first k2 entries of every list again -- the short list of every unflagged row)
+int knn3_select_flags(const float* x, int B, int N, int k, int drop, int k2, int32_t* idx, int32_t* idx2, uint8_t* tie,
+                      hipStream_t st);
 
 // persistent grid: a multiple of the XCD count so that block % 8 == XCD for every block
 inline int persistent_blocks(long long work_items, int blocks_per_cu) {

@@ -71,14 +71,15 @@ struct TopList {
 // holds the sentinel index INT_MAX; it is replaced by `fallback` (a valid row, the query itself) before it is written,
 // so a NaN / Inf input row can never turn into an out-of-range neighbour index downstream (the reference's topk also
 // returns valid indices there; the NaN shows up in the loss and engine/train.py:91-95 skips the batch).
-// ``msel`` > k + drop with ``tie_row``: the walk continues to rank msel - 1 (K1 >= msel) and *tie_row is set to 1 when two
+// ``msel`` > k + drop with ``tie_row``: the walk continues to rank msel - 1 (K1 >= msel) and bit 0 of *tie_row is set when two
 // neighbouring ranks below msel hold EQUAL distances -- the only rows on which torch.topk's answer is not the
-// (distance, index) order (csrc/knn_exact.hip) --, else to 0.
+// (distance, index) order (csrc/knn_exact.hip); bit 1: the same among the first msel2 ranks (the window of a second, shorter list).
 template <int K1, int T, bool PAIRS = false>
 __device__ __forceinline__ void merge_write(const int2* __restrict__ lists, int my_list, int sub, int k,
                                             int drop, bool valid, int32_t* __restrict__ out_row,
                                             int nrows, int fallback, int2* __restrict__ out_pairs = nullptr,
-                                            int msel = 0, uint8_t* __restrict__ tie_row = nullptr) {
+                                            int msel = 0, uint8_t* __restrict__ tie_row = nullptr, int msel2 = 0,
+                                            int32_t* __restrict__ out_row2 = nullptr, int k2 = 0) {
     const int2* mine = lists + (size_t)my_list * K1;
     int ptr = 0;
     int2 h = mine[0];
@@ -87,7 +88,7 @@ __device__ __forceinline__ void merge_write(const int2* __restrict__ lists, int 
     const int m = k + drop;
     const int mm = tie_row && msel > m ? msel : m;
     float prev = 0.f;
-    bool tie = false;
+    bool tie = false, tie2 = false;                   // tie2: among the first msel2 ranks (the short list's window)
     for (int r = 0; r < mm; ++r) {
         float bd = hd;
         int bi = hi;
@@ -110,15 +111,19 @@ __device__ __forceinline__ void merge_write(const int2* __restrict__ lists, int 
                 hi = INT_MAX;
             }
         }
-        tie = tie || (r > 0 && bd == prev);
+        const bool eq = r > 0 && bd == prev;
+        tie = tie || eq;
+        tie2 = tie2 || (eq && r < msel2);
         prev = bd;
         if (PAIRS) {
             if (sub == 0) out_pairs[r] = make_int2(__float_as_int(bd), bi);
         } else if (valid && sub == 0 && r >= drop && r < m) {
-            out_row[r - drop] = (unsigned)bi < (unsigned)nrows ? bi : fallback;
+            const int o = (unsigned)bi < (unsigned)nrows ? bi : fallback;
+            out_row[r - drop] = o;
+            if (out_row2 && r - drop < k2) out_row2[r - drop] = o;          // the short list: the prefix (final unless flagged)
         }
     }
-    if (tie_row && valid && sub == 0) *tie_row = tie ? 1 : 0;
+    if (tie_row && valid && sub == 0) *tie_row = (tie ? 1 : 0) | (tie2 ? 2 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -129,7 +134,7 @@ __device__ __forceinline__ void merge_write(const int2* __restrict__ lists, int 
 template <int K1, int T>
 __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ x, int N, int k, int drop,
                                                    int32_t* __restrict__ idx, int chunk, int msel,
-                                                   uint8_t* __restrict__ tie) {
+                                                   uint8_t* __restrict__ tie, int msel2, int32_t* __restrict__ idx2, int k2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* pts = reinterpret_cast<float4*>(smem);
     int2* lists = reinterpret_cast<int2*>(smem);          // aliases pts once the scan is over
@@ -168,7 +173,8 @@ __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ x, 
     __syncthreads();                       // every lane is done with pts: reuse the LDS for the lists
     top.store(lists + (size_t)tid * K1);   // each lane re-reads only its own list: no further barrier
     merge_write<K1, T>(lists, tid, t, k, drop, valid, idx + ((size_t)b * N + (valid ? q : 0)) * k, N, valid ? q : 0, nullptr,
-                       msel, tie ? tie + (size_t)b * N + (valid ? q : 0) : nullptr);
+                       msel, tie ? tie + (size_t)b * N + (valid ? q : 0) : nullptr, msel2,
+                       idx2 ? idx2 + ((size_t)b * N + (valid ? q : 0)) * k2 : nullptr, k2);
 }
 
 __device__ __forceinline__ unsigned sortable_key(float f) {
@@ -191,12 +197,14 @@ __device__ __forceinline__ unsigned sortable_key(float f) {
 // those msel nearest hold EQUAL distances (see merge_write).
 template <int S>
 __global__ __launch_bounds__(256) void knn3_wave_kernel(const float* __restrict__ x, int N, int k, int drop,
-                                                        int32_t* __restrict__ idx, int msel, uint8_t* __restrict__ tie) {
+                                                        int32_t* __restrict__ idx, int msel, uint8_t* __restrict__ tie,
+                                                        int msel2, int32_t* __restrict__ idx2, int k2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* pts = reinterpret_cast<float4*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int2* sv = reinterpret_cast<int2*>(pts + N) + (size_t)wave * KNN3W_CAP;
+    float* sd = reinterpret_cast<float*>(reinterpret_cast<int2*>(pts + N) + 4 * KNN3W_CAP) + wave * 64;   // ranked distances (tie flags)
     const int b = blockIdx.y;
     const float* xb = x + (size_t)b * N * 3;
     for (int j = tid; j < N; j += 256) {
@@ -243,25 +251,28 @@ __global__ __launch_bounds__(256) void knn3_wave_kernel(const float* __restrict_
         }
         __builtin_amdgcn_wave_barrier();
         int32_t* out = idx + ((size_t)b * N + q) * k;
-        bool tied = false;
+        int32_t* out2 = idx2 ? idx2 + ((size_t)b * N + q) * k2 : nullptr;   // the short list: the prefix (final unless flagged)
+        bool tied = false, tied2 = false;                     // tied2: inside the first msel2 ranks
         if (n <= KNN3W_CAP) {
             for (int e = lane; e < n; e += 64) {
                 const int2 me = sv[e];
                 const float de = __int_as_float(me.x);
                 int rank = 0;
-                bool eq_lo = false, eq_hi = false;            // an equal distance at a lower / a higher index
                 for (int f = 0; f < n; ++f) {
                     const int2 o = sv[f];
                     const float df = __int_as_float(o.x);
-                    const bool eq = df == de;
-                    rank += (df < de || (eq && o.y < me.y)) ? 1 : 0;
-                    eq_lo = eq_lo || (eq && o.y < me.y);
-                    eq_hi = eq_hi || (eq && o.y > me.y);
+                    rank += (df < de || (df == de && o.y < me.y)) ? 1 : 0;
                 }
                 if (rank >= drop && rank < m) out[rank - drop] = me.y;
-                // equal distances occupy neighbouring ranks: the pair lies below ms when this entry does and its partner is the
-                // previous rank, or the next one and that is still below ms
-                tied = tied || (rank < ms && (eq_lo || (eq_hi && rank + 1 < ms)));
+                if (out2 && rank >= drop && rank - drop < k2) out2[rank - drop] = me.y;
+                if (tie && rank < ms) sd[rank] = de;           // the ms nearest distances in rank order (ranks are a permutation)
+            }
+            if (tie) {
+                // equal distances occupy neighbouring ranks: one compare per rank instead of two more tests per ranked pair
+                __builtin_amdgcn_wave_barrier();
+                const bool eq = lane + 1 < ms && sd[lane] == sd[lane + 1];
+                tied = eq;
+                tied2 = eq && lane + 1 < msel2;
             }
         } else {
             // more survivors than scratch (heavily duplicated points): extract the m smallest (distance, index)
@@ -292,13 +303,15 @@ __global__ __launch_bounds__(256) void knn3_wave_kernel(const float* __restrict_
                     if (z) live = z; else wj |= 1 << bit;
                 }
                 if (lane == 0 && r >= drop && r < m) out[r - drop] = wj;
+                if (lane == 0 && out2 && r >= drop && r - drop < k2) out2[r - drop] = wj;
                 tied = tied || (r > 0 && wk == pk);
+                tied2 = tied2 || (r > 0 && r < msel2 && wk == pk);
                 pk = wk; pj = wj;
             }
         }
         if (tie) {
-            const bool any_tied = __ballot(tied) != 0ull;
-            if (lane == 0) tie[(size_t)b * N + q] = any_tied ? 1 : 0;
+            const int flags = (__ballot(tied) != 0ull ? 1 : 0) | (__ballot(tied2) != 0ull ? 2 : 0);
+            if (lane == 0) tie[(size_t)b * N + q] = (uint8_t)flags;
         }
         __builtin_amdgcn_wave_barrier();                      // sv is reused by the next query
     }
@@ -876,7 +889,8 @@ static int pick_k1(int m) {
 }
 
 template <int K1, int T>
-static int launch_knn3(const float* x, int B, int N, int k, int drop, int32_t* idx, hipStream_t st, int msel, uint8_t* tie) {
+static int launch_knn3(const float* x, int B, int N, int k, int drop, int32_t* idx, hipStream_t st, int msel, uint8_t* tie,
+                       int msel2, int32_t* idx2, int k2) {
     const int chunk = N < 4096 ? N : 4096;
     size_t lds = (size_t)chunk * 16;
     if (lds < (size_t)256 * K1 * 8) lds = (size_t)256 * K1 * 8;
@@ -887,38 +901,39 @@ static int launch_knn3(const float* x, int B, int N, int k, int drop, int32_t* i
     }
     constexpr int Q = 256 / T;
     dim3 grid((N + Q - 1) / Q, B);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, N, k, drop, idx, chunk, msel, tie);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, N, k, drop, idx, chunk, msel, tie, msel2, idx2, k2);
     return check_launch();
 }
 
 template <int S>
-static int launch_knn3_wave(const float* x, int B, int N, int k, int drop, int32_t* idx, hipStream_t st, int msel, uint8_t* tie) {
-    const size_t lds = (size_t)N * 16 + (size_t)4 * KNN3W_CAP * 8;
+static int launch_knn3_wave(const float* x, int B, int N, int k, int drop, int32_t* idx, hipStream_t st, int msel, uint8_t* tie,
+                            int msel2, int32_t* idx2, int k2) {
+    const size_t lds = (size_t)N * 16 + (size_t)4 * KNN3W_CAP * 8 + 4 * 64 * 4;
     auto kern = knn3_wave_kernel<S>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
     }
-    hipLaunchKernelGGL(kern, dim3((N + 4 * KNN3W_QW - 1) / (4 * KNN3W_QW), B), dim3(256), lds, st, x, N, k, drop, idx, msel, tie);
+    hipLaunchKernelGGL(kern, dim3((N + 4 * KNN3W_QW - 1) / (4 * KNN3W_QW), B), dim3(256), lds, st, x, N, k, drop, idx, msel, tie, msel2, idx2, k2);
     return check_launch();
 }
 
 template <int K1>
 static int launch_knn3_t(const float* x, int B, int N, int k, int drop, int32_t* idx, hipStream_t st, int msel = 0,
-                         uint8_t* tie = nullptr) {
+                         uint8_t* tie = nullptr, int msel2 = 0, int32_t* idx2 = nullptr, int k2 = 0) {
     const long long nq = (long long)B * N;
     // one wave per query while the per-lane distances fit in registers (<= 65 per lane: N <= 4160, the dense clouds of
     // BASELINE configs[3]; 1.8 ms with the per-lane-list kernel below at B=64 N=4096)
     if (N >= 64 && (nq < 131072 || N > 64 * 17)) {
-        if (N <= 64 * 5) return launch_knn3_wave<5>(x, B, N, k, drop, idx, st, msel, tie);
-        if (N <= 64 * 9) return launch_knn3_wave<9>(x, B, N, k, drop, idx, st, msel, tie);
-        if (N <= 64 * 17) return launch_knn3_wave<17>(x, B, N, k, drop, idx, st, msel, tie);
-        if (N <= 64 * 33) return launch_knn3_wave<33>(x, B, N, k, drop, idx, st, msel, tie);
-        if (N <= 64 * 65) return launch_knn3_wave<65>(x, B, N, k, drop, idx, st, msel, tie);
+        if (N <= 64 * 5) return launch_knn3_wave<5>(x, B, N, k, drop, idx, st, msel, tie, msel2, idx2, k2);
+        if (N <= 64 * 9) return launch_knn3_wave<9>(x, B, N, k, drop, idx, st, msel, tie, msel2, idx2, k2);
+        if (N <= 64 * 17) return launch_knn3_wave<17>(x, B, N, k, drop, idx, st, msel, tie, msel2, idx2, k2);
+        if (N <= 64 * 33) return launch_knn3_wave<33>(x, B, N, k, drop, idx, st, msel, tie, msel2, idx2, k2);
+        if (N <= 64 * 65) return launch_knn3_wave<65>(x, B, N, k, drop, idx, st, msel, tie, msel2, idx2, k2);
     }
-    if (nq >= 131072) return launch_knn3<K1, 1>(x, B, N, k, drop, idx, st, msel, tie);
-    if (nq >= 32768) return launch_knn3<K1, 4>(x, B, N, k, drop, idx, st, msel, tie);
-    return launch_knn3<K1, 16>(x, B, N, k, drop, idx, st, msel, tie);
+    if (nq >= 131072) return launch_knn3<K1, 1>(x, B, N, k, drop, idx, st, msel, tie, msel2, idx2, k2);
+    if (nq >= 32768) return launch_knn3<K1, 4>(x, B, N, k, drop, idx, st, msel, tie, msel2, idx2, k2);
+    return launch_knn3<K1, 16>(x, B, N, k, drop, idx, st, msel, tie, msel2, idx2, k2);
 }
 
 // how the N % 32 remainder queries of the feature path are handled
@@ -1150,21 +1165,23 @@ static int launch_knn_feat_bf16(const bf16_t* x, const float* quad, int B, int N
     return check_launch();
 }
 
-// xyz search of csrc/knn_exact.hip: ranks [drop, k + drop) by (distance, index) into idx (B,N,k) and, per row, whether two of the
-// k + drop + 1 nearest hold equal distances (tie, B*N bytes)
-int knn3_select_flags(const float* x, int B, int N, int k, int drop, int32_t* idx, uint8_t* tie, hipStream_t st) {
+// xyz search of csrc/knn_exact.hip: ranks [drop, k + drop) by (distance, index) into idx (B,N,k) and, per row (tie, B*N bytes),
+// bit 0: two of the k + drop + 1 nearest hold equal distances; bit 1: two of the k2 + drop + 1 nearest do
+int knn3_select_flags(const float* x, int B, int N, int k, int drop, int k2, int32_t* idx, int32_t* idx2, uint8_t* tie,
+                      hipStream_t st) {
     const int m = k + drop;
     const int msel = m + 1 < N ? m + 1 : N;
+    const int msel2 = k2 > 0 ? k2 + drop + 1 : 0;              // (k2 < k: inside msel)
     switch (pick_k1(msel)) {
-        case 3: return launch_knn3_t<3>(x, B, N, k, drop, idx, st, msel, tie);
-        case 5: return launch_knn3_t<5>(x, B, N, k, drop, idx, st, msel, tie);
-        case 6: return launch_knn3_t<6>(x, B, N, k, drop, idx, st, msel, tie);
-        case 9: return launch_knn3_t<9>(x, B, N, k, drop, idx, st, msel, tie);
-        case 10: return launch_knn3_t<10>(x, B, N, k, drop, idx, st, msel, tie);
-        case 17: return launch_knn3_t<17>(x, B, N, k, drop, idx, st, msel, tie);
-        case 21: return launch_knn3_t<21>(x, B, N, k, drop, idx, st, msel, tie);
-        case 22: return launch_knn3_t<22>(x, B, N, k, drop, idx, st, msel, tie);
-        case 33: return launch_knn3_t<33>(x, B, N, k, drop, idx, st, msel, tie);
+        case 3: return launch_knn3_t<3>(x, B, N, k, drop, idx, st, msel, tie, msel2, idx2, k2);
+        case 5: return launch_knn3_t<5>(x, B, N, k, drop, idx, st, msel, tie, msel2, idx2, k2);
+        case 6: return launch_knn3_t<6>(x, B, N, k, drop, idx, st, msel, tie, msel2, idx2, k2);
+        case 9: return launch_knn3_t<9>(x, B, N, k, drop, idx, st, msel, tie, msel2, idx2, k2);
+        case 10: return launch_knn3_t<10>(x, B, N, k, drop, idx, st, msel, tie, msel2, idx2, k2);
+        case 17: return launch_knn3_t<17>(x, B, N, k, drop, idx, st, msel, tie, msel2, idx2, k2);
+        case 21: return launch_knn3_t<21>(x, B, N, k, drop, idx, st, msel, tie, msel2, idx2, k2);
+        case 22: return launch_knn3_t<22>(x, B, N, k, drop, idx, st, msel, tie, msel2, idx2, k2);
+        case 33: return launch_knn3_t<33>(x, B, N, k, drop, idx, st, msel, tie, msel2, idx2, k2);
         default: return HSP_ERR_UNSUPPORTED;
     }
 }

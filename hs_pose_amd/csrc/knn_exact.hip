@@ -190,6 +190,126 @@ template <class A> __device__ void tk_sort_short(A& a, int first, int last) {
     tk_sort(a, first, last);
 }
 
+// ---- short arrays on the lanes, WAVE-PARALLEL forms (modelled lane by lane against the sequential routines in
+// tools/sim_tie_pass.py: 3 400 tie-rich rows, all list lengths / row lengths of the stack, zero mismatches) -----------------------
+// A single wave running a scalar program retires one instruction every ~5-8 clocks (nothing else hides its dependent issue), so
+// the sequential routines above cost ~300 clocks per element step on the lanes and about the same on LDS (measured with
+// -DHSP_TIE_PROF: 21 us for Pool_layer's heap_select over a 1028-entry row, 13 us for nth_element, 7 us for the sort of 20).
+// What is parallel in them:
+//   __adjust_heap + __push_heap: the hole sinks along the path of "larger child" choices, which every node can make at once
+//       (two ballots); the walk over those masks is scalar; the value then rises to just below the deepest path node that is not
+//       below it (one ballot + find-last-bit); net effect: path nodes above the landing slot take their path child's entry.
+//   __unguarded_partition_pivot on <= 64 entries: the t-th entry from the left that is not below the pivot swaps with the t-th
+//       from the right that is not above it while the former lies left of the latter -- ranks from two ballots, partners through
+//       64-entry LDS tables, the swap a lane shuffle.
+//   the final insertion sorts: stable, i.e. a rank by (value, position): count + ds_permute.
+__device__ __forceinline__ float rl_f(float x, int p) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), p)); }
+__device__ __forceinline__ int rl_i(int x, int p) { return __builtin_amdgcn_readlane(x, p); }
+
+// std::__adjust_heap(first = lane 0, hole0, len, value) on a heap whose node j lives in lane j
+__device__ __forceinline__ void lh_adjust(LaneAcc& H, int lane, int hole0, int len, float valv, int vali) {
+    const int l = 2 * lane + 1, r = l + 1;
+    const float vl = __shfl(H.v, l & 63), vr = __shfl(H.v, r & 63);
+    const int il = __shfl(H.i, l & 63), ir = __shfl(H.i, r & 63);
+    const bool two = r < len;
+    const bool right = two && !(vr < vl);                      // child = 2 (child + 1); if (h[child] < h[child - 1]) --child;
+    const bool left = (two && vr < vl) || (!two && l < len);   // (a last node with a left child only: the even-length case)
+    const unsigned long long mR = __ballot(right), mL = __ballot(left);
+    int cur = hole0;
+    unsigned long long path = 1ull << cur;
+    for (;;) {
+        if ((mR >> cur) & 1ull) cur = 2 * cur + 2;
+        else if ((mL >> cur) & 1ull) cur = 2 * cur + 1;
+        else break;
+        path |= 1ull << cur;
+    }
+    const bool onp = (path >> lane) & 1ull;
+    // __push_heap from the leaf: the hole passes a parent while parent < value; the parents' entries are the path nodes' OWN
+    // (the sink moved each up by one) -- so the value lands on the deepest path node below hole0 that is not below it, else on hole0
+    const unsigned long long fail = __ballot(onp && lane != hole0 && !(H.v < valv));
+    const int s = fail ? 63 - __builtin_clzll(fail) : hole0;
+    if (onp && lane < s) { H.v = right ? vr : vl; H.i = right ? ir : il; }
+    if (lane == s) { H.v = valv; H.i = vali; }
+}
+__device__ __forceinline__ void lh_make_heap(LaneAcc& H, int lane, int len) {
+    if (len < 2) return;
+    for (int parent = (len - 2) / 2; parent >= 0; --parent) lh_adjust(H, lane, parent, len, rl_f(H.v, parent), rl_i(H.i, parent));
+}
+__device__ __forceinline__ void lh_sort_heap(LaneAcc& H, int lane, int len) {
+    for (int last = len - 1; last >= 1; --last) {              // __pop_heap(first, last, last)
+        const float valv = rl_f(H.v, last);
+        const int vali = rl_i(H.i, last);
+        const float tv = rl_f(H.v, 0);
+        const int ti = rl_i(H.i, 0);
+        if (lane == last) { H.v = tv; H.i = ti; }
+        lh_adjust(H, lane, 0, last, valv, vali);
+    }
+}
+// std::__unguarded_partition_pivot(first, last) on lane-resident entries; SA / SB: 64 ints of LDS each
+__device__ __forceinline__ int lp_partition(LaneAcc& H, int lane, int first, int last, int* SA, int* SB) {
+    const int x = first + 1, y = first + (last - first) / 2, z = last - 1;
+    const float va = rl_f(H.v, x), vb = rl_f(H.v, y), vc = rl_f(H.v, z);
+    int sel;
+    if (va < vb) sel = vb < vc ? y : (va < vc ? z : x);
+    else sel = va < vc ? x : (vb < vc ? z : y);
+    const float fv = rl_f(H.v, first), pv = rl_f(H.v, sel);
+    const int fi = rl_i(H.i, first), si = rl_i(H.i, sel);
+    if (lane == first) { H.v = pv; H.i = si; }
+    if (lane == sel) { H.v = fv; H.i = fi; }
+    const bool in = lane > first && lane < last;
+    const bool a = in && !(H.v < pv), b = in && !(pv < H.v);
+    const unsigned long long ba = __ballot(a), bb = __ballot(b);
+    const int ra = __popcll(ba & ((1ull << lane) - 1ull)), rb = lane == 63 ? 0 : __popcll(bb >> (lane + 1));
+    if (a) SA[ra] = lane;
+    if (b) SB[rb] = lane;
+    __builtin_amdgcn_wave_barrier();
+    const int nA = __popcll(ba), nB = __popcll(bb), nmin = nA < nB ? nA : nB;
+    const int pb = (a && ra < nmin) ? SB[ra] : -1;
+    const int T = __popcll(__ballot(pb > lane));               // (the pairs that swap are a prefix)
+    int partner = lane;
+    if (a && ra < T) partner = pb;
+    if (b && rb < T) partner = SA[rb];
+    H.v = __shfl(H.v, partner);
+    H.i = __shfl(H.i, partner);
+    const int aT = T < nA ? SA[T] : 0x7fffffff, bp = T > 0 ? SB[T - 1] : last;
+    __builtin_amdgcn_wave_barrier();
+    return __builtin_amdgcn_readfirstlane(aT < bp ? aT : bp);
+}
+// stable sort of [first, last) == what __insertion_sort / __unguarded_linear_insert leave
+__device__ __forceinline__ void lp_ranksort(LaneAcc& H, int lane, int first, int last) {
+    const bool in = lane >= first && lane < last;
+    int cnt = 0;
+    for (int t = first; t < last; ++t) {
+        const float vt = rl_f(H.v, t);
+        cnt += (vt < H.v || (vt == H.v && t < lane)) ? 1 : 0;
+    }
+    const int dest = in ? first + cnt : lane;
+    H.v = __int_as_float(__builtin_amdgcn_ds_permute(dest << 2, __float_as_int(H.v)));
+    H.i = __builtin_amdgcn_ds_permute(dest << 2, H.i);
+}
+// std::__introselect on lane-resident entries
+__device__ void lp_introselect(LaneAcc& H, int lane, int first, int nth, int last, int depth, int* SA, int* SB) {
+    while (last - first > 3) {
+        if (depth == 0) { tk_heap_select(H, first, nth + 1, last); tk_swap(H, first, nth); return; }   // (sequential: never seen)
+        --depth;
+        const int cut = lp_partition(H, lane, first, last, SA, SB);
+        if (cut <= nth) first = cut; else last = cut;
+    }
+    lp_ranksort(H, lane, first, last);
+}
+// std::sort of at most 32 lane-resident entries: of the two parts a partition leaves only one can exceed 16, so
+// __introsort_loop's recursion never has work pending; the final insertion sort runs over the whole range
+__device__ void lp_sort(LaneAcc& H, int lane, int first, int last, int* SA, int* SB) {
+    int f = first, l = last, d = 2 * tkd_lg(last - first > 0 ? last - first : 1);
+    while (l - f > 16) {
+        if (d == 0) { tk_heap_select(H, f, l, l); tk_sort_heap(H, f, l); break; }                      // (sequential: never seen)
+        --d;
+        const int cut = lp_partition(H, lane, f, l, SA, SB);
+        if (l - cut > 16) f = cut; else l = cut;
+    }
+    lp_ranksort(H, lane, first, last);
+}
+
 // ---- the same partition step by a whole wave -------------------------------------------------------------------------------------
 // libstdc++'s __unguarded_partition walks two pointers towards each other over elements the other pointer has not touched yet, so
 // its swaps are exactly: the t-th element from the LEFT that is not below the pivot <-> the t-th element from the RIGHT that is not
@@ -235,17 +355,37 @@ __device__ int tkw_partition_pivot(TkE* q, int* LA, int* LB, int first, int last
     __builtin_amdgcn_wave_barrier();
     const int nmin = nA < nB ? nA : nB;
     int T = 0;
-    for (int base = 0; base < nmin; base += 64) {
-        const int t = base + lane;
-        const bool ok = t < nmin && LA[t < nmin ? t : 0] < LB[t < nmin ? nB - 1 - t : 0];
-        const int c = __popcll(__ballot(ok));
+    for (int base = 0; base < nmin; base += 256) {          // four 64-pair groups per round trip
+        int la[4], lb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = base + 64 * u + lane;
+            la[u] = LA[t < nmin ? t : 0];
+            lb[u] = LB[t < nmin ? nB - 1 - t : 0];
+        }
+        int c = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = base + 64 * u + lane;
+            const int cu = __popcll(__ballot(t < nmin && la[u] < lb[u]));
+            c += (c == 64 * u) ? cu : 0;                    // (the pairs that swap are a prefix: stop counting at the first gap)
+        }
         T += c;
-        if (c < 64) break;                                  // (the pairs that swap are a prefix)
+        if (c < 256) break;
     }
-    for (int t = lane; t < T; t += 64) {
-        const int a = LA[t], b = LB[nB - 1 - t];
-        const TkE ex = q[a], ey = q[b];
-        q[a] = ey; q[b] = ex;
+    for (int t0 = lane; t0 < T; t0 += 256) {
+        int pa[4], pb[4];
+        TkE ex[4], ey[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + 64 * u < T ? t0 + 64 * u : T - 1;
+            pa[u] = LA[t]; pb[u] = LB[nB - 1 - t];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { ex[u] = q[pa[u]]; ey[u] = q[pb[u]]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (t0 + 64 * u < T) { q[pa[u]] = ey[u]; q[pb[u]] = ex[u]; }
     }
     const int aT = T < nA ? LA[T] : 0x7fffffff, bp = T > 0 ? LB[nB - T] : hi;
     __builtin_amdgcn_wave_barrier();
@@ -280,7 +420,7 @@ __device__ void tkw_nth_element(TkE* q, int* LA, int* LB, int nth, int n, int la
     LaneAcc R;
     const TkE e = q[first + (lane < len ? lane : 0)];
     R.v = e.v; R.i = e.i;
-    tk_introselect(R, 0, nth - first, len, depth);
+    lp_introselect(R, lane, 0, nth - first, len, depth, LA, LB);
     if (lane < len) { TkE o; o.v = R.v; o.i = R.i; q[first + lane] = o; }
     __builtin_amdgcn_wave_barrier();
 }
@@ -299,8 +439,8 @@ __device__ LaneAcc tkw_topk(TkE* q, int* LA, int* LB, int m, int N, int lane) {
         const TkE e0 = q[lane < m ? lane : 0];
         H.v = e0.v; H.i = e0.i;
         TIE_STAMP(1);
-        tk_make_heap(H, 0, m);
-        float top = H.get(0).v;
+        lh_make_heap(H, lane, m);
+        float top = rl_f(H.v, 0);
         TIE_STAMP(2);
         for (int base = m; base < N; base += 64) {
             const int p = base + lane;
@@ -312,14 +452,14 @@ __device__ LaneAcc tkw_topk(TkE* q, int* LA, int* LB, int m, int N, int lane) {
                 TkE val;
                 val.v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e.v), l));
                 val.i = __builtin_amdgcn_readlane(e.i, l);
-                tk_adjust_heap(H, 0, 0, m, val);               // __pop_heap(first, middle, i) minus the store to *i (never read again)
-                top = H.get(0).v;
+                lh_adjust(H, lane, 0, m, val.v, val.i);        // __pop_heap(first, middle, i) minus the store to *i (never read again)
+                top = rl_f(H.v, 0);
                 const unsigned long long later = l == 63 ? 0ull : ~((2ull << l) - 1ull);
                 mask = __ballot(valid && e.v < top) & later;
             }
         }
         TIE_STAMP(3);
-        tk_sort_heap(H, 0, m);
+        lh_sort_heap(H, lane, m);
         TIE_STAMP(4);
     } else {
         TIE_STAMP(5);
@@ -327,7 +467,7 @@ __device__ LaneAcc tkw_topk(TkE* q, int* LA, int* LB, int m, int N, int lane) {
         TIE_STAMP(6);
         const TkE e0 = q[lane < m ? lane : 0];
         H.v = e0.v; H.i = e0.i;
-        tk_sort_short(H, 0, m - 1);
+        lp_sort(H, lane, 0, m - 1, LA, LB);
         TIE_STAMP(7);
     }
     return H;
@@ -400,13 +540,22 @@ __global__ __launch_bounds__(64) void knn_xyz_ties_kernel(const float* __restric
     int* LB = LA + N;
     const int lane = threadIdx.x;
     const int rows = B * N;
-    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int G = gridDim.x, w = blockIdx.x;
+    // wave w owns rows w, w + G, ...; their flags are read 64 at a time (one round trip per 64 rows: a per-row read made the pass
+    // cost ~1 us per unflagged row and wave -- 0.4 ms at B = 64, N = 4096).  The selection already wrote every row's short list as
+    // the prefix of its long one: final wherever bit 1 is clear (the k2 + drop + 1 nearest are pairwise different, and a tie
+    // further down the long list cannot reach the short one)
+    for (int base = 0; base < rows; base += 64 * G) {
+      const int row_l = base + lane * G + w;
+      const int fl = row_l < rows ? (int)tie[row_l] : 0;
+      unsigned long long todo = __ballot(fl != 0);
+      while (todo) {
+        const int tl = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const int row = base + tl * G + w;
+        const int flags = __builtin_amdgcn_readlane(fl, tl);
         int32_t* out = idx + (size_t)row * k;
         int32_t* out2 = idx2 ? idx2 + (size_t)row * k2 : nullptr;
-        if (!tie[row]) {                                       // (wave-uniform)
-            if (out2 && lane < k2) out2[lane] = out[lane];
-            continue;
-        }
         const int b = row / N, i = row - b * N;
         const float* xb = x + (size_t)b * N * 3;
         const float qx = xb[i * 3], qy = xb[i * 3 + 1], qz = xb[i * 3 + 2];
@@ -415,10 +564,11 @@ __global__ __launch_bounds__(64) void knn_xyz_ties_kernel(const float* __restric
         TIE_STAMP(0);
         // the list whose search leaves q untouched (partial_sort) goes first: one fill serves both
         const int m1 = k + drop, m2 = k2 + drop;
-        const bool second_first = out2 && !tkw_topk_destroys(m2, N) && tkw_topk_destroys(m1, N);
+        const bool want2 = out2 && (flags & 2);
+        const bool second_first = want2 && !tkw_topk_destroys(m2, N) && tkw_topk_destroys(m1, N);
         bool filled = false;
-        for (int pass = 0; pass < (out2 ? 2 : 1); ++pass) {
-            const bool short_list = (pass == 0) == second_first && out2;
+        for (int pass = 0; pass < (want2 ? 2 : 1); ++pass) {
+            const bool short_list = (pass == 0) == second_first && want2;
             if (!filled) {
                 for (int j0 = lane; j0 < N; j0 += 8 * 64) {                 // eight rows' loads in flight per lane
                     float px[8], py[8], pz[8];
@@ -448,6 +598,7 @@ __global__ __launch_bounds__(64) void knn_xyz_ties_kernel(const float* __restric
             if (lane >= drop && lane < m) o[lane - drop] = H.i;
             __builtin_amdgcn_wave_barrier();
         }
+      }
     }
 }
 
@@ -475,7 +626,7 @@ extern "C" int hsp_knn_xyz_f32(const float* xyz, int B, int N, int k, int k2, in
     if (m + 1 > 33) return HSP_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < hsp_knn_xyz_workspace_bytes(B, N)) return HSP_ERR_WORKSPACE;
     uint8_t* tie = reinterpret_cast<uint8_t*>(ws);
-    int rc = knn3_select_flags(xyz, B, N, k, drop, idx, tie, as_stream(stream));
+    int rc = knn3_select_flags(xyz, B, N, k, drop, k2, idx, idx2, tie, as_stream(stream));
     if (rc) return rc;
     const size_t lds = (size_t)N * (sizeof(TkE) + 2 * sizeof(int));
     if (lds > 160 * 1024) return HSP_ERR_UNSUPPORTED;
@@ -487,7 +638,9 @@ extern "C" int hsp_knn_xyz_f32(const float* xyz, int B, int N, int k, int k2, in
     const long long rows = (long long)B * N;
     const int per_cu = (int)(160 * 1024 / (lds > 16 * 1024 ? lds : 16 * 1024));      // resident single-wave workgroups per CU
     const long long cap = (long long)HSP_NUM_CU * (per_cu < 1 ? 1 : per_cu);
-    const int grid = (int)(rows < cap ? rows : cap);
+    // one wave per 8 rows at most: a tie-free batch then dispatches a few hundred workgroups, not thousands (6 us -> 3 us at N = 257)
+    const long long want = (rows + 7) / 8;
+    const int grid = (int)(want < cap ? want : cap);
     hipLaunchKernelGGL(knn_xyz_ties_kernel, dim3(grid), dim3(64), lds, as_stream(stream), xyz, tie, B, N, k, k2, drop, idx, idx2,
                        tie_rows);
     return check_launch();
