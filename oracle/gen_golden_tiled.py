@@ -50,17 +50,7 @@ NAMES = ["recon", "face_normal", "face_dis", "face_f", "p_green_R", "p_red_R", "
 N_PTS = 1028
 
 
-def tiled_batch(bases, seed):
-    """(B, 1028, 3): cloud b = bases[b] closed-form points at ~0.8 m, brought to 1028 points the way the reference's loader
-    does it (load_data.py:314-316)"""
-    clouds = []
-    for b, L in enumerate(bases):
-        pcl = oc.hash_tensor((L, 3), seed + 17 * b, 0.05).numpy()
-        pcl[:, 2] += np.float32(0.8)
-        if L < N_PTS:
-            pcl = np.concatenate([np.tile(pcl, (N_PTS // L, 1)), pcl[:N_PTS % L]], axis=0)
-        clouds.append(pcl)
-    return torch.from_numpy(np.stack(clouds, 0).astype(np.float32))
+tiled_batch = oc.tiled_batch
 
 
 class Recorder:

@@ -19,6 +19,7 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -686,3 +687,45 @@ def fps_case(name: str):
         p[150:300] = p[0:150]
         return p.double().numpy(), 40
     raise KeyError(name)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# closed-form inputs shared by the fixture generators (oracle/gen_golden_tiled.py, gen_golden_eval_loop.py) and the tests
+# ------------------------------------------------------------------------------------------------------------------------------
+def tiled_batch(bases, seed, n_pts=1028):
+    """(B, n_pts, 3) float32: cloud b = bases[b] closed-form points at ~0.8 m, brought to n_pts points the way the reference's
+    loader pads a short crop (datasets/load_data.py:314-316: whole repetitions, then the leading remainder)"""
+    clouds = []
+    for b, L in enumerate(bases):
+        pcl = hash_tensor((L, 3), seed + 17 * b, 0.05).numpy()
+        pcl[:, 2] += np.float32(0.8)
+        if L < n_pts:
+            pcl = np.concatenate([np.tile(pcl, (n_pts // L, 1)), pcl[:n_pts % L]], axis=0)
+        clouds.append(pcl)
+    return torch.from_numpy(np.stack(clouds, 0).astype(np.float32))
+
+
+EVAL_LOOP_IMAGES = {1: (1028,), 4: (1028, 350, 1028, 1028), 6: (1028, 1028, 900, 1028, 1028, 514)}   # base points per instance
+EVAL_LOOP_SEED = 300
+
+
+def eval_loop_move_bn_stats(state):
+    """running statistics off their defaults, closed form (a trained checkpoint's are not 0 / 1)"""
+    for i, (k, v) in enumerate(sorted(state.items())):
+        if k.endswith("running_mean"):
+            hash_fill_(v, 9000 + i, 0.05)
+        elif k.endswith("running_var"):
+            hash_fill_(v, 9000 + i, 0.4)
+            v.abs_().add_(0.6)
+
+
+def eval_loop_inputs(n_inst):
+    """(PC (n,1028,3), obj_id (n,1) int64, mean_shape (n,3), sym (n,4)) of one surrogate image (evaluate.py:91-96)"""
+    pts = tiled_batch(EVAL_LOOP_IMAGES[n_inst], EVAL_LOOP_SEED + 10 * n_inst)
+    obj = torch.from_numpy((hash_unit(n_inst, EVAL_LOOP_SEED + n_inst) * 6).astype(np.int64)).view(n_inst, 1)
+    mean_shape = hash_tensor((n_inst, 3), EVAL_LOOP_SEED + 100 + n_inst, 0.05) + 0.15
+    sym = torch.zeros(n_inst, 4)
+    for i in range(n_inst):
+        if i % 3 == 0:
+            sym[i] = torch.tensor([1.0, 1.0, 0.0, 1.0])           # bottle-like: the red axis is dropped (geom_utils.py:238)
+    return pts, obj, mean_shape, sym

@@ -24,17 +24,8 @@ def golden(name):
 
 
 def tiled_batch(ref, bases, seed, n_pts=1028):
-    """(B, n_pts, 3) float32: cloud b = bases[b] closed-form points at ~0.8 m, brought to n_pts the way the reference's loader
-    pads a short crop (datasets/load_data.py:314-316: whole repetitions, then the leading remainder) -- the inputs of
-    oracle/gen_golden_tiled.py, rebuilt here so the fixtures carry outputs only"""
-    clouds = []
-    for b, L in enumerate(bases):
-        pcl = ref.hash_tensor((L, 3), seed + 17 * b, 0.05).numpy()
-        pcl[:, 2] += np.float32(0.8)
-        if L < n_pts:
-            pcl = np.concatenate([np.tile(pcl, (n_pts // L, 1)), pcl[:n_pts % L]], axis=0)
-        clouds.append(pcl)
-    return torch.from_numpy(np.stack(clouds, 0).astype(np.float32))
+    """the inputs of oracle/gen_golden_tiled.py, rebuilt (oracle/ref_cpu.py::tiled_batch) so the fixtures carry outputs only"""
+    return ref.tiled_batch(bases, seed, n_pts)
 
 
 @pytest.fixture(scope="session")
