@@ -232,7 +232,9 @@ def dry_run(args, rank, world, device, result_out):
                 "dtype": args.dtype, "data": "synthetic", "dry_run": True,
                 "config": {"workload": "DRY RUN (no kernels): stub step = one gradient-sized all-reduce; launcher / contract check only",
                            "global_batch": world * B, "points": N, "parallelism": f"dp{world}",
-                           "backend": dist.get_backend() if dist.is_initialized() else "none"},
+                           "backend": dist.get_backend() if dist.is_initialized() else "none",
+                           "process_group": {"backend": dist.get_backend() if dist.is_initialized() else None,
+                                             "world_size": dist.get_world_size() if dist.is_initialized() else 1}},
                 "roofline": None, "cpu_baseline": None}
         print(json.dumps(line), file=result_out, flush=True)
     if dist.is_initialized():
@@ -297,6 +299,7 @@ def main():
     from hs_pose_amd.config import FLAGS
     from hs_pose_amd.FaceRecon import FaceRecon
     from hs_pose_amd.parallel import GradReducer, graphed_step_with_exchange, init_distributed
+    from hs_pose_amd.parallel import describe as parallel_describe
 
     rank, world, device = init_distributed()
     if args.dry_run:
@@ -462,15 +465,16 @@ def main():
                                    + ("bf16 feature storage + bf16 MFMA products, fp32 geometry / accumulation / parameters, "
                                       "train-mode BN, random-init weights (BASELINE configs[3] shape when B=64 N=4096)" if bf16 else
                                       "fp32, train-mode BN, random-init weights (BASELINE configs[1] shape)"),
-                       "global_batch": world * B, "points": N, "parallelism": f"dp{world}", "hipgraph": graphed is not None, "split_graph": bool(graphed is not None and graphed.split), "grad_exchange": ("none" if world == 1 else "2 all-reduces, first overlapped with backward" if graphed is not None and graphed.split else "1 all-reduce after backward" if graphed is not None else "bucketed, hook-driven"),
+                       "global_batch": world * B, "points": N, "parallelism": f"dp{world}", "process_group": parallel_describe(), "hipgraph": graphed is not None, "split_graph": bool(graphed is not None and graphed.split), "grad_exchange": ("none" if world == 1 else "2 all-reduces, first overlapped with backward" if graphed is not None and graphed.split else "1 all-reduce after backward" if graphed is not None else "bucketed, hook-driven"),
                        "libhsp_ms_per_step": round(hsp_ms, 4),
                        # dense per-point products: hand-written csrc/gemm_rows.hip vs the BLAS library, per composite shape
                        "dense_products": ("fp32 in / out / accumulation; products on the bf16 matrix cores from exact three-way bf16 "
-                                          "splits of both operands, 6 of the 9 slice products (csrc/gemm_x3.hip: error vs fp64 at or "
-                                          "below an fp32 GEMM's, tests/test_gpu_gemm_x3.py); feature-space distance tiles, K = 3 "
+                                          "splits of both operands, 6 of the 9 slice products (csrc/gemm_x3.hip: error vs fp64 within "
+                                          "about 3x max / 2x rms of an fp32 library GEMM's, profiles/r04/x3_error.txt, "
+                                          "tests/test_gpu_gemm_x3.py); feature-space distance tiles, K = 3 "
                                           "products and the eval-mode forward on the fp32 matrix cores" if not bf16 else
                                           "bf16 operands on the bf16 matrix cores, fp32 accumulation"),
-                       "gemm": {"mode": ops.GEMM_MODE}},
+                       "gemm": {"mode": getattr(ops, "gemm_mode", "own")}},
             "roofline": roof,
             "roofline_longest_calls": roof_all,
             "step_roofline": step_roof,
@@ -494,7 +498,7 @@ def main():
             except Exception as exc:
                 line["config"]["bf16_b64_n4096_error"] = f"{type(exc).__name__}: {exc}"[:200]
             try:
-                other = "library" if ops.GEMM_MODE == "own" else "own"
+                other = "library" if getattr(ops, "gemm_mode", "own") == "own" else "own"
                 d = side_run(["--steps", "20", "--warmup", "5"], {"HSP_GEMM": other})
                 line["config"].update({f"{other}_gemm_ms_per_step": d["ms_per_step"], f"{other}_gemm_clouds_per_s": d["value"]})
             except Exception as exc:

@@ -16,12 +16,6 @@ from . import gcn3d, ops, ops_bf16
 from .config import FLAGS
 
 
-def _bn_rows(bn, x):
-    """BatchNorm1d over channels of a (B,N,C) tensor == reference's transpose->bn->transpose (FaceRecon.py:90)."""
-    b, n, c = x.shape
-    return bn(x.reshape(b * n, c)).view(b, n, c)
-
-
 def _conv_bn_relu_rows(seq, x, n_blocks, first=None):
     """Apply n_blocks x (Conv1d k=1, BatchNorm1d, ReLU) of an nn.Sequential to (R, C) rows.  first: the first Conv1d's output when
     the caller already has it, as (rows, BatchNorm first-pass buffer) (``ops.fan_linear_rows``)."""

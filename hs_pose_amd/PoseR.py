@@ -1,8 +1,8 @@
 """Drop-in mirror of the reference's ``network/fs_net_repo/PoseR.py`` (rotation heads).
 
 Same parameter names (conv1..4, bn1..3).  The reference feeds (B,C,N) into Conv1d(k=1); here the
-trunk runs point-major as (B*N,C) GEMMs (hipBLASLt through torch), which is the layout the HS stack
-already produces -- ``forward`` still accepts the reference's (B,C,N), ``forward_rows`` takes (B,N,C).
+trunk runs point-major as (B*N,C) products on the hand-written kernels (``ops.linear_rows``: csrc/gemm_x3.hip, no BLAS
+library), which is the layout the HS stack already produces -- ``forward`` still accepts the reference's (B,C,N), ``forward_rows`` takes (B,N,C).
 """
 import torch
 import torch.nn as nn

@@ -3,7 +3,9 @@
 
 The binding carries the reference's own extension surface (tools/pyTorchChamferDistance/chamfer_distance.cpp:180-185:
 ``forward`` / ``forward_cuda`` / ``backward`` / ``backward_cuda``) and the eval-mode HS layers as one call each; the ctypes
-binding (``_lib.py``) stays the training path's and the ABI tests'.  There is no fallback: a missing module raises."""
+binding (``_lib.py``) stays the training path's and the ABI tests'.  ``ext()`` raises when the module is missing; the inference
+forms in ``ops.py`` ask ``ops._ext_ok()`` first and issue the same libhsp.so launches through ctypes otherwise (still the HIP
+kernels: there is no CPU path anywhere); ``chamfer.py`` has no ctypes twin and lets the error through."""
 import importlib
 import os
 

@@ -177,10 +177,28 @@ def knn(x, k, drop_first=True, transposed_view=False, _plain_xyz=False):
     return idx
 
 
+_ext_state = None
+
+
+def _ext_ok():
+    """True when the compiled binding (hs_pose_amd/_hsp_torch.so) loads.  It only SHORTENS the host side of the no-grad inference
+    forms -- one C++ call issues the launch sequence the ctypes route below issues from Python, the same libhsp.so kernels either
+    way -- so a host where only libhsp.so builds (no torch / python headers for hsp_torch.cpp) still runs inference, through
+    ctypes.  hs_pose_amd/chamfer.py, the reference extension's own surface, has no ctypes twin and raises."""
+    global _ext_state
+    if _ext_state is None:
+        from . import _ext
+        try:
+            _ext_state = bool(_ext.available()) and _ext.ext() is not None
+        except _ext.HspExtError:
+            _ext_state = False
+    return _ext_state
+
+
 def center_cloud(points):
     """(points - mean over the points, mean (B,1,3)) with the mean in the reference's summation order (PoseNet9D.py:25)"""
     pts = _req(points.detach(), torch.float32, "center_cloud.points")
-    if _timer is None:
+    if _timer is None and _ext_ok():
         from ._ext import ext
         return ext().center_cloud(pts)
     B, N, _ = pts.shape
@@ -436,7 +454,7 @@ def pool_layer(feat, xyz, idx, qsel, k):
     """(feature_map_pool (B,Nq,C), vertices_pool (B,Nq,3)) of Pool_layer for fp32 rows; xyz carries no gradient."""
     if (_timer is None and not torch.is_grad_enabled() and feat.is_cuda and feat.dtype == torch.float32 and feat.is_contiguous()
             and xyz.dtype == torch.float32 and xyz.is_contiguous() and idx.dtype == torch.int32 and idx.is_contiguous()
-            and qsel.dtype == torch.int32 and qsel.dim() == 1 and qsel.is_contiguous()):
+            and qsel.dtype == torch.int32 and qsel.dim() == 1 and qsel.is_contiguous() and _ext_ok()):
         from ._ext import ext
         v, out = ext().pool_forward(xyz, feat, idx, qsel, k)
         return out, v
@@ -627,10 +645,10 @@ def wgrad(A2, B2, out=None, colsum=False):
 def _wgrad_ragged_ok(A2, B2, out):
     """A2^T B2 with M = A2.shape[1] NOT a multiple of 64 (the heads' first layers: K = 1286 / 1289 / 771 input columns,
     PoseR.py:27, PoseTs.py:32, FaceRecon.py:38,116) on the x3 kernel: fp32 rows of A2 on a 16-byte pitch that covers ceil4(M)
-    (``assemble_feat`` / ``cat_rows_pitched`` lay them out so), N a multiple of 128, own-GEMM mode"""
+    (``assemble_feat`` / ``cat_rows_pitched`` lay them out so), N a multiple of 128"""
     K, M = A2.shape
     N = B2.shape[1]
-    return (GEMM_MODE == "own" and M % 64 != 0 and M >= 128 and N % 128 == 0
+    return (M % 64 != 0 and M >= 128 and N % 128 == 0
             and -(-M // 128) * (N // 128) >= 4 and A2.dtype == torch.float32 and B2.dtype == torch.float32 and A2.is_cuda
             and A2.stride(1) == 1 and B2.stride(1) == 1 and out.stride(1) == 1 and A2.stride(0) % 4 == 0 and B2.stride(0) % 4 == 0
             and A2.stride(0) >= (M + 3) // 4 * 4 and A2.data_ptr() % 16 == 0 and B2.data_ptr() % 16 == 0)
@@ -793,7 +811,9 @@ class X3Planes:
             e = dict(src=W.detach(), planes=torch.zeros(3, N, kp, dtype=torch.bfloat16, device=W.device), N=N, K=K, kp=kp,
                      transpose=bool(transpose), ver=W._version)
             if self.max_entries and len(self.entries) >= self.max_entries:      # the process-wide registry of ad-hoc callers:
-                self.entries.pop(next(iter(self.entries)))                      # oldest out (a network's own registry is unbounded)
+                # oldest out (a network's own registry is unbounded) -- its planes are parked like a replaced table, not freed:
+                # a captured hipGraph may still read them
+                self._old_tables.append(self.entries.pop(next(iter(self.entries)))["planes"])
             self.entries[k_] = e
             self._split([e])                                   # this matrix now ...
             if self.table is not None:
@@ -859,7 +879,7 @@ GEMM_X3 = True         # False (tools/gemm_gap.py, profiling): the products stay
 
 def x3_refresh():
     """re-split every weight matrix of the current registry (one launch); call once per forward, before the first product"""
-    if GEMM_X3 and GEMM_MODE != "library":
+    if GEMM_X3:
         x3_planes.refresh()
 
 
@@ -902,7 +922,7 @@ def linear_bn_part_ok(x2, W, bias):
     """a Linear (R, K) x (N, K)^T + bias whose product can also leave the first pass of the train-mode BatchNorm behind it
     (``hsp_gemm_x3_bias_bn_f32``)"""
     R, N = x2.shape[0], W.shape[0]
-    return (GEMM_MODE == "own" and bias is not None and R >= 256 and x2.dtype == torch.float32 and N % 4 == 0 and 256 % (N // 4) == 0
+    return (bias is not None and R >= 256 and x2.dtype == torch.float32 and N % 4 == 0 and 256 % (N // 4) == 0
             and gemm_x3_ok(x2, W, None, None, bias, None, None, None, None, R, N) and lib().hsp_gemm_x3_bn_tiles(R, N) <= 512)
 
 
@@ -953,9 +973,26 @@ def gemm_x3(A1, B1, nn1=False, A2=None, B2=None, nn2=False, bias=None, resid=Non
 # gradients.  No BLAS-library call.  (The comparison against the tuned BLAS library that bench.py reports lives in
 # tools/library_gemm.py.)
 # ------------------------------------------------------------------------------------------------
-GEMM_MODE = "own"      # a constant of the product.  tools/library_gemm.py (bench.py's comparison figure, the tests' second
-                       # mode) swaps the composites below for BLAS-library calls and sets this to "library", which also
-                       # switches off the fusions that only the hand-written kernels offer.
+# (tools/library_gemm.py -- bench.py's comparison figure, the tests' second mode -- REPLACES the composites below with BLAS-library
+# calls and the ``*_ok`` predicates of the fusions only the hand-written kernels offer with ``False``; nothing in this module
+# asks which of the two is running.)
+
+
+def _layer_out_bn_ok(x2, w_ste, F2, Wa, t2, out3, relu):
+    """the layer's out product can also leave the first pass of the BatchNorm behind it (``gemm_x3_bn``)"""
+    return (x2.shape[1] != 3 and not relu
+            and gemm_x3_ok(x2, w_ste, F2, Wa, None, F2, t2, None, None, x2.shape[0], out3.shape[2])
+            and (x2.shape[0] + 63) // 64 <= 512 and out3.shape[1] >= 64)
+
+
+def _ste_moments_ok(C):
+    """the surface layer's (C, 3) STE gradient from the coordinate moments of g (``colsum_rows_xyz``) instead of a product"""
+    return C % 4 == 0 and 256 % (C // 4) == 0
+
+
+def _thin_wgrad_ok(Cout, Cin, R, g):
+    """a thin per-point output layer's weight gradient on the split-K kernel through a gradient zero-padded to 64 columns"""
+    return Cout < 64 and Cin % 64 == 0 and R >= 1024 and g.is_contiguous()
 
 
 def _al16(t):
@@ -1006,9 +1043,7 @@ def _fm_rows(X2, weights, bias, out=None):
 
 def _layer_out_rows(x2, w_ste, F2, Wa, t2, out3, relu=False, bn_shift=None):
     """... ``bn_shift`` not None (own mode, x3 shapes): also returns the BatchNorm first-pass buffer of the result (else None)"""
-    if (bn_shift is not None and GEMM_MODE == "own" and x2.shape[1] != 3 and not relu
-            and gemm_x3_ok(x2, w_ste, F2, Wa, None, F2, t2, None, None, x2.shape[0], out3.shape[2])
-            and (x2.shape[0] + 63) // 64 <= 512 and out3.shape[1] >= 64):
+    if bn_shift is not None and _layer_out_bn_ok(x2, w_ste, F2, Wa, t2, out3, relu):
         B_, N_, C_ = out3.shape
         return gemm_x3_bn(x2, w_ste, F2, Wa, F2, t2.contiguous(), N_, out3.view(B_ * N_, C_))
     _layer_out_rows_plain(x2, w_ste, F2, Wa, t2, out3, relu)
@@ -1227,7 +1262,7 @@ def exact_forward():
 def _ext_inference():
     """True when an eval-mode forward may take the C++ binding's one-call forms (csrc/hsp_torch.cpp): exact scope, no autograd
     graph to record, no per-call event timer attached (bench.py --breakdown times the ctypes calls)"""
-    return _exact and _timer is None and not torch.is_grad_enabled()
+    return _exact and _timer is None and not torch.is_grad_enabled() and _ext_ok()
 
 
 def _f32c(*ts):
@@ -1402,7 +1437,7 @@ class _SurfaceLayer(torch.autograd.Function):
         g2, F2, x2 = g.view(B * N, C), F3.view(B * N, C), xyz.view(B * N, 3)
         Wa, Wb = w_conv2[:, :C], w_conv2[:, C:]
         g_conv2 = torch.empty_like(w_conv2)
-        own_ste = GEMM_MODE == "own" and C % 4 == 0 and 256 % (C // 4) == 0
+        own_ste = _ste_moments_ok(C)
         if own_ste:
             # gt = sum_i g and the per-cloud coordinate moments of g in one pass; the STE gradient g^T xyz is their sum over the
             # batch, taken as a rider of the gt^T fg launch: no library GEMM for the (C, 3) product
@@ -1498,7 +1533,7 @@ class _LinearRows(torch.autograd.Function):
         if (Cout % 64 == 0 and Cin % 64 == 0) or _wgrad_ragged_ok(x2, g, g):
             gwt, gb = wgrad(x2, g, colsum=True)                 # (Cin, Cout) = dW^T, column sums of g = db
             gw = gwt.t()
-        elif GEMM_MODE == "own" and Cout < 64 and Cin % 64 == 0 and R >= 1024 and g.is_contiguous():
+        elif _thin_wgrad_ok(Cout, Cin, R, g):
             # a thin per-point output layer (the 3- and 30-wide last layers of FaceRecon.py:48,68 over B*N rows): g padded to
             # 64 zero columns takes the split-K kernel -- the library's 16448-deep 30 x 128 product is a 100 us launch
             gp = g.new_zeros(R, 64)
@@ -1522,6 +1557,9 @@ class _FanGroup:
         self.gx = None
         self.members = 0             # set by fan_linear_rows
         self.seen = 0                # members whose backward has run in the current pass
+
+    def end_of_pass(self):
+        self.gx, self.seen = None, 0
 
 
 class _FanMember(torch.autograd.Function):
@@ -1562,18 +1600,21 @@ class _FanMember(torch.autograd.Function):
                 if grp.gx is None:
                     grp.gx = ret = torch.empty(R, K, dtype=torch.float32, device=x.device)
                     gemm_own(g, wk, True, out=grp.gx)
+                    # the buffer lives for THIS backward pass only: if a member's backward never runs in it (an unused head
+                    # output, autograd.grad on a subset of the outputs) the next pass must not find it and add into it
+                    torch.autograd.Variable._execution_engine.queue_callback(grp.end_of_pass)
                 else:
                     gemm_own(g, wk, True, resid=grp.gx, out=grp.gx)
         gwt, gb = wgrad(x if xw is None else xw, g, colsum=True)                     # (Cin, Cout) = dW^T, column sums of g = db
         grp.seen += 1
         if grp.members and grp.seen >= grp.members:          # last member of this pass: a second backward over the same graph
-            grp.gx, grp.seen = None, 0                       # (retain_graph, gradient checks) starts a fresh buffer
+            grp.end_of_pass()                                # (retain_graph, gradient checks) starts a fresh buffer
         return ret, None, None, gwt.t(), (gb if ctx.has_bias else None)
 
 
 def fan_linear_rows_ok(x, xyz, weights):
     """shapes ``fan_linear_rows`` takes on the hand-written kernels (else the caller keeps one ``linear_rows`` per layer)"""
-    if GEMM_MODE != "own" or not GEMM_X3 or x.dtype != torch.float32 or not x.is_cuda or x.dim() != 2:
+    if not GEMM_X3 or x.dtype != torch.float32 or not x.is_cuda or x.dim() != 2:
         return False
     R, K = x.shape
     if R < 1024 or x.stride(1) != 1 or x.data_ptr() % 16 or (x.stride(0) * 4) % 16 or x.stride(0) < (K + 3) // 4 * 4:
@@ -1657,7 +1698,7 @@ class _CloudCatLinear(torch.autograd.Function):
 def cloud_cat_linear_ok(fg, x, xyz, W):
     B, Cg = fg.shape
     R, Cx = x.shape
-    return (GEMM_MODE == "own" and GEMM_X3 and fg.dtype == torch.float32 and x.dtype == torch.float32 and x.is_cuda and R % B == 0
+    return (GEMM_X3 and fg.dtype == torch.float32 and x.dtype == torch.float32 and x.is_cuda and R % B == 0
             and R // B >= 128 and W.shape[1] == Cg + Cx + 3 and W.shape[0] % 128 == 0 and Cx % 4 == 0 and Cg % 4 == 0
 )
 
@@ -1904,7 +1945,7 @@ def bn_relu(x, bn, relu=True, out_dtype=None, fork=False, partial=None):
     if (not fused and not bn.training and bn.affine and bn.track_running_stats and x.is_cuda and x.dtype == torch.float32
             and C % 4 == 0 and x.is_contiguous()):
         # eval mode: ((x - m) * invstd) * w + b in ATen's own operation order (hsp_bn_eval_f32), relu fused
-        if _timer is None and not torch.is_grad_enabled():
+        if _timer is None and not torch.is_grad_enabled() and _ext_ok():
             from ._ext import ext
             y = ext().bn_eval(x, bn.running_mean, bn.running_var, _eval_invstd(bn), bn.weight, bn.bias, bn.eps, relu)
             return (y, y.view_as(y)) if fork else y

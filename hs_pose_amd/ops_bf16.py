@@ -265,7 +265,7 @@ class _SurfaceLayerBf16(torch.autograd.Function):
         _, c2T_b = copies_of(w_conv2)
         g2, F2, x2 = g.view(B * N, C), F3.view(B * N, C), xyz.view(B * N, 3)
         Wb = w_conv2[:, C:]
-        own_ste = ops.GEMM_MODE == "own" and C % 4 == 0 and 256 % (C // 4) == 0 and B <= 64
+        own_ste = ops._ste_moments_ok(C) and B <= 64
         g_conv2 = torch.empty_like(w_conv2)
         if own_ste:      # gt and the coordinate moments of g in one pass; g^T xyz = their sum over the batch (no cast, no GEMM)
             mom = ops.colsum_rows_xyz(g, xyz)

@@ -40,6 +40,21 @@ def init_distributed():
     return rank, world, device
 
 
+def describe():
+    """what the process group actually is, for the bench line of an N > 1 run: the backend torch.distributed reports ('nccl' IS RCCL
+    on ROCm), the rank count IT sees (not the one the command line asked for) and the collective library's version string"""
+    if not dist.is_initialized():
+        return {"backend": None, "world_size": 1, "collective_library": None}
+    lib = None
+    if dist.get_backend() == "nccl":
+        try:
+            v = torch.cuda.nccl.version()
+            lib = "rccl " + (".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v))
+        except Exception as exc:                              # never lose the line to a version query
+            lib = f"rccl (version query failed: {type(exc).__name__})"
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "collective_library": lib}
+
+
 def shard_range(n_items: int, rank: int, world: int):
     """contiguous [lo, hi) slice of a global batch for this rank (sizes differ by at most one)."""
     base, rem = divmod(n_items, world)

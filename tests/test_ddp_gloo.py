@@ -100,38 +100,59 @@ class _FakeGraphedStep:
 
 def _worker_graphed(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from hs_pose_amd import parallel
     from hs_pose_amd.parallel import graphed_step_with_exchange, init_distributed
     init_distributed()
-    for split in (False, True):
-        fake = _FakeGraphedStep(rank, split)
-        for step in range(3):
-            graphed_step_with_exchange(fake, world)
-            want = sum(torch.randn(1000, generator=torch.Generator().manual_seed(100 * step + r)) for r in range(world)) / world
-            assert torch.allclose(fake.flat_grad, want, rtol=1e-6, atol=1e-7), (split, step)
-        assert fake.calls == (["first", "second"] * 3 if split else ["run"] * 3)
+    assert dist.get_world_size() == world
+    issued = []                                            # every collective this rank issues: (op, element count, async?)
+    real_all_reduce = dist.all_reduce
+
+    def spy(t, *a, **kw):
+        issued.append(("all_reduce", t.numel(), bool(kw.get("async_op", False))))
+        return real_all_reduce(t, *a, **kw)
+    parallel.dist.all_reduce = spy
+    try:
+        for split in (False, True):
+            fake = _FakeGraphedStep(rank, split)
+            for step in range(3):
+                graphed_step_with_exchange(fake, world)
+                want = sum(torch.randn(1000, generator=torch.Generator().manual_seed(100 * step + r)) for r in range(world)) / world
+                assert torch.allclose(fake.flat_grad, want, rtol=1e-6, atol=1e-7), (split, step)
+            assert fake.calls == (["first", "second"] * 3 if split else ["run"] * 3)
+    finally:
+        parallel.dist.all_reduce = real_all_reduce
+    # every rank issued the SAME collectives in the SAME order (a rank that skipped or reordered one would hang RCCL, not fail):
+    # one flat all-reduce per step unsplit; split: the coarse levels' 700 elements (async, under the second graph), then the rest
+    assert issued == [("all_reduce", 1000, False)] * 3 + [("all_reduce", 700, True), ("all_reduce", 300, True)] * 3, issued
+    seqs = [None] * world
+    dist.all_gather_object(seqs, issued)
+    assert all(s_ == issued for s_ in seqs)
     # the training driver's exchange: flat gradient buffers (one per parameter group) averaged in place
     from hs_pose_amd.parallel import mean_flat_gradients
     bufs = [torch.full((50,), float(rank + 1)), torch.arange(7, dtype=torch.float32) * (rank + 1)]
     mean_flat_gradients(bufs)
-    assert torch.allclose(bufs[0], torch.full((50,), 1.5)) and torch.allclose(bufs[1], torch.arange(7, dtype=torch.float32) * 1.5)
+    mean_rank = (world + 1) / 2.0
+    assert torch.allclose(bufs[0], torch.full((50,), mean_rank)) and torch.allclose(bufs[1], torch.arange(7, dtype=torch.float32) * mean_rank)
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, "ok"))
 
 
-def test_graphed_step_exchange_world2_gloo():
-    """the gradient exchange bench.py uses around the graph replays (one all-reduce, or two with the first overlapped):
-    flat buffer == mean over the ranks, every step"""
+@pytest.mark.parametrize("world", [2, 4])
+def test_graphed_step_exchange_gloo(world):
+    """the gradient exchange bench.py uses around the graph replays (one all-reduce, or two with the first overlapped), on 2 and 4
+    ranks against a stub of graph.GraphedStep: flat buffer == mean over the ranks every step, and the sequence of collectives is
+    identical on every rank (element counts and order, gathered and compared)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_graphed, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_graphed, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(timeout=120)
-    got = sorted(q.get(timeout=5) for _ in range(2))
-    assert got == [(0, "ok"), (1, "ok")]
+        p.join(timeout=180)
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert got == [(r, "ok") for r in range(world)]
     assert all(p.exitcode == 0 for p in procs)
 
 

@@ -199,3 +199,47 @@ def test_inference_forward_takes_the_binding(dev, ref, monkeypatch):
     torch.manual_seed(11)
     want = net(pts, obj)[2]                              # grad enabled: autograd nodes over ctypes
     _eq(got, want.detach(), "feat")
+
+
+def test_every_tensor_argument_is_checked(dev, ref, m):
+    """a host tensor anywhere in an argument list (a CPU running_mean, a CPU STE weight) is an error, not a host pointer handed to a
+    kernel; a bias of the wrong length and a too-narrow pool index are refused; and with the binding declared unavailable the
+    no-grad inference forms issue the same launches through ctypes (ops._ext_ok)"""
+    from hs_pose_amd import gcn3d, ops
+    C, S, k = 32, 3, 4
+    xyz = ref.hash_tensor((1, 96, 3), 9601, 0.1).to(dev)
+    X = torch.relu(ref.hash_tensor((1, 96, C), 9602, 1.0)).to(dev)
+    layer = gcn3d.HS_layer(C, C, S).to(dev).eval()
+    idx_x, idx_f = ops.knn(xyz, k), ops.knn(X, k)
+    args = [xyz, X, idx_f, idx_x, k, S, layer.weights.detach(), layer.bias.detach(), layer.directions.detach(),
+            layer.STE_layer.weight.detach(), layer.conv2.weight.detach()]
+    for pos in (6, 7, 8, 9, 10):
+        bad = list(args)
+        bad[pos] = bad[pos].cpu()
+        with pytest.raises(RuntimeError, match="expected a tensor on"):
+            m.hs_layer_forward(*bad)
+    bad = list(args)
+    bad[7] = bad[7][:-1].contiguous()
+    with pytest.raises(RuntimeError, match="bias"):
+        m.hs_layer_forward(*bad)
+    bn = torch.nn.BatchNorm1d(C).to(dev).eval()
+    with pytest.raises(RuntimeError, match="expected a tensor on"):
+        m.bn_eval(X, bn.running_mean.cpu(), bn.running_var, None, bn.weight, bn.bias, bn.eps, False)
+    with pytest.raises(RuntimeError, match="invstd"):
+        m.bn_eval(X, bn.running_mean, bn.running_var, torch.ones(C - 1, device=dev), bn.weight, bn.bias, bn.eps, False)
+    sel = torch.arange(24, dtype=torch.int32, device=dev)
+    with pytest.raises(RuntimeError, match="idx must be"):
+        m.pool_forward(xyz, X, idx_x[:, :, :2].contiguous(), sel, 4)
+    # the ctypes route of the same no-grad forms
+    with torch.no_grad(), ops.exact_scope(True):
+        a = ops.hs_layer(*args)
+        pa = ops.pool_layer(X, xyz, idx_x, sel, 4)
+        prev, ops._ext_state = ops._ext_state, False
+        try:
+            b = ops.hs_layer(*args)
+            pb = ops.pool_layer(X, xyz, idx_x, sel, 4)
+            cb = ops.center_cloud(xyz)
+        finally:
+            ops._ext_state = prev
+        ca = ops.center_cloud(xyz)
+    _eq(a, b, "hs_layer: binding vs ctypes"), _eq(pa[0], pb[0], "pool: binding vs ctypes"), _eq(ca[0], cb[0], "centre: binding vs ctypes")

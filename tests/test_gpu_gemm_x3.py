@@ -126,11 +126,7 @@ def test_small_rows_and_outer(dev, M, N, K):
     assert (got.double() - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item())
     c = torch.randn(M, N, generator=g).to(dev)
     out = torch.empty(K, 2 * N, device=dev)
-    prev, ops.GEMM_MODE = ops.GEMM_MODE, "own"
-    try:
-        ops._tiny_tn(A, c, out[:, N:])
-    finally:
-        ops.GEMM_MODE = prev
+    ops._tiny_tn(A, c, out[:, N:])
     want = A.double().t() @ c.double()
     assert (out[:, N:].double() - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item())
 
@@ -154,11 +150,7 @@ def test_colsum_rows_xyz(dev, dtype):
     fg = torch.randn(B, C, generator=g_).to(dev)
     out = torch.empty(C, C, device=dev)
     gste = torch.empty(C, 3, device=dev)
-    prev, ops.GEMM_MODE = ops.GEMM_MODE, "own"
-    try:
-        ops._tiny_tn(mom[:, :C], fg, out, mom=mom, gste=gste)
-    finally:
-        ops.GEMM_MODE = prev
+    ops._tiny_tn(mom[:, :C], fg, out, mom=mom, gste=gste)
     want = gd.reshape(B * N, C).t() @ xyz.double().reshape(B * N, 3)
     assert (gste.double() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
     assert (out.double() - want0.t() @ fg.double()).abs().max().item() <= 1e-4 * max(1.0, (want0.t() @ fg.double()).abs().max().item())

@@ -692,14 +692,10 @@ def test_out_product_leaves_batchnorm_first_pass(dev, B, N, Cin, C):
     w_ste = (torch.randn(C, Cin, generator=g_) * 0.05).to(dev)
     Wa = (torch.randn(C, 2 * C, generator=g_) * 0.05).to(dev)[:, :C]
     t2 = torch.randn(B, C, generator=g_).to(dev)
-    prev, ops.GEMM_MODE = ops.GEMM_MODE, "own"
-    try:
-        out_a = torch.empty(B, N, C, device=dev)
-        part = ops._layer_out_rows(x2, w_ste, F2, Wa, t2, out_a, bn_shift=True)
-        out_b = torch.empty(B, N, C, device=dev)
-        assert ops._layer_out_rows(x2, w_ste, F2, Wa, t2, out_b) is None
-    finally:
-        ops.GEMM_MODE = prev
+    out_a = torch.empty(B, N, C, device=dev)
+    part = ops._layer_out_rows(x2, w_ste, F2, Wa, t2, out_a, bn_shift=True)
+    out_b = torch.empty(B, N, C, device=dev)
+    assert ops._layer_out_rows(x2, w_ste, F2, Wa, t2, out_b) is None
     if part is None:
         pytest.skip("shape not taken by the x3 out product")
     assert torch.equal(out_a, out_b)

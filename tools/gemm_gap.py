@@ -4,6 +4,10 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from hs_pose_amd import ops
+from tools import library_gemm
+_ORIG = {n_: getattr(ops, n_) for n_ in ("_fm_rows", "_layer_out_rows_plain", "_mm_nn", "_mm_nt", "_grad_in_rows", "_tiny_tn", "wgrad",
+                                       "_wgrad_ragged_ok", "linear_bn_part_ok", "_layer_out_bn_ok", "_ste_moments_ok", "_thin_wgrad_ok",
+                                       "fan_linear_rows_ok", "cloud_cat_linear_ok", "x3_refresh")}
 
 dev = torch.device("cuda:0")
 
@@ -50,7 +54,10 @@ if __name__ == "__main__":
         for cname, fl, fn in comps:
             t = {}
             for mode in ("x3", "own", "library"):
-                ops.GEMM_MODE = "library" if mode == "library" else "own"
+                for n_, f_ in _ORIG.items():                 # (the product has no mode switch: the library column swaps the
+                    setattr(ops, n_, f_)                     # composites in, tools/library_gemm.py, and back out)
+                if mode == "library":
+                    library_gemm.enable()
                 ops.GEMM_X3 = mode == "x3"
                 t[mode] = timeit(fn)
                 tot[mode] = tot.get(mode, 0.0) + t[mode]

@@ -1,9 +1,10 @@
 """The BLAS-library comparison of bench.py and of the tests' second GEMM mode -- NOT part of the product.
 
 hs_pose_amd/ops.py computes every dense product on hand-written kernels.  ``enable()`` swaps the layer composites of that module
-for calls into the BLAS library through torch (hipBLASLt / rocBLAS, TunableOp-selected when ``tune``) and sets
-``ops.GEMM_MODE = "library"``, which also switches off the fusions only the hand-written kernels offer (BatchNorm first pass in a
-product's epilogue, grouped input gradients, ...): the figure a user would get from the same network on stock PyTorch GEMMs.
+for calls into the BLAS library through torch (hipBLASLt / rocBLAS, TunableOp-selected when ``tune``) and REPLACES the ``*_ok``
+predicates of the fusions only the hand-written kernels offer (BatchNorm first pass in a product's epilogue, grouped input
+gradients, ...) with ``False``: the figure a user would get from the same network on stock PyTorch GEMMs.  ``ops.gemm_mode`` (an
+attribute this shim adds; the product has no such notion) says "library" afterwards.
 bench.py runs it in a child process (HSP_GEMM=library) and reports ``library_gemm_ms_per_step`` next to the headline."""
 import torch
 
@@ -67,9 +68,19 @@ def enable(monkeypatch=None, tune=False):
             out.copy_(A2.t() @ B2)
         return (out, B2.sum(dim=0)) if colsum else out
 
+    def never(*a, **kw):
+        return False
+
     for name, fn in (("_fm_rows", fm_rows), ("_layer_out_rows_plain", layer_out_rows_plain), ("_mm_nn", mm_nn), ("_mm_nt", mm_nt),
-                     ("_grad_in_rows", grad_in_rows), ("_tiny_tn", tiny_tn), ("wgrad", wgrad), ("GEMM_MODE", "library")):
-        put(name, fn)
+                     ("_grad_in_rows", grad_in_rows), ("_tiny_tn", tiny_tn), ("wgrad", wgrad), ("gemm_mode", "library"),
+                     # the own-kernel fusions: off
+                     ("_wgrad_ragged_ok", never), ("linear_bn_part_ok", never), ("_layer_out_bn_ok", never), ("_ste_moments_ok", never),
+                     ("_thin_wgrad_ok", never), ("fan_linear_rows_ok", never), ("cloud_cat_linear_ok", never),
+                     ("x3_refresh", lambda: None)):
+        if monkeypatch is not None and not hasattr(ops, name):
+            monkeypatch.setattr(ops, name, fn, raising=False)
+        else:
+            put(name, fn)
     if tune:
         from tools import gemm_tuning
         gemm_tuning.enable()

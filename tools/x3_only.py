@@ -3,7 +3,6 @@ sys.path.insert(0, "/root/repo")
 import torch
 from hs_pose_amd import ops
 dev = torch.device("cuda:0")
-ops.GEMM_MODE = "own"
 B, S = 16, 7
 for name, N, Cin, C in [("conv_1", 1028, 128, 128), ("conv_3", 257, 256, 256)]:
     M = B * N
