@@ -29,8 +29,9 @@ inline hipStream_t as_stream(hspStream_t s) { return reinterpret_cast<hipStream_
 // knn.hip -> knn_exact.hip: the xyz search by (distance, index) plus per-row flags: bit 0 "two of the k + drop + 1 nearest are equally
 // far", bit 1 the same for the k2 + drop + 1 nearest
 // (idx2 (B,N,k2), may be null: the first k2 entries of every list again -- the short list of every unflagged row)
+// *needs_tie_pass: false when the selection replayed its flagged rows itself (then tie is not written)
 int knn3_select_flags(const float* x, int B, int N, int k, int drop, int k2, int32_t* idx, int32_t* idx2, uint8_t* tie,
-                      hipStream_t st);
+                      hipStream_t st, bool* needs_tie_pass);
 
 // persistent grid: a multiple of the XCD count so that block % 8 == XCD for every block
 inline int persistent_blocks(long long work_items, int blocks_per_cu) {

@@ -10,6 +10,7 @@
 //   quad   = ATen row-sum order (quad_kernel below), dist = ((inner*-2)+quad[j])+quad[i]
 //   select = ascending (distance, index); strict '<' keeps the lower index on exact ties.
 #include "common.h"
+#include "tie_pass.h"
 #include <float.h>
 
 namespace hsp {
@@ -198,13 +199,21 @@ __device__ __forceinline__ unsigned sortable_key(float f) {
 template <int S>
 __global__ __launch_bounds__(256) void knn3_wave_kernel(const float* __restrict__ x, int N, int k, int drop,
                                                         int32_t* __restrict__ idx, int msel, uint8_t* __restrict__ tie,
-                                                        int msel2, int32_t* __restrict__ idx2, int k2) {
+                                                        int msel2, int32_t* __restrict__ idx2, int k2, int tie_inline) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* pts = reinterpret_cast<float4*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int2* sv = reinterpret_cast<int2*>(pts + N) + (size_t)wave * KNN3W_CAP;
     float* sd = reinterpret_cast<float*>(reinterpret_cast<int2*>(pts + N) + 4 * KNN3W_CAP) + wave * 64;   // ranked distances (tie flags)
+    // tie_inline: a row whose flags come out non-zero is replayed HERE through libstdc++'s routines (tie_pass.h) from the distances
+    // this wave already holds in registers, instead of being left to a second launch (knn_xyz_ties_kernel: ~5 us per call even when
+    // no row is flagged).  A scratch row per wave, compiled in for the small clouds only (S <= 9: N <= 576): the replay costs
+    // the kernel ~50 VGPRs (1.24 -> 2.15 ms at B = 64, N = 4096 when every variant carried it), and at N = 1028 it bought nothing
+    // -- one scratch row per workgroup under an LDS lock ran the bench cloud's 4 flagged rows no sooner than the second launch
+    // does (54.7 vs 33.8 + 20.6 us) and a tiled cloud 3x slower (994 vs 335 us: the workgroup's waves queue on the lock).
+    char* tie_mem = reinterpret_cast<char*>(reinterpret_cast<float*>(reinterpret_cast<int2*>(pts + N) + 4 * KNN3W_CAP) + 4 * 64);
+    TkE* tq = reinterpret_cast<TkE*>(tie_mem + (size_t)wave * 16 * N);
     const int b = blockIdx.y;
     const float* xb = x + (size_t)b * N * 3;
     for (int j = tid; j < N; j += 256) {
@@ -311,7 +320,36 @@ __global__ __launch_bounds__(256) void knn3_wave_kernel(const float* __restrict_
         }
         if (tie) {
             const int flags = (__ballot(tied) != 0ull ? 1 : 0) | (__ballot(tied2) != 0ull ? 2 : 0);
-            if (lane == 0) tie[(size_t)b * N + q] = (uint8_t)flags;
+            if (!tie_inline) {
+                if (lane == 0) tie[(size_t)b * N + q] = (uint8_t)flags;
+            } else if (S <= 9 && flags) {                     // (wave-uniform)
+                int* LA = reinterpret_cast<int*>(tq + N);
+                int* LB = LA + N;
+                // (as knn_xyz_ties_kernel: the list whose search leaves the row untouched -- partial_sort -- goes first)
+                const int m2 = k2 + drop;
+                const bool want2 = out2 && (flags & 2);
+                const bool second_first = want2 && !tkw_topk_destroys(m2, N) && tkw_topk_destroys(m, N);
+                bool filled = false;
+                for (int pass = 0; pass < (want2 ? 2 : 1); ++pass) {
+                    const bool short_list = (pass == 0) == second_first && want2;
+                    if (!filled) {
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+                            const int j = lane + 64 * s;
+                            TkE e;
+                            e.v = d[s]; e.i = j;
+                            if (j < N) tq[j] = e;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    const int mm = short_list ? m2 : m;
+                    const LaneAcc H = tkw_topk(tq, LA, LB, mm, N, lane);
+                    filled = !tkw_topk_destroys(mm, N);
+                    int32_t* o = short_list ? out2 : out;
+                    if (lane >= drop && lane < mm) o[lane - drop] = H.i;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
         }
         __builtin_amdgcn_wave_barrier();                      // sv is reused by the next query
     }
@@ -905,16 +943,21 @@ static int launch_knn3(const float* x, int B, int N, int k, int drop, int32_t* i
     return check_launch();
 }
 
+// small clouds replay their flagged rows inside the selection kernel; larger ones keep the separate pass (see knn3_wave_kernel)
+static int knn3_wave_tie_inline(int N) { return N <= 64 * 9 ? 1 : 0; }
+
 template <int S>
 static int launch_knn3_wave(const float* x, int B, int N, int k, int drop, int32_t* idx, hipStream_t st, int msel, uint8_t* tie,
                             int msel2, int32_t* idx2, int k2) {
-    const size_t lds = (size_t)N * 16 + (size_t)4 * KNN3W_CAP * 8 + 4 * 64 * 4;
+    const int tie_inline = tie ? knn3_wave_tie_inline(N) : 0;
+    const size_t lds = (size_t)N * 16 + (size_t)4 * KNN3W_CAP * 8 + 4 * 64 * 4 +
+                       (tie_inline ? (size_t)16 * N * 4 : 0);
     auto kern = knn3_wave_kernel<S>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
     }
-    hipLaunchKernelGGL(kern, dim3((N + 4 * KNN3W_QW - 1) / (4 * KNN3W_QW), B), dim3(256), lds, st, x, N, k, drop, idx, msel, tie, msel2, idx2, k2);
+    hipLaunchKernelGGL(kern, dim3((N + 4 * KNN3W_QW - 1) / (4 * KNN3W_QW), B), dim3(256), lds, st, x, N, k, drop, idx, msel, tie, msel2, idx2, k2, tie_inline);
     return check_launch();
 }
 
@@ -1168,7 +1211,9 @@ static int launch_knn_feat_bf16(const bf16_t* x, const float* quad, int B, int N
 // xyz search of csrc/knn_exact.hip: ranks [drop, k + drop) by (distance, index) into idx (B,N,k) and, per row (tie, B*N bytes),
 // bit 0: two of the k + drop + 1 nearest hold equal distances; bit 1: two of the k2 + drop + 1 nearest do
 int knn3_select_flags(const float* x, int B, int N, int k, int drop, int k2, int32_t* idx, int32_t* idx2, uint8_t* tie,
-                      hipStream_t st) {
+                      hipStream_t st, bool* needs_tie_pass) {
+    // the wave kernel replays its flagged rows itself (tie_inline); the per-lane-list kernel and the dense clouds leave flags
+    *needs_tie_pass = !(N >= 64 && (long long)B * N < 131072 && knn3_wave_tie_inline(N) != 0);
     const int m = k + drop;
     const int msel = m + 1 < N ? m + 1 : N;
     const int msel2 = k2 > 0 ? k2 + drop + 1 : 0;              // (k2 < k: inside msel)
