@@ -110,6 +110,9 @@ class FaceRecon(nn.Module):
         else:
             ops.x3_refresh()                          # fp32 weights -> the three bf16 slices of the x3 products (one launch)
         with gcn3d.knn_scope():
+            # the two coarse levels' vertices, neighbour lists and up-sampling maps in one launch, up front (they depend on the
+            # coordinates and the host-drawn pool rows only)
+            up = gcn3d.prefetch_levels(vertices, k, self.pool_1.neighbor_num) if self.pool_1.neighbor_num == self.pool_2.neighbor_num else None
             od = self.feature_dtype if self.feature_dtype == torch.bfloat16 else None
             fork0 = od is None and not self.keep_backward_cut and torch.is_grad_enabled()
             if fork0:
@@ -156,8 +159,7 @@ class FaceRecon(nn.Module):
             k2 = min(k, v_pool_2.shape[1] // 8)
             fm_4 = self.conv_4(v_pool_2, fm_pool_2, k2)
 
-        nearest_pool_1 = ops.nn1(vertices, v_pool_1)
-        nearest_pool_2 = ops.nn1(vertices, v_pool_2)
+        nearest_pool_1, nearest_pool_2 = up if up is not None else (ops.nn1(vertices, v_pool_1), ops.nn1(vertices, v_pool_2))
         # nearest up-sampling of the coarse levels, the one-hot category columns and the concat in one kernel
         # (the reference's one_hot = zeros(bs, obj_c).scatter_(1, cat_id.long(), 1), FaceRecon.py:80-85, is built inside the kernel)
         ops.ONE_HOT_WIDTH = FLAGS.obj_c

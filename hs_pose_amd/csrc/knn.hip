@@ -196,11 +196,14 @@ __device__ __forceinline__ unsigned sortable_key(float f) {
 
 // ``tie`` (may be null) with ``msel`` = k + drop + 1: the selection runs one rank past the answer and tie[row] says whether two of
 // those msel nearest hold EQUAL distances (see merge_write).
+// The body serves two launches: knn3_wave_kernel (a whole (B,N,3) tensor) and geometry_levels_kernel (the coarse levels of the
+// stack, whose points are ROWS sel[j] of the finer cloud: ``sel`` / ``sel_outer`` / ``vout``).  xb: the cloud the rows come from; row0: this cloud's
+// first row in idx / idx2 / tie; qblock: which 4 * QW queries of the cloud this workgroup takes.
 template <int S>
-__global__ __launch_bounds__(256) void knn3_wave_kernel(const float* __restrict__ x, int N, int k, int drop,
-                                                        int32_t* __restrict__ idx, int msel, uint8_t* __restrict__ tie,
-                                                        int msel2, int32_t* __restrict__ idx2, int k2, int tie_inline) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void knn3_wave_body(char* smem, const float* __restrict__ xb, const int32_t* __restrict__ sel,
+                                               const int32_t* __restrict__ sel_outer, float* __restrict__ vout, int N, int k, int drop, int32_t* __restrict__ idx,
+                                               int msel, uint8_t* __restrict__ tie, int msel2, int32_t* __restrict__ idx2, int k2,
+                                               int tie_inline, size_t row0, int qblock, int QW) {
     float4* pts = reinterpret_cast<float4*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -214,17 +217,18 @@ __global__ __launch_bounds__(256) void knn3_wave_kernel(const float* __restrict_
     // does (54.7 vs 33.8 + 20.6 us) and a tiled cloud 3x slower (994 vs 335 us: the workgroup's waves queue on the lock).
     char* tie_mem = reinterpret_cast<char*>(reinterpret_cast<float*>(reinterpret_cast<int2*>(pts + N) + 4 * KNN3W_CAP) + 4 * 64);
     TkE* tq = reinterpret_cast<TkE*>(tie_mem + (size_t)wave * 16 * N);
-    const int b = blockIdx.y;
-    const float* xb = x + (size_t)b * N * 3;
     for (int j = tid; j < N; j += 256) {
-        const float px = xb[j * 3 + 0], py = xb[j * 3 + 1], pz = xb[j * 3 + 2];
+        int r = sel ? sel[j] : j;                             // row j of this level = row sel[j] of the level it was drawn from,
+        r = sel_outer ? sel_outer[r] : r;                     // which is row sel_outer[.] of the cloud xb
+        const float px = xb[r * 3 + 0], py = xb[r * 3 + 1], pz = xb[r * 3 + 2];
         pts[j] = make_float4(px, py, pz, quad3(px, py, pz));
+        if (vout && qblock == 0) { vout[j * 3] = px; vout[j * 3 + 1] = py; vout[j * 3 + 2] = pz; }   // the level's vertices
     }
     __syncthreads();
     const int m = k + drop;
     const int ms = tie && msel > m ? msel : m;                       // ranks looked at
-    for (int qi = 0; qi < KNN3W_QW; ++qi) {
-        const int q = (blockIdx.x * 4 + wave) * KNN3W_QW + qi;       // wave-uniform
+    for (int qi = 0; qi < QW; ++qi) {
+        const int q = (qblock * 4 + wave) * QW + qi;                 // wave-uniform
         if (q >= N) break;
         const float4 qp = pts[q];
         float d[S];
@@ -259,8 +263,8 @@ __global__ __launch_bounds__(256) void knn3_wave_kernel(const float* __restrict_
             n += __popcll(bal);
         }
         __builtin_amdgcn_wave_barrier();
-        int32_t* out = idx + ((size_t)b * N + q) * k;
-        int32_t* out2 = idx2 ? idx2 + ((size_t)b * N + q) * k2 : nullptr;   // the short list: the prefix (final unless flagged)
+        int32_t* out = idx + (row0 + q) * k;
+        int32_t* out2 = idx2 ? idx2 + (row0 + q) * k2 : nullptr;   // the short list: the prefix (final unless flagged)
         bool tied = false, tied2 = false;                     // tied2: inside the first msel2 ranks
         if (n <= KNN3W_CAP) {
             for (int e = lane; e < n; e += 64) {
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(256) void knn3_wave_kernel(const float* __restrict_
         if (tie) {
             const int flags = (__ballot(tied) != 0ull ? 1 : 0) | (__ballot(tied2) != 0ull ? 2 : 0);
             if (!tie_inline) {
-                if (lane == 0) tie[(size_t)b * N + q] = (uint8_t)flags;
+                if (lane == 0) tie[row0 + q] = (uint8_t)flags;
             } else if (S <= 9 && flags) {                     // (wave-uniform)
                 int* LA = reinterpret_cast<int*>(tq + N);
                 int* LB = LA + N;
@@ -353,6 +357,16 @@ __global__ __launch_bounds__(256) void knn3_wave_kernel(const float* __restrict_
         }
         __builtin_amdgcn_wave_barrier();                      // sv is reused by the next query
     }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void knn3_wave_kernel(const float* __restrict__ x, int N, int k, int drop,
+                                                        int32_t* __restrict__ idx, int msel, uint8_t* __restrict__ tie,
+                                                        int msel2, int32_t* __restrict__ idx2, int k2, int tie_inline, int QW) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.y;
+    knn3_wave_body<S>(smem, x + (size_t)b * N * 3, nullptr, nullptr, nullptr, N, k, drop, idx, msel, tie, msel2, idx2, k2, tie_inline,
+                      (size_t)b * N, (int)blockIdx.x, QW);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -882,21 +896,20 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
 // top-1 nearest source row per target row (C == 3); d = (s2[j] + t2[i]) - 2*inner   (gcn3d.py:34)
 // grid (ceil(Nt/256), B), block 256, dynamic LDS = Ns*16
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nn1_kernel(const float* __restrict__ tgt, int Nt,
-                                                  const float* __restrict__ src, int Ns,
-                                                  int32_t* __restrict__ idx) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void nn1_body(char* smem, const float* __restrict__ tb, int Nt, const float* __restrict__ sb,
+                                         const int32_t* __restrict__ sel, const int32_t* __restrict__ sel_outer, int Ns,
+                                         int32_t* __restrict__ idx_b, int tblock) {
     float4* pts = reinterpret_cast<float4*>(smem);
-    const int b = blockIdx.y;
-    const float* sb = src + (size_t)b * Ns * 3;
     for (int j = threadIdx.x; j < Ns; j += 256) {
-        const float px = sb[j * 3], py = sb[j * 3 + 1], pz = sb[j * 3 + 2];
+        int r = sel ? sel[j] : j;                                  // (source row j as a row of the cloud sb: see knn3_wave_body)
+        r = sel_outer ? sel_outer[r] : r;
+        const float px = sb[r * 3], py = sb[r * 3 + 1], pz = sb[r * 3 + 2];
         pts[j] = make_float4(px, py, pz, quad3(px, py, pz));
     }
     __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = tblock * 256 + threadIdx.x;
     if (i >= Nt) return;
-    const float* tp = tgt + ((size_t)b * Nt + i) * 3;
+    const float* tp = tb + (size_t)i * 3;
     const float tx = tp[0], ty = tp[1], tz = tp[2];
     const float t2 = quad3(tx, ty, tz);
     float best = INFINITY;
@@ -907,7 +920,65 @@ __global__ __launch_bounds__(256) void nn1_kernel(const float* __restrict__ tgt,
         const float d = sub_rn(add_rn(c.w, t2), mul_rn(2.0f, inner));
         if (j == 0 || d < best) { best = d; bi = j; }
     }
-    idx[(size_t)b * Nt + i] = bi;
+    idx_b[i] = bi;
+}
+
+__global__ __launch_bounds__(256) void nn1_kernel(const float* __restrict__ tgt, int Nt,
+                                                  const float* __restrict__ src, int Ns,
+                                                  int32_t* __restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.y;
+    nn1_body(smem, tgt + (size_t)b * Nt * 3, Nt, src + (size_t)b * Ns * 3, nullptr, nullptr, Ns, idx + (size_t)b * Nt, (int)blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The geometry of the two coarse levels of the stack in ONE launch.  Pool_layer keeps a random subset of its input points
+// (gcn3d.py:243-245), so the level-1 cloud is rows sel1 of the input cloud and the level-2 cloud rows sel2 of level 1 -- both known
+// before the forward starts (the draws are host-side).  Everything the forward later asks of them depends on coordinates only:
+//   level 1: get_neighbor_index(v1, k1) (RF-P + the ORL branches of conv_2 / conv_3) and Pool_layer's own k = kpool list,
+//   level 2: get_neighbor_index(v2, k2) (conv_4),
+//   get_nearest_index(vertices, v1), get_nearest_index(vertices, v2)                         (FaceRecon.py:100-101),
+// four mutually independent small searches that were four launches of 6-13 us spread over the forward (each mostly latency);
+// as block ranges of one grid they run side by side.  Same bodies as knn3_wave_kernel / nn1_kernel: identical lists, tie replay
+// included.  grid (nb1 + nb2 + 2 * ceil(N0 / 256), B), block 256.
+// ------------------------------------------------------------------------------------------------
+struct GeoArgs {
+    const float* xyz; int N0;
+    const int32_t* sel1; int N1;
+    const int32_t* sel2; int N2;
+    int k1, kpool, k2, drop;
+    float* v1; float* v2;
+    int32_t* idx1; int32_t* idx1p; int32_t* idx2; int32_t* up1; int32_t* up2;
+    int nb1, nb2, nbt;
+};
+
+template <int S>
+__global__ __launch_bounds__(256) void geometry_levels_kernel(GeoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.y;
+    int t = (int)blockIdx.x;
+    const float* xb = a.xyz + (size_t)b * a.N0 * 3;
+    if (t < a.nb1) {
+        const int m = a.k1 + a.drop;
+        knn3_wave_body<S>(smem, xb, a.sel1, nullptr, a.v1 + (size_t)b * a.N1 * 3, a.N1, a.k1, a.drop, a.idx1, m + 1 < a.N1 ? m + 1 : a.N1,
+                          reinterpret_cast<uint8_t*>(smem) /* non-null: detect ties */, a.kpool > 0 ? a.kpool + a.drop + 1 : 0, a.idx1p,
+                          a.kpool, 1, (size_t)b * a.N1, t, 1);
+        return;
+    }
+    t -= a.nb1;
+    if (t < a.nb2) {
+        const int m = a.k2 + a.drop;
+        knn3_wave_body<S>(smem, xb, a.sel2, a.sel1, a.v2 + (size_t)b * a.N2 * 3, a.N2, a.k2, a.drop, a.idx2, m + 1 < a.N2 ? m + 1 : a.N2,
+                          reinterpret_cast<uint8_t*>(smem), 0, nullptr, 0, 1, (size_t)b * a.N2, t, 1);
+        return;
+    }
+    t -= a.nb2;
+    if (t < a.nbt) {
+        nn1_body(smem, xb, a.N0, xb, a.sel1, nullptr, a.N1, a.up1 + (size_t)b * a.N0, t);
+        return;
+    }
+    t -= a.nbt;
+    nn1_body(smem, xb, a.N0, xb, a.sel2, a.sel1, a.N2, a.up2 + (size_t)b * a.N0, t);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -957,7 +1028,11 @@ static int launch_knn3_wave(const float* x, int B, int N, int k, int drop, int32
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
     }
-    hipLaunchKernelGGL(kern, dim3((N + 4 * KNN3W_QW - 1) / (4 * KNN3W_QW), B), dim3(256), lds, st, x, N, k, drop, idx, msel, tie, msel2, idx2, k2, tie_inline);
+    // queries per wave: four amortise the cloud's staging; a small batch (the coarse levels) takes one so that its few thousand
+    // queries spread over the chip instead of queueing four deep behind 272 workgroups
+    const int QW = (long long)B * N >= 8192 ? KNN3W_QW : 1;
+    hipLaunchKernelGGL(kern, dim3((N + 4 * QW - 1) / (4 * QW), B), dim3(256), lds, st, x, N, k, drop, idx, msel, tie, msel2, idx2, k2,
+                       tie_inline, QW);
     return check_launch();
 }
 
@@ -1324,6 +1399,30 @@ extern "C" int hsp_knn_bf16(const hsp_bf16_t* x, int B, int N, int C, int k, int
         case 21: return launch_knn_feat_bf16<21>(x, quad, B, N, C, k, drop, idx, st);
         default: return launch_knn_feat_bf16<33>(x, quad, B, N, C, k, drop, idx, st);
     }
+}
+
+extern "C" int hsp_geometry_levels_f32(const float* xyz, int B, int N0, const int32_t* sel1, int N1, const int32_t* sel2, int N2,
+                                       int k1, int kpool, int k2, int drop_first, float* v1, float* v2, int32_t* idx1,
+                                       int32_t* idx1_pool, int32_t* idx2, int32_t* up1, int32_t* up2, hspStream_t stream) {
+    if (!xyz || !sel1 || !sel2 || !v1 || !v2 || !idx1 || !idx2 || !up1 || !up2 || B <= 0 || N0 <= 0 || k1 <= 0 || k2 <= 0 || kpool < 0 ||
+        (kpool > 0) != (idx1_pool != nullptr) || kpool > k1)
+        return HSP_ERR_BAD_ARG;
+    const int drop = drop_first ? 1 : 0;
+    // the wave-per-query search with its in-kernel tie replay: 64 <= N <= 576 points per level, lists of at most 31 + drop entries
+    if (N1 < 64 || N1 > 64 * 9 || N2 < 64 || N2 > 64 * 9 || k1 + drop + 1 > 33 || k2 + drop + 1 > 33 || k1 + drop > N1 || k2 + drop > N2 ||
+        N2 > N1 || N1 > N0)
+        return HSP_ERR_UNSUPPORTED;
+    GeoArgs a;
+    a.xyz = xyz; a.N0 = N0; a.sel1 = sel1; a.N1 = N1; a.sel2 = sel2; a.N2 = N2; a.k1 = k1; a.kpool = kpool; a.k2 = k2; a.drop = drop;
+    a.v1 = v1; a.v2 = v2; a.idx1 = idx1; a.idx1p = idx1_pool; a.idx2 = idx2; a.up1 = up1; a.up2 = up2;
+    a.nb1 = (N1 + 3) / 4; a.nb2 = (N2 + 3) / 4; a.nbt = (N0 + 255) / 256;
+    const int Nm = N1 > N2 ? N1 : N2;
+    const size_t lds = (size_t)Nm * 16 + (size_t)4 * KNN3W_CAP * 8 + 4 * 64 * 4 + (size_t)16 * Nm * 4;
+    if (lds > 64 * 1024) return HSP_ERR_UNSUPPORTED;
+    const dim3 grid(a.nb1 + a.nb2 + 2 * a.nbt, B);
+    if (Nm <= 64 * 5) hipLaunchKernelGGL(geometry_levels_kernel<5>, grid, dim3(256), lds, as_stream(stream), a);
+    else hipLaunchKernelGGL(geometry_levels_kernel<9>, grid, dim3(256), lds, as_stream(stream), a);
+    return check_launch();
 }
 
 extern "C" int hsp_nn1_f32(const float* tgt, int Nt, const float* src, int Ns, int B, int32_t* idx,

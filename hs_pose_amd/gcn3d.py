@@ -37,12 +37,53 @@ POOL_K = 4                                 # Pool_layer's list length in FaceRec
 def knn_scope():
     """Within the scope, xyz-space KNN results are memoised per (vertices tensor -- by identity --, list length); the first
     search of a resolution also produces the POOL_K-list of the Pool_layer that follows (ops.knn_xyz: one search, two lists)."""
-    global _knn_memo
+    global _knn_memo, _levels
     prev, _knn_memo = _knn_memo, {}
+    prev_levels, _levels = _levels, None
     try:
         yield
     finally:
-        _knn_memo = prev
+        _knn_memo, _levels = prev, prev_levels
+
+
+# ------------------------------------------------------------------------------------------------
+# the coarse levels' geometry, prefetched (one launch for what used to be four spread over the forward)
+# ------------------------------------------------------------------------------------------------
+_levels = None          # id(level-0 vertices) / id(v1) -> dict(vertices, sel, v_pool); "up": [up1, up2]
+
+
+def prefetch_levels(vertices, k, pool_k=None):
+    """FaceRecon's two Pool_layers keep rows that are drawn on the HOST (torch.randperm, gcn3d.py:243) and depend on nothing the
+    network computes, so everything the forward will ask of the two coarse clouds -- their vertices, their neighbour lists, the
+    nearest-point maps of the up-sampling -- can be computed from the input cloud at once (ops.geometry_levels).  Draws (or takes
+    from the pool_index_feed) both index sets in the reference's order, fills the knn_scope memo for the two levels and remembers
+    the kept rows for the Pool_layers.  Returns (up1, up2) or None when the shapes are not the fused kernel's (nothing is consumed
+    then, and the layers do their own searches as before).  Call inside knn_scope()."""
+    global _levels
+    _levels = None
+    if _knn_memo is None or vertices.dtype != torch.float32 or vertices.requires_grad or not vertices.is_cuda:
+        return None
+    pool_k = POOL_K if pool_k is None else pool_k
+    n0 = vertices.shape[1]
+    n1 = int(n0 / 4)
+    n2 = int(n1 / 4)
+    k1, k2 = min(k, n1 // 8), min(k, n2 // 8)
+    if not (64 <= n2 <= n1 <= 576) or k1 <= pool_k or k1 < 1 or k2 < 1:
+        return None
+    if _pool_feed is not None:
+        sel1, sel2 = next(_pool_feed), next(_pool_feed)
+        assert sel1.numel() == n1 and sel2.numel() == n2 and sel1.dtype == torch.int32
+    else:                                                    # the reference's own draws, in its order (pool_1, then pool_2)
+        sel1 = torch.randperm(n0)[:n1].to(device=vertices.device, dtype=torch.int32)
+        sel2 = torch.randperm(n1)[:n2].to(device=vertices.device, dtype=torch.int32)
+    geo = ops.geometry_levels(vertices, sel1, sel2, k1, pool_k, k2)
+    if geo is None:
+        raise RuntimeError("prefetch_levels: shape check and kernel disagree")      # (indices already consumed: cannot fall back)
+    v1, v2 = geo["v1"], geo["v2"]
+    _knn_memo[id(v1)] = (v1, {k1: geo["idx1"], pool_k: geo["idx1_pool"]})
+    _knn_memo[id(v2)] = (v2, {k2: geo["idx2"]})
+    _levels = {id(vertices): (vertices, sel1, v1), id(v1): (v1, sel2, v2), "up": (geo["up1"], geo["up2"])}
+    return _levels["up"]
 
 
 def _xyz_knn(vertices, k):
@@ -257,6 +298,16 @@ class Pool_layer(nn.Module):
         bs, vertice_num, _ = vertices.size()
         neighbor_index = _xyz_knn(vertices, self.neighbor_num)
         pool_num = int(vertice_num / self.pooling_rate)
+        pre = _levels.get(id(vertices)) if _levels is not None else None
+        if pre is not None and pre[0] is vertices and pre[1].numel() == pool_num and self.pooling_rate == 4:
+            # the kept rows were drawn, and the pooled vertices gathered, by prefetch_levels: only the features are pooled here
+            # (the SAME vertices tensor is handed on, so the next level finds its prefetched neighbour lists)
+            _, sel, v_pool = pre
+            if feature_map.dtype == torch.float32 and feature_map.shape[2] >= 12:
+                feature_map_pool, _ = ops.pool_layer(feature_map, vertices, neighbor_index, sel, self.neighbor_num)
+            else:
+                feature_map_pool = ops.gather_max(feature_map, neighbor_index, self.neighbor_num, qsel=sel)
+            return v_pool, feature_map_pool
         if _pool_feed is not None:
             sel = next(_pool_feed)
             assert sel.numel() == pool_num and sel.dtype == torch.int32

@@ -143,6 +143,29 @@ def knn_xyz(xyz, k, k2=0, drop_first=True):
     return idx, idx2
 
 
+def geometry_levels(xyz, sel1, sel2, k1, kpool, k2):
+    """the coordinate work of the two coarse levels in one launch (hsp_geometry_levels_f32): given the rows Pool_layer keeps at
+    each level (sel1 of the input cloud, sel2 of level 1; int32 device vectors), returns a dict with the levels' vertices ``v1`` /
+    ``v2``, the neighbour lists ``idx1`` (k1) / ``idx1_pool`` (kpool) / ``idx2`` (k2) and the nearest-point maps ``up1`` / ``up2``
+    of the input cloud onto them (FaceRecon.py:100-101) -- or None when the shapes are outside the fused kernel's range (the
+    caller then keeps the separate searches)."""
+    x = _req(xyz.detach(), torch.float32, "geometry_levels.xyz")
+    s1, s2 = _req(sel1, torch.int32, "geometry_levels.sel1"), _req(sel2, torch.int32, "geometry_levels.sel2")
+    B, N0, C = x.shape
+    N1, N2 = s1.numel(), s2.numel()
+    if C != 3 or not (64 <= N2 <= N1 <= 576) or N1 > N0 or k1 + 2 > 33 or k2 + 2 > 33 or k1 + 1 > N1 or k2 + 1 > N2 or not 0 < kpool <= k1:
+        return None
+    dev = x.device
+    out = dict(v1=torch.empty(B, N1, 3, dtype=torch.float32, device=dev), v2=torch.empty(B, N2, 3, dtype=torch.float32, device=dev),
+               idx1=torch.empty(B, N1, k1, dtype=torch.int32, device=dev), idx1_pool=torch.empty(B, N1, kpool, dtype=torch.int32, device=dev),
+               idx2=torch.empty(B, N2, k2, dtype=torch.int32, device=dev), up1=torch.empty(B, N0, dtype=torch.int32, device=dev),
+               up2=torch.empty(B, N0, dtype=torch.int32, device=dev))
+    _run("hsp_geometry_levels_f32", (_p(x), B, N0, _p(s1), N1, _p(s2), N2, k1, kpool, k2, 1, _p(out["v1"]), _p(out["v2"]), _p(out["idx1"]),
+                                     _p(out["idx1_pool"]), _p(out["idx2"]), _p(out["up1"]), _p(out["up2"]), _stream()),
+         key=f"B{B}N{N0}/{N1}/{N2}", abytes=B * (12 * N0 + 4 * (N1 * (k1 + kpool + 3) + N2 * (k2 + 3)) + 8 * N0))
+    return out
+
+
 def knn(x, k, drop_first=True, transposed_view=False, _plain_xyz=False):
     """int32 (B,N,k) nearest rows of x (B,N,C) per row; semantics of gcn3d.get_neighbor_index.  ``transposed_view`` (exact scope
     only): the reference holds these rows as the transposed view of a (B,C,N) tensor, which changes how its |x|^2 rounds."""

@@ -78,6 +78,19 @@ int hsp_knn_exact_f32(const float *x, int B, int N, int C, int k, int drop_first
 size_t hsp_knn_xyz_workspace_bytes(int B, int N);
 int hsp_knn_xyz_f32(const float *xyz, int B, int N, int k, int k2, int drop_first, int32_t *idx, int32_t *idx2, void *ws,
                     size_t ws_bytes, int *tie_rows, hspStream_t stream);
+/* The coordinate work of the stack's two coarse levels in ONE launch (FaceRecon.py:91-101, gcn3d.py:236,243-245).  Pool_layer keeps
+ * rows sel1 (N1 of them, int32, device) of the input cloud and then rows sel2 (N2) of that level; the draws are host-side and known
+ * before the forward, and everything later asked of the two clouds depends on coordinates only:
+ *   v1 (B,N1,3), v2 (B,N2,3)                      the levels' vertices
+ *   idx1 (B,N1,k1), idx1_pool (B,N1,kpool)        get_neighbor_index(v1, k1) and Pool_layer's own list (kpool = 0: none, pass NULL)
+ *   idx2 (B,N2,k2)                                get_neighbor_index(v2, k2)
+ *   up1, up2 (B,N0)                               get_nearest_index(vertices, v1 / v2)
+ * Four independent small searches that cost a launch each (6-13 us, mostly latency); here they are block ranges of one grid.  Same
+ * results as hsp_knn_xyz_f32 / hsp_nn1_f32 (torch.topk's order among equal distances included).  64 <= N2 <= N1 <= 576, else
+ * HSP_ERR_UNSUPPORTED (the caller keeps the separate calls). */
+int hsp_geometry_levels_f32(const float *xyz, int B, int N0, const int32_t *sel1, int N1, const int32_t *sel2, int N2, int k1,
+                            int kpool, int k2, int drop_first, float *v1, float *v2, int32_t *idx1, int32_t *idx1_pool,
+                            int32_t *idx2, int32_t *up1, int32_t *up2, hspStream_t stream);
 /* hsp_knn_f32 with the |x|^2 order chosen as above */
 int hsp_knn_quadmode_f32(const float *x, int B, int N, int C, int k, int drop_first, int32_t *idx, void *ws, size_t ws_bytes,
                          int quad_mode, hspStream_t stream);

@@ -195,6 +195,14 @@ def test_exact_stack_tiled(dev, ref, flags, monkeypatch):
             feat_lists.append(o)
         return o
     monkeypatch.setattr(ops, "knn_xyz", rec_xyz)
+    real_geo = ops.geometry_levels
+
+    def rec_geo(xyz, sel1, sel2, k1, kpool, k2):             # (the two coarse levels' lists come out of one fused launch)
+        geo = real_geo(xyz, sel1, sel2, k1, kpool, k2)
+        if geo is not None:
+            xyz_lists[(sel1.numel(), k1)], xyz_lists[(sel1.numel(), kpool)], xyz_lists[(sel2.numel(), k2)] = geo["idx1"], geo["idx1_pool"], geo["idx2"]
+        return geo
+    monkeypatch.setattr(ops, "geometry_levels", rec_geo)
     monkeypatch.setattr(ops, "knn", rec_knn)
     torch.manual_seed(1)
     with torch.no_grad():

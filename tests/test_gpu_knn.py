@@ -205,3 +205,34 @@ def test_knn_non_finite_rows_give_valid_indices(dev, ref, B, N, C, k):
     # a cloud made of NaN only: still valid indices
     idx = ops.knn(torch.full((1, N, C), float("nan"), device=dev), k).cpu().numpy()
     assert idx.min() >= 0 and idx.max() < N
+
+
+@pytest.mark.parametrize("B,N0,tiled", [(16, 1028, False), (3, 1028, True), (2, 1100, True), (2, 2304, False), (2, 2304, True)])
+def test_geometry_levels_equals_the_separate_searches(dev, ref, B, N0, tiled):
+    """hsp_geometry_levels_f32 (the coarse levels' vertices, neighbour lists and up-sampling maps as block ranges of one launch)
+    against the calls it replaces: rows gathered by torch, ops.knn_xyz / ops.knn per level, ops.nn1 -- bit for bit, on a random
+    cloud and on a tiled one (duplicates: the in-kernel tie replay, both branches of ATen's topk)"""
+    from hs_pose_amd import ops
+    if tiled:
+        x = ref.tiled_batch([N0 * 2 // 5] * B, 700 + N0, N0)
+    else:
+        x = ref.hash_tensor((B, N0, 3), 701 + N0, 0.05)
+    x = (x - x.mean(dim=1, keepdim=True)).to(dev)
+    n1, n2 = N0 // 4, N0 // 16
+    g = torch.Generator().manual_seed(N0)
+    sel1 = torch.randperm(N0, generator=g)[:n1].to(device=dev, dtype=torch.int32)
+    sel2 = torch.randperm(n1, generator=g)[:n2].to(device=dev, dtype=torch.int32)
+    k1, k2 = min(20, n1 // 8), min(20, n2 // 8)
+    geo = ops.geometry_levels(x, sel1, sel2, k1, 4, k2)
+    assert geo is not None
+    v1 = x[:, sel1.long()].contiguous()
+    v2 = v1[:, sel2.long()].contiguous()
+    assert torch.equal(geo["v1"], v1) and torch.equal(geo["v2"], v2)
+    i1, i1p = ops.knn_xyz(v1, k1, 4)
+    assert torch.equal(geo["idx1"], i1) and torch.equal(geo["idx1_pool"], i1p)
+    assert torch.equal(geo["idx2"], ops.knn(v2, k2))
+    assert torch.equal(geo["up1"], ops.nn1(x, v1)) and torch.equal(geo["up2"], ops.nn1(x, v2))
+    if tiled:
+        assert not torch.equal(i1[:, :, :4], i1p) or n1 < 320
+    # outside the fused kernel's range the caller is told so
+    assert ops.geometry_levels(x[:, :200].contiguous(), sel1[:50].contiguous() % 200, sel2[:12].contiguous() % 50, 6, 4, 1) is None

@@ -360,6 +360,14 @@ def test_stack_tiled_trainbn(dev, ref, flags, monkeypatch):
             xyz_lists[(x.shape[1], k2)] = b
         return a, b
     monkeypatch.setattr(ops, "knn_xyz", rec_xyz)
+    real_geo = ops.geometry_levels
+
+    def rec_geo(xyz, sel1, sel2, k1, kpool, k2):             # (the two coarse levels' lists come out of one fused launch)
+        geo = real_geo(xyz, sel1, sel2, k1, kpool, k2)
+        if geo is not None:
+            xyz_lists[(sel1.numel(), k1)], xyz_lists[(sel1.numel(), kpool)], xyz_lists[(sel2.numel(), k2)] = geo["idx1"], geo["idx1_pool"], geo["idx2"]
+        return geo
+    monkeypatch.setattr(ops, "geometry_levels", rec_geo)
     forced = ForcedFeatKnn(monkeypatch, g, dev)
     net = build()
     torch.manual_seed(1)
