@@ -6,7 +6,7 @@
 # Second half: the bf16 dense-cloud configuration (BASELINE configs[3]).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-RD=${1:-r04}
+RD=${1:-r05}
 O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O $R/profiles/$RD
 for c in FETCH_SIZE WRITE_SIZE; do
