@@ -178,6 +178,8 @@ __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ x, 
                        idx2 ? idx2 + ((size_t)b * N + (valid ? q : 0)) * k2 : nullptr, k2);
 }
 
+#define KNN_TAU_LOW_BIT 18     // radix select of the pruning bound: key bits 31..18 (sign, exponent, 5 mantissa bits)
+
 __device__ __forceinline__ unsigned sortable_key(float f) {
     const unsigned u = __float_as_uint(f);
     return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
@@ -193,6 +195,7 @@ __device__ __forceinline__ unsigned sortable_key(float f) {
 // ------------------------------------------------------------------------------------------------
 #define KNN3W_QW 4
 #define KNN3W_CAP 128   // survivor scratch entries per wave (typically ~k + 4 are used)
+#define KNN3W_SV (KNN3W_CAP + 4)   // ... + four sentinel entries behind the last survivor (the ranking loop reads four at a time)
 
 // ``tie`` (may be null) with ``msel`` = k + drop + 1: the selection runs one rank past the answer and tie[row] says whether two of
 // those msel nearest hold EQUAL distances (see merge_write).
@@ -207,15 +210,15 @@ __device__ __forceinline__ void knn3_wave_body(char* smem, const float* __restri
     float4* pts = reinterpret_cast<float4*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int2* sv = reinterpret_cast<int2*>(pts + N) + (size_t)wave * KNN3W_CAP;
-    float* sd = reinterpret_cast<float*>(reinterpret_cast<int2*>(pts + N) + 4 * KNN3W_CAP) + wave * 64;   // ranked distances (tie flags)
+    int2* sv = reinterpret_cast<int2*>(pts + N) + (size_t)wave * KNN3W_SV;
+    float* sd = reinterpret_cast<float*>(reinterpret_cast<int2*>(pts + N) + 4 * KNN3W_SV) + wave * 64;   // ranked distances (tie flags)
     // tie_inline: a row whose flags come out non-zero is replayed HERE through libstdc++'s routines (tie_pass.h) from the distances
     // this wave already holds in registers, instead of being left to a second launch (knn_xyz_ties_kernel: ~5 us per call even when
     // no row is flagged).  A scratch row per wave, compiled in for the small clouds only (S <= 9: N <= 576): the replay costs
     // the kernel ~50 VGPRs (1.24 -> 2.15 ms at B = 64, N = 4096 when every variant carried it), and at N = 1028 it bought nothing
     // -- one scratch row per workgroup under an LDS lock ran the bench cloud's 4 flagged rows no sooner than the second launch
     // does (54.7 vs 33.8 + 20.6 us) and a tiled cloud 3x slower (994 vs 335 us: the workgroup's waves queue on the lock).
-    char* tie_mem = reinterpret_cast<char*>(reinterpret_cast<float*>(reinterpret_cast<int2*>(pts + N) + 4 * KNN3W_CAP) + 4 * 64);
+    char* tie_mem = reinterpret_cast<char*>(reinterpret_cast<float*>(reinterpret_cast<int2*>(pts + N) + 4 * KNN3W_SV) + 4 * 64);
     TkE* tq = reinterpret_cast<TkE*>(tie_mem + (size_t)wave * 16 * N);
     for (int j = tid; j < N; j += 256) {
         int r = sel ? sel[j] : j;                             // row j of this level = row sel[j] of the level it was drawn from,
@@ -246,22 +249,27 @@ __device__ __forceinline__ void knn3_wave_body(char* smem, const float* __restri
         const unsigned key = sortable_key(lmin);
         unsigned prefix = 0;
         int need = ms;
-        for (int bit = 31; bit >= 0; --bit) {
+        // (the bound only has to be >= the ms-th smallest minimum: the descent stops after the sign, the exponent and five mantissa
+        // bits and fills the rest with ones -- tau up to 3 % high, a survivor or two more for the ranking, 18 ballot rounds fewer)
+        for (int bit = 31; bit >= KNN_TAU_LOW_BIT; --bit) {
             const unsigned hi = bit == 31 ? 0u : (0xffffffffu << (bit + 1));
             const bool zero = ((key ^ prefix) & hi) == 0 && ((key >> bit) & 1u) == 0;
             const int c0 = __popcll(__ballot(zero));
             if (need > c0) { need -= c0; prefix |= 1u << bit; }
         }
+        prefix |= (1u << KNN_TAU_LOW_BIT) - 1u;
         const float tau = __uint_as_float(prefix ^ ((prefix >> 31) ? 0x80000000u : 0xffffffffu));
         int n = 0;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const bool keep = d[s] <= tau;                    // +inf padding never passes a finite tau
             const unsigned long long bal = __ballot(keep);
+            if (bal == 0ull) continue;                        // (wave-uniform: most slots of a dense cloud hold no survivor)
             const int pos = n + __popcll(bal & ((1ull << lane) - 1ull));
             if (keep && pos < KNN3W_CAP) sv[pos] = make_int2(__float_as_int(d[s]), lane + 64 * s);
             n += __popcll(bal);
         }
+        if (lane < 4 && n <= KNN3W_CAP) sv[n + lane] = make_int2(__float_as_int(INFINITY), INT_MAX);   // sentinels: rank nothing
         __builtin_amdgcn_wave_barrier();
         int32_t* out = idx + (row0 + q) * k;
         int32_t* out2 = idx2 ? idx2 + (row0 + q) * k2 : nullptr;   // the short list: the prefix (final unless flagged)
@@ -271,10 +279,13 @@ __device__ __forceinline__ void knn3_wave_body(char* smem, const float* __restri
                 const int2 me = sv[e];
                 const float de = __int_as_float(me.x);
                 int rank = 0;
-                for (int f = 0; f < n; ++f) {
-                    const int2 o = sv[f];
-                    const float df = __int_as_float(o.x);
-                    rank += (df < de || (df == de && o.y < me.y)) ? 1 : 0;
+                for (int f = 0; f < n; f += 4) {               // four entries per round trip (the loop waits on LDS, not on the ALU)
+                    const int4 o01 = *reinterpret_cast<const int4*>(sv + f), o23 = *reinterpret_cast<const int4*>(sv + f + 2);
+                    const float d0 = __int_as_float(o01.x), d1 = __int_as_float(o01.z), d2 = __int_as_float(o23.x), d3 = __int_as_float(o23.z);
+                    rank += (d0 < de || (d0 == de && o01.y < me.y)) ? 1 : 0;
+                    rank += (d1 < de || (d1 == de && o01.w < me.y)) ? 1 : 0;
+                    rank += (d2 < de || (d2 == de && o23.y < me.y)) ? 1 : 0;
+                    rank += (d3 < de || (d3 == de && o23.w < me.y)) ? 1 : 0;
                 }
                 if (rank >= drop && rank < m) out[rank - drop] = me.y;
                 if (out2 && rank >= drop && rank - drop < k2) out2[rank - drop] = me.y;
@@ -511,12 +522,13 @@ __device__ __forceinline__ void knn_select_wave(const float* dl, int2* sv, int N
     const unsigned key = sortable_key(lmin);
     unsigned prefix = 0;
     int need = m;
-    for (int bit = 31; bit >= 0; --bit) {
+    for (int bit = 31; bit >= KNN_TAU_LOW_BIT; --bit) {     // (a bound, not the exact value: see knn3_wave_body)
         const unsigned hi = bit == 31 ? 0u : (0xffffffffu << (bit + 1));
         const bool zero = ((key ^ prefix) & hi) == 0 && ((key >> bit) & 1u) == 0;
         const int c0 = __popcll(__ballot(zero));
         if (need > c0) { need -= c0; prefix |= 1u << bit; }
     }
+    prefix |= (1u << KNN_TAU_LOW_BIT) - 1u;
     const float tau = __uint_as_float(prefix ^ ((prefix >> 31) ? 0x80000000u : 0xffffffffu));   // key -> float
     int n = 0;
     for (int j0 = 0; j0 < N; j0 += 64) {
@@ -1021,7 +1033,7 @@ template <int S>
 static int launch_knn3_wave(const float* x, int B, int N, int k, int drop, int32_t* idx, hipStream_t st, int msel, uint8_t* tie,
                             int msel2, int32_t* idx2, int k2) {
     const int tie_inline = tie ? knn3_wave_tie_inline(N) : 0;
-    const size_t lds = (size_t)N * 16 + (size_t)4 * KNN3W_CAP * 8 + 4 * 64 * 4 +
+    const size_t lds = (size_t)N * 16 + (size_t)4 * KNN3W_SV * 8 + 4 * 64 * 4 +
                        (tie_inline ? (size_t)16 * N * 4 : 0);
     auto kern = knn3_wave_kernel<S>;
     if (lds > 64 * 1024) {
@@ -1417,7 +1429,7 @@ extern "C" int hsp_geometry_levels_f32(const float* xyz, int B, int N0, const in
     a.v1 = v1; a.v2 = v2; a.idx1 = idx1; a.idx1p = idx1_pool; a.idx2 = idx2; a.up1 = up1; a.up2 = up2;
     a.nb1 = (N1 + 3) / 4; a.nb2 = (N2 + 3) / 4; a.nbt = (N0 + 255) / 256;
     const int Nm = N1 > N2 ? N1 : N2;
-    const size_t lds = (size_t)Nm * 16 + (size_t)4 * KNN3W_CAP * 8 + 4 * 64 * 4 + (size_t)16 * Nm * 4;
+    const size_t lds = (size_t)Nm * 16 + (size_t)4 * KNN3W_SV * 8 + 4 * 64 * 4 + (size_t)16 * Nm * 4;
     if (lds > 64 * 1024) return HSP_ERR_UNSUPPORTED;
     const dim3 grid(a.nb1 + a.nb2 + 2 * a.nbt, B);
     if (Nm <= 64 * 5) hipLaunchKernelGGL(geometry_levels_kernel<5>, grid, dim3(256), lds, as_stream(stream), a);
