@@ -39,6 +39,9 @@ SIGNATURES = {
     "hsp_knn_xyz_workspace_bytes": (_sz, [_i, _i]),
     "hsp_knn_xyz_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "hsp_geometry_levels_f32": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hsp_geometry_all_workspace_bytes": (_sz, [_i, _i]),
+    "hsp_geometry_all_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                  _vp]),
     "hsp_knn_quadmode_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp]),
     "hsp_quad_outer_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "hsp_center_cloud_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp]),

@@ -952,7 +952,7 @@ __global__ __launch_bounds__(256) void nn1_kernel(const float* __restrict__ tgt,
 //   get_nearest_index(vertices, v1), get_nearest_index(vertices, v2)                         (FaceRecon.py:100-101),
 // four mutually independent small searches that were four launches of 6-13 us spread over the forward (each mostly latency);
 // as block ranges of one grid they run side by side.  Same bodies as knn3_wave_kernel / nn1_kernel: identical lists, tie replay
-// included.  grid (nb1 + nb2 + 2 * ceil(N0 / 256), B), block 256.
+// included.  1-D grid, block 256.
 // ------------------------------------------------------------------------------------------------
 struct GeoArgs {
     const float* xyz; int N0;
@@ -962,13 +962,27 @@ struct GeoArgs {
     float* v1; float* v2;
     int32_t* idx1; int32_t* idx1p; int32_t* idx2; int32_t* up1; int32_t* up2;
     int nb1, nb2, nbt;
+    // optional rider (hsp_geometry_all_f32): the tie pass of the LEVEL-0 search, which depends on that search's flags only and
+    // otherwise costs its own launch right behind it (one flagged row = 14 us of latency with the chip idle)
+    const uint8_t* tie0; int B, k0, kpool0; int32_t* idx0; int32_t* idx0p; int nbtie;
 };
 
 template <int S>
 __global__ __launch_bounds__(256) void geometry_levels_kernel(GeoArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int b = blockIdx.y;
+    // 1-D grid: [tie workers of the whole batch | per cloud: level-1 search, level-2 search, the two nearest-point maps].  The tie
+    // workers come FIRST in dispatch order: a flagged row is the longest job of the launch.
     int t = (int)blockIdx.x;
+    if (t < a.nbtie) {
+        const int wave = threadIdx.x >> 6;                    // (four waves per workgroup, each with its own scratch row)
+        tie_rows_xyz(smem + (size_t)wave * 16 * a.N0, a.xyz, a.tie0, a.B, a.N0, a.k0, a.kpool0, a.drop, a.idx0, a.idx0p, nullptr,
+                     t * 4 + wave, a.nbtie * 4, threadIdx.x & 63);
+        return;
+    }
+    t -= a.nbtie;
+    const int per_cloud = a.nb1 + a.nb2 + 2 * a.nbt;
+    const int b = t / per_cloud;
+    t -= b * per_cloud;
     const float* xb = a.xyz + (size_t)b * a.N0 * 3;
     if (t < a.nb1) {
         const int m = a.k1 + a.drop;
@@ -1413,6 +1427,37 @@ extern "C" int hsp_knn_bf16(const hsp_bf16_t* x, int B, int N, int C, int k, int
     }
 }
 
+static int geometry_impl(const float* xyz, int B, int N0, const int32_t* sel1, int N1, const int32_t* sel2, int N2, int k1, int kpool,
+                         int k2, int drop, float* v1, float* v2, int32_t* idx1, int32_t* idx1_pool, int32_t* idx2, int32_t* up1,
+                         int32_t* up2, const uint8_t* tie0, int k0, int kpool0, int32_t* idx0, int32_t* idx0_pool, hipStream_t st) {
+    GeoArgs a;
+    a.xyz = xyz; a.N0 = N0; a.sel1 = sel1; a.N1 = N1; a.sel2 = sel2; a.N2 = N2; a.k1 = k1; a.kpool = kpool; a.k2 = k2; a.drop = drop;
+    a.v1 = v1; a.v2 = v2; a.idx1 = idx1; a.idx1p = idx1_pool; a.idx2 = idx2; a.up1 = up1; a.up2 = up2;
+    a.nb1 = (N1 + 3) / 4; a.nb2 = (N2 + 3) / 4; a.nbt = (N0 + 255) / 256;
+    a.tie0 = tie0; a.B = B; a.k0 = k0; a.kpool0 = kpool0; a.idx0 = idx0; a.idx0p = idx0_pool;
+    a.nbtie = tie0 ? (int)(((long long)B * N0 + 31) / 32) : 0;  // one tie wave per 8 rows of the level-0 search
+    const int Nm = N1 > N2 ? N1 : N2;
+    size_t lds = (size_t)Nm * 16 + (size_t)4 * KNN3W_SV * 8 + 4 * 64 * 4 + (size_t)16 * Nm * 4;
+    if (tie0 && lds < (size_t)4 * 16 * N0) lds = (size_t)4 * 16 * N0;
+    if (lds > 160 * 1024) return HSP_ERR_UNSUPPORTED;
+    const dim3 grid(a.nbtie + (a.nb1 + a.nb2 + 2 * a.nbt) * B);
+    auto launch = [&](auto kern) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+        return check_launch();
+    };
+    return Nm <= 64 * 5 ? launch(geometry_levels_kernel<5>) : launch(geometry_levels_kernel<9>);
+}
+
+static bool geometry_levels_ok(int N0, int N1, int N2, int k1, int k2, int drop) {
+    // the wave-per-query search with its in-kernel tie replay: 64 <= N <= 576 points per level, lists of at most 31 + drop entries
+    return !(N1 < 64 || N1 > 64 * 9 || N2 < 64 || N2 > 64 * 9 || k1 + drop + 1 > 33 || k2 + drop + 1 > 33 || k1 + drop > N1 ||
+             k2 + drop > N2 || N2 > N1 || N1 > N0);
+}
+
 extern "C" int hsp_geometry_levels_f32(const float* xyz, int B, int N0, const int32_t* sel1, int N1, const int32_t* sel2, int N2,
                                        int k1, int kpool, int k2, int drop_first, float* v1, float* v2, int32_t* idx1,
                                        int32_t* idx1_pool, int32_t* idx2, int32_t* up1, int32_t* up2, hspStream_t stream) {
@@ -1420,21 +1465,37 @@ extern "C" int hsp_geometry_levels_f32(const float* xyz, int B, int N0, const in
         (kpool > 0) != (idx1_pool != nullptr) || kpool > k1)
         return HSP_ERR_BAD_ARG;
     const int drop = drop_first ? 1 : 0;
-    // the wave-per-query search with its in-kernel tie replay: 64 <= N <= 576 points per level, lists of at most 31 + drop entries
-    if (N1 < 64 || N1 > 64 * 9 || N2 < 64 || N2 > 64 * 9 || k1 + drop + 1 > 33 || k2 + drop + 1 > 33 || k1 + drop > N1 || k2 + drop > N2 ||
-        N2 > N1 || N1 > N0)
+    if (!geometry_levels_ok(N0, N1, N2, k1, k2, drop)) return HSP_ERR_UNSUPPORTED;
+    return geometry_impl(xyz, B, N0, sel1, N1, sel2, N2, k1, kpool, k2, drop, v1, v2, idx1, idx1_pool, idx2, up1, up2, nullptr, 0, 0,
+                         nullptr, nullptr, as_stream(stream));
+}
+
+extern "C" size_t hsp_geometry_all_workspace_bytes(int B, int N0) {
+    if (B <= 0 || N0 <= 0) return 0;
+    return ((size_t)B * N0 + 255) & ~(size_t)255;
+}
+
+extern "C" int hsp_geometry_all_f32(const float* xyz, int B, int N0, int k0, int kpool0, const int32_t* sel1, int N1,
+                                    const int32_t* sel2, int N2, int k1, int kpool, int k2, int drop_first, int32_t* idx0,
+                                    int32_t* idx0_pool, float* v1, float* v2, int32_t* idx1, int32_t* idx1_pool, int32_t* idx2,
+                                    int32_t* up1, int32_t* up2, void* ws, size_t ws_bytes, hspStream_t stream) {
+    if (!xyz || !sel1 || !sel2 || !v1 || !v2 || !idx0 || !idx1 || !idx2 || !up1 || !up2 || B <= 0 || N0 <= 0 || k0 <= 0 || k1 <= 0 ||
+        k2 <= 0 || kpool < 0 || kpool0 < 0 || (kpool > 0) != (idx1_pool != nullptr) || (kpool0 > 0) != (idx0_pool != nullptr) ||
+        kpool > k1 || kpool0 > k0)
+        return HSP_ERR_BAD_ARG;
+    const int drop = drop_first ? 1 : 0;
+    // level 0 on the wave search WITHOUT the in-kernel replay (its tie pass rides here): 576 < N0 <= 1088, a batch below 131072 rows
+    if (!geometry_levels_ok(N0, N1, N2, k1, k2, drop) || N0 <= 64 * 9 || N0 > 64 * 17 || (long long)B * N0 >= 131072 ||
+        k0 + drop + 1 > 33 || k0 + drop > N0)
         return HSP_ERR_UNSUPPORTED;
-    GeoArgs a;
-    a.xyz = xyz; a.N0 = N0; a.sel1 = sel1; a.N1 = N1; a.sel2 = sel2; a.N2 = N2; a.k1 = k1; a.kpool = kpool; a.k2 = k2; a.drop = drop;
-    a.v1 = v1; a.v2 = v2; a.idx1 = idx1; a.idx1p = idx1_pool; a.idx2 = idx2; a.up1 = up1; a.up2 = up2;
-    a.nb1 = (N1 + 3) / 4; a.nb2 = (N2 + 3) / 4; a.nbt = (N0 + 255) / 256;
-    const int Nm = N1 > N2 ? N1 : N2;
-    const size_t lds = (size_t)Nm * 16 + (size_t)4 * KNN3W_SV * 8 + 4 * 64 * 4 + (size_t)16 * Nm * 4;
-    if (lds > 64 * 1024) return HSP_ERR_UNSUPPORTED;
-    const dim3 grid(a.nb1 + a.nb2 + 2 * a.nbt, B);
-    if (Nm <= 64 * 5) hipLaunchKernelGGL(geometry_levels_kernel<5>, grid, dim3(256), lds, as_stream(stream), a);
-    else hipLaunchKernelGGL(geometry_levels_kernel<9>, grid, dim3(256), lds, as_stream(stream), a);
-    return check_launch();
+    if (!ws || ws_bytes < hsp_geometry_all_workspace_bytes(B, N0)) return HSP_ERR_WORKSPACE;
+    uint8_t* tie = reinterpret_cast<uint8_t*>(ws);
+    bool needs_pass = true;
+    int rc = knn3_select_flags(xyz, B, N0, k0, drop, kpool0, idx0, idx0_pool, tie, as_stream(stream), &needs_pass);
+    if (rc) return rc;
+    if (!needs_pass) return HSP_ERR_UNSUPPORTED;               // (cannot happen inside the range above)
+    return geometry_impl(xyz, B, N0, sel1, N1, sel2, N2, k1, kpool, k2, drop, v1, v2, idx1, idx1_pool, idx2, up1, up2, tie, k0, kpool0,
+                         idx0, idx0_pool, as_stream(stream));
 }
 
 extern "C" int hsp_nn1_f32(const float* tgt, int Nt, const float* src, int Ns, int B, int32_t* idx,

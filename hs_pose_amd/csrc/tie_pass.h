@@ -459,4 +459,74 @@ __device__ inline LaneAcc tkw_topk(TkE* q, int* LA, int* LB, int m, int N, int l
     return H;
 }
 
+// one WAVE's share (rows w, w + G, ...) of the tie pass of a coordinate search; scratch: 16 N bytes of LDS owned by this wave
+__device__ inline void tie_rows_xyz(char* scratch, const float* __restrict__ x, const uint8_t* __restrict__ tie, int B, int N,
+                                    int k, int k2, int drop, int32_t* __restrict__ idx, int32_t* __restrict__ idx2,
+                                    int* __restrict__ nties, int w, int G, int lane) {
+    TkE* q = reinterpret_cast<TkE*>(scratch);
+    int* LA = reinterpret_cast<int*>(q + N);
+    int* LB = LA + N;
+    const int rows = B * N;
+    // wave w owns rows w, w + G, ...; their flags are read 64 at a time (one round trip per 64 rows: a per-row read made the pass
+    // cost ~1 us per unflagged row and wave -- 0.4 ms at B = 64, N = 4096).  The selection already wrote every row's short list as
+    // the prefix of its long one: final wherever bit 1 is clear (the k2 + drop + 1 nearest are pairwise different, and a tie
+    // further down the long list cannot reach the short one)
+    for (int base = 0; base < rows; base += 64 * G) {
+      const int row_l = base + lane * G + w;
+      const int fl = row_l < rows ? (int)tie[row_l] : 0;
+      unsigned long long todo = __ballot(fl != 0);
+      while (todo) {
+        const int tl = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const int row = base + tl * G + w;
+        const int flags = __builtin_amdgcn_readlane(fl, tl);
+        int32_t* out = idx + (size_t)row * k;
+        int32_t* out2 = idx2 ? idx2 + (size_t)row * k2 : nullptr;
+        const int b = row / N, i = row - b * N;
+        const float* xb = x + (size_t)b * N * 3;
+        const float qx = xb[i * 3], qy = xb[i * 3 + 1], qz = xb[i * 3 + 2];
+        const float qq = quad3(qx, qy, qz);
+        if (lane == 0 && nties) atomicAdd(nties, 1);
+        TIE_STAMP(0);
+        // the list whose search leaves q untouched (partial_sort) goes first: one fill serves both
+        const int m1 = k + drop, m2 = k2 + drop;
+        const bool want2 = out2 && (flags & 2);
+        const bool second_first = want2 && !tkw_topk_destroys(m2, N) && tkw_topk_destroys(m1, N);
+        bool filled = false;
+        for (int pass = 0; pass < (want2 ? 2 : 1); ++pass) {
+            const bool short_list = (pass == 0) == second_first && want2;
+            if (!filled) {
+                for (int j0 = lane; j0 < N; j0 += 8 * 64) {                 // eight rows' loads in flight per lane
+                    float px[8], py[8], pz[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = j0 + 64 * u < N ? j0 + 64 * u : N - 1;
+                        px[u] = xb[j * 3]; py[u] = xb[j * 3 + 1]; pz[u] = xb[j * 3 + 2];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = j0 + 64 * u;
+                        const float inner = dot3_chain(qx, qy, qz, px[u], py[u], pz[u]);
+                        // (NaN / +inf -> FLT_MAX as in the selection kernels: the partition loops need a total order)
+                        TkE e;
+                        e.v = fminf(add_rn(add_rn(mul_rn(inner, -2.0f), quad3(px[u], py[u], pz[u])), qq), 3.402823466e+38f);
+                        e.i = j;
+                        if (j < N) q[j] = e;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                TIE_STAMP(8);
+            }
+            const int m = short_list ? m2 : m1;
+            const LaneAcc H = tkw_topk(q, LA, LB, m, N, lane);
+            filled = !tkw_topk_destroys(m, N);
+            int32_t* o = short_list ? out2 : out;
+            if (lane >= drop && lane < m) o[lane - drop] = H.i;
+            __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+}
+
+
 }  // namespace hsp

@@ -76,7 +76,12 @@ def prefetch_levels(vertices, k, pool_k=None):
     else:                                                    # the reference's own draws, in its order (pool_1, then pool_2)
         sel1 = torch.randperm(n0)[:n1].to(device=vertices.device, dtype=torch.int32)
         sel2 = torch.randperm(n1)[:n2].to(device=vertices.device, dtype=torch.int32)
-    geo = ops.geometry_levels(vertices, sel1, sel2, k1, pool_k, k2)
+    # with the input cloud's own search in the same pair of launches where the shapes allow (its tie pass rides in the levels' launch)
+    geo = ops.geometry_all(vertices, k, pool_k, sel1, sel2, k1, pool_k, k2) if k > pool_k else None
+    if geo is not None:
+        _knn_memo[id(vertices)] = (vertices, {k: geo["idx0"], pool_k: geo["idx0_pool"]})
+    else:
+        geo = ops.geometry_levels(vertices, sel1, sel2, k1, pool_k, k2)
     if geo is None:
         raise RuntimeError("prefetch_levels: shape check and kernel disagree")      # (indices already consumed: cannot fall back)
     v1, v2 = geo["v1"], geo["v2"]

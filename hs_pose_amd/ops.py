@@ -143,6 +143,32 @@ def knn_xyz(xyz, k, k2=0, drop_first=True):
     return idx, idx2
 
 
+def geometry_all(xyz, k0, kpool0, sel1, sel2, k1, kpool, k2):
+    """``knn_xyz(xyz, k0, kpool0)`` AND ``geometry_levels`` in two launches instead of three (hsp_geometry_all_f32: the input cloud's
+    tie pass rides in the levels' launch).  The dict of ``geometry_levels`` plus ``idx0`` / ``idx0_pool``; None outside the fused
+    kernel's range."""
+    x = _req(xyz.detach(), torch.float32, "geometry_all.xyz")
+    s1, s2 = _req(sel1, torch.int32, "geometry_all.sel1"), _req(sel2, torch.int32, "geometry_all.sel2")
+    B, N0, C = x.shape
+    N1, N2 = s1.numel(), s2.numel()
+    if (C != 3 or not (64 <= N2 <= N1 <= 576) or not (576 < N0 <= 1088) or B * N0 >= 131072 or k1 + 2 > 33 or k2 + 2 > 33 or k0 + 2 > 33
+            or k1 + 1 > N1 or k2 + 1 > N2 or not 0 < kpool <= k1 or not 0 < kpool0 < k0):
+        return None
+    dev = x.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    out = dict(v1=torch.empty(B, N1, 3, dtype=torch.float32, device=dev), v2=torch.empty(B, N2, 3, dtype=torch.float32, device=dev),
+               idx0=torch.empty(B, N0, k0, **i32), idx0_pool=torch.empty(B, N0, kpool0, **i32),
+               idx1=torch.empty(B, N1, k1, **i32), idx1_pool=torch.empty(B, N1, kpool, **i32), idx2=torch.empty(B, N2, k2, **i32),
+               up1=torch.empty(B, N0, **i32), up2=torch.empty(B, N0, **i32))
+    wsb = lib().hsp_geometry_all_workspace_bytes(B, N0)
+    ws = _ws(wsb, dev)
+    _run("hsp_geometry_all_f32", (_p(x), B, N0, k0, kpool0, _p(s1), N1, _p(s2), N2, k1, kpool, k2, 1, _p(out["idx0"]), _p(out["idx0_pool"]),
+                                  _p(out["v1"]), _p(out["v2"]), _p(out["idx1"]), _p(out["idx1_pool"]), _p(out["idx2"]), _p(out["up1"]),
+                                  _p(out["up2"]), _p(ws), wsb, _stream()),
+         key=f"B{B}N{N0}/{N1}/{N2}k{k0}", abytes=B * (12 * N0 + 4 * (N0 * (k0 + kpool0) + N1 * (k1 + kpool + 3) + N2 * (k2 + 3)) + 8 * N0))
+    return out
+
+
 def geometry_levels(xyz, sel1, sel2, k1, kpool, k2):
     """the coordinate work of the two coarse levels in one launch (hsp_geometry_levels_f32): given the rows Pool_layer keeps at
     each level (sel1 of the input cloud, sel2 of level 1; int32 device vectors), returns a dict with the levels' vertices ``v1`` /

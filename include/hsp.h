@@ -91,6 +91,15 @@ int hsp_knn_xyz_f32(const float *xyz, int B, int N, int k, int k2, int drop_firs
 int hsp_geometry_levels_f32(const float *xyz, int B, int N0, const int32_t *sel1, int N1, const int32_t *sel2, int N2, int k1,
                             int kpool, int k2, int drop_first, float *v1, float *v2, int32_t *idx1, int32_t *idx1_pool,
                             int32_t *idx2, int32_t *up1, int32_t *up2, hspStream_t stream);
+/* hsp_knn_xyz_f32 on the input cloud (idx0 (B,N0,k0), idx0_pool (B,N0,kpool0)) AND hsp_geometry_levels_f32 in two launches instead of
+ * three: the level-0 search's tie pass depends on that search's flags only, so it rides in the levels' launch as a further block
+ * range (a flagged row is ~14 us of latency during which the chip would otherwise idle).  576 < N0 <= 1088 and the levels' limits,
+ * else HSP_ERR_UNSUPPORTED (the caller keeps the separate calls).  ws: hsp_geometry_all_workspace_bytes (the level-0 flags). */
+size_t hsp_geometry_all_workspace_bytes(int B, int N0);
+int hsp_geometry_all_f32(const float *xyz, int B, int N0, int k0, int kpool0, const int32_t *sel1, int N1, const int32_t *sel2, int N2,
+                         int k1, int kpool, int k2, int drop_first, int32_t *idx0, int32_t *idx0_pool, float *v1, float *v2,
+                         int32_t *idx1, int32_t *idx1_pool, int32_t *idx2, int32_t *up1, int32_t *up2, void *ws, size_t ws_bytes,
+                         hspStream_t stream);
 /* hsp_knn_f32 with the |x|^2 order chosen as above */
 int hsp_knn_quadmode_f32(const float *x, int B, int N, int C, int k, int drop_first, int32_t *idx, void *ws, size_t ws_bytes,
                          int quad_mode, hspStream_t stream);

@@ -203,6 +203,15 @@ def test_exact_stack_tiled(dev, ref, flags, monkeypatch):
             xyz_lists[(sel1.numel(), k1)], xyz_lists[(sel1.numel(), kpool)], xyz_lists[(sel2.numel(), k2)] = geo["idx1"], geo["idx1_pool"], geo["idx2"]
         return geo
     monkeypatch.setattr(ops, "geometry_levels", rec_geo)
+    real_all = ops.geometry_all
+
+    def rec_all(xyz, k0, kpool0, sel1, sel2, k1, kpool, k2):   # (... and, where the shapes allow, the input cloud's lists with them)
+        geo = real_all(xyz, k0, kpool0, sel1, sel2, k1, kpool, k2)
+        if geo is not None:
+            xyz_lists[(xyz.shape[1], k0)], xyz_lists[(xyz.shape[1], kpool0)] = geo["idx0"], geo["idx0_pool"]
+            xyz_lists[(sel1.numel(), k1)], xyz_lists[(sel1.numel(), kpool)], xyz_lists[(sel2.numel(), k2)] = geo["idx1"], geo["idx1_pool"], geo["idx2"]
+        return geo
+    monkeypatch.setattr(ops, "geometry_all", rec_all)
     monkeypatch.setattr(ops, "knn", rec_knn)
     torch.manual_seed(1)
     with torch.no_grad():

@@ -234,5 +234,14 @@ def test_geometry_levels_equals_the_separate_searches(dev, ref, B, N0, tiled):
     assert torch.equal(geo["up1"], ops.nn1(x, v1)) and torch.equal(geo["up2"], ops.nn1(x, v2))
     if tiled:
         assert not torch.equal(i1[:, :, :4], i1p) or n1 < 320
+    # the same with the input cloud's own search in the pair of launches (its tie pass rides in the levels' launch)
+    geo2 = ops.geometry_all(x, 20, 4, sel1, sel2, k1, 4, k2)
+    if 576 < N0 <= 1088:
+        i0, i0p = ops.knn_xyz(x, 20, 4)
+        assert torch.equal(geo2["idx0"], i0) and torch.equal(geo2["idx0_pool"], i0p)
+        for key in ("v1", "v2", "idx1", "idx1_pool", "idx2", "up1", "up2"):
+            assert torch.equal(geo2[key], geo[key]), key
+    else:
+        assert geo2 is None
     # outside the fused kernel's range the caller is told so
     assert ops.geometry_levels(x[:, :200].contiguous(), sel1[:50].contiguous() % 200, sel2[:12].contiguous() % 50, 6, 4, 1) is None
