@@ -29,6 +29,11 @@ inline hipStream_t as_stream(hspStream_t s) { return reinterpret_cast<hipStream_
 // knn.hip -> knn_exact.hip: the xyz search by (distance, index) plus per-row flags: bit 0 "two of the k + drop + 1 nearest are equally
 // far", bit 1 the same for the k2 + drop + 1 nearest
 // (idx2 (B,N,k2), may be null: the first k2 entries of every list again -- the short list of every unflagged row)
+// knn.hip -> knn_exact.hip: the feature-space search (any C != 3) with a flag byte per row "two of the k + drop + 1 nearest are equally
+// far"; ws / ws_bytes as for hsp_knn_f32 (|x|^2 per row comes first in it); dmat (may be null): the (B, N, N) distances as
+// [candidate][query], left for the tie pass
+int knn_feat_select_flags(const float* x, int B, int N, int C, int k, int drop, int quad_mode, int32_t* idx, void* ws, size_t ws_bytes,
+                          uint8_t* tie, float* dmat, hspStream_t stream);
 // *needs_tie_pass: false when the selection replayed its flagged rows itself (then tie is not written)
 int knn3_select_flags(const float* x, int B, int N, int k, int drop, int k2, int32_t* idx, int32_t* idx2, uint8_t* tie,
                       hipStream_t st, bool* needs_tie_pass);

@@ -510,10 +510,12 @@ __global__ __launch_bounds__(256) void quad_kernel(const float* __restrict__ x, 
 // dl: N floats (N >= 64), sv: N int2 of scratch, both LDS
 // ------------------------------------------------------------------------------------------------
 
+// tie (may be null): *tie = 1 when two of the m + 1 nearest hold equal distances (the selection then runs to rank m), else 0
 __device__ __forceinline__ void knn_select_wave(const float* dl, int2* sv, int N, int k, int drop,
-                                                int32_t* __restrict__ out) {
+                                                int32_t* __restrict__ out, uint8_t* __restrict__ tie = nullptr) {
     const int lane = threadIdx.x & 63;
     const int m = k + drop;
+    const int ms = tie && m + 1 <= N ? m + 1 : m;
     float lmin = INFINITY;
     // real rows with a NaN / +inf distance count as FLT_MAX (ties by index): m valid candidates always exist, every
     // output slot is written (see merge_write)
@@ -521,7 +523,7 @@ __device__ __forceinline__ void knn_select_wave(const float* dl, int2* sv, int N
     // radix select, most significant bit first: the m-th smallest of the 64 keys
     const unsigned key = sortable_key(lmin);
     unsigned prefix = 0;
-    int need = m;
+    int need = ms;
     for (int bit = 31; bit >= KNN_TAU_LOW_BIT; --bit) {     // (a bound, not the exact value: see knn3_wave_body)
         const unsigned hi = bit == 31 ? 0u : (0xffffffffu << (bit + 1));
         const bool zero = ((key ^ prefix) & hi) == 0 && ((key >> bit) & 1u) == 0;
@@ -540,18 +542,32 @@ __device__ __forceinline__ void knn_select_wave(const float* dl, int2* sv, int N
         n += __popcll(bal);
     }
     __builtin_amdgcn_wave_barrier();
+    bool tied = false;
     for (int e = lane; e < n; e += 64) {
         const int2 me = sv[e];
         const float de = __int_as_float(me.x);
         int rank = 0;
+        bool eq_lo = false, eq_hi = false;                    // an equal distance at a lower / a higher index
         for (int f = 0; f < n; ++f) {
             const int2 o = sv[f];
             const float df = __int_as_float(o.x);
-            rank += (df < de || (df == de && o.y < me.y)) ? 1 : 0;
+            const bool eq = df == de;
+            rank += (df < de || (eq && o.y < me.y)) ? 1 : 0;
+            eq_lo = eq_lo || (eq && o.y < me.y);
+            eq_hi = eq_hi || (eq && o.y > me.y);
         }
         if (rank >= drop && rank < m) out[rank - drop] = me.y;
+        // (equal distances occupy neighbouring ranks: the pair lies below ms when this entry does and its partner is the previous
+        // rank, or the next one and that is still below ms)
+        tied = tied || (rank < ms && (eq_lo || (eq_hi && rank + 1 < ms)));
+    }
+    if (tie) {
+        const bool any_tied = __ballot(tied) != 0ull;
+        if (lane == 0) *tie = any_tied ? 1 : 0;
     }
 }
+
+
 
 // ------------------------------------------------------------------------------------------------
 // remainder queries of the feature path.  N = 1028 = 32*32 + 4 leaves 4 queries per cloud that would
@@ -565,7 +581,8 @@ __device__ __forceinline__ void knn_select_wave(const float* dl, int2* sv, int N
 template <int K1>
 __device__ __forceinline__ void knn_feat_tail_body(char* smem, const float* __restrict__ x,
                                                    const float* __restrict__ quad, int N, int C, int k, int drop,
-                                                   int q, int32_t* __restrict__ idx) {
+                                                   int q, int32_t* __restrict__ idx, uint8_t* __restrict__ tie,
+                                                   float* __restrict__ dmat) {
     const int Np = (N + 3) & ~3;                              // keeps sv / sq 16-byte aligned
     float* dl = reinterpret_cast<float*>(smem);               // N distances
     int2* sv = reinterpret_cast<int2*>(dl + Np);              // selection scratch
@@ -610,7 +627,8 @@ __device__ __forceinline__ void knn_feat_tail_body(char* smem, const float* __re
         if (j3 < N) dl[j3] = add_rn(add_rn(mul_rn(a3, -2.0f), quadb[j3]), qn);
     }
     __syncthreads();
-    if (tid < 64) knn_select_wave(dl, sv, N, k, drop, idx + ((size_t)b * N + q) * k);
+    if (dmat) for (int j = tid; j < N; j += 256) dmat[((size_t)b * N + j) * N + q] = dl[j];
+    if (tid < 64) knn_select_wave(dl, sv, N, k, drop, idx + ((size_t)b * N + q) * k, tie ? tie + (size_t)b * N + q : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -627,7 +645,8 @@ __global__ __launch_bounds__(256) void knn_feat_sym_tail_kernel(const float* __r
                                                                 const float* __restrict__ quad,
                                                                 const float* __restrict__ dtail, int N, int C,
                                                                 int k, int drop, int nfull,
-                                                                int32_t* __restrict__ idx) {
+                                                                int32_t* __restrict__ idx, uint8_t* __restrict__ tie,
+                                                                float* __restrict__ dmat) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int rem = N - nfull, b = blockIdx.y;
@@ -663,7 +682,8 @@ __global__ __launch_bounds__(256) void knn_feat_sym_tail_kernel(const float* __r
         dl[nfull + lane] = add_rn(add_rn(mul_rn(a, -2.0f), quadb[nfull + lane]), quadb[q]);
     }
     __builtin_amdgcn_wave_barrier();
-    knn_select_wave(dl, sv, N, k, drop, idx + ((size_t)b * N + q) * k);
+    if (dmat) for (int j = lane; j < N; j += 64) dmat[((size_t)b * N + j) * N + q] = dl[j];
+    knn_select_wave(dl, sv, N, k, drop, idx + ((size_t)b * N + q) * k, tie ? tie + (size_t)b * N + q : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -688,12 +708,13 @@ template <int K1, bool FULLK>
 __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restrict__ x,
                                                        const float* __restrict__ quad, int N, int C, int k,
                                                        int drop, int32_t* __restrict__ idx, int full_tiles,
-                                                       int ntail, float* __restrict__ dtail) {
+                                                       int ntail, float* __restrict__ dtail, int msel,
+                                                       uint8_t* __restrict__ tie, float* __restrict__ dmat) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // remainder queries: one workgroup each.  They take the LOWEST block ids so that they are dispatched
     // first and run alongside the MFMA tiles instead of after them.
     if ((int)blockIdx.x < ntail) {
-        knn_feat_tail_body<K1>(smem, x, quad, N, C, k, drop, full_tiles * 32 + (int)blockIdx.x, idx);
+        knn_feat_tail_body<K1>(smem, x, quad, N, C, k, drop, full_tiles * 32 + (int)blockIdx.x, idx, tie, dmat);
         return;
     }
     const int Cp = (C + 63) & ~63;          // K padded to a multiple of 64 with zeros (adds exact 0s)
@@ -870,6 +891,13 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
             }
             __builtin_amdgcn_wave_barrier();
             const int c0 = tile * 32 + 4 * h;
+            if (dmat && qvalid) {                           // (exact scope, small batches) the distance matrix, [candidate][query]:
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {              // 32 queries = 128 contiguous bytes per store
+                    const int cand = c0 + (r & 3) + 8 * (r >> 2);
+                    if (cand < N) dmat[((size_t)b * N + cand) * N + q] = stash[r * 64 + lane];
+                }
+            }
             // software-pipelined: the next survivor is fetched from the stash while the current one is inserted
             bool has = m != 0;
             int r = has ? __builtin_ctz(m) : 0;              // ascending r == ascending candidate index
@@ -901,7 +929,8 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
     const int src = (ml >> 1) * 64 + (ml & 1) * 32 + mq;
     const int oq = q0 + mq;
     const bool ovalid = oq < N;
-    merge_write<K1, 8>(lists, src, ml, k, drop, ovalid, idx + ((size_t)b * N + (ovalid ? oq : 0)) * k, N, ovalid ? oq : 0);
+    merge_write<K1, 8>(lists, src, ml, k, drop, ovalid, idx + ((size_t)b * N + (ovalid ? oq : 0)) * k, N, ovalid ? oq : 0, nullptr,
+                       msel, tie ? tie + (size_t)b * N + (ovalid ? oq : 0) : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1106,7 +1135,7 @@ static int knn_feat_rem_mode(int B, int N, int C) {
 
 template <int K1>
 static int launch_knn_feat(const float* x, const float* quad, float* dtail, int B, int N, int C, int k, int drop,
-                           int32_t* idx, hipStream_t st) {
+                           int32_t* idx, hipStream_t st, int msel = 0, uint8_t* tie = nullptr, float* dmat = nullptr) {
     const size_t lds = knn_feat_lds(C, K1);
     const bool fullk = (C & 63) == 0 && (size_t)N * C * 4 < ((size_t)1 << 31);
     auto kern = fullk ? knn_feat_kernel<K1, true> : knn_feat_kernel<K1, false>;
@@ -1120,7 +1149,7 @@ static int launch_knn_feat(const float* x, const float* quad, float* dtail, int 
     }
     const int ntail = mode == KF_REM_WG ? rem : 0;
     hipLaunchKernelGGL(kern, dim3(full_tiles + ntail, B), dim3(256), lds, st, x, quad, N, C, k, drop, idx, full_tiles,
-                       ntail, mode == KF_REM_SYM ? dtail : nullptr);
+                       ntail, mode == KF_REM_SYM ? dtail : nullptr, msel, tie, dmat);
     int rc = check_launch();
     if (rc || mode != KF_REM_SYM) return rc;
     const size_t lds_s = (size_t)4 * (12 * ((size_t)N + 3) + (size_t)(1 + rem) * C * 4);
@@ -1130,7 +1159,7 @@ static int launch_knn_feat(const float* x, const float* quad, float* dtail, int 
         if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
     }
     hipLaunchKernelGGL(knn_feat_sym_tail_kernel, dim3((rem + 3) / 4, B), dim3(256), lds_s, st, x, quad, dtail, N, C, k,
-                       drop, N - rem, idx);
+                       drop, N - rem, idx, tie, dmat);
     return check_launch();
 }
 
@@ -1347,13 +1376,16 @@ extern "C" size_t hsp_knn_workspace_bytes(int B, int N, int C, int k) {
 extern "C" int hsp_quad_outer_f32(const float* x, int B, int N, int C, float* quad, hspStream_t stream);
 
 // quad_mode 0: |x|^2 in ATen's order for a CONTIGUOUS (B,N,C) tensor; 1: for the transposed view of a (B,C,N) tensor (exact.hip)
+// tie (feature path only, may be null): B*N flag bytes -- the selection runs one rank past the answer and says per row whether two
+// of the k + drop + 1 nearest hold equal distances (csrc/knn_exact.hip replays those rows in torch.topk's order)
 static int knn_f32_impl(const float* x, int B, int N, int C, int k, int drop_first, int32_t* idx, void* ws,
-                        size_t ws_bytes, int quad_mode, hspStream_t stream) {
+                        size_t ws_bytes, int quad_mode, hspStream_t stream, uint8_t* tie = nullptr, float* dmat = nullptr) {
     if (!x || !idx || B <= 0 || N <= 0 || C <= 0 || k <= 0) return HSP_ERR_BAD_ARG;
     const int drop = drop_first ? 1 : 0;
     const int m = k + drop;
     if (m > N || k > HSP_MAX_K) return HSP_ERR_BAD_ARG;
-    const int K1 = pick_k1(m);
+    const int msel = tie && C != 3 ? (m + 1 < N ? m + 1 : N) : 0;
+    const int K1 = pick_k1(msel > m ? msel : m);
     if (!K1) return HSP_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);
 #define HSP_K1_SWITCH(CALL)                                  \
@@ -1386,7 +1418,7 @@ static int knn_f32_impl(const float* x, int B, int N, int C, int k, int drop_fir
         rc = check_launch();
     }
     if (rc) return rc;
-#define CALLF(K) launch_knn_feat<K>(x, quad, quad + rows, B, N, C, k, drop, idx, st)
+#define CALLF(K) launch_knn_feat<K>(x, quad, quad + rows, B, N, C, k, drop, idx, st, msel, tie, dmat)
     HSP_K1_SWITCH(CALLF)
 #undef CALLF
 #undef HSP_K1_SWITCH
@@ -1400,6 +1432,14 @@ extern "C" int hsp_knn_quadmode_f32(const float* x, int B, int N, int C, int k, 
                                     size_t ws_bytes, int quad_mode, hspStream_t stream) {
     return knn_f32_impl(x, B, N, C, k, drop_first, idx, ws, ws_bytes, quad_mode, stream);
 }
+
+namespace hsp {
+// knn_exact.hip: the feature-space search by (distance, index) + a flag byte per row (ws as hsp_knn_workspace_bytes: |x|^2 first)
+int knn_feat_select_flags(const float* x, int B, int N, int C, int k, int drop, int quad_mode, int32_t* idx, void* ws, size_t ws_bytes,
+                          uint8_t* tie, float* dmat, hspStream_t stream) {
+    return knn_f32_impl(x, B, N, C, k, drop, idx, ws, ws_bytes, quad_mode, stream, tie, dmat);
+}
+}  // namespace hsp
 
 extern "C" int hsp_knn_bf16(const hsp_bf16_t* x, int B, int N, int C, int k, int drop_first, int32_t* idx, void* ws,
                             size_t ws_bytes, hspStream_t stream) {

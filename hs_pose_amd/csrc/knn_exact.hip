@@ -21,55 +21,108 @@
 
 namespace hsp {
 
-// one wave per query row.  cand (B,N,mc): the mc = min(m + 1, N) nearest by (distance, index) from hsp_knn_f32 (no drop).
-__global__ __launch_bounds__(64) void knn_ties_kernel(const float* __restrict__ x, const float* __restrict__ quad,
-                                                      const int32_t* __restrict__ cand, int N, int C, int k, int drop, int mc,
-                                                      int32_t* __restrict__ idx, int* __restrict__ nties) {
+// ---- feature rows (C != 3): the tie pass over FLAGGED rows only ------------------------------------------------------------------
+// knn_feat_select_flags has written every row's (distance, index)-ordered list and a flag per row (two of the k + drop + 1 nearest
+// equally far).  A fixed grid of single-wave workgroups reads the flags 64 rows at a time; a flagged row gets its N distances again
+// -- the k-ordered fma chain of torch.bmm, ((inner * -2) + |c|^2) + |q|^2, four candidate rows per lane in flight, the query row
+// broadcast from LDS -- and libstdc++'s algorithm (tie_pass.h).  (Round 4 visited EVERY row with one wave that recomputed its 22
+// candidates' distances to find out: 31 us per call whatever the data held.)
+__global__ __launch_bounds__(64) void knn_feat_ties_rows_kernel(const float* __restrict__ x, const float* __restrict__ quad,
+                                                                const uint8_t* __restrict__ tie, const float* __restrict__ dmat, int B,
+                                                                int N, int C, int k, int drop, int32_t* __restrict__ idx,
+                                                                int* __restrict__ nties) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    TkE* q = reinterpret_cast<TkE*>(smem);                     // N entries (tie rows only)
+    TkE* q = reinterpret_cast<TkE*>(smem);                     // N entries
     int* LA = reinterpret_cast<int*>(q + N);                   // N: partition scratch
     int* LB = LA + N;
+    float* sq = reinterpret_cast<float*>(LB + N);              // the query row (C floats, 16-byte aligned: N * 16 bytes precede it)
     const int lane = threadIdx.x;
-    const int b = blockIdx.y, i = blockIdx.x;
+    const int rows = B * N, G = gridDim.x, w = blockIdx.x;
     const int m = k + drop;
-    const float* xb = x + (size_t)b * N * C;
-    const float* xi = xb + (size_t)i * C;
-    const float* qb = quad ? quad + (size_t)b * N : nullptr;
-    auto quad_of = [&](int j) {
-        if (qb) return qb[j];
-        const float* p = xb + (size_t)j * 3;
-        return quad3(p[0], p[1], p[2]);
-    };
-    auto dist_to = [&](int j, float qi) {
-        const float* xj = xb + (size_t)j * C;
-        float acc = 0.f;
-        if ((C & 3) == 0) {
-            for (int c = 0; c < C; c += 4) {                                 // torch.bmm: k-ordered chain from 0
-                const float4 a = *reinterpret_cast<const float4*>(xi + c), bq = *reinterpret_cast<const float4*>(xj + c);
-                acc = __fmaf_rn(a.x, bq.x, acc); acc = __fmaf_rn(a.y, bq.y, acc);
-                acc = __fmaf_rn(a.z, bq.z, acc); acc = __fmaf_rn(a.w, bq.w, acc);
+    for (int base = 0; base < rows; base += 64 * G) {
+        const int row_l = base + lane * G + w;
+        const int fl = row_l < rows ? (int)tie[row_l] : 0;
+        unsigned long long todo = __ballot(fl != 0);
+        while (todo) {
+            const int tl = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const int row = base + tl * G + w;
+            const int b = row / N, i = row - b * N;
+            const float* xb = x + (size_t)b * N * C;
+            const float* qb = quad + (size_t)b * N;
+            for (int c = lane; c < C; c += 64) sq[c] = xb[(size_t)i * C + c];
+            __builtin_amdgcn_wave_barrier();
+            const float qi = qb[i];
+            if (lane == 0 && nties) atomicAdd(nties, 1);
+            if (dmat) {
+                // the selection kernel left the row's distances (as [candidate][query]: a strided column, every load in flight at
+                // once) -- recomputing them is ~0.5 MB of feature rows streamed by ONE wave, ~30 us of the 40 a flagged row cost
+                const float* col = dmat + (size_t)b * N * N + i;
+                for (int j0 = lane; j0 < N; j0 += 8 * 64) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(j0 + 64 * u < N ? j0 + 64 * u : N - 1) * N];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = j0 + 64 * u;
+                        if (j < N) { TkE e; e.v = fminf(v[u], 3.402823466e+38f); e.i = j; q[j] = e; }
+                    }
+                }
+            } else
+            for (int j0 = lane; j0 < N; j0 += 4 * 64) {
+                const float* r[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) r[u] = xb + (size_t)(j0 + 64 * u < N ? j0 + 64 * u : N - 1) * C;
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                if ((C & 15) == 0) {
+                    for (int c = 0; c < C; c += 16) {                    // torch.bmm: k-ordered chain from 0; 16 loads in flight per lane
+                        float4 v[4][4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) v[t][u] = *reinterpret_cast<const float4*>(r[u] + c + 4 * t);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const float4 a = *reinterpret_cast<const float4*>(sq + c + 4 * t);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                acc[u] = __fmaf_rn(a.w, v[t][u].w, __fmaf_rn(a.z, v[t][u].z, __fmaf_rn(a.y, v[t][u].y, __fmaf_rn(a.x, v[t][u].x, acc[u]))));
+                        }
+                    }
+                } else if ((C & 3) == 0) {
+                    for (int c = 0; c < C; c += 4) {
+                        const float4 a = *reinterpret_cast<const float4*>(sq + c);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float4 v = *reinterpret_cast<const float4*>(r[u] + c);
+                            acc[u] = __fmaf_rn(a.w, v.w, __fmaf_rn(a.z, v.z, __fmaf_rn(a.y, v.y, __fmaf_rn(a.x, v.x, acc[u]))));
+                        }
+                    }
+                } else {
+                    for (int c = 0; c < C; ++c) {
+                        const float a = sq[c];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc[u] = __fmaf_rn(a, r[u][c], acc[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + 64 * u;
+                    if (j < N) {
+                        TkE e;                                           // gcn3d.py:21, left to right; NaN / +inf -> FLT_MAX (a total order)
+                        e.v = fminf(add_rn(add_rn(mul_rn(acc[u], -2.0f), qb[j]), qi), 3.402823466e+38f);
+                        e.i = j;
+                        q[j] = e;
+                    }
+                }
             }
-        } else {
-            for (int c = 0; c < C; ++c) acc = __fmaf_rn(xi[c], xj[c], acc);
+            __builtin_amdgcn_wave_barrier();
+            const LaneAcc H = tkw_topk(q, LA, LB, m, N, lane);
+            int32_t* out = idx + (size_t)row * k;
+            if (lane >= drop && lane < m) out[lane - drop] = H.i;
+            __builtin_amdgcn_wave_barrier();
         }
-        return add_rn(add_rn(mul_rn(acc, -2.0f), quad_of(j)), qi);           // gcn3d.py:21, left to right
-    };
-    const float qi = quad_of(i);
-    const int32_t* cr = cand + ((size_t)b * N + i) * mc;
-    const int cj = lane < mc ? cr[lane] : 0;
-    const float dc = lane < mc ? dist_to(cj, qi) : INFINITY;
-    const float dn = __shfl_down(dc, 1);
-    const bool tie = lane + 1 < mc && dc == dn;
-    int32_t* out = idx + ((size_t)b * N + i) * k;
-    if (__ballot(tie) == 0ull) {
-        if (lane >= drop && lane < m) out[lane - drop] = cj;
-        return;
     }
-    for (int j = lane; j < N; j += 64) { q[j].v = dist_to(j, qi); q[j].i = j; }
-    __syncthreads();
-    if (lane == 0 && nties) atomicAdd(nties, 1);
-    const LaneAcc H = tkw_topk(q, LA, LB, m, N, lane);
-    if (lane >= drop && lane < m) out[lane - drop] = H.i;
 }
 
 // ---- coordinates (C == 3): the tie pass over FLAGGED rows only -------------------------------------------------------------------
@@ -131,12 +184,18 @@ extern "C" int hsp_knn_xyz_f32(const float* xyz, int B, int N, int k, int k2, in
     return check_launch();
 }
 
+// the selection kernel leaves the (B, N, N) distances for the tie pass while that is a small buffer (an image's instances at
+// N = 1028: 4 MB each); beyond 64 MB a flagged row's distances are recomputed
+static bool knn_exact_keeps_distances(int B, int N) { return (size_t)B * N * N * sizeof(float) <= ((size_t)64 << 20); }
+
 extern "C" size_t hsp_knn_exact_workspace_bytes(int B, int N, int C, int k, int drop_first) {
     if (B <= 0 || N <= 0 || C <= 0 || k <= 0) return 0;
     const int m = k + (drop_first ? 1 : 0);
     const int mc = m + 1 < N ? m + 1 : N;
     const size_t inner = hsp_knn_workspace_bytes(B, N, C, mc);
-    return ((inner + 255) & ~(size_t)255) + (size_t)B * N * mc * sizeof(int32_t) + 256;
+    size_t bytes = ((inner + 255) & ~(size_t)255) + (((size_t)B * N + 255) & ~(size_t)255) + 256;   // |x|^2 (+ remainder rows), row flags
+    if (C != 3 && knn_exact_keeps_distances(B, N)) bytes += (size_t)B * N * N * sizeof(float);       // + the distance matrix
+    return bytes;
 }
 
 extern "C" int hsp_knn_quadmode_f32(const float* x, int B, int N, int C, int k, int drop_first, int32_t* idx, void* ws,
@@ -153,16 +212,26 @@ extern "C" int hsp_knn_exact_f32(const float* x, int B, int N, int C, int k, int
     if (!ws || ws_bytes < hsp_knn_exact_workspace_bytes(B, N, C, k, drop_first)) return HSP_ERR_WORKSPACE;
     if (C == 3) return hsp_knn_xyz_f32(x, B, N, k, 0, drop_first, idx, nullptr, ws, ws_bytes, tie_rows, stream);   // flags + flagged rows
     const size_t inner = (hsp_knn_workspace_bytes(B, N, C, mc) + 255) & ~(size_t)255;
-    int32_t* cand = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + inner);
-    int rc = hsp_knn_quadmode_f32(x, B, N, C, mc, 0, cand, ws, inner, C == 3 ? 0 : quad_mode, stream);
+    uint8_t* tie = reinterpret_cast<uint8_t*>(ws) + inner;
+    float* dmat = knn_exact_keeps_distances(B, N)
+                      ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + inner + ((((size_t)B * N + 255) & ~(size_t)255) + 256))
+                      : nullptr;
+    int rc = knn_feat_select_flags(x, B, N, C, k, drop, quad_mode, idx, ws, inner, tie, dmat, stream);
     if (rc) return rc;
-    const size_t lds = (size_t)N * (sizeof(TkE) + 2 * sizeof(int));
+    const size_t lds = (size_t)N * (sizeof(TkE) + 2 * sizeof(int)) + (size_t)((C + 3) & ~3) * sizeof(float);
     if (lds > 160 * 1024) return HSP_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_ties_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_feat_ties_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
         if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
     }
-    const float* quad = C == 3 ? nullptr : reinterpret_cast<const float*>(ws);      // hsp_knn_f32 left |x|^2 there
-    hipLaunchKernelGGL(knn_ties_kernel, dim3(N, B), dim3(64), lds, as_stream(stream), x, quad, cand, N, C, k, drop, mc, idx, tie_rows);
+    const float* quad = reinterpret_cast<const float*>(ws);                           // knn_feat_select_flags left |x|^2 there
+    const long long rows = (long long)B * N;
+    const int per_cu = (int)(160 * 1024 / (lds > 16 * 1024 ? lds : 16 * 1024));
+    // (as many waves as fit: ~2 % of the rows of real activations are flagged, and two of them in one wave double the pass)
+    const long long cap = (long long)HSP_NUM_CU * (per_cu < 1 ? 1 : per_cu);
+    const int grid = (int)(rows < cap ? rows : cap);
+    hipLaunchKernelGGL(knn_feat_ties_rows_kernel, dim3(grid), dim3(64), lds, as_stream(stream), x, quad, tie, dmat, B, N, C, k, drop, idx,
+                       tie_rows);
     return check_launch();
 }
