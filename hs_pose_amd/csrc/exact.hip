@@ -133,7 +133,28 @@ __device__ float aten_outer_sum(F elem, int size, int col, int cols) {
 // |x|^2 per row of x (B,N,C) as torch.sum(v ** 2, dim=2) evaluates it when v is the TRANSPOSED VIEW of a (B,C,N) tensor --
 // what FaceRecon.py:94-95 hands conv_3: relu(bn(...)).transpose(1, 2) is never made contiguous, so the channel sum is an
 // outer sum over columns n (gcn3d.py:20)
-__global__ __launch_bounds__(256) void quad_outer_kernel(const float* __restrict__ x, int N, int C, float* __restrict__ quad) {
+// One wave per 64 rows: the rows are staged whole in LDS with coalesced loads (a thread walking its own row read one float per 1 KB
+// stride, 256 dependent misses: 37 us for 1028 x 256 -- the longest small kernel of an inference forward), then lane r runs row r's
+// sum in ATen's order from LDS (pitch C + 1: the lanes' walks fall on different banks).
+__global__ __launch_bounds__(64) void quad_outer_kernel(const float* __restrict__ x, int N, int C, float* __restrict__ quad) {
+    extern __shared__ float qo_tile[];                 // 64 x (C + 1)
+    const int lane = threadIdx.x, b = blockIdx.y, n0 = blockIdx.x * 64;
+    const int P = C + 1;
+    const float* xb = x + ((size_t)b * N + n0) * C;
+    const int nrows = min(64, N - n0);
+    for (int e = lane; e < nrows * C; e += 64) {       // consecutive lanes, consecutive floats
+        const int r = e / C, c = e - r * C;
+        qo_tile[r * P + c] = xb[e];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int n = n0 + lane;
+    if (lane >= nrows) return;
+    const float* row = qo_tile + lane * P;
+    quad[(size_t)b * N + n] = aten_outer_sum([&](int c) { const float v = row[c]; return mul_rn(v, v); }, C, n, N);
+}
+
+// (rows too wide for the LDS tile: a thread per row, straight from global memory)
+__global__ __launch_bounds__(256) void quad_outer_wide_kernel(const float* __restrict__ x, int N, int C, float* __restrict__ quad) {
     const int n = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
     if (n >= N) return;
     const float* row = x + ((size_t)b * N + n) * C;
@@ -231,7 +252,16 @@ extern "C" int hsp_bn_eval_f32(const float* x, long long R, int C, const float* 
 
 extern "C" int hsp_quad_outer_f32(const float* x, int B, int N, int C, float* quad, hspStream_t stream) {
     if (!x || !quad || B <= 0 || N <= 0 || C <= 0) return HSP_ERR_BAD_ARG;
-    hipLaunchKernelGGL(quad_outer_kernel, dim3((N + 255) / 256, B), dim3(256), 0, as_stream(stream), x, N, C, quad);
+    const size_t lds = (size_t)64 * (C + 1) * sizeof(float);
+    if (lds <= 64 * 1024 + 1024 && lds <= 160 * 1024) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(quad_outer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
+        }
+        hipLaunchKernelGGL(quad_outer_kernel, dim3((N + 63) / 64, B), dim3(64), lds, as_stream(stream), x, N, C, quad);
+    } else {
+        hipLaunchKernelGGL(quad_outer_wide_kernel, dim3((N + 255) / 256, B), dim3(256), 0, as_stream(stream), x, N, C, quad);
+    }
     return check_launch();
 }
 
