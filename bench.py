@@ -41,6 +41,8 @@ def _latest_traffic_json():
 
 
 TRAFFIC_JSON = _latest_traffic_json()
+# the same round's graph_calls.json (tools/graph_call_us.py over the committed graph-replay trace): kernels' durations INSIDE the replay
+GRAPH_CALLS_JSON = os.path.join(os.path.dirname(TRAFFIC_JSON), "graph_calls.json")
 
 
 def u1_algorithmic(N, k=20, S=7):
@@ -242,8 +244,10 @@ def dry_run(args, rank, world, device, result_out):
         dist.destroy_process_group()
 
 
-def roofline_of(kname, kkey, kd, bf16, traffic):
-    """the roofline object of one C-ABI call: algorithmic flops (GEMM-shaped calls) or bytes per launch / its HIP-event average"""
+def roofline_of(kname, kkey, kd, bf16, traffic, graph_calls=None):
+    """the roofline object of one C-ABI call: algorithmic flops (GEMM-shaped calls) or bytes per launch / its HIP-event average.
+    ``graph_calls``: the committed in-graph durations (tools/graph_call_us.py) -- when the call is in it, ``in_graph`` prices the same
+    algorithmic work on the kernels' durations inside the replayed graph (no gaps between a call's kernels, no eager launch path)."""
     from hs_pose_amd import ops
     if kd.get("aflops", 0) > 0:           # GEMM-shaped kernel (feature-space distance tiles / weight gradient): MFMA roofline
         peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
@@ -257,6 +261,12 @@ def roofline_of(kname, kkey, kd, bf16, traffic):
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "avg_us": round(kd["avg_us"], 2),
                 "algorithmic_bytes_per_launch": kd["abytes"], "traffic": None}
     roof["traffic"] = traffic.get(f"{kname}[{kkey}]", {}).get("hbm_bytes_per_launch")
+    gc = (graph_calls or {}).get(f"{kname}[{kkey}]")
+    if gc:
+        us = gc["in_graph_us"]
+        work = kd["aflops"] / 1e12 if roof["bound"] == "mfma" else kd["abytes"] / 1e9
+        roof["in_graph"] = {"avg_us": us, "achieved": round(work / (us * 1e-6), 3), "frac": round(work / (us * 1e-6) / roof["peak"], 5),
+                            "kernels": [k_["kernel"].split("(")[0] for k_ in gc["kernels"]]}
     sb = ops.design_stream_bytes.get((kname, kkey))
     if sb:                                 # the bytes the kernel streams by design (uint16 winning-row slots, winners' support values)
         roof["kernel_stream_bytes_per_launch"] = sb
@@ -412,9 +422,22 @@ def main():
 
     if rank == 0:
         summ = timer.summary()
-        # dominant kernel = the single C-ABI launch with the longest average duration (per launch, not per shape key:
-        # two layers that share a shape are two launches)
-        (kname, kkey), kd = max(summ.items(), key=lambda kv: kv[1]["avg_us"])
+        graph_calls = {}
+        if graphed is not None and not bf16 and B == 16 and N == 1028:
+            try:                           # the committed graph-replay trace of this configuration, per C-ABI call
+                with open(GRAPH_CALLS_JSON) as f:
+                    graph_calls = json.load(f)["calls"]
+            except Exception:
+                graph_calls = {}
+        # dominant call = the single C-ABI launch with the longest duration (per launch, not per shape key: two layers that share a
+        # shape are two launches) -- by its kernels' durations inside the replayed graph where the committed trace has the call
+        # (the timed region IS the replay; HIP events around a call of the eager re-issue also count the gaps between its
+        # kernels), else by the eager HIP-event average
+        def _dur(item):
+            (n_, k_), d_ = item
+            gc = graph_calls.get(f"{n_}[{k_}]")
+            return gc["in_graph_us"] if gc else d_["avg_us"]
+        (kname, kkey), kd = max(summ.items(), key=_dur)
         hsp_ms = sum(d["total_ms"] for d in summ.values()) / args.steps
         traffic = {}
         try:                               # HBM bytes per launch measured with rocprofv3 PMC passes (committed with the profile)
@@ -422,13 +445,15 @@ def main():
                 traffic = json.load(f)
         except Exception:
             pass
-        roof = roofline_of(kname, kkey, kd, bf16, traffic)
+        roof = roofline_of(kname, kkey, kd, bf16, traffic, graph_calls)
+        roof["dominant_by"] = ("kernel durations inside the replayed graph (" + os.path.relpath(GRAPH_CALLS_JSON, ROOT) + ")"
+                               if graph_calls.get(f"{kname}[{kkey}]") else "HIP events around the call")
         roof["traffic_source"] = (os.path.relpath(TRAFFIC_JSON, ROOT) + " (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE passes of this command; "
                                   "committed with the round's profile, not re-measured by this run)")
         # the same object for the five longest calls of the step (the "dominant" one above can change between runs when two
         # calls are within noise of each other: hsp_knn_f32[C128] and hsp_rf_conv_fwd[N1028] both sit near 85-100 us)
-        top = sorted(summ.items(), key=lambda kv: -kv[1]["avg_us"])[:5]
-        roof_all = [roofline_of(n_, k_, d_, bf16, traffic) for (n_, k_), d_ in top]
+        top = sorted(summ.items(), key=lambda kv: -_dur(kv))[:5]
+        roof_all = [roofline_of(n_, k_, d_, bf16, traffic, graph_calls) for (n_, k_), d_ in top]
         roof["avg_us_source"] = ("HIP events around the call, in the timed region" if graphed is None else
                                  "HIP events around the call, the same K steps re-issued eagerly right after the timed "
                                  "graph replays (events cannot be recorded inside a replay)")

@@ -17,7 +17,7 @@ import sys
 MAP = {
     ("knn_feat_kernel<21, true", "131072"): "hsp_knn_f32[B16N1028C128k20]",
     ("knn_feat_kernel<9, true", "8192"): "hsp_knn_f32[B16N64C256k8]",
-    ("knn3_wave_kernel<17", "266240"): "hsp_knn_xyz_f32[B16N1028k20]",
+    ("knn3_wave_kernel<17", "266240"): "hsp_geometry_all_f32[B16N1028/257/64k20]",
     ("rf_fwd_pipe_kernel<true, 1, false, float", "524288"): "hsp_rf_surface_fwd[B16N1028k20S7C128]",
     ("rf_fwd_pipe_kernel<false, 1, true, float", "524288"): "hsp_rf_conv_fwd[B16N1028k20S7C128]",
     ("rf_fwd_pipe_kernel<false, 2, false, float", "524288"): "hsp_rf_conv_fwd[B16N257k20S7C256]",

@@ -1,8 +1,9 @@
 #!/bin/bash
 # regenerate the judged artifacts of a round under gpurun_out/refresh (then copied into profiles/<round>/ by hand).
 #   tools/refresh_profiles.sh <round dir, e.g. r02>      -- run on the GPU box via gpurun
-# Order matters: the PMC traffic passes first (bench.py reads profiles/<round>/traffic.json for roofline.traffic), then the
-# bench line of the same build, then rocprofv3 kernel stats / per-shape table / per-call event breakdown of that command.
+# Order matters: the PMC traffic passes first (bench.py reads profiles/<round>/traffic.json for roofline.traffic), then rocprofv3
+# kernel stats / per-shape table of the graph replay (-> graph_calls.json, which bench.py reads too), then the bench line of the
+# same build and the per-call event breakdown of that command.
 # Second half: the bf16 dense-cloud configuration (BASELINE configs[3]).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -15,12 +16,14 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python $R/tools/pmc_traffic.py $O/k_pmc_FETCH_SIZE.csv $O/k_pmc_WRITE_SIZE.csv $O/traffic.json > /dev/null
 cp $O/traffic.json $R/profiles/$RD/traffic.json
-python $R/bench.py > $O/k_bench.json 2> $O/bench.err
-tail -1 $O/k_bench.json | cut -c1-300
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline --no-u3 --no-side > $O/stats_bench.log 2>&1
 cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/k_graph_kernel_stats.csv
 T=$(find $O/stats -name '*kernel_trace.csv' | head -1)
 python $R/tools/trace_by_shape.py $T auto > $O/k_per_shape_kernel_us.txt
+python $R/tools/graph_call_us.py $O/k_per_shape_kernel_us.txt > $R/profiles/$RD/graph_calls.json
+# the bench line AFTER the trace: it prices its dominant call on profiles/$RD/graph_calls.json
+python $R/bench.py > $O/k_bench.json 2> $O/bench.err
+tail -1 $O/k_bench.json | cut -c1-300
 python $R/bench.py --steps 20 --warmup 5 --breakdown --no-cpu-baseline --no-u3 --no-side > $O/k_breakdown_eager_events.txt 2>&1
 # comparison figure: the BLAS library for the dense products (tools/library_gemm.py)
 HSP_GEMM=library python $R/bench.py --no-cpu-baseline --no-u3 --no-side > $O/k_bench_gemm_library.json 2>/dev/null
