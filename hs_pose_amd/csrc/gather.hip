@@ -115,6 +115,131 @@ __global__ __launch_bounds__(256) void orl_partial_kernel(const FT* __restrict__
     }
 }
 
+// The same global feature with the cloud's column slab resident in LDS (round 5).  orl_partial_kernel gathers k rows of 512+ bytes per
+// point through the texture path: 168 MB of L2 requests per N = 1028, C = 128 call, which is what its 17 us are (VALU 13 % busy).
+// Here a workgroup owns (cloud, 8 channels): the slab feat[b][:, c0:c0+8] is read ONCE into LDS (48-byte rows: 12-float pitch, so
+// that random rows spread over the banks), a thread takes (point, 4 channels), walks the point's k neighbours with ds_read_b128,
+// writes the winning slots and keeps the column sums; the workgroup folds them in a fixed order and writes fg itself -- no partial
+// buffer, no fold launch.  N <= 1150, k = 20, contiguous lists (64 KB of LDS with the list strips); anything else keeps the chunked form.
+//
+// The kernel is bound by VALU ISSUE, not by memory: 1028 x 128 x 20 compare / select triples over 1024 SIMDs are ~3.5 us, and one
+// workgroup per CU means every other instruction of the pass is on the critical path (a first form with an integer division per staged
+// index ran 26 us with every load and store removed).  Hence: lists staged as ready-made LDS byte offsets by a flat coalesced copy
+// (contiguous lists only), 512 threads (two waves per SIMD cover each other's LDS latency), max first and the winning slot by a
+// descending equality scan (2.5 instead of 3 instructions per element).
+#ifdef HSP_ORL_PROF
+static __device__ long long* g_orl_prof = nullptr;     // tools/prof_orl_tile.py: clock64 stamps of workgroup 0, wave 0
+#define ORL_STAMP(slot) do { if (g_orl_prof && blockIdx.x == 0 && threadIdx.x == 0) g_orl_prof[slot] = clock64(); } while (0)
+#else
+#define ORL_STAMP(slot) do { } while (0)
+#endif
+#define ORLT_TC 8
+#define ORLT_PITCH4 3            // float4 units per LDS row
+#define ORLT_WG 512
+// max(a, b, c) of plain numbers in ONE instruction (fmaxf compiles to three: it quiets NaNs first); NaNs are not ordered by the
+// product's max either (orl_partial_kernel compares with >)
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// K is a template constant (the HS layers' k = 20 is the only instance): every neighbour loop is straight-line code -- run-time "n < k"
+// guards turned the first form into 180 branches -- and all K rows of a (point, 4 channels) sit in registers (80 of the 128 VGPRs a
+// 512-thread workgroup has)
+template <typename FT, int K>
+__global__ __launch_bounds__(ORLT_WG) void orl_tile_kernel(const FT* __restrict__ feat, const int32_t* __restrict__ idx, int B, int N,
+                                                           int C, uint8_t* __restrict__ argmax, float* __restrict__ fg,
+                                                           float inv_n) {
+    static_assert(K % 2 == 0 && K >= 4, "a wave's 32 K staged indices are K / 2 per lane");
+    constexpr int k = K;
+    extern __shared__ __attribute__((aligned(16))) float4 orl_tile[];      // N x ORLT_PITCH4, then ORLT_WG / 64 strips of 32 k ushorts
+    __shared__ float4 red[2 * (ORLT_WG / 64)];
+    // workgroups are dealt to the 8 XCDs round-robin: all column tiles of a cloud go to ONE XCD (cloud = xcd + 8 j), so that the
+    // 32-byte slices of a feature line and the 8-byte slices of an argmax line meet in one L2 instead of eight
+    const int T = C / ORLT_TC, L = blockIdx.x;
+    int b, c0;
+    if ((B & 7) == 0) { const int slot = L >> 3; b = (L & 7) + 8 * (slot / T); c0 = (slot % T) * ORLT_TC; }
+    else { b = L / T; c0 = (L % T) * ORLT_TC; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const FT* fb = feat + (size_t)b * N * C + c0;
+    ORL_STAMP(0);
+    for (int i = tid; i < N; i += ORLT_WG) {
+        orl_tile[i * ORLT_PITCH4] = Feat<FT>::ld4(fb + (size_t)i * C);
+        orl_tile[i * ORLT_PITCH4 + 1] = Feat<FT>::ld4(fb + (size_t)i * C + 4);
+    }
+    const int q = lane & 1, pw = lane >> 1;                    // a wave: 32 points x two 4-channel groups
+    constexpr int EPL = K / 2, PASS = 32 * (ORLT_WG / 64);
+    // Neighbour lists: the wave's 32 points of a pass own 32 k CONSECUTIVE indices; the wave copies them coalesced (k / 2 dwords per
+    // lane), one pass AHEAD, into its own LDS strip -- as byte offsets of the slab rows.
+    unsigned short* strip = reinterpret_cast<unsigned short*>(orl_tile + (size_t)N * ORLT_PITCH4) + wave * (32 * k);   // (N x 48 < 65536)
+    const int32_t* ib = idx + (size_t)b * N * k;
+    const int last = N * k - 1;
+    int nxt[EPL];
+    auto fetch = [&](int i0) {                                 // lists of points i0 + 32 wave ... + 32 (past the cloud: any entry)
+        const int e0 = (i0 + 32 * wave) * k + lane;
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) nxt[u] = ib[min(e0 + 64 * u, last)];
+    };
+    fetch(0);
+    __syncthreads();                                           // slab complete
+    ORL_STAMP(1);
+    const char* slab = reinterpret_cast<const char*>(orl_tile) + q * 16;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i0 = 0; i0 < N; i0 += PASS) {
+        __builtin_amdgcn_wave_barrier();                       // (the strip is the wave's own: program order is the only hazard)
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) strip[lane + 64 * u] = (unsigned short)(nxt[u] * (int)(ORLT_PITCH4 * sizeof(float4)));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        ORL_STAMP(2 + 3 * (i0 / PASS));
+        if (i0 + PASS < N) fetch(i0 + PASS);
+        const int i = i0 + 32 * wave + pw;
+        if (i < N) {
+            const unsigned short* my = strip + pw * k;
+            float4 f[K];
+#pragma unroll
+            for (int n = 0; n < K; ++n) f[n] = *reinterpret_cast<const float4*>(slab + my[n]);
+            ORL_STAMP(3 + 3 * (i0 / PASS));
+            float4 best = f[0];
+#pragma unroll
+            for (int n = 1; n + 1 < K; n += 2) {
+                best.x = max3_raw(best.x, f[n].x, f[n + 1].x); best.y = max3_raw(best.y, f[n].y, f[n + 1].y);
+                best.z = max3_raw(best.z, f[n].z, f[n + 1].z); best.w = max3_raw(best.w, f[n].w, f[n + 1].w);
+            }
+            if ((K & 1) == 0) {
+                best.x = max3_raw(best.x, f[K - 1].x, f[K - 1].x); best.y = max3_raw(best.y, f[K - 1].y, f[K - 1].y);
+                best.z = max3_raw(best.z, f[K - 1].z, f[K - 1].z); best.w = max3_raw(best.w, f[K - 1].w, f[K - 1].w);
+            }
+            int a0 = 0, a1 = 0, a2 = 0, a3 = 0;               // descending scan: the FIRST slot holding the maximum, as torch.max
+#pragma unroll
+            for (int n = K - 1; n >= 1; --n) {
+                a0 = f[n].x == best.x ? n : a0; a1 = f[n].y == best.y ? n : a1;
+                a2 = f[n].z == best.z ? n : a2; a3 = f[n].w == best.w ? n : a3;
+            }
+            a0 = f[0].x == best.x ? 0 : a0; a1 = f[0].y == best.y ? 0 : a1; a2 = f[0].z == best.z ? 0 : a2; a3 = f[0].w == best.w ? 0 : a3;
+            *reinterpret_cast<uchar4*>(argmax + ((size_t)b * N + i) * C + c0 + (q << 2)) =
+                make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
+            s.x += best.x; s.y += best.y; s.z += best.z; s.w += best.w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        ORL_STAMP(4 + 3 * (i0 / PASS));
+    }
+    ORL_STAMP(30);
+    // fixed-order fold: within the wave over the 32 point slots of each parity (xor 2 ... 32), then the waves in order
+#pragma unroll
+    for (int d = 2; d < 64; d <<= 1) {
+        s.x += __shfl_xor(s.x, d); s.y += __shfl_xor(s.y, d); s.z += __shfl_xor(s.z, d); s.w += __shfl_xor(s.w, d);
+    }
+    if (lane < 2) red[wave * 2 + q] = s;
+    __syncthreads();
+    if (tid < 2) {
+        float4 t = red[q];
+        for (int w = 1; w < ORLT_WG / 64; ++w) { const float4 v = red[w * 2 + q]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        *reinterpret_cast<float4*>(fg + (size_t)b * C + c0 + (q << 2)) = make_float4(t.x * inv_n, t.y * inv_n, t.z * inv_n, t.w * inv_n);
+    }
+    ORL_STAMP(31);
+}
+
 // out[b][c] = scale * sum_chunk part[b][chunk][c]   (also the generic "column sum per cloud" second stage)
 __global__ __launch_bounds__(256) void chunk_fold_kernel(const float* __restrict__ part, int B, int nchunk, int C,
                                                          float scale, float* __restrict__ out) {
@@ -897,6 +1022,12 @@ extern "C" int hsp_points_max_bwd(const float* grad_out, const int32_t* argrow, 
     return check_launch();
 }
 
+#ifdef HSP_ORL_PROF
+extern "C" int hsp_debug_set_orl_prof(void* dev_buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(hsp::g_orl_prof), &dev_buf, sizeof(void*)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" size_t hsp_orl_workspace_bytes(int B, int N, int C) {
     if (B <= 0 || N <= 0 || C <= 0 || (!colsum_vec4(C) && C > 256)) return 0;
     const int rows = chunk_rows(B, N, C);
@@ -910,6 +1041,12 @@ static int orl_global_fwd_impl(const FT* feat, const int32_t* idx, int B, int N,
     if ((C & 3) || (256 % (C >> 2)) || k > 255) return HSP_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < hsp_orl_workspace_bytes(B, N, C)) return HSP_ERR_WORKSPACE;
     hipStream_t st = as_stream(stream);
+    const size_t lds_tile = (size_t)N * ORLT_PITCH4 * sizeof(float4) + (ORLT_WG / 2) * (size_t)k * sizeof(short);   // slab + the waves' list strips
+    if ((C % ORLT_TC) == 0 && lds_tile <= 64 * 1024 && N >= 128 && k == 20 && kstride == k) {          // fg written by the kernel itself
+        hipLaunchKernelGGL((orl_tile_kernel<FT, 20>), dim3(C / ORLT_TC * B), dim3(ORLT_WG), lds_tile, st, feat, idx, B, N, C, argmax, fg,
+                           1.0f / (float)N);
+        return check_launch();
+    }
     const int rows = chunk_rows(B, N, C);
     const int nchunk = (N + rows - 1) / rows;
     float* part = reinterpret_cast<float*>(ws);
