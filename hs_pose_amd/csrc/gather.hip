@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256) void orl_partial_kernel(const FT* __restrict__
 // Here a workgroup owns (cloud, 8 channels): the slab feat[b][:, c0:c0+8] is read ONCE into LDS (48-byte rows: 12-float pitch, so
 // that random rows spread over the banks), a thread takes (point, 4 channels), walks the point's k neighbours with ds_read_b128,
 // writes the winning slots and keeps the column sums; the workgroup folds them in a fixed order and writes fg itself -- no partial
-// buffer, no fold launch.  N <= 1150, k = 20, contiguous lists (64 KB of LDS with the list strips); anything else keeps the chunked form.
+// buffer, no fold launch.  k = 20, contiguous lists, the slab within 144 KB of LDS (fp32: N <= 2800; bf16 rows stay raw, 24-byte pitch:
+// N <= 5600); anything else keeps the chunked form.
 //
 // The kernel is bound by VALU ISSUE, not by memory: 1028 x 128 x 20 compare / select triples over 1024 SIMDs are ~3.5 us, and one
 // workgroup per CU means every other instruction of the pass is on the critical path (a first form with an integer division per staged
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void orl_partial_kernel(const FT* __restrict__
 // descending equality scan (2.5 instead of 3 instructions per element).
 #ifdef HSP_ORL_PROF
 static __device__ long long* g_orl_prof = nullptr;     // tools/prof_orl_tile.py: clock64 stamps of workgroup 0, wave 0
-#define ORL_STAMP(slot) do { if (g_orl_prof && blockIdx.x == 0 && threadIdx.x == 0) g_orl_prof[slot] = clock64(); } while (0)
+#define ORL_STAMP(slot) do { if (g_orl_prof && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_orl_prof[slot] = clock64(); } while (0)
 #else
 #define ORL_STAMP(slot) do { } while (0)
 #endif
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(ORLT_WG) void orl_tile_kernel(const FT* __restrict_
                                                            float inv_n) {
     static_assert(K % 2 == 0 && K >= 4, "a wave's 32 K staged indices are K / 2 per lane");
     constexpr int k = K;
-    extern __shared__ __attribute__((aligned(16))) float4 orl_tile[];      // N x ORLT_PITCH4, then ORLT_WG / 64 strips of 32 k ushorts
+    extern __shared__ __attribute__((aligned(16))) float4 orl_tile[];      // N slab rows, then ORLT_WG / 64 strips of 32 k ushorts
     __shared__ float4 red[2 * (ORLT_WG / 64)];
     // workgroups are dealt to the 8 XCDs round-robin: all column tiles of a cloud go to ONE XCD (cloud = xcd + 8 j), so that the
     // 32-byte slices of a feature line and the 8-byte slices of an argmax line meet in one L2 instead of eight
@@ -163,15 +164,24 @@ __global__ __launch_bounds__(ORLT_WG) void orl_tile_kernel(const FT* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FT* fb = feat + (size_t)b * N * C + c0;
     ORL_STAMP(0);
+    // slab rows: fp32 -> 8 floats on a 48-byte pitch; bf16 -> the 16 raw bytes on a 24-byte pitch (N = 4096 fits in 96 KB)
+    constexpr int ROWB = sizeof(FT) == 4 ? 48 : 24, SH = sizeof(FT) == 4 ? 4 : 3;     // row offset = 3 idx << SH
+    char* const slab0 = reinterpret_cast<char*>(orl_tile);
     for (int i = tid; i < N; i += ORLT_WG) {
-        orl_tile[i * ORLT_PITCH4] = Feat<FT>::ld4(fb + (size_t)i * C);
-        orl_tile[i * ORLT_PITCH4 + 1] = Feat<FT>::ld4(fb + (size_t)i * C + 4);
+        if constexpr (sizeof(FT) == 4) {
+            *reinterpret_cast<float4*>(slab0 + i * ROWB) = Feat<FT>::ld4(fb + (size_t)i * C);
+            *reinterpret_cast<float4*>(slab0 + i * ROWB + 16) = Feat<FT>::ld4(fb + (size_t)i * C + 4);
+        } else {
+            const uint4 v = *reinterpret_cast<const uint4*>(fb + (size_t)i * C);
+            *reinterpret_cast<uint2*>(slab0 + i * ROWB) = make_uint2(v.x, v.y);
+            *reinterpret_cast<uint2*>(slab0 + i * ROWB + 8) = make_uint2(v.z, v.w);
+        }
     }
     const int q = lane & 1, pw = lane >> 1;                    // a wave: 32 points x two 4-channel groups
     constexpr int EPL = K / 2, PASS = 32 * (ORLT_WG / 64);
     // Neighbour lists: the wave's 32 points of a pass own 32 k CONSECUTIVE indices; the wave copies them coalesced (k / 2 dwords per
     // lane), one pass AHEAD, into its own LDS strip -- as byte offsets of the slab rows.
-    unsigned short* strip = reinterpret_cast<unsigned short*>(orl_tile + (size_t)N * ORLT_PITCH4) + wave * (32 * k);   // (N x 48 < 65536)
+    unsigned short* strip = reinterpret_cast<unsigned short*>(slab0 + (size_t)N * ROWB) + wave * (32 * k);   // entries 3 idx (< 65536 up to N = 21845)
     const int32_t* ib = idx + (size_t)b * N * k;
     const int last = N * k - 1;
     int nxt[EPL];
@@ -183,12 +193,12 @@ __global__ __launch_bounds__(ORLT_WG) void orl_tile_kernel(const FT* __restrict_
     fetch(0);
     __syncthreads();                                           // slab complete
     ORL_STAMP(1);
-    const char* slab = reinterpret_cast<const char*>(orl_tile) + q * 16;
+    const char* slab = slab0 + q * (ROWB / 3);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i0 = 0; i0 < N; i0 += PASS) {
         __builtin_amdgcn_wave_barrier();                       // (the strip is the wave's own: program order is the only hazard)
 #pragma unroll
-        for (int u = 0; u < EPL; ++u) strip[lane + 64 * u] = (unsigned short)(nxt[u] * (int)(ORLT_PITCH4 * sizeof(float4)));
+        for (int u = 0; u < EPL; ++u) strip[lane + 64 * u] = (unsigned short)(nxt[u] * 3);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         ORL_STAMP(2 + 3 * (i0 / PASS));
@@ -198,7 +208,15 @@ __global__ __launch_bounds__(ORLT_WG) void orl_tile_kernel(const FT* __restrict_
             const unsigned short* my = strip + pw * k;
             float4 f[K];
 #pragma unroll
-            for (int n = 0; n < K; ++n) f[n] = *reinterpret_cast<const float4*>(slab + my[n]);
+            for (int n = 0; n < K; ++n) {
+                const char* rp = slab + ((unsigned)my[n] << SH);
+                if constexpr (sizeof(FT) == 4) f[n] = *reinterpret_cast<const float4*>(rp);
+                else {
+                    const uint2 u2 = *reinterpret_cast<const uint2*>(rp);
+                    f[n] = make_float4(__uint_as_float(u2.x << 16), __uint_as_float(u2.x & 0xffff0000u), __uint_as_float(u2.y << 16),
+                                       __uint_as_float(u2.y & 0xffff0000u));
+                }
+            }
             ORL_STAMP(3 + 3 * (i0 / PASS));
             float4 best = f[0];
 #pragma unroll
@@ -459,8 +477,10 @@ __global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const FT* __restr
     const int j0 = blockIdx.x * TC;
     const int cg = tid % G, pl = tid / G;
     const int j = j0 + cg * 4;
+    ORL_STAMP(40);
     for (int q = tid; q < Nsrc * G; q += 256) *reinterpret_cast<float4*>(acc + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
+    ORL_STAMP(41);
     // FL points per pass: their arg-max bytes / gradients first, then the dependent neighbour-index gathers, then the
     // LDS adds -- two global round trips per pass instead of two per point
 #ifndef SCATTER_FL
@@ -528,6 +548,7 @@ __global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const FT* __restr
         }
     }
     __syncthreads();
+    ORL_STAMP(42);
     // flush: every thread handles FL (row, group) elements at a time with all their global loads issued before the
     // first dependent add (one element per iteration left the 2-3 loads of each store as a serial latency chain:
     // 23 of the kernel's 31 us at B=16 N=1028 C=128)
@@ -562,6 +583,7 @@ __global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const FT* __restr
             }
         }
     }
+    ORL_STAMP(43);
 }
 
 // out[b,i,:] += f[b,i,:] + t[b,:]   -- the residual + per-cloud ORL bias of an HS layer in one pass
@@ -1041,10 +1063,18 @@ static int orl_global_fwd_impl(const FT* feat, const int32_t* idx, int B, int N,
     if ((C & 3) || (256 % (C >> 2)) || k > 255) return HSP_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < hsp_orl_workspace_bytes(B, N, C)) return HSP_ERR_WORKSPACE;
     hipStream_t st = as_stream(stream);
-    const size_t lds_tile = (size_t)N * ORLT_PITCH4 * sizeof(float4) + (ORLT_WG / 2) * (size_t)k * sizeof(short);   // slab + the waves' list strips
-    if ((C % ORLT_TC) == 0 && lds_tile <= 64 * 1024 && N >= 128 && k == 20 && kstride == k) {          // fg written by the kernel itself
-        hipLaunchKernelGGL((orl_tile_kernel<FT, 20>), dim3(C / ORLT_TC * B), dim3(ORLT_WG), lds_tile, st, feat, idx, B, N, C, argmax, fg,
-                           1.0f / (float)N);
+    const size_t lds_tile = (size_t)N * (sizeof(FT) == 4 ? 48 : 24) + (ORLT_WG / 2) * (size_t)k * sizeof(short);   // slab + the waves' list strips
+    if ((C % ORLT_TC) == 0 && lds_tile <= 144 * 1024 && N >= 128 && N <= 21845 && k == 20 && kstride == k) {   // fg written by the kernel itself
+        auto kern = orl_tile_kernel<FT, 20>;
+        if (lds_tile > 64 * 1024) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+                if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
+                attr_set = true;
+            }
+        }
+        hipLaunchKernelGGL(kern, dim3(C / ORLT_TC * B), dim3(ORLT_WG), lds_tile, st, feat, idx, B, N, C, argmax, fg, 1.0f / (float)N);
         return check_launch();
     }
     const int rows = chunk_rows(B, N, C);

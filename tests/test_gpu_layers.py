@@ -152,6 +152,36 @@ def test_orl_global_fwd_bwd(dev, ref, monkeypatch, deterministic):
     gclose(fg.grad, feat.grad, "orl dfeat")
 
 
+@pytest.mark.parametrize("dtype,B,N,C,k", [("f32", 16, 1028, 128, 20), ("f32", 3, 257, 256, 20), ("f32", 2, 2500, 64, 20),
+                                          ("bf16", 3, 4096, 128, 20), ("bf16", 2, 1024, 256, 20), ("f32", 2, 300, 64, 8)])
+def test_orl_global_slab_form(dev, dtype, B, N, C, k):
+    """hsp_orl_global_fwd(_bf16) at the shapes that take the LDS column-slab kernel (k = 20; the last case keeps the chunked form):
+    the winning slot is torch.max's (first maximum) for every (point, channel), the mean agrees to fp32 summation-order error.
+    Duplicated rows make equal maxima common (the tiled-cloud case)."""
+    from hs_pose_amd import ops, ops_bf16
+    g = torch.Generator().manual_seed(N + C)
+    xyz = (torch.randn(B, N, 3, generator=g) * 0.05).to(dev)
+    feat = torch.randn(B, N, C, generator=g)
+    feat[:, N // 2:] = feat[:, : N - N // 2]                    # exact duplicates among the neighbours' values
+    feat = feat.to(dev)
+    idx = ops.knn(xyz, k)
+    if dtype == "bf16":
+        fb = feat.bfloat16()
+        fg, arg = ops_bf16._orl_fwd(fb, idx, k)
+        vals = fb.float()
+    else:
+        fg, arg = ops._orl_fwd_raw(feat, idx, k)
+        vals = feat
+    nb = torch.gather(vals.unsqueeze(1).expand(B, N, N, C), 2, idx.long().unsqueeze(-1).expand(B, N, k, C)) if N <= 300 else None
+    if nb is None:                                               # (B, N, k, C) gather without the (B, N, N, C) view
+        nb = vals[torch.arange(B, device=dev)[:, None, None], idx.long()]
+    mx, am = nb.max(dim=2)
+    first = (nb == mx.unsqueeze(2)).float().argmax(dim=2)        # first slot holding the maximum
+    assert torch.equal(arg.long(), first)
+    want = mx.double().mean(dim=1)
+    assert (fg.double() - want).abs().max().item() <= 2e-6 * want.abs().max().item() + 1e-7
+
+
 @pytest.mark.parametrize("shared", [False, True])
 def test_gather_rows_fwd_bwd(dev, ref, shared):
     from hs_pose_amd import ops

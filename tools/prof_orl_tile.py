@@ -22,7 +22,7 @@ from hs_pose_amd._lib import lib
 dev = torch.device("cuda:0")
 L = lib()
 L.hsp_debug_set_orl_prof.argtypes = [ctypes.c_void_p]
-prof = torch.zeros(32, dtype=torch.int64, device=dev)
+prof = torch.zeros(48, dtype=torch.int64, device=dev)
 assert L.hsp_debug_set_orl_prof(ctypes.c_void_p(prof.data_ptr())) == 0
 g = torch.Generator().manual_seed(0)
 for B, N, C, k in [(16, 1028, 128, 20), (16, 257, 256, 20), (4, 1028, 128, 20)]:
@@ -38,3 +38,15 @@ for B, N, C, k in [(16, 1028, 128, 20), (16, 257, 256, 20), (4, 1028, 128, 20)]:
     order = [(s, v) for s, v in enumerate(t) if v]
     t0 = order[0][1]
     print(f"B={B} N={N} C={C}: " + " ".join(f"[{s}]+{v - t0}" for s, v in order))
+    # the backward (scatter_tile_bwd_kernel, broadcast gradient): zeroed / swept / flushed
+    fr = f.clone().requires_grad_(True)
+    out = ops.orl_global(fr, idx, k)
+    gup = torch.randn_like(out)
+    for _ in range(3):
+        prof.zero_()
+        fr.grad = None
+        out.backward(gup, retain_graph=True)
+        torch.cuda.synchronize()
+    t = prof.cpu().tolist()
+    order = [(s, v) for s, v in enumerate(t) if v and s >= 40]
+    print("    backward: " + " ".join(f"[{s}]+{v - order[0][1]}" for s, v in order))
