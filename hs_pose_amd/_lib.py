@@ -168,6 +168,11 @@ def lib():
                 f"{LIB_PATH} not found: the HIP extension is not built. Run "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C hs_pose_amd/csrc`). "
                 "hs_pose_amd has no CPU / eager fallback.")
+        # torch first: its wheel carries its own libamdhip64.so, and libhsp.so's NEEDED entry (same soname) must resolve to THAT copy.
+        # Loaded before torch, libhsp.so pulls in /opt/rocm's runtime; torch then brings a second one, the device is initialised in one
+        # and the kernels are registered in the other: every launch fails with "no ROCm-capable device is detected" (seen when
+        # build() and smoke() ran in one process).
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

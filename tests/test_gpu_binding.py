@@ -243,3 +243,22 @@ def test_every_tensor_argument_is_checked(dev, ref, m):
             ops._ext_state = prev
         ca = ops.center_cloud(xyz)
     _eq(a, b, "hs_layer: binding vs ctypes"), _eq(pa[0], pb[0], "pool: binding vs ctypes"), _eq(ca[0], cb[0], "centre: binding vs ctypes")
+
+
+@pytest.mark.gpu
+def test_library_loaded_before_torch_still_launches():
+    """the C-ABI library opened BEFORE anything imported torch (what build() followed by smoke() in one process does): its HIP
+    runtime must be the one torch initialises -- with two runtimes in the process every launch fails with hipErrorNoDevice"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from hs_pose_amd._lib import lib\n"
+            "assert lib().hsp_version() >= 100\n"
+            "import torch\n"
+            "from hs_pose_amd import ops\n"
+            "idx = ops.knn(torch.randn(1, 64, 3, device='cuda:0'), 8)\n"
+            "torch.cuda.synchronize(); print('ok', tuple(idx.shape))\n") % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok (1, 64, 8)" in out.stdout, out.stderr[-800:]
