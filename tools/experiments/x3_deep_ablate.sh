@@ -1,7 +1,7 @@
 #!/bin/bash
 # ablation builds of the deep gemm_x3 pipeline (X3_ABL bits: 1 no MFMA, 2 no global loads, 4 no split / LDS writes); results are WRONG by
-# construction, only the times mean something.  Build here (no GPU needed): bash tools/x3_ablate.sh build ; run on the GPU box: bash tools/x3_ablate.sh run
-R=$(cd $(dirname $0)/.. && pwd)
+# construction, only the times mean something.  Build here (no GPU needed): bash tools/experiments/x3_deep_ablate.sh (after applying gemm_x3_deep_pipeline.patch) build ; run on the GPU box: bash tools/experiments/x3_deep_ablate.sh (after applying gemm_x3_deep_pipeline.patch) run
+R=$(cd $(dirname $0)/../.. && pwd)
 C=$R/hs_pose_amd/csrc
 mkdir -p $R/build_tmp
 if [ "$1" = build ]; then
