@@ -153,16 +153,19 @@ def test_orl_global_fwd_bwd(dev, ref, monkeypatch, deterministic):
 
 
 @pytest.mark.parametrize("dtype,B,N,C,k", [("f32", 16, 1028, 128, 20), ("f32", 3, 257, 256, 20), ("f32", 2, 2500, 64, 20),
-                                          ("bf16", 3, 4096, 128, 20), ("bf16", 2, 1024, 256, 20), ("f32", 2, 300, 64, 8)])
+                                          ("bf16", 3, 4096, 128, 20), ("bf16", 2, 1024, 256, 20), ("f32", 2, 300, 64, 8),
+                                          ("f32", 1, 128, 64, 20), ("f32", 1, 129, 8, 20), ("f32", 1, 2850, 8, 20),
+                                          ("f32", 1, 3000, 8, 20), ("bf16", 1, 5000, 8, 20), ("f32", 9, 257, 128, 20)])
 def test_orl_global_slab_form(dev, dtype, B, N, C, k):
-    """hsp_orl_global_fwd(_bf16) at the shapes that take the LDS column-slab kernel (k = 20; the last case keeps the chunked form):
+    """hsp_orl_global_fwd(_bf16) at the shapes that take the LDS column-slab kernel (k = 20; k = 8 and the 3000-point fp32 cloud,
+    whose slab is past the 144 KB limit, keep the chunked form; 128 is the smallest cloud that takes it, B = 9 the plain tile -> XCD map):
     the winning slot is torch.max's (first maximum) for every (point, channel), the mean agrees to fp32 summation-order error.
     Duplicated rows make equal maxima common (the tiled-cloud case)."""
     from hs_pose_amd import ops, ops_bf16
     g = torch.Generator().manual_seed(N + C)
     xyz = (torch.randn(B, N, 3, generator=g) * 0.05).to(dev)
     feat = torch.randn(B, N, C, generator=g)
-    feat[:, N // 2:] = feat[:, : N - N // 2]                    # exact duplicates among the neighbours' values
+    feat[:, N // 2:] = feat[:, : N - N // 2].clone()            # exact duplicates among the neighbours' values
     feat = feat.to(dev)
     idx = ops.knn(xyz, k)
     if dtype == "bf16":
