@@ -1,6 +1,6 @@
 #!/bin/bash
 # ablation builds of the deep gemm_x3 pipeline (X3_ABL bits: 1 no MFMA, 2 no global loads, 4 no split / LDS writes); results are WRONG by
-# construction, only the times mean something.  Build here (no GPU needed): bash tools/experiments/x3_deep_ablate.sh (after applying gemm_x3_deep_pipeline.patch) build ; run on the GPU box: bash tools/experiments/x3_deep_ablate.sh (after applying gemm_x3_deep_pipeline.patch) run
+# construction, only the times mean something.  Build here (no GPU needed): bash tools/experiments/x3_deep_ablate.sh (after applying an X3_ABL build of gemm_x3_deep_pipeline_wm4.patch) build ; run on the GPU box: bash tools/experiments/x3_deep_ablate.sh (after applying gemm_x3_deep_pipeline.patch) run
 R=$(cd $(dirname $0)/../.. && pwd)
 C=$R/hs_pose_amd/csrc
 mkdir -p $R/build_tmp
