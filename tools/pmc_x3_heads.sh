@@ -1,16 +1,15 @@
 #!/bin/bash
 # memory-path counters of gemm_x3 on the deep-K head shapes (tools/time_x3_tall.py); run on the GPU box via gpurun -> gpurun_out/pmc_x3
+# NOTE (round 5): only the two TCC passes finish -- a pass with TA_* / TCP_* counters did not complete within 15 minutes on this
+# pool (twice), the SQ set is in tools/pmc_x3_one.sh.  The loop below stops after the TCC passes for that reason.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pmc_x3
 rm -rf $O; mkdir -p $O
 i=0
-for set in "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUSY_avr TCC_TAG_STALL_sum" \
-           "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum" \
-           "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum GRBM_GUI_ACTIVE" \
-           "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS"; do
+for set in "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUSY_avr TCC_TAG_STALL_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p$i -- python $R/tools/time_x3_tall.py > $O/p$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p$i -- python $R/tools/x3_one.py > $O/p$i.log 2>&1
   f=$(find $O/p$i -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && cp "$f" $O/pass$i.csv
   rm -rf $O/p$i
