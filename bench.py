@@ -308,7 +308,7 @@ def main():
     from hs_pose_amd import ops
     from hs_pose_amd.config import FLAGS
     from hs_pose_amd.FaceRecon import FaceRecon
-    from hs_pose_amd.parallel import GradReducer, graphed_step_with_exchange, init_distributed
+    from hs_pose_amd.parallel import GradReducer, all_reduce_, choose_exchange_form, graphed_step_with_exchange, init_distributed
     from hs_pose_amd.parallel import describe as parallel_describe
 
     rank, world, device = init_distributed()
@@ -343,24 +343,42 @@ def main():
             reducer.finish()
 
     graphed = None
+    exchange_info = {"reason": "eager step (--no-graph or no capture)"}
     use_dist = dist.is_initialized()
     if not args.no_graph:
         # hipGraph replay of zero_grad+fwd+bwd (hs_pose_amd/graph.py); the Pool_layer randperm draws stay on
         # the host, before each replay.  Data parallel: the captured step also packs all gradients into one
         # flat buffer, which is mean-all-reduced with a single RCCL collective after every replay.
         from hs_pose_amd.graph import GraphedStep
-        # HSP_SPLIT_GRAPH=1: the step captured as two graphs cut below the coarse levels, so that the all-reduce of their
-        # gradients (78 % of the bytes) runs on RCCL's stream under the N=1028 layers' backward.  Opt-in: with a 1-rank
-        # group the second graph launch + the asynchronous work cost 0.15 ms per step on this runtime, about what the
-        # overlap can hide of a 12.4 MB exchange over xGMI, so the default is ONE all-reduce.
-        want_split = use_dist and os.environ.get("HSP_SPLIT_GRAPH") == "1"
-        for split in ([True, False] if want_split else [False]):
+        # Two forms: ONE graph + one all-reduce after it, or the step captured as two graphs cut below the coarse levels, so that
+        # the all-reduce of their gradients (78 % of the bytes) runs on RCCL's stream under the N=1028 layers' backward (the
+        # second graph launch + the asynchronous work cost ~0.15 ms per step on a 1-rank group).
+        # Data parallel (world > 1): BOTH forms are captured and a start-up probe (3 exchanged replays each way, MAX over the
+        # ranks, rank 0's decision broadcast) picks one -- the overlapped two-graph form unless the single all-reduce is more
+        # than 3 % faster; HSP_SPLIT_GRAPH=1 / 0 forces a form.  config.grad_exchange records what ran and why.
+        forced = {"1": "split", "0": "single"}.get(os.environ.get("HSP_SPLIT_GRAPH", ""))
+        if use_dist and world == 1 and forced is None:
+            forced = "single"                              # a forced 1-rank group (test hook): nothing to overlap
+        forms = {}
+        for name in (["split", "single"] if use_dist else ["single"]):
+            if forced is not None and name != forced:
+                continue
             try:
-                graphed = GraphedStep(net, centred, obj, dfeat, flat_grads=use_dist, split=split)
-                break
-            except Exception as exc:                       # capture unsupported -> next form / eager, say so
-                print(f"[bench] hipGraph capture (split={split}) failed ({type(exc).__name__}: {exc})", file=sys.stderr)
-                graphed = None
+                forms[name] = GraphedStep(net, centred, obj, dfeat, flat_grads=use_dist, split=(name == "split"))
+            except Exception as exc:                       # capture unsupported -> other form / eager, say so
+                print(f"[bench] hipGraph capture (split={name == 'split'}) failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+        if use_dist and not forms and forced is not None:  # the forced form did not capture: try the other before going eager
+            other = "single" if forced == "split" else "split"
+            try:
+                forms[other] = GraphedStep(net, centred, obj, dfeat, flat_grads=True, split=(other == "split"))
+            except Exception as exc:
+                print(f"[bench] hipGraph capture (split={other == 'split'}) failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+        if use_dist:
+            chosen, exchange_info = choose_exchange_form(forms, world, sync=torch.cuda.synchronize, forced=forced)
+            graphed = forms.get(chosen)
+        else:
+            graphed, exchange_info = forms.get("single"), {"reason": "one rank, no process group"}
+        forms = None
     if graphed is None and use_dist and world > 1:
         reducer = GradReducer(params)                      # bucketed all-reduce launched from autograd hooks
 
@@ -417,7 +435,7 @@ def main():
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if dist.is_initialized():
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        all_reduce_(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
 
     if rank == 0:
@@ -490,7 +508,7 @@ def main():
                                    + ("bf16 feature storage + bf16 MFMA products, fp32 geometry / accumulation / parameters, "
                                       "train-mode BN, random-init weights (BASELINE configs[3] shape when B=64 N=4096)" if bf16 else
                                       "fp32, train-mode BN, random-init weights (BASELINE configs[1] shape)"),
-                       "global_batch": world * B, "points": N, "parallelism": f"dp{world}", "process_group": parallel_describe(), "hipgraph": graphed is not None, "split_graph": bool(graphed is not None and graphed.split), "grad_exchange": ("none" if world == 1 else "2 all-reduces, first overlapped with backward" if graphed is not None and graphed.split else "1 all-reduce after backward" if graphed is not None else "bucketed, hook-driven"),
+                       "global_batch": world * B, "points": N, "parallelism": f"dp{world}", "process_group": parallel_describe(), "hipgraph": graphed is not None, "split_graph": bool(graphed is not None and graphed.split), "grad_exchange": ("none" if not use_dist else "2 all-reduces, first overlapped with backward" if graphed is not None and graphed.split else "1 all-reduce after backward" if graphed is not None else "bucketed, hook-driven"), "grad_exchange_choice": exchange_info,
                        "libhsp_ms_per_step": round(hsp_ms, 4),
                        # dense per-point products: hand-written csrc/gemm_rows.hip vs the BLAS library, per composite shape
                        "dense_products": ("fp32 in / out / accumulation; products on the bf16 matrix cores from exact three-way bf16 "

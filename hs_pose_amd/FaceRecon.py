@@ -112,7 +112,8 @@ class FaceRecon(nn.Module):
         with gcn3d.knn_scope():
             # the two coarse levels' vertices, neighbour lists and up-sampling maps in one launch, up front (they depend on the
             # coordinates and the host-drawn pool rows only)
-            up = gcn3d.prefetch_levels(vertices, k, self.pool_1.neighbor_num) if self.pool_1.neighbor_num == self.pool_2.neighbor_num else None
+            up = (gcn3d.prefetch_levels(vertices, k, self.pool_1.neighbor_num, rates=(self.pool_1.pooling_rate, self.pool_2.pooling_rate))
+                  if self.pool_1.neighbor_num == self.pool_2.neighbor_num else None)
             od = self.feature_dtype if self.feature_dtype == torch.bfloat16 else None
             fork0 = od is None and not self.keep_backward_cut and torch.is_grad_enabled()
             if fork0:

@@ -137,8 +137,11 @@ static __device__ long long* g_orl_prof = nullptr;     // tools/prof_orl_tile.py
 #define ORLT_TC 8
 #define ORLT_PITCH4 3            // float4 units per LDS row
 #define ORLT_WG 512
-// max(a, b, c) of plain numbers in ONE instruction (fmaxf compiles to three: it quiets NaNs first); NaNs are not ordered by the
-// product's max either (orl_partial_kernel compares with >)
+// max(a, b, c) of plain numbers in ONE instruction (fmaxf compiles to three: it quiets NaNs first).  NaN activations: v_max3_f32
+// returns the non-NaN operand, so this kernel MASKS a NaN neighbour (the maximum of the others wins; a NaN-only column takes slot
+// 0), where the chunked orl_partial_kernel (compares with >) and torch.max keep a NaN that sits in the first slot.  Neither form
+// orders NaNs; a NaN activation is an upstream fault (engine/train.py:91-95 skips such a step on its NaN loss), not a case the
+// kernels promise to agree on.
 __device__ __forceinline__ float max3_raw(float a, float b, float c) {
     float r;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -1066,13 +1069,9 @@ static int orl_global_fwd_impl(const FT* feat, const int32_t* idx, int B, int N,
     const size_t lds_tile = (size_t)N * (sizeof(FT) == 4 ? 48 : 24) + (ORLT_WG / 2) * (size_t)k * sizeof(short);   // slab + the waves' list strips
     if ((C % ORLT_TC) == 0 && lds_tile <= 144 * 1024 && N >= 128 && N <= 21845 && k == 20 && kstride == k) {   // fg written by the kernel itself
         auto kern = orl_tile_kernel<FT, 20>;
-        if (lds_tile > 64 * 1024) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-                if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
-                attr_set = true;
-            }
+        if (lds_tile > 64 * 1024) {                          // per device, so on every such launch (a process may drive several GPUs)
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
         }
         hipLaunchKernelGGL(kern, dim3(C / ORLT_TC * B), dim3(ORLT_WG), lds_tile, st, feat, idx, B, N, C, argmax, fg, 1.0f / (float)N);
         return check_launch();

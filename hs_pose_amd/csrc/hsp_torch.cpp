@@ -112,6 +112,12 @@ at::Tensor knn_i32(const at::Tensor& x, int k, bool drop_first, bool exact, bool
         auto ws = bytes_ws(wsb, x);
         ok(hsp_knn_exact_f32(fp(x), B, N, C, k, drop_first, transposed_view ? 1 : 0, idx.data_ptr<int32_t>(), ws.data_ptr(), wsb,
                              nullptr, cur_stream()), "hsp_knn_exact_f32");
+    } else if (C == 3 && k + (drop_first ? 1 : 0) + 1 <= 33 && N >= 2 && (size_t)N * 16 <= 160 * 1024) {
+        // coordinates: torch.topk's order among equal distances, like every xyz search of the package (ops.knn_xyz)
+        const size_t wsb = hsp_knn_xyz_workspace_bytes(B, N);
+        auto ws = bytes_ws(wsb, x);
+        ok(hsp_knn_xyz_f32(fp(x), B, N, k, 0, drop_first, idx.data_ptr<int32_t>(), nullptr, ws.data_ptr(), wsb, nullptr, cur_stream()),
+           "hsp_knn_xyz_f32");
     } else {
         const size_t wsb = hsp_knn_workspace_bytes(B, N, C, k);
         auto ws = bytes_ws(wsb, x);

@@ -163,11 +163,13 @@ extern "C" int hsp_knn_xyz_f32(const float* xyz, int B, int N, int k, int k2, in
     if (m + 1 > 33) return HSP_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < hsp_knn_xyz_workspace_bytes(B, N)) return HSP_ERR_WORKSPACE;
     uint8_t* tie = reinterpret_cast<uint8_t*>(ws);
+    // the tie pass keeps a whole row of candidates in LDS: clouds beyond 10 240 points are refused BEFORE anything is launched (the
+    // caller then takes hsp_knn_f32's (distance, index) order, which has no such bound -- ops.knn_xyz does)
+    const size_t lds = (size_t)N * (sizeof(TkE) + 2 * sizeof(int));
+    if (lds > 160 * 1024) return HSP_ERR_UNSUPPORTED;
     bool needs_pass = true;
     int rc = knn3_select_flags(xyz, B, N, k, drop, k2, idx, idx2, tie, as_stream(stream), &needs_pass);
     if (rc || !needs_pass) return rc;                      // (tie_rows is only counted by the separate pass)
-    const size_t lds = (size_t)N * (sizeof(TkE) + 2 * sizeof(int));
-    if (lds > 160 * 1024) return HSP_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_xyz_ties_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds);

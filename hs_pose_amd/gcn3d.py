@@ -52,7 +52,7 @@ def knn_scope():
 _levels = None          # id(level-0 vertices) / id(v1) -> dict(vertices, sel, v_pool); "up": [up1, up2]
 
 
-def prefetch_levels(vertices, k, pool_k=None):
+def prefetch_levels(vertices, k, pool_k=None, rates=(4, 4)):
     """FaceRecon's two Pool_layers keep rows that are drawn on the HOST (torch.randperm, gcn3d.py:243) and depend on nothing the
     network computes, so everything the forward will ask of the two coarse clouds -- their vertices, their neighbour lists, the
     nearest-point maps of the up-sampling -- can be computed from the input cloud at once (ops.geometry_levels).  Draws (or takes
@@ -68,7 +68,11 @@ def prefetch_levels(vertices, k, pool_k=None):
     n1 = int(n0 / 4)
     n2 = int(n1 / 4)
     k1, k2 = min(k, n1 // 8), min(k, n2 // 8)
-    if not (64 <= n2 <= n1 <= 576) or k1 <= pool_k or k1 < 1 or k2 < 1:
+    # every condition of ops.geometry_levels / geometry_all is checked HERE, before an index draw is consumed (a refusal after the
+    # draws could not fall back without drawing again, out of the reference's order); ``rates``: the two Pool_layers' pooling rates
+    # (another rate than 4 and the layers would ignore the prefetch and draw a second time)
+    if (tuple(rates) != (4, 4) or vertices.shape[2] != 3 or not (64 <= n2 <= n1 <= 576) or k1 <= pool_k or k1 < 1 or k2 < 1
+            or k1 + 2 > 33 or k2 + 2 > 33 or k1 + 1 > n1 or k2 + 1 > n2):
         return None
     if _pool_feed is not None:
         sel1, sel2 = next(_pool_feed), next(_pool_feed)

@@ -115,6 +115,7 @@ class GraphedStep:
         self.feat = None
         self.flat_grad = self.flat_late = self.flat_early = None
         self.split = bool(split)
+        face_recon.keep_backward_cut = False           # (a split capture of the same network sets it; this object's form decides)
         if flat_grads or split:
             self.flat_grad = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
         self._upload_pool_indices()

@@ -131,7 +131,8 @@ def knn_xyz(xyz, k, k2=0, drop_first=True):
         raise HspError("knn_xyz: expects (B,N,3) coordinates")
     k2 = int(k2) if k2 and k2 < k else 0
     m = k + (1 if drop_first else 0)
-    if m + 1 > 33 or N < 2:                                 # beyond the tie pass's list length: the (distance, index) order
+    if m + 1 > 33 or N < 2 or N * 16 > 160 * 1024:         # beyond the tie pass's list length / its one-row-in-LDS bound
+                                                            # (N > 10 240): the (distance, index) order, any N
         idx = knn(x, k, drop_first, _plain_xyz=True)
         return idx, (idx[:, :, :k2].contiguous() if k2 else None)
     idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
@@ -833,14 +834,21 @@ class X3Planes:
     """The registry of ONE network (FaceRecon / PoseNet9D own one and make it current for their forward; the autograd nodes
     remember it for their backward).  Entries keep a reference to the weight view they split, so an address cannot be reused by
     another matrix while its entry lives; the registry -- tables, planes and references -- goes away with the network.  A table
-    that was replaced (a matrix registered later) is parked, not freed: a captured hipGraph may still point to it."""
+    that was replaced (a matrix registered later) is parked, not freed, ONCE a hipGraph capture has read this registry: the captured
+    graph may still point to it.  A registry no capture has touched (ad-hoc callers, gradient checks) frees what it replaces, so the
+    ``max_entries`` bound of the process-wide registry does bound device memory."""
 
     def __init__(self, max_entries=0):
         self.entries = {}            # key -> dict(src (kept alive), planes, N, K, kp, transpose, ver: src._version at the split)
         self.table = None            # device table of every entry (rebuilt when an entry is added)
         self.total_tiles = 0
         self._old_tables = []
+        self._captured = False       # a capture has read planes / the table of this registry
         self.max_entries = max_entries
+
+    def _park(self, t):
+        if self._captured:
+            self._old_tables.append(t)
 
     @staticmethod
     def _key(W, transpose):
@@ -850,6 +858,8 @@ class X3Planes:
         """(planes (3, N, kp) bf16, kp, plane stride) of the fp32 matrix W: (N, K) rows, or (K, N) rows with ``transpose``"""
         k_ = self._key(W, transpose)
         e = self.entries.get(k_)
+        if not self._captured and torch.cuda.is_current_stream_capturing():
+            self._captured = True
         if e is None:
             if torch.cuda.is_current_stream_capturing():
                 raise HspError("gemm_x3: a weight matrix was first seen inside a graph capture (run one eager step first)")
@@ -862,11 +872,11 @@ class X3Planes:
             if self.max_entries and len(self.entries) >= self.max_entries:      # the process-wide registry of ad-hoc callers:
                 # oldest out (a network's own registry is unbounded) -- its planes are parked like a replaced table, not freed:
                 # a captured hipGraph may still read them
-                self._old_tables.append(self.entries.pop(next(iter(self.entries)))["planes"])
+                self._park(self.entries.pop(next(iter(self.entries)))["planes"])
             self.entries[k_] = e
             self._split([e])                                   # this matrix now ...
             if self.table is not None:
-                self._old_tables.append(self.table)
+                self._park(self.table)
             self.table, self.total_tiles = self._table_of(list(self.entries.values()))   # ... and the table of all for refresh()
         elif e["ver"] != e["src"]._version and not torch.cuda.is_current_stream_capturing():
             # the weights moved in place (optimizer.step, load_state_dict) since these planes were cut and nobody called
@@ -896,6 +906,8 @@ class X3Planes:
     def refresh(self):
         if not self.entries:
             return
+        if not self._captured and torch.cuda.is_current_stream_capturing():
+            self._captured = True
         ents = list(self.entries.values())
         _run("hsp_split_params_x3", (_p(self.table), len(ents), self.total_tiles, _stream()), key=f"n{len(ents)}",
              abytes=sum(10 * e["N"] * e["K"] for e in ents))

@@ -20,24 +20,49 @@ import torch.distributed as dist
 
 
 def init_distributed():
-    """(rank, world_size, device) from the torchrun environment; RCCL ('nccl') on GPU, gloo on CPU."""
+    """(rank, world_size, device) from the torchrun environment; RCCL ('nccl') on GPU, gloo on CPU.
+
+    Two environment hooks let a box with ONE GPU run the N > 1 path through the real kernels (tests/test_gpu_dp_shared.py):
+    ``HSP_DIST_BACKEND`` (default ``nccl`` on a GPU, ``gloo`` on the CPU) names the backend and ``HSP_DIST_DEVICE`` (e.g. ``cuda:0``)
+    puts every rank on that device instead of ``cuda:LOCAL_RANK``.  RCCL refuses two ranks on one device, so the shared-device form
+    goes over gloo, whose collectives on device buffers are staged through the host here (``all_reduce_``)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     force = os.environ.get("HSP_FORCE_DIST", "0") == "1"      # test hook: 1-rank process group
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available()
-    device = torch.device(f"cuda:{local}") if use_cuda else torch.device("cpu")
+    device = torch.device(os.environ.get("HSP_DIST_DEVICE") or f"cuda:{local}") if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
+    backend = os.environ.get("HSP_DIST_BACKEND") or ("nccl" if use_cuda else "gloo")
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if use_cuda:
+        if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, device
+
+
+class _Done:
+    """the handle of a collective that has already completed (host-staged gloo exchange of a device buffer)"""
+
+    def wait(self):
+        return True
+
+
+def all_reduce_(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
+    """``dist.all_reduce`` in place on ``t``.  Over RCCL (and for host tensors) it is exactly that call.  Over gloo with a DEVICE
+    buffer -- the shared-GPU test form of ``init_distributed`` -- the buffer goes to the host, is reduced there and comes back,
+    synchronously; ``async_op`` then returns a completed handle (no overlap is claimed for that form)."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        host = t.detach().cpu()
+        dist.all_reduce(host, op=op, group=group)
+        t.copy_(host)
+        return _Done() if async_op else None
+    return dist.all_reduce(t, op=op, group=group, async_op=async_op)
 
 
 def describe():
@@ -113,7 +138,7 @@ class GradReducer:
             g = p.grad if p.grad is not None else torch.zeros_like(p)
             flat[off:off + n].copy_(g.reshape(-1))
             off += n
-        self._works[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works[bi] = all_reduce_(flat, group=self.group, async_op=True)
 
     def finish(self):
         """wait for every bucket, average, scatter back.  Parameters that received no gradient this step
@@ -155,13 +180,13 @@ def graphed_step_with_exchange(graphed, world, group=None):
     if not getattr(graphed, "split", False):
         graphed.run()
         if world > 1 or dist.is_initialized():
-            dist.all_reduce(graphed.flat_grad, op=dist.ReduceOp.SUM, group=group)
+            all_reduce_(graphed.flat_grad, group=group)
             graphed.flat_grad.mul_(1.0 / world)
         return
     graphed.run_first()
-    late = dist.all_reduce(graphed.flat_late, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    late = all_reduce_(graphed.flat_late, group=group, async_op=True)
     graphed.run_second()                                   # overlaps the exchange above
-    early = dist.all_reduce(graphed.flat_early, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    early = all_reduce_(graphed.flat_early, group=group, async_op=True)
     late.wait()
     early.wait()
     graphed.flat_grad.mul_(1.0 / world)
@@ -176,9 +201,47 @@ def mean_flat_gradients(buffers, group=None):
     world = dist.get_world_size(group)
     if world == 1:
         return
-    works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=True) for b in buffers]
+    works = [all_reduce_(b, group=group, async_op=True) for b in buffers]
     for w in works:
         w.wait()
     inv = 1.0 / world
     for b in buffers:
         b.mul_(inv)
+
+
+def choose_exchange_form(forms, world, group=None, replays=3, sync=None, forced=None):
+    """Which gradient-exchange form a data-parallel run uses: ``"split"`` (two graphs, the coarse levels' all-reduce under the
+    fine levels' backward -- the default whenever more than one rank runs) or ``"single"`` (one graph, one all-reduce after it).
+
+    ``forms`` maps those names to captured steps (``graph.GraphedStep``-like objects; a form whose capture failed is simply
+    absent).  With both present a start-up probe times ``replays`` exchanged steps each way (one untimed step first), takes the
+    MAX over the ranks of each time, and rank 0's decision is broadcast so that every rank issues the same collectives: the
+    split form stays unless the single form is more than 3 % faster.  ``forced`` ("split" / "single", from HSP_SPLIT_GRAPH=1 / 0)
+    skips the probe.  Returns ``(name, info)`` with ``info`` = what was measured and why, for the bench line."""
+    import time
+    names = [n for n in ("split", "single") if forms.get(n) is not None]
+    if not names:
+        return None, {"reason": "no captured form"}
+    if forced in names:
+        return forced, {"reason": f"forced by HSP_SPLIT_GRAPH ({forced})"}
+    if len(names) == 1 or world == 1 or not dist.is_initialized():
+        pick = names[0] if world > 1 or len(names) == 1 else "single"
+        return pick, {"reason": "only one form captured" if len(names) == 1 else "one rank: nothing to overlap"}
+    sync = sync or (lambda: None)
+    times = {}
+    for n in names:                                          # same order on every rank: identical collective sequences
+        graphed_step_with_exchange(forms[n], world, group)
+        sync(); dist.barrier(group)
+        t0 = time.perf_counter()
+        for _ in range(replays):
+            graphed_step_with_exchange(forms[n], world, group)
+        sync()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.barrier(group)
+        gathered = [None] * dist.get_world_size(group)
+        dist.all_gather_object(gathered, float(t.item()), group=group)
+        times[n] = 1e3 * max(gathered) / replays
+    decision = ["split" if times["split"] <= 1.03 * times["single"] else "single"]
+    dist.broadcast_object_list(decision, src=0, group=group)    # rank 0 decides
+    return decision[0], {"reason": "start-up probe (max over ranks, rank 0 decides; split kept unless single is > 3 % faster)",
+                         "probe_ms_per_step": {k: round(v, 4) for k, v in times.items()}, "replays": replays}

@@ -77,7 +77,11 @@ int hsp_knn_exact_f32(const float *x, int B, int N, int C, int k, int drop_first
  * xyz kernel run one rank past the answer; it flags the rows that hold two equal distances among those k + drop + 1 nearest, and
  * a fixed-grid pass replays only the flagged rows through libstdc++'s routines (csrc/knn_exact.hip).  A tie-free batch pays one
  * small launch.  This is what every xyz search of the package goes through, training included.
- * ws: hsp_knn_xyz_workspace_bytes (the row flags); tie_rows (may be NULL): device int, += number of flagged rows. */
+ * N <= 10 240 (the replay keeps one row of candidates in LDS; beyond it HSP_ERR_UNSUPPORTED is returned before any launch and the
+ * caller falls back on hsp_knn_f32's (distance, index) order).
+ * ws: hsp_knn_xyz_workspace_bytes (the row flags); tie_rows (may be NULL): device int, += number of flagged rows -- counted by
+ * the SEPARATE replay pass only: for N <= 576 with B N < 131 072 the selection kernel replays its flagged rows inline and leaves
+ * tie_rows untouched. */
 size_t hsp_knn_xyz_workspace_bytes(int B, int N);
 int hsp_knn_xyz_f32(const float *xyz, int B, int N, int k, int k2, int drop_first, int32_t *idx, int32_t *idx2, void *ws,
                     size_t ws_bytes, int *tie_rows, hspStream_t stream);

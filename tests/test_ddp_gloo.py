@@ -164,3 +164,78 @@ def test_shard_range_covers_batch():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+class _TimedFake(_FakeGraphedStep):
+    """a stub step that takes a given time per exchanged step (the probe's clock is wall time)"""
+
+    def __init__(self, rank, split, seconds):
+        super().__init__(rank, split)
+        self.seconds = seconds
+
+    def run(self):
+        import time
+        time.sleep(self.seconds)
+        super().run()
+
+    def run_second(self):
+        import time
+        time.sleep(self.seconds)
+        super().run_second()
+
+
+def _worker_choice(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from hs_pose_amd.parallel import choose_exchange_form, init_distributed
+    init_distributed()
+    got = {}
+    # (split seconds, single seconds) per rank: the MAX over the ranks decides, and rank 1 is the slow one in case "b"
+    cases = {"a_split_faster": ((0.002, 0.002), (0.02, 0.02)),           # split clearly faster on both ranks
+             "b_single_faster_on_max": ((0.002, 0.03), (0.01, 0.01)),    # split faster on rank 0 only: max over ranks says single
+             "c_tie_keeps_split": ((0.01, 0.01), (0.01, 0.01))}
+    for name, (t_split, t_single) in cases.items():
+        forms = {"split": _TimedFake(rank, True, t_split[rank]), "single": _TimedFake(rank, False, t_single[rank])}
+        pick, info = choose_exchange_form(forms, world, replays=3)
+        assert set(info["probe_ms_per_step"]) == {"split", "single"} and info["replays"] == 3
+        # one untimed + three timed exchanged steps of EACH form on every rank, whatever is chosen
+        assert forms["split"].calls == ["first", "second"] * 4 and forms["single"].calls == ["run"] * 4
+        got[name] = pick
+    # forced forms and degenerate inputs never probe (no step of the stub runs)
+    f = {"split": _TimedFake(rank, True, 0.0), "single": _TimedFake(rank, False, 0.0)}
+    assert choose_exchange_form(f, world, forced="single")[0] == "single" and choose_exchange_form(f, world, forced="split")[0] == "split"
+    assert choose_exchange_form({"single": f["single"]}, world)[0] == "single"
+    assert choose_exchange_form({"split": f["split"], "single": None}, world, forced="single")[0] == "split"   # forced form absent
+    assert choose_exchange_form({}, world)[0] is None
+    assert f["split"].calls == [] and f["single"].calls == []
+    every = [None] * world
+    dist.all_gather_object(every, got)
+    assert all(e == got for e in every), every               # all ranks agree (a disagreement would deadlock the collectives)
+    assert got["a_split_faster"] == "split" and got["c_tie_keeps_split"] == "split", got
+    assert got["b_single_faster_on_max"] == "single", got
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, "ok"))
+
+
+def test_exchange_form_choice_gloo():
+    """the start-up probe bench.py uses when more than one rank runs: both forms timed over the same number of exchanged steps on
+    every rank, MAX over the ranks, one decision for all; the overlapped two-graph form is the default (kept on ties), the single
+    all-reduce wins only when it is measurably faster; HSP_SPLIT_GRAPH forces a form without probing"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_choice, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got == [(0, "ok"), (1, "ok")]
+    assert all(p.exitcode == 0 for p in procs)
+
+
+def test_exchange_form_single_rank_needs_no_group():
+    from hs_pose_amd.parallel import choose_exchange_form
+    a, b = _FakeGraphedStep(0, True), _FakeGraphedStep(0, False)
+    pick, info = choose_exchange_form({"split": a, "single": b}, 1)
+    assert pick == "single" and a.calls == [] and b.calls == [] and "one rank" in info["reason"]

@@ -1,0 +1,91 @@
+"""SURVEY 8e on real kernels with ONE GPU: two data-parallel ranks share cuda:0 (process group over gloo: RCCL refuses two
+ranks on a device; parallel.init_distributed's HSP_DIST_BACKEND / HSP_DIST_DEVICE hooks), each with its own 16 clouds, its own
+train-mode BatchNorm statistics and its own Pool_layer randperm stream -- the reference has no distributed code at all
+(engine/train.py:23), so the statement under test is the survey's:
+
+  (i)   rank r's ``feat`` and gradients == a single-process run on rank r's clouds with rank r's randperm seed (bit for bit in
+        the fixed-order backward, HSP_DETERMINISTIC=1; to 1e-5 of scale with the default atomics-ordered backward),
+  (ii)  the exchanged flat buffer == the mean of the two single-process gradients (<= 1e-6 of scale), both exchange forms,
+  (iii) ``bench.py --gpus 2`` under the same hooks prints ``n_gpus: 2`` and ``process_group.world_size: 2``.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _torchrun(port):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", str(port)]
+
+
+def _env(deterministic):
+    env = dict(os.environ, HSP_DIST_BACKEND="gloo", HSP_DIST_DEVICE="cuda:0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               HSP_DETERMINISTIC=deterministic)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSP_FORCE_DIST", "HSP_SPLIT_GRAPH"):
+        env.pop(k, None)
+    return env
+
+
+@pytest.mark.parametrize("deterministic", ["1", "0"])
+def test_two_ranks_share_the_gpu_real_network(dev, tmp_path, monkeypatch, deterministic):
+    out = subprocess.run(_torchrun(29571 + int(deterministic)) + [os.path.join(ROOT, "tests", "_dp_shared_gpu_check.py"), str(tmp_path)],
+                         env=_env(deterministic), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "DP_SHARED_GPU_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _dp_shared_gpu_check as w
+    from hs_pose_amd import ops
+    monkeypatch.setattr(ops, "DETERMINISTIC", deterministic == "1")
+    for split in (False, True):
+        ranks = [torch.load(os.path.join(tmp_path, f"rank{r}_split{int(split)}.pt")) for r in range(2)]
+        assert not torch.equal(ranks[0]["feat"], ranks[1]["feat"]), "ranks saw identical data: the test would prove nothing"
+        single = []
+        for r in range(2):
+            net, gs, rec = w.local_step(r, dev, split)             # the single-process run of rank r's step, in THIS process
+            del net, gs
+            single.append(rec)
+            # (i) forward: bit for bit, in the local step and in the exchanged step
+            assert torch.equal(rec["feat"], ranks[r]["feat"]), (split, r)
+            assert torch.equal(rec["feat"], ranks[r]["feat_after_exchange_step"]), (split, r)
+            assert set(rec["grads"]) == set(ranks[r]["grads"]) and len(rec["grads"]) >= 26
+            for name, g in rec["grads"].items():
+                got = ranks[r]["grads"][name]
+                if deterministic == "1":
+                    assert torch.equal(g, got), (split, r, name)
+                else:
+                    scale = float(g.abs().max()) + 1e-30
+                    assert float((g - got).abs().max()) <= 1e-5 * scale, (split, r, name)
+        # (ii) what the exchange left on EVERY rank == mean of the single-process gradients
+        worst = 0.0
+        for name in single[0]["grads"]:
+            want = (single[0]["grads"][name].double() + single[1]["grads"][name].double()) / 2
+            scale = float(want.abs().max()) + 1e-30
+            tol = 1e-6 if deterministic == "1" else 2e-5
+            for r in range(2):
+                err = float((ranks[r]["exchanged"][name].double() - want).abs().max()) / scale
+                worst = max(worst, err)
+                assert err <= tol, (split, r, name, err)
+            assert torch.equal(ranks[0]["exchanged"][name], ranks[1]["exchanged"][name]), (split, name)
+        print(f"dp shared-gpu deterministic={deterministic} split={split}: max |exchanged - mean| / scale = {worst:.2e}")
+
+
+def test_bench_two_ranks_share_the_gpu(dev):
+    """(iii) the bench line of a 2-rank run under the same hooks: both forms captured, the start-up probe chooses, n_gpus == 2"""
+    out = subprocess.run(_torchrun(29575) + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                                             "--no-cpu-baseline", "--no-gemm-tuning", "--no-u3", "--no-side"],
+                         env=_env("0"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and cfg["process_group"]["world_size"] == 2 and cfg["process_group"]["backend"] == "gloo"
+    assert cfg["global_batch"] == 32 and line["scaling"] == "weak" and line["value"] > 0 and cfg["hipgraph"] is True
+    choice = cfg["grad_exchange_choice"]
+    assert set(choice["probe_ms_per_step"]) == {"split", "single"} and cfg["split_graph"] in (True, False)
+    assert cfg["grad_exchange"].startswith("2 all-reduces" if cfg["split_graph"] else "1 all-reduce")
