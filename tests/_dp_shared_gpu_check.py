@@ -60,10 +60,29 @@ def main():
     assert describe()["world_size"] == 2
     for split in (False, True):
         net, gs, rec = local_step(rank, device, split)
-        torch.manual_seed(100 + rank)                      # same draws again, now with the exchange
-        graphed_step_with_exchange(gs, world)
-        torch.cuda.synchronize()
+        # the same draws again, now with the exchange.  What each collective is HANDED is snapshotted (a second replay of the same
+        # step differs from the first by the fp32 atomics' arrival order, so "exchanged == mean of the operands" is checked on the
+        # operands of THIS replay): the flat buffer before its all-reduce, or its [late | early] halves in the two-graph form
+        from hs_pose_amd import parallel
+        handed, real = [], parallel.all_reduce_
+
+        def spy(t, *a, **kw):
+            torch.cuda.synchronize()
+            handed.append(t.detach().clone())
+            return real(t, *a, **kw)
+        parallel.all_reduce_ = spy
+        try:
+            torch.manual_seed(100 + rank)
+            graphed_step_with_exchange(gs, world)
+            torch.cuda.synchronize()
+        finally:
+            parallel.all_reduce_ = real
+        assert len(handed) == (2 if split else 1) and sum(h.numel() for h in handed) == gs.flat_grad.numel()
         rec["exchanged"] = named_grads(net, gs)
+        after = gs.flat_grad.clone()
+        gs.flat_grad.copy_(torch.cat(handed))              # (views by name of what went INTO the exchange)
+        rec["handed"] = named_grads(net, gs)
+        gs.flat_grad.copy_(after)
         rec["feat_after_exchange_step"] = gs.feat.detach().clone().cpu()
         torch.save(rec, os.path.join(out_dir, f"rank{rank}_split{int(split)}.pt"))
         del gs, net
