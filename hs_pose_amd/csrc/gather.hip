@@ -302,6 +302,12 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const FT* __restric
     }
 }
 
+__device__ __forceinline__ float fma_plain(float a, float b, float c) {
+    float r;
+    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // colsum + the three coordinate moments of the rows in one pass (HSlayer_surface backward: gt = sum_i g and the STE weight
 // gradient g^T xyz, gcn3d.py:85): part[b][chunk][slot][c], slot 0 = sum g, slot 1..3 = sum g * (x, y, z)
 template <typename FT>
@@ -323,8 +329,12 @@ __global__ __launch_bounds__(256) void colsum_xyz_partial_kernel(const FT* __res
         s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            s[q + 1].x = __fmaf_rn(v.x, w[q], s[q + 1].x); s[q + 1].y = __fmaf_rn(v.y, w[q], s[q + 1].y);
-            s[q + 1].z = __fmaf_rn(v.z, w[q], s[q + 1].z); s[q + 1].w = __fmaf_rn(v.w, w[q], s[q + 1].w);
+            // plain v_fma_f32, spelled out: hipcc packs these into v_pk_fma_f32 with op_sel picking the coordinate out of the
+            // loaded (x, y, z) register run, and that form returned wrong LOW halves (the .x / .z sums of the y moment, lanes 16-31
+            // of each half-wave) whenever another process's MFMA kernels shared the GPU -- 3-8 % of the replays, 1-3 % off
+            // (tools/dbg_ste2.py, tests/test_gpu_dp_shared.py); never alone on the GPU.  The scalar form has not deviated once.
+            s[q + 1].x = fma_plain(v.x, w[q], s[q + 1].x); s[q + 1].y = fma_plain(v.y, w[q], s[q + 1].y);
+            s[q + 1].z = fma_plain(v.z, w[q], s[q + 1].z); s[q + 1].w = fma_plain(v.w, w[q], s[q + 1].w);
         }
     }
 #pragma unroll

@@ -567,7 +567,113 @@ __device__ __forceinline__ void knn_select_wave(const float* dl, int2* sv, int N
     }
 }
 
-
+// The same selection with the candidates' distances in REGISTERS (S per lane, N <= 64 S) and the survivors ranked lane-against-lane:
+// knn_select_wave walks the survivor list in LDS once per survivor (a dependent ds_read per step: ~100 clocks x ~28 survivors, and
+// ~10 000 clocks a query measured with nine waves selecting side by side); here lane e holds survivor e and the list is broadcast
+// from registers (v_readlane_b32 with a scalar index: no memory round trip), one 64-bit compare per pair.  The radix descent is a
+// chain of vector-compare -> scalar-count -> scalar-select steps that waits on itself, so a wave runs NQ (1 or 2) queries through it
+// side by side: two independent chains interleave and take about the time of one.  Same bound, same (distance, index) ranks,
+// same tie flag as knn_select_wave; more than 64 survivors (heavily duplicated rows) fall back on it.
+// dl[u], out[u], tie[u]: query u's distances / output row / flag byte; sv: 64 * NQ int2 of scratch (+ N for the fall-back).
+template <int S, int NQ, bool TIE>
+__device__ __forceinline__ void knn_select_wave_regs(const float* const (&dl)[NQ], int2* sv, int N, int k, int drop,
+                                                     int32_t* const (&out)[NQ], uint8_t* const (&tie)[NQ]) {
+    const int lane = threadIdx.x & 63;
+    const int m = k + drop;
+    const int ms = TIE && m + 1 <= N ? m + 1 : m;
+    float v[NQ][S];
+    unsigned key[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        float lmin = INFINITY;
+#pragma unroll
+        for (int s_ = 0; s_ < S; ++s_) {
+            const int j = lane + 64 * s_;
+            const float raw = dl[u][j < N ? j : N - 1];               // (clamped address: all S loads of both queries in flight together)
+            // NaN / +inf of a real row -> FLT_MAX (see knn_select_wave); -0.0 -> +0.0 (equal as floats, not as key bits)
+            v[u][s_] = j < N ? add_rn(fminf(raw, FLT_MAX), 0.0f) : INFINITY;
+            lmin = fminf(lmin, v[u][s_]);
+        }
+        key[u] = sortable_key(lmin);
+    }
+    unsigned prefix[NQ];
+    int need[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) { prefix[u] = 0; need[u] = ms; }
+    for (int bit = 31; bit >= KNN_TAU_LOW_BIT; --bit) {
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const bool zero = (key[u] ^ prefix[u]) < (1u << bit);    // bits 31..bit+1 equal the prefix and bit `bit` is 0
+            const int c0 = __popcll(__ballot(zero));
+            if (need[u] > c0) { need[u] -= c0; prefix[u] |= 1u << bit; }
+        }
+    }
+    int n[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        const unsigned pf = prefix[u] | ((1u << KNN_TAU_LOW_BIT) - 1u);
+        const float tau = __uint_as_float(pf ^ ((pf >> 31) ? 0x80000000u : 0xffffffffu));
+        n[u] = 0;
+#pragma unroll
+        for (int s_ = 0; s_ < S; ++s_) {
+            const bool keep = v[u][s_] <= tau;                    // +inf padding never passes a finite tau
+            const unsigned long long bal = __ballot(keep);
+            const int pos = n[u] + __popcll(bal & ((1ull << lane) - 1ull));
+            if (keep && pos < 64) sv[u * 64 + pos] = make_int2(__float_as_int(v[u][s_]), lane + 64 * s_);
+            n[u] += __popcll(bal);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    int2 me[NQ];
+    unsigned khi[NQ];
+    unsigned long long ke[NQ];
+    int rank[NQ];
+    bool eq_lo[NQ], eq_hi[NQ];
+    int nmax = 0;
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        const int nu = n[u] <= 64 ? n[u] : 0;                      // (an overflowing query is redone below)
+        me[u] = lane < nu ? sv[u * 64 + lane] : make_int2(__float_as_int(INFINITY), INT_MAX);
+        khi[u] = sortable_key(__int_as_float(me[u].x));
+        ke[u] = ((unsigned long long)khi[u] << 32) | (unsigned)me[u].y;
+        rank[u] = 0; eq_lo[u] = false; eq_hi[u] = false;
+        nmax = nu > nmax ? nu : nmax;
+    }
+    // ranks by ONE 64-bit compare per pair: key = (sortable distance bits, index).  Lanes past a query's survivors hold the largest
+    // key, so running both queries to the longer list changes no rank.
+    // (four list entries per trip: the list is padded with largest keys up to lane 63, which rank nothing)
+    for (int f0 = 0; f0 < nmax; f0 += 4) {
+#pragma unroll
+        for (int df = 0; df < 4; ++df) {
+            const int f = f0 + df;
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const unsigned fh = (unsigned)__builtin_amdgcn_readlane((int)khi[u], f);
+                const unsigned fl = (unsigned)__builtin_amdgcn_readlane(me[u].y, f);
+                const unsigned long long kf = ((unsigned long long)fh << 32) | fl;
+                rank[u] += kf < ke[u] ? 1 : 0;
+                if (TIE) {
+                    eq_lo[u] = eq_lo[u] || (fh == khi[u] && fl < (unsigned)me[u].y);
+                    eq_hi[u] = eq_hi[u] || (fh == khi[u] && fl > (unsigned)me[u].y);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        if (n[u] > 64) {                                           // (wave-uniform)
+            __builtin_amdgcn_wave_barrier();
+            knn_select_wave(dl[u], sv + 64 * NQ, N, k, drop, out[u], TIE ? tie[u] : nullptr);
+            continue;
+        }
+        if (lane < n[u] && rank[u] >= drop && rank[u] < m) out[u][rank[u] - drop] = me[u].y;
+        if (TIE) {
+            const bool tied = lane < n[u] && rank[u] < ms && (eq_lo[u] || (eq_hi[u] && rank[u] + 1 < ms));
+            const bool any_tied = __ballot(tied) != 0ull;
+            if (lane == 0) *tie[u] = any_tied ? 1 : 0;
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // remainder queries of the feature path.  N = 1028 = 32*32 + 4 leaves 4 queries per cloud that would
@@ -934,6 +1040,291 @@ __global__ __launch_bounds__(256, 3) void knn_feat_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// feature path, SMALL clouds (64 <= N <= 320: the two coarse levels of the stack, N = 257 and N = 64; C % 64 == 0).
+// knn_feat_kernel gives each of its four waves every fourth candidate tile and a sorted list per lane; at N = 257 that is 144
+// workgroups whose wave 0 walks three tiles one after the other, inserts every candidate of the first one and then merges eight
+// 21-entry lists: 25 / 41 us (C = 128 / 256) for 1.7 / 3.5 us of matrix work.  Here a workgroup is QT queries of one cloud and ONE
+// WAVE PER CANDIDATE TILE (9 waves at N = 257): every wave runs a single 32 x 32 chain of k-ordered MFMA steps (the same chain:
+// identical distance bits), the QT x N distances go to LDS and the queries are then selected by knn_select_wave (radix bound over
+// ballots + ranking of the ~k + 4 survivors, ~600 wave instructions a query), QT / waves rounds per wave.
+//   |x|^2 is computed in the kernel (quad_in == nullptr): each wave has its 32 candidate rows in LDS anyway and adds their squares
+//   in ATen's order (quad32_kernel's: partial accumulator s = 8 k + l takes the elements 32 i + s in ascending i, then slots 1..3
+//   into slot 0, then the eight vector lanes in order) -- lane (row, hh) keeps the sixteen accumulators s = 16 hh .. 16 hh + 15 of
+//   its row.  One launch per search instead of two (the |x|^2 kernel was ~5 us of pure latency in front of each).
+// QT <= 32 is chosen so that the batch's workgroups just fill the 256 CUs (QT = 17 at B = 16, N = 257: 16 x 16 workgroups; the
+// unused query columns of the MFMA repeat the last query): the matrix work of a workgroup does not depend on QT -- one chain per
+// wave -- and the selection, which is bound by instruction issue, shrinks with it.  A remainder of at most 4 rows (N = 257) is not
+// given an MFMA tile but one wave's fma chains.  grid (ceil(N / QT), B), block 64 * max(tiles, 8) (waves beyond the tiles only select).
+// ------------------------------------------------------------------------------------------------
+#ifdef HSP_KNN_PROF
+static __device__ long long* g_knn_prof = nullptr;     // tools/prof_knn_small.py: clock64 stamps of workgroup (0, 0), lane 0 of every wave
+#define KNN_STAMP(slot) do { if (g_knn_prof && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) g_knn_prof[(threadIdx.x >> 6) * 8 + (slot)] = clock64(); } while (0)
+#else
+#define KNN_STAMP(slot) do { } while (0)
+#endif
+__global__ __launch_bounds__(640) void knn_feat_small_kernel(const float* __restrict__ x, const float* __restrict__ quad_in,
+                                                             float* __restrict__ quad_out, int N, int C, int k, int drop,
+                                                             int32_t* __restrict__ idx, uint8_t* __restrict__ tie,
+                                                             float* __restrict__ dmat, int mtiles, int QT) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int nw = (int)blockDim.x >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int ntiles = (N + 31) >> 5, nchunks = C >> 6;
+    const int rem = N - mtiles * 32;          // > 0: the last rows (at most 4) are not a candidate tile but extra QUERY columns (below)
+    const int QR = QT + (rem > 0 ? rem : 0);  // rows of the query tile: the workgroup's queries, then the remainder rows
+    const int QS = C + 4;                     // query row stride (floats)
+    const int NP = ntiles * 32, DS = NP + 1;  // distance row stride: odd, so the 32 query columns of a store hit 32 banks
+    float* qtile = reinterpret_cast<float*>(smem);                 // QR x QS
+    float* ctiles = qtile + QR * QS;                               // mtiles x 32 x KF_CT_STRIDE (wave-private chunks)
+    float* quadl = ctiles + (size_t)ntiles * 32 * KF_CT_STRIDE;    // NP: |c|^2, +inf past N
+    float* dl = quadl + NP;                                        // QT x DS distances
+    const int b = blockIdx.y, q0 = (int)blockIdx.x * QT;
+    const float* xb = x + (size_t)b * N * C;
+    const bool mma = wave < mtiles;
+    const bool remw = rem > 0 && wave == mtiles;
+    float* ctile = ctiles + (size_t)(mma ? wave : 0) * 32 * KF_CT_STRIDE;
+
+    KNN_STAMP(0);
+    // this wave's candidate tile, chunk 0: in flight under the query staging
+    float2 pre[16];
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)((size_t)N * C * 4), 0x00020000);
+    const int lane_off = (h * C + 2 * col) * 4, row2 = 2 * C * 4;
+    auto prefetch = [&](int chunk) {
+        const int s0 = (wave * 32 * C + chunk * 64) * 4;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(xrs, lane_off, s0 + it * row2, 0);   // rows past N read 0
+            pre[it] = make_float2(__int_as_float(v[0]), __int_as_float(v[1]));
+        }
+    };
+    if (mma) prefetch(0);
+    // ---- the QR query rows, de-interleaved per 64-chunk: [chunk][even 32 | odd 32]; four 16-byte loads in flight per thread
+    {
+        const int C4 = C >> 2, total = QR * C4, bd = (int)blockDim.x;
+        for (int e0 = tid; e0 < total; e0 += 4 * bd) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * bd;
+                const int row = e / C4, p = e - row * C4;
+                const int src = row < QT ? q0 + row : mtiles * 32 + (row - QT);
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < total && src < N) v[u] = *reinterpret_cast<const float4*>(xb + (size_t)src * C + 4 * p);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * bd;
+                if (e < total) {
+                    const int row = e / C4, p = e - row * C4;
+                    float* dst = qtile + row * QS + (p >> 4) * 64 + 2 * (p & 15);     // elements 4p .. 4p+3: pairs 2p, 2p+1 of the row
+                    *reinterpret_cast<float2*>(dst) = make_float2(v[u].x, v[u].z);
+                    *reinterpret_cast<float2*>(dst + 32) = make_float2(v[u].y, v[u].w);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    KNN_STAMP(1);
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float ra = 0.f;                                          // remainder wave: inner product of (remainder query, remainder row) of this lane
+    if (mma) {
+        float sq[16];                                       // ATen's partial accumulators 16 h .. 16 h + 15 of candidate row `col`
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) sq[s_] = 0.f;
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int e = it * 64 + lane;
+                const int row = e >> 5, pair = e & 31;
+                ctile[row * KF_CT_STRIDE + pair] = pre[it].x;
+                ctile[row * KF_CT_STRIDE + 32 + pair] = pre[it].y;
+            }
+            if (chunk + 1 < nchunks) prefetch(chunk + 1);
+            __builtin_amdgcn_wave_barrier();
+            const float* arow = ctile + col * KF_CT_STRIDE + h * 32;
+            const float* brow = qtile + min(col, QR - 1) * QS + chunk * 64 + h * 32;
+            if (!quad_in) {
+                // elements 64 c + s (i = 2 c) then 64 c + 32 + s (i = 2 c + 1) of row `col`, s = 16 h + 2 j (+ 1): the even element of a
+                // pair sits at [s / 2], the odd one at [32 + s / 2] of the staged chunk
+                const float* sr = ctile + col * KF_CT_STRIDE + 8 * h;
+                const float4 e0 = *reinterpret_cast<const float4*>(sr), e1 = *reinterpret_cast<const float4*>(sr + 4);
+                const float4 o0 = *reinterpret_cast<const float4*>(sr + 32), o1 = *reinterpret_cast<const float4*>(sr + 36);
+                const float4 f0 = *reinterpret_cast<const float4*>(sr + 16), f1 = *reinterpret_cast<const float4*>(sr + 20);
+                const float4 p0 = *reinterpret_cast<const float4*>(sr + 48), p1 = *reinterpret_cast<const float4*>(sr + 52);
+                const float ev[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+                const float od[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+                const float ev2[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                const float od2[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    sq[2 * j] = add_rn(sq[2 * j], mul_rn(ev[j], ev[j]));
+                    sq[2 * j + 1] = add_rn(sq[2 * j + 1], mul_rn(od[j], od[j]));
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    sq[2 * j] = add_rn(sq[2 * j], mul_rn(ev2[j], ev2[j]));
+                    sq[2 * j + 1] = add_rn(sq[2 * j + 1], mul_rn(od2[j], od2[j]));
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float4 a4 = *reinterpret_cast<const float4*>(arow + 4 * g);
+                const float4 b4 = *reinterpret_cast<const float4*>(brow + 4 * g);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        KNN_STAMP(2);
+        const int cand = wave * 32 + col;
+        float qv;
+        if (quad_in) {
+            qv = cand < N ? quad_in[(size_t)b * N + cand] : INFINITY;
+        } else {
+            // slots 1..3 into slot 0: t_l = ((a_l + a_{l+8}) + a_{l+16}) + a_{l+24}; this half holds a_{16 h + 0..15}
+            float t[8];
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                const float lo = add_rn(sq[l], sq[l + 8]);                   // h == 0: a_l + a_{l+8}
+                const float p16 = __shfl_xor(sq[l], 32), p24 = __shfl_xor(sq[l + 8], 32);   // the other half's a_{16 + l}, a_{24 + l}
+                t[l] = add_rn(add_rn(lo, p16), p24);                          // (meaningful in the h == 0 lanes)
+            }
+            float fin = 0.f;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) fin = add_rn(fin, t[l]);
+            qv = cand < N ? fin : INFINITY;
+            if (quad_out && blockIdx.x == 0 && h == 0 && cand < N) quad_out[(size_t)b * N + cand] = fin;
+        }
+        if (h == 0) quadl[cand] = qv;
+        KNN_STAMP(3);
+    } else if (remw) {
+        // ---- the N % 32 <= 4 last rows.  As CANDIDATES of the workgroup's queries they cost no tile: they ride as query columns
+        // QT .. QT + rem - 1 of every MFMA, and the chain of (candidate row j, column of remainder row t) IS the chain of (query j,
+        // candidate t) -- the same products in the same k order -- so the tile that holds the workgroup's own queries as candidate
+        // rows delivers d(q, t) (epilogue below).  What no tile holds are the rem x rem pairs of remainder QUERIES (only the last
+        // workgroups of a cloud own any): spelled-out fma chains, lane = (own remainder query, remainder row), both rows from the
+        // staged query tile.  This wave also computes the remainder rows' |x|^2 (quad32_kernel's order, 32 lanes per row).
+        const int tq = lane / rem, tc = lane - tq * rem;             // query mtiles*32 + tq against candidate mtiles*32 + tc
+        const int qrow = mtiles * 32 + tq - q0;                       // its row of the query tile, if this workgroup owns it
+        if (tq < rem && qrow >= 0 && qrow < QT) {
+            const float* qa = qtile + qrow * QS;
+            const float* qb = qtile + (QT + tc) * QS;
+            float a = 0.f;
+            for (int c8 = 0; c8 < C; c8 += 8) {
+                const int o = (c8 >> 6) * 64 + ((c8 & 63) >> 1);
+                const float4 ae = *reinterpret_cast<const float4*>(qa + o), ao = *reinterpret_cast<const float4*>(qa + o + 32);
+                const float4 be = *reinterpret_cast<const float4*>(qb + o), bo = *reinterpret_cast<const float4*>(qb + o + 32);
+                a = __fmaf_rn(ao.y, bo.y, __fmaf_rn(ae.y, be.y, __fmaf_rn(ao.x, bo.x, __fmaf_rn(ae.x, be.x, a))));
+                a = __fmaf_rn(ao.w, bo.w, __fmaf_rn(ae.w, be.w, __fmaf_rn(ao.z, bo.z, __fmaf_rn(ae.z, be.z, a))));
+            }
+            ra = a;
+        }
+        for (int t = h; t < 32; t += 2) {
+            const int cand = mtiles * 32 + t;
+            float fin = INFINITY;
+            if (t < rem) {                                    // (uniform per half-wave)
+                if (quad_in) {
+                    fin = quad_in[(size_t)b * N + cand];
+                } else {
+                    const float* row = xb + (size_t)cand * C;
+                    float a = 0.f;
+                    for (int i = 0; i < (C >> 5); ++i) { const float v = row[i * 32 + col]; a = add_rn(a, mul_rn(v, v)); }
+                    const int base = lane & 32;
+                    float tt = a;
+                    tt = add_rn(tt, __shfl(a, base | ((col + 8) & 31)));
+                    tt = add_rn(tt, __shfl(a, base | ((col + 16) & 31)));
+                    tt = add_rn(tt, __shfl(a, base | ((col + 24) & 31)));
+                    fin = 0.f;
+#pragma unroll
+                    for (int l = 0; l < 8; ++l) fin = add_rn(fin, __shfl(tt, base | l));
+                    if (quad_out && blockIdx.x == 0 && col == 0) quad_out[(size_t)b * N + cand] = fin;
+                }
+            }
+            if (col == 0) quadl[cand] = fin;
+        }
+        KNN_STAMP(3);
+    }
+    __syncthreads();
+    KNN_STAMP(4);
+    if (mma) {
+        // (wave-uniform) does this tile hold some of the workgroup's own queries as candidate rows?  Only then do the remainder
+        // rows' columns carry anything (at most two waves of a workgroup)
+        const bool holds_own = rem > 0 && wave * 32 < q0 + QT && wave * 32 + 32 > q0;
+        if (col < QT) {                                     // own queries against this wave's candidate tile
+            const int q = q0 + col;
+            const float qq = q < N ? quadl[q] : 0.f;
+            float* drow = dl + col * DS + wave * 32 + 4 * h;
+            float* mrow = dmat && q < N ? dmat + ((size_t)b * N + wave * 32 + 4 * h) * N + q : nullptr;   // [candidate][query], as knn_feat_kernel
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 qc = *reinterpret_cast<const float4*>(quadl + wave * 32 + 8 * g + 4 * h);
+                const float qcv[4] = {qc.x, qc.y, qc.z, qc.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float d = add_rn(add_rn(mul_rn(acc[4 * g + u], -2.0f), qcv[u]), qq);
+                    drow[8 * g + u] = d;                                                  // (rows past N: +inf, never read)
+                    if (mrow && wave * 32 + 8 * g + 4 * h + u < N) mrow[(size_t)(8 * g + u) * N] = d;
+                }
+            }
+        } else if (holds_own && col < QR) {                 // a remainder row's column: rows of this tile that are OWN QUERIES
+            const int c = mtiles * 32 + (col - QT);
+            const float qcand = quadl[c];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (q >= q0 && q < q0 + QT) {
+                    const float d = add_rn(add_rn(mul_rn(acc[r], -2.0f), qcand), quadl[q]);
+                    dl[(q - q0) * DS + c] = d;
+                    if (dmat) dmat[((size_t)b * N + c) * N + q] = d;
+                }
+            }
+        }
+    } else if (remw) {
+        const int tq = lane / rem, tc = lane - tq * rem;
+        const int q = mtiles * 32 + tq, c = mtiles * 32 + tc;
+        if (tq < rem && q >= q0 && q < q0 + QT) {
+            const float d = add_rn(add_rn(mul_rn(ra, -2.0f), quadl[c]), quadl[q]);
+            dl[(q - q0) * DS + c] = d;
+            if (dmat) dmat[((size_t)b * N + c) * N + q] = d;
+        }
+    }
+    __syncthreads();                                        // distances complete; the candidate chunks are dead: selection scratch
+    KNN_STAMP(5);
+    // two queries per wave and pass (knn_select_wave_regs): scratch = 128 survivor slots + N for the fall-back
+    int2* sv = reinterpret_cast<int2*>(ctiles) + (size_t)wave * (128 + N);
+    const int nq = min(QT, N - q0);                         // queries of this workgroup
+    if (nq <= nw) {                                         // a query per wave is enough
+        if (wave < nq) {
+            const float* const dls[1] = {dl + wave * DS};
+            int32_t* const outs[1] = {idx + ((size_t)b * N + q0 + wave) * k};
+            uint8_t* const ties[1] = {tie ? tie + (size_t)b * N + q0 + wave : nullptr};
+            if (tie) knn_select_wave_regs<5, 1, true>(dls, sv, N, k, drop, outs, ties);
+            else knn_select_wave_regs<5, 1, false>(dls, sv, N, k, drop, outs, ties);
+        }
+    } else {
+        for (int ql = 2 * wave; ql < nq; ql += 2 * nw) {
+            const int q = q0 + ql;
+            const int ql1 = ql + 1 < nq ? ql + 1 : ql;      // (an odd count: the last query is simply done twice)
+            const float* const dls[2] = {dl + ql * DS, dl + ql1 * DS};
+            int32_t* const outs[2] = {idx + ((size_t)b * N + q) * k, idx + ((size_t)b * N + q0 + ql1) * k};
+            uint8_t* const ties[2] = {tie ? tie + (size_t)b * N + q : nullptr, tie ? tie + (size_t)b * N + q0 + ql1 : nullptr};
+            if (tie) knn_select_wave_regs<5, 2, true>(dls, sv, N, k, drop, outs, ties);
+            else knn_select_wave_regs<5, 2, false>(dls, sv, N, k, drop, outs, ties);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    KNN_STAMP(6);
+}
+
+// ------------------------------------------------------------------------------------------------
 // top-1 nearest source row per target row (C == 3); d = (s2[j] + t2[i]) - 2*inner   (gcn3d.py:34)
 // grid (ceil(Nt/256), B), block 256, dynamic LDS = Ns*16
 // ------------------------------------------------------------------------------------------------
@@ -1131,6 +1522,44 @@ static int knn_feat_rem_mode(int B, int N, int C) {
     }
     const size_t lds_t = (size_t)C * 4 + (size_t)12 * (N + 3);
     return ((C & 3) == 0 && lds_t <= knn_feat_lds(C, 3)) ? KF_REM_WG : KF_REM_TILE;
+}
+
+// knn_feat_small_kernel: LDS bytes for QT queries per workgroup, and the QT that makes the batch's workgroups fill the chip once
+static size_t knn_feat_small_lds(int N, int C, int QT) {
+    const int ntiles = (N + 31) / 32, rem = (N & 31) <= 4 ? (N & 31) : 0;
+    const size_t fl = (size_t)(QT + rem) * (C + 4) + (size_t)ntiles * 32 * KF_CT_STRIDE + (size_t)ntiles * 32 + (size_t)QT * (ntiles * 32 + 1);
+    // (the selection scratch aliases the candidate chunks: (128 + N) int2 per wave)
+    const int nw = ntiles > 8 ? ntiles : 8;
+    const size_t scratch = (size_t)nw * (128 + N) * 2, chunks = (size_t)ntiles * 32 * KF_CT_STRIDE;
+    return (fl + (scratch > chunks ? scratch - chunks : 0)) * 4;
+}
+static int knn_feat_small_qt(int B, int N, int C) {           // 0: not this kernel's shape
+    if (N < 64 || N > 320 || (C & 63) || C >= 512 ||   // (C >= 512: ATen sums |x|^2 in cascade levels, quad_kernel)
+        (size_t)N * C * 4 >= ((size_t)1 << 31)) return 0;
+    const int rem = (N & 31) <= 4 ? (N & 31) : 0;
+    const int per_cloud = HSP_NUM_CU / B > 0 ? HSP_NUM_CU / B : 1;      // workgroups a cloud may have
+    int qt = (N + per_cloud - 1) / per_cloud;
+    if (qt < 2) qt = 2;
+    if (qt > 32 - rem) qt = 32 - rem;                          // (the remainder rows ride as query columns)
+    while (qt > 2 && knn_feat_small_lds(N, C, qt) > 160 * 1024) --qt;
+    return knn_feat_small_lds(N, C, qt) <= 160 * 1024 ? qt : 0;
+}
+
+static int launch_knn_feat_small(int QT, const float* x, const float* quad_in, float* quad_out, int B, int N, int C, int k, int drop,
+                                 int32_t* idx, hipStream_t st, uint8_t* tie, float* dmat) {
+    const size_t lds = knn_feat_small_lds(N, C, QT);
+    auto kern = knn_feat_small_kernel;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }
+    }
+    const int ntiles = (N + 31) / 32;
+    const int rem = N & 31;
+    const int mtiles = (rem > 0 && rem <= 4) ? N / 32 : ntiles;      // MFMA tiles; a short remainder goes to one wave's fma chains
+    const int nw = ntiles > 8 ? ntiles : 8;
+    hipLaunchKernelGGL(kern, dim3((N + QT - 1) / QT, B), dim3(64 * nw), lds, st, x, quad_in, quad_out, N, C, k, drop, idx, tie, dmat,
+                       mtiles, QT);
+    return check_launch();
 }
 
 template <int K1>
@@ -1365,6 +1794,12 @@ int knn3_select_flags(const float* x, int B, int N, int k, int drop, int k2, int
 
 using namespace hsp;
 
+#ifdef HSP_KNN_PROF
+extern "C" int hsp_debug_set_knn_prof(void* dev_buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(hsp::g_knn_prof), &dev_buf, sizeof(void*)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" size_t hsp_knn_workspace_bytes(int B, int N, int C, int k) {
     (void)k;
     if (C == 3 || B <= 0 || N <= 0) return 0;
@@ -1409,6 +1844,19 @@ static int knn_f32_impl(const float* x, int B, int N, int C, int k, int drop_fir
     float* quad = reinterpret_cast<float*>(ws);
     const long long rows = (long long)B * N;
     int rc;
+    const int small_qt = getenv("HSP_KNN_NO_SMALL") ? 0 : knn_feat_small_qt(B, N, C);
+    if (small_qt) {
+        // the coarse levels' searches: one launch, |x|^2 inside it (contiguous rows; the transposed view's sum order keeps its own
+        // kernel).  The exact search's replay pass reads |x|^2 from ws: the kernel leaves it there when flags are asked for.
+        const float* qin = nullptr;
+        if (quad_mode == 1) {
+            rc = hsp_quad_outer_f32(x, B, N, C, quad, stream);
+            if (rc) return rc;
+            qin = quad;
+        }
+        float* qout = (tie && !qin) ? quad : nullptr;
+        return launch_knn_feat_small(small_qt, x, qin, qout, B, N, C, k, drop, idx, st, tie, dmat);
+    }
     if (quad_mode == 1) rc = hsp_quad_outer_f32(x, B, N, C, quad, stream);
     else {
         if (C >= 8 && C < 512 && (C & 7) == 0)

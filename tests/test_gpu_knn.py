@@ -132,6 +132,35 @@ def test_knn_duplicate_points(dev, ref, oc):
     assert np.array_equal(idx, oc.knn(xg.numpy(), 20))
 
 
+@pytest.mark.parametrize("B,N,C,k,drop", [
+    (16, 257, 128, 20, 1), (16, 257, 256, 20, 1), (16, 64, 256, 8, 1),     # the stack's coarse levels (QT = 17 / 17 / 4)
+    (1, 257, 128, 20, 1), (1, 64, 256, 8, 1),                              # one image instance: QT = 2
+    (3, 65, 64, 20, 1), (5, 68, 192, 8, 0),                                # 1 / 4 remainder rows as query columns, one full tile
+    (7, 260, 128, 20, 1), (2, 259, 64, 5, 1),                              # remainder rows owned by several workgroups
+    (4, 80, 128, 8, 1), (9, 300, 64, 20, 1), (2, 320, 448, 31, 1),         # long remainders: a padded MFMA tile; C = 448; K = 32 lists
+    (40, 96, 128, 20, 1), (300, 64, 64, 8, 1),                             # more clouds than CUs: QT = 32
+])
+def test_knn_small_cloud_kernel(dev, ref, oc, B, N, C, k, drop):
+    """knn_feat_small_kernel (64 <= N <= 320, C % 64 == 0, C < 512): one wave per candidate tile, |x|^2 in the kernel, the remainder
+    rows as query columns, register selection two queries at a time -- every branch of its shape logic against the C oracle, plus the
+    exact scope's flags + distance matrix on the same shapes (torch.topk's order)."""
+    from hs_pose_amd import ops
+    x = torch.relu(ref.hash_tensor((B, N, C), 4000 + N + C + k, 0.3))
+    idx = ops.knn(x.to(dev), k, drop_first=bool(drop)).cpu().numpy()
+    want = oc.knn(x.numpy(), k, drop)
+    assert np.array_equal(idx, want), f"{(idx != want).sum()} of {idx.size} differ"
+    if B <= 16 and k + drop + 1 <= 33:
+        # duplicated rows (a tiled cloud's features): ties in every row, some rows with more survivors than the 64 register slots
+        xt = x[:min(B, 3)].clone()
+        xt[:, N // 2:] = xt[:, :N - N // 2].clone()
+        xt[:, 5:5 + min(70, N // 3)] = xt[:, 3:4].clone()
+        idx = ops.knn(xt.to(dev), k, drop_first=bool(drop)).cpu().numpy()
+        assert np.array_equal(idx, oc.knn(xt.numpy(), k, drop))
+        with ops.exact_scope(True):
+            idx = ops.knn(xt.to(dev), k, drop_first=bool(drop)).cpu().numpy()
+        assert np.array_equal(idx, oc.knn_topk(xt.numpy(), k, drop))
+
+
 @pytest.mark.parametrize("name", ["nn1_1028_257", "nn1_1028_64"])
 def test_nn1_golden(dev, ref, name):
     from hs_pose_amd import gcn3d
