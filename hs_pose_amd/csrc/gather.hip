@@ -470,10 +470,14 @@ __global__ __launch_bounds__(256) void gather_max_bwd_kernel(const float* __rest
 // gradient (ORL: d fg / N for every query) the accumulated quantity is an integer COUNT, so that
 // branch is exactly reproducible.  MODE 0: arg-max routed (gather_max), MODE 1: plain row scatter
 // (gather_rows: nearest-neighbour up-sampling backward, many queries per source row).
-// grid (C/TC, B), block 256, dynamic LDS = Nsrc*TC*4
+// grid (C/TC, B), block NT, dynamic LDS = Nsrc*TC*4.  NT: the kernel is a chain of memory round trips per workgroup (zero the tile;
+// per pass of FL points: arg-max bytes + gradients, then the dependent neighbour indices, then the LDS adds; flush), and at the
+// stack's widths the grid is 128 workgroups (C = 128, TC = 16, B = 16) -- half the chip, each CU holding ONE 256-thread workgroup
+// that walks its 1028 points in 4 passes.  With 1024 threads the same workgroup does it in one: the round trips of a pass are
+// in flight for four times the points (launch_scatter_tile picks NT from the grid).
 // FT: storage type of gout (per-query gradients) / gfeat / extra; the broadcast row `gbc` (B,C) is always fp32
-template <int TC, int MODE, typename FT>
-__global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const FT* __restrict__ gout, const float* __restrict__ gbc,
+template <int TC, int MODE, typename FT, int NT>
+__global__ __launch_bounds__(NT) void scatter_tile_bwd_kernel(const FT* __restrict__ gout, const float* __restrict__ gbc,
                                                                int gstride,
                                                                int gbcast, const int32_t* __restrict__ idx,
                                                                int idx_shared, const int32_t* __restrict__ qsel,
@@ -485,13 +489,13 @@ __global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const FT* __restr
     float* acc = reinterpret_cast<float*>(smem);
     int* cnt = reinterpret_cast<int*>(smem);
     constexpr int G = TC / 4;
-    constexpr int PL = 256 / G;
+    constexpr int PL = NT / G;
     const int tid = threadIdx.x, b = blockIdx.y;
     const int j0 = blockIdx.x * TC;
     const int cg = tid % G, pl = tid / G;
     const int j = j0 + cg * 4;
     ORL_STAMP(40);
-    for (int q = tid; q < Nsrc * G; q += 256) *reinterpret_cast<float4*>(acc + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = tid; q < Nsrc * G; q += NT) *reinterpret_cast<float4*>(acc + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     ORL_STAMP(41);
     // FL points per pass: their arg-max bytes / gradients first, then the dependent neighbour-index gathers, then the
@@ -568,11 +572,11 @@ __global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const FT* __restr
     float4 gb = make_float4(0.f, 0.f, 0.f, 0.f);
     if (MODE == 0 && gbcast) gb = *reinterpret_cast<const float4*>(gbc + (size_t)b * C + j);   // (q % G == cg for all of a thread's q)
     const int total = Nsrc * G;
-    for (int q0 = tid; q0 < total; q0 += 256 * FL) {
+    for (int q0 = tid; q0 < total; q0 += NT * FL) {
         float4 o[FL], x[FL];
 #pragma unroll
         for (int u = 0; u < FL; ++u) {
-            const int q = min(q0 + u * 256, total - 1);
+            const int q = min(q0 + u * NT, total - 1);
             const int m = q / G, g4 = q - m * G;
             const size_t off = ((size_t)b * Nsrc + m) * C + j0 + g4 * 4;
             o[u] = accumulate ? Feat<FT>::ld4(gfeat + off) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(256) void scatter_tile_bwd_kernel(const FT* __restr
         }
 #pragma unroll
         for (int u = 0; u < FL; ++u) {
-            const int q = q0 + u * 256;
+            const int q = q0 + u * NT;
             if (q < total) {
                 const int m = q / G, g4 = q - m * G;
                 float4 v;
@@ -644,18 +648,29 @@ static int launch_scatter_tile(int tc, const FT* gout, const float* gbc, int gst
                                int kstride, int C, FT* gfeat, int accumulate, const FT* extra, hipStream_t st) {
     const size_t lds = (size_t)Nsrc * tc * 4;
     dim3 grid(C / tc, B);
-#define SC_LAUNCH(TC)                                                                                              \
+    // threads per workgroup: 1024 while the grid covers at most half the CUs, 512 up to one workgroup per CU (measured at B = 16:
+    // N = 1028, C = 128 -- 128 workgroups -- 17.7 -> 15.6 us with 1024 threads, the flush 9 200 -> 3 500 clocks; N = 257, C = 256 --
+    // 256 workgroups -- no better with 1024 than with 256: 9.3 vs 8.9 us)
+    const long long wgs = (long long)(C / tc) * B;
+    int nt = 2 * wgs <= HSP_NUM_CU ? 1024 : wgs <= HSP_NUM_CU ? 512 : 256;
+    if (const char* f = getenv("HSP_SCATTER_NT")) nt = atoi(f);                       // (experiments: 256 = the round-5 form)
+#define SC_LAUNCH_NT(TC, NT_)                                                                                      \
     {                                                                                                              \
-        auto kern = scatter_tile_bwd_kernel<TC, MODE, FT>;                                                             \
+        auto kern = scatter_tile_bwd_kernel<TC, MODE, FT, NT_>;                                                    \
         if (lds > 64 * 1024) {                                                                                     \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
             if (e != hipSuccess) { set_last_hip_error(e); return HSP_ERR_LAUNCH; }                                 \
         }                                                                                                          \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, gout, gbc, gstride, gbcast, idx, idx_shared, qsel, argmax, Nsrc, \
+        hipLaunchKernelGGL(kern, grid, dim3(NT_), lds, st, gout, gbc, gstride, gbcast, idx, idx_shared, qsel, argmax, Nsrc, \
                            Nidx, Nq, kstride, C, gfeat, accumulate, extra);                                        \
     }
+#define SC_LAUNCH(TC)                                                                                              \
+    {                                                                                                              \
+        if (nt == 1024) SC_LAUNCH_NT(TC, 1024) else if (nt == 512) SC_LAUNCH_NT(TC, 512) else SC_LAUNCH_NT(TC, 256) \
+    }
     if (tc == 16) SC_LAUNCH(16) else if (tc == 8) SC_LAUNCH(8) else SC_LAUNCH(4)
+#undef SC_LAUNCH_NT
 #undef SC_LAUNCH
     return check_launch();
 }
