@@ -574,7 +574,7 @@ __device__ __forceinline__ void knn_select_wave(const float* dl, int2* sv, int N
 // chain of vector-compare -> scalar-count -> scalar-select steps that waits on itself, so a wave runs NQ (1 or 2) queries through it
 // side by side: two independent chains interleave and take about the time of one.  Same bound, same (distance, index) ranks,
 // same tie flag as knn_select_wave; more than 64 survivors (heavily duplicated rows) fall back on it.
-// dl[u], out[u], tie[u]: query u's distances / output row / flag byte; sv: 64 * NQ int2 of scratch (+ N for the fall-back).
+// dl[u], out[u], tie[u]: query u's distances / output row / flag byte; sv: max(64 * NQ, N) int2 of scratch.
 template <int S, int NQ, bool TIE>
 __device__ __forceinline__ void knn_select_wave_regs(const float* const (&dl)[NQ], int2* sv, int N, int k, int drop,
                                                      int32_t* const (&out)[NQ], uint8_t* const (&tie)[NQ]) {
@@ -663,7 +663,7 @@ __device__ __forceinline__ void knn_select_wave_regs(const float* const (&dl)[NQ
     for (int u = 0; u < NQ; ++u) {
         if (n[u] > 64) {                                           // (wave-uniform)
             __builtin_amdgcn_wave_barrier();
-            knn_select_wave(dl[u], sv + 64 * NQ, N, k, drop, out[u], TIE ? tie[u] : nullptr);
+            knn_select_wave(dl[u], sv, N, k, drop, out[u], TIE ? tie[u] : nullptr);   // (the survivor slots are dead: every lane holds its entry)
             continue;
         }
         if (lane < n[u] && rank[u] >= drop && rank[u] < m) out[u][rank[u] - drop] = me[u].y;
@@ -672,6 +672,22 @@ __device__ __forceinline__ void knn_select_wave_regs(const float* const (&dl)[NQ
             const bool any_tied = __ballot(tied) != 0ull;
             if (lane == 0) *tie[u] = any_tied ? 1 : 0;
         }
+    }
+}
+
+// one query, N <= 1088 in registers (17 per lane), else the LDS walk
+__device__ __forceinline__ void knn_select_wave_any(const float* dl, int2* sv, int N, int k, int drop, int32_t* __restrict__ out,
+                                                    uint8_t* __restrict__ tie) {
+    if (N > 64 * 17) { knn_select_wave(dl, sv, N, k, drop, out, tie); return; }
+    const float* const dls[1] = {dl};
+    int32_t* const outs[1] = {out};
+    uint8_t* const ties[1] = {tie};
+    if (N <= 64 * 5) {
+        if (tie) knn_select_wave_regs<5, 1, true>(dls, sv, N, k, drop, outs, ties);
+        else knn_select_wave_regs<5, 1, false>(dls, sv, N, k, drop, outs, ties);
+    } else {
+        if (tie) knn_select_wave_regs<17, 1, true>(dls, sv, N, k, drop, outs, ties);
+        else knn_select_wave_regs<17, 1, false>(dls, sv, N, k, drop, outs, ties);
     }
 }
 
@@ -734,7 +750,7 @@ __device__ __forceinline__ void knn_feat_tail_body(char* smem, const float* __re
     }
     __syncthreads();
     if (dmat) for (int j = tid; j < N; j += 256) dmat[((size_t)b * N + j) * N + q] = dl[j];
-    if (tid < 64) knn_select_wave(dl, sv, N, k, drop, idx + ((size_t)b * N + q) * k, tie ? tie + (size_t)b * N + q : nullptr);
+    if (tid < 64) knn_select_wave_any(dl, sv, N, k, drop, idx + ((size_t)b * N + q) * k, tie ? tie + (size_t)b * N + q : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -789,7 +805,7 @@ __global__ __launch_bounds__(256) void knn_feat_sym_tail_kernel(const float* __r
     }
     __builtin_amdgcn_wave_barrier();
     if (dmat) for (int j = lane; j < N; j += 64) dmat[((size_t)b * N + j) * N + q] = dl[j];
-    knn_select_wave(dl, sv, N, k, drop, idx + ((size_t)b * N + q) * k, tie ? tie + (size_t)b * N + q : nullptr);
+    knn_select_wave_any(dl, sv, N, k, drop, idx + ((size_t)b * N + q) * k, tie ? tie + (size_t)b * N + q : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
