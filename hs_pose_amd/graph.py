@@ -7,8 +7,8 @@
 * ``GraphedNetwork``    -- ``posenet`` forward / backward of the FULL model as two graphs behind one autograd node, for
   ``engine/train.py``'s step (losses and optimizer stay eager).
 * ``GraphedInference``  -- the timed body of ``evaluation/evaluate.py`` (eval forward + generate_RT).
-* ``GraphedTrainStep``  -- the whole training step incl. the losses as one graph (checked, but needs a runtime flag and
-  is slower than the above on ROCm 7.2; kept as the capture-safe reference form).
+* ``GraphedTrainStep``  -- the whole training step incl. augmentation, losses, backward and the gradient norm as ONE graph
+  (+ one fused optimizer launch): what ``bench.py`` times as unit U3.
 
 Static shapes, static input / gradient buffers.  The only host work of the reference's forward -- the two
 ``torch.randperm`` draws of the Pool_layers on the CPU default generator (gcn3d.py:243) -- happens BEFORE each replay,
@@ -252,11 +252,12 @@ class GraphedTrainStep:
     7.2's default AQL-packet capture of graph kernel nodes, so the constructor demanded ``DEBUG_CLR_GRAPH_PACKET_CAPTURE=0``.
     With the heads on ``ops.linear_rows`` / ``ops.points_max`` and the losses in libhsp's five kernels the captured step
     replays equal to the eager step under the DEFAULT runtime (tests/test_gpu_train_graph.py, B=4 N=256 and B=16 N=1028:
-    every loss term, gradient and updated parameter), and the flag is no longer needed.  The replay of this one large
-    graph is still slower (30 ms at B=16 N=1028) than the eager step with ``GraphedNetwork`` (10 ms), which stays the
-    default training path; under rocprofv3 (which dispatches the nodes one by one) the same replay spans 11.4 ms for
-    10.2 ms of kernel time, so the cost is in the runtime's execution of the mixed kernel / copy node graph, not in the
-    kernels.
+    every loss term, gradient and updated parameter), and the flag is no longer needed.  Rounds 2-5 measured ``run()`` at
+    30 ms per step at B=16 N=1028 and blamed the runtime's execution of the graph; round 6 found the replay itself takes the
+    kernels' 8.0 ms and the rest was HOST time in ``_host_draws``: the jitter draw was scaled by a 49 k-element CPU multiply
+    that woke an over-subscribed OpenMP pool (8 ms) and uploaded from pageable memory (a wait for the previous replay).  With
+    the draw scaled in serial pieces into the pinned ring, ``run()`` is 8.2 ms -- replay + 0.15 ms -- and this is the form
+    ``bench.py`` reports for unit U3.
 
     Build it BEFORE the network's first eager backward: autograd binds each parameter's gradient accumulator to the
     stream of its first use, and an accumulator bound to another stream than the capture stream is executed outside
@@ -293,7 +294,19 @@ class GraphedTrainStep:
 
     def _host_draws(self):
         if FLAGS.train:
-            self.noise.copy_(torch.rand(self.noise.shape) * FLAGS.aug_pc_r)
+            # (through the pinned ring, like the pool indices: a copy from pageable memory waits for the previous replay, and the
+            # host then cannot queue step i + 1 under step i -- 8 ms of replay + the graph launch's own host time per step, measured
+            # 21-41 ms where the replay alone takes 8.1)
+            # The scaling runs in pieces below ATen's parallel grain (32768 elements): a 49 k-element multiply wakes the whole
+            # OpenMP pool, and with more threads than the container has cores (128 vs a 16-CPU quota on the GPU box) that one
+            # multiply cost 8 ms of host time per step.
+            r = FLAGS.aug_pc_r
+
+            def fill(pinned):
+                src, dst = torch.rand(self.noise.shape).view(-1), pinned.view(-1)
+                for o in range(0, src.numel(), 16384):
+                    torch.mul(src[o:o + 16384], r, out=dst[o:o + 16384])
+            staging.upload(fill, self.noise.shape, torch.float32, self.noise.device, out=self.noise)
         upload_pool_indices(self.pool_idx, self.n_points)
 
     def _body(self):

@@ -43,8 +43,23 @@ def agg(path, counter):
     return {k: sum(v) / len(v) for k, v in a.items()}
 
 
-def main(fetch_csv, write_csv, out_json):
+def total(path, counter):
+    """(sum of the counter over EVERY dispatch of the run, dispatches of libhsp kernels)"""
+    t, n = 0.0, 0
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            t += float(r["Counter_Value"])
+            n += 1 if ("hsp::" in r["Kernel_Name"] or "gather_rows" in r["Kernel_Name"]) else 0
+    return t, n
+
+
+def main(fetch_csv, write_csv, out_json, valu_csv=None, steps=None, clouds=None, tag="step"):
+    """steps / clouds: the profiled run's step count (bench.py: warm-up + K + the steps added for the >= 50-step median) and clouds
+    per step -- with them the file also carries the STEP-level measured traffic (SURVEY 8d asks for the measured fraction next to the
+    algorithmic one): sum over every dispatch of 2 * FETCH_SIZE + WRITE_SIZE, per step and per cloud.  valu_csv: a third pass with
+    SQ_INSTS_VALU -> VALU wave-instructions per launch of the issue-bound kernels (bench.py prices them on the instruction floor)."""
     f, w = agg(fetch_csv, "FETCH_SIZE"), agg(write_csv, "WRITE_SIZE")
+    v = agg(valu_csv, "SQ_INSTS_VALU") if valu_csv else {}
     out = {}
     for (name, grid), fv in f.items():
         for (frag, g), key in MAP.items():
@@ -53,9 +68,20 @@ def main(fetch_csv, write_csv, out_json):
                 out[key] = {"FETCH_SIZE_KiB": round(fv, 1), "WRITE_SIZE_KiB": round(wv, 1),
                             "hbm_bytes_per_launch": int((2 * fv + wv) * 1024),
                             "correction": "reads doubled (gfx950 FETCH_SIZE counts 64 B per 128 B request)"}
+                if (name, grid) in v:
+                    out[key]["valu_wave_insts_per_launch"] = int(v[(name, grid)])
+    if steps and clouds:
+        ft, _ = total(fetch_csv, "FETCH_SIZE")
+        wt, _ = total(write_csv, "WRITE_SIZE")
+        steps, clouds = int(steps), int(clouds)
+        per_step = (2 * ft + wt) * 1024 / steps
+        out["__%s__" % tag] = {"profiled_steps": steps, "clouds_per_step": clouds, "FETCH_SIZE_KiB_total": round(ft, 1),
+                               "WRITE_SIZE_KiB_total": round(wt, 1), "measured_hbm_bytes_per_step": int(per_step),
+                               "measured_hbm_bytes_per_cloud": int(per_step / clouds),
+                               "how": "sum over every dispatch of the PMC runs of (2 * FETCH_SIZE + WRITE_SIZE) KiB / profiled steps"}
     json.dump(out, open(out_json, "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:8])

@@ -7,14 +7,15 @@
 # Second half: the bf16 dense-cloud configuration (BASELINE configs[3]).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-RD=${1:-r05}
+RD=${1:-r06}
 O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O $R/profiles/$RD
-for c in FETCH_SIZE WRITE_SIZE; do
+# (bench.py --steps 4 --warmup 2 --no-graph issues 2 + 4 + 46 = 52 steps: the median is always taken over >= 50)
+for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 4 --warmup 2 --no-graph --no-cpu-baseline --no-u3 --no-side > $O/pmc_$c.log 2>&1
   cp $(find $O/pmc_$c -name '*counter_collection.csv' | head -1) $O/k_pmc_$c.csv
 done
-python $R/tools/pmc_traffic.py $O/k_pmc_FETCH_SIZE.csv $O/k_pmc_WRITE_SIZE.csv $O/traffic.json > /dev/null
+python $R/tools/pmc_traffic.py $O/k_pmc_FETCH_SIZE.csv $O/k_pmc_WRITE_SIZE.csv $O/traffic.json $O/k_pmc_SQ_INSTS_VALU.csv 52 16 step_f32_b16_n1028 > /dev/null
 cp $O/traffic.json $R/profiles/$RD/traffic.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline --no-u3 --no-side > $O/stats_bench.log 2>&1
 cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/k_graph_kernel_stats.csv
@@ -33,7 +34,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/bpmc_$c -- python $R/bench.py $BF --steps 2 --warmup 1 --no-graph > $O/bpmc_$c.log 2>&1
   cp $(find $O/bpmc_$c -name '*counter_collection.csv' | head -1) $O/b_pmc_$c.csv
 done
-python $R/tools/pmc_traffic.py $O/b_pmc_FETCH_SIZE.csv $O/b_pmc_WRITE_SIZE.csv $O/b_traffic.json > /dev/null
+python $R/tools/pmc_traffic.py $O/b_pmc_FETCH_SIZE.csv $O/b_pmc_WRITE_SIZE.csv $O/b_traffic.json "" 51 64 step_bf16_b64_n4096 > /dev/null
 python - $O/traffic.json $O/b_traffic.json $R/profiles/$RD/traffic.json <<'PY'
 import json, sys
 a = json.load(open(sys.argv[1])); a.update(json.load(open(sys.argv[2]))); json.dump(a, open(sys.argv[3], "w"), indent=1, sort_keys=True)
