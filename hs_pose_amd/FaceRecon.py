@@ -63,6 +63,7 @@ class FaceRecon(nn.Module):
     feat_consumers = None            # PoseNet9D: callable (feat rows, xyz) -> conv1d_block[0]'s output (ops.fan_linear_rows)
     keep_backward_cut = False
     backward_cut = None
+    exact_train = os.environ.get("HSP_EXACT_TRAIN") == "1"
     feature_dtype = torch.float32
     _bf16 = None
 
@@ -99,7 +100,14 @@ class FaceRecon(nn.Module):
             self._x3 = ops.X3Planes()
         # eval mode: the forward in the reference's own operation order, so that the feature-space neighbour search sees the
         # reference's bits (ops.exact_scope); train mode: the faster products
-        with ops.x3_scope(self._x3), ops.exact_scope(not self.training and self.feature_dtype == torch.float32):
+        # ``exact_train`` (HSP_EXACT_TRAIN=1, or set the attribute): the reference-order arithmetic under train-mode BatchNorm too.
+        # Measured in round 6 (tools/exact_train_probe.py, fixture stack_refinit_trainbn_1028, free-running): every ordered neighbour
+        # list of every HS layer equals the reference's and the six pose / size outputs agree to 9e-6 (fast products: 0.91 / 0.76 /
+        # 0.63 / 0.86 of the rows, 4e-2) -- for 2.12 instead of 1.71 ms per training step of the HS stack (fp32 matrix cores instead
+        # of the bf16 x3 products, BatchNorm's first pass not fused into the layer's out product).  Off by default: the step that is
+        # timed is the fast one; tests/test_gpu_stack.py holds the switched-on form to 1e-4.
+        exact = (not self.training or self.exact_train) and self.feature_dtype == torch.float32
+        with ops.x3_scope(self._x3), ops.exact_scope(exact):
             return self._forward(vertices, cat_id)
 
     def _forward(self, vertices, cat_id):
@@ -128,7 +136,7 @@ class FaceRecon(nn.Module):
             def layer_bn(conv, bn, *a):
                 """bn_relu(conv(...)); fp32 rows in train mode: the layer's out product also leaves the first pass of the
                 BatchNorm statistics (ops.hs_layer bn_shift), whatever the fork mode -- graph and eager twins stay bit-equal"""
-                if od is None and bn.training and bn.track_running_stats and torch.is_grad_enabled():
+                if od is None and bn.training and bn.track_running_stats and torch.is_grad_enabled() and not ops.exact_forward():
                     out, part = conv(*a, bn_shift=True)
                     return ops.bn_relu(out, bn, fork=fork, partial=part)
                 if conv is self.conv_3 and ops.exact_forward():

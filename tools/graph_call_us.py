@@ -10,7 +10,7 @@ import sys
 
 CALLS = {
     "hsp_knn_f32[B16N1028C128k20]": [("hsp::knn_feat_kernel<21, true>", "8192x16"), ("hsp::knn_feat_sym_tail_kernel", "256x16"),
-                                     ("hsp::quad32_kernel", "131584x1")],
+                                     ("hsp::quad32_kernel", "526336x1")],
     "hsp_rf_conv_fwd[B16N1028k20S7C128]": [("hsp::rf_fwd_pipe_kernel<false, 1, true, float>", "524288x1")],
     "hsp_rf_conv_bwd_scatter[B16N1028S7C128]": [("hsp::rf_bwd_tile_kernel<16, false, true, float, 1>", "28672x16")],
     "hsp_rf_surface_fwd[B16N1028k20S7C128]": [("hsp::rf_fwd_pipe_kernel<true, 1, false, float>", "524288x1")],
