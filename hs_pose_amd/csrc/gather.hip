@@ -652,8 +652,7 @@ static int launch_scatter_tile(int tc, const FT* gout, const float* gbc, int gst
     // N = 1028, C = 128 -- 128 workgroups -- 17.7 -> 15.6 us with 1024 threads, the flush 9 200 -> 3 500 clocks; N = 257, C = 256 --
     // 256 workgroups -- no better with 1024 than with 256: 9.3 vs 8.9 us)
     const long long wgs = (long long)(C / tc) * B;
-    int nt = 2 * wgs <= HSP_NUM_CU ? 1024 : wgs <= HSP_NUM_CU ? 512 : 256;
-    if (const char* f = getenv("HSP_SCATTER_NT")) nt = atoi(f);                       // (experiments: 256 = the round-5 form)
+    const int nt = 2 * wgs <= HSP_NUM_CU ? 1024 : wgs <= HSP_NUM_CU ? 512 : 256;
 #define SC_LAUNCH_NT(TC, NT_)                                                                                      \
     {                                                                                                              \
         auto kern = scatter_tile_bwd_kernel<TC, MODE, FT, NT_>;                                                    \

@@ -1860,7 +1860,7 @@ static int knn_f32_impl(const float* x, int B, int N, int C, int k, int drop_fir
     float* quad = reinterpret_cast<float*>(ws);
     const long long rows = (long long)B * N;
     int rc;
-    const int small_qt = getenv("HSP_KNN_NO_SMALL") ? 0 : knn_feat_small_qt(B, N, C);
+    const int small_qt = knn_feat_small_qt(B, N, C);
     if (small_qt) {
         // the coarse levels' searches: one launch, |x|^2 inside it (contiguous rows; the transposed view's sum order keeps its own
         // kernel).  The exact search's replay pass reads |x|^2 from ws: the kernel leaves it there when flags are asked for.
