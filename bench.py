@@ -410,7 +410,8 @@ def main():
         # ranks, rank 0's decision broadcast) picks one -- the overlapped two-graph form unless the single all-reduce is more
         # than 3 % faster; HSP_SPLIT_GRAPH=1 / 0 forces a form.  config.grad_exchange records what ran and why.
         forced = {"1": "split", "0": "single"}.get(os.environ.get("HSP_SPLIT_GRAPH", ""))
-        if use_dist and world == 1 and forced is None:
+        probe_anyway = os.environ.get("HSP_SPLIT_GRAPH") == "probe"      # test hook: run the probe on a forced 1-rank group too
+        if use_dist and world == 1 and forced is None and not probe_anyway:
             forced = "single"                              # a forced 1-rank group (test hook): nothing to overlap
         forms = {}
         for name in (["split", "single"] if use_dist else ["single"]):
@@ -427,7 +428,8 @@ def main():
             except Exception as exc:
                 print(f"[bench] hipGraph capture (split={other == 'split'}) failed ({type(exc).__name__}: {exc})", file=sys.stderr)
         if use_dist:
-            chosen, exchange_info = choose_exchange_form(forms, world, sync=torch.cuda.synchronize, forced=forced)
+            chosen, exchange_info = choose_exchange_form(forms, world, sync=torch.cuda.synchronize, forced=forced,
+                                                         probe_single_rank=probe_anyway)
             graphed = forms.get(chosen)
         else:
             graphed, exchange_info = forms.get("single"), {"reason": "one rank, no process group"}

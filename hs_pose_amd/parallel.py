@@ -209,7 +209,7 @@ def mean_flat_gradients(buffers, group=None):
         b.mul_(inv)
 
 
-def choose_exchange_form(forms, world, group=None, replays=3, sync=None, forced=None):
+def choose_exchange_form(forms, world, group=None, replays=3, sync=None, forced=None, probe_single_rank=False):
     """Which gradient-exchange form a data-parallel run uses: ``"split"`` (two graphs, the coarse levels' all-reduce under the
     fine levels' backward -- the default whenever more than one rank runs) or ``"single"`` (one graph, one all-reduce after it).
 
@@ -217,14 +217,15 @@ def choose_exchange_form(forms, world, group=None, replays=3, sync=None, forced=
     absent).  With both present a start-up probe times ``replays`` exchanged steps each way (one untimed step first), takes the
     MAX over the ranks of each time, and rank 0's decision is broadcast so that every rank issues the same collectives: the
     split form stays unless the single form is more than 3 % faster.  ``forced`` ("split" / "single", from HSP_SPLIT_GRAPH=1 / 0)
-    skips the probe.  Returns ``(name, info)`` with ``info`` = what was measured and why, for the bench line."""
+    skips the probe; ``probe_single_rank`` runs it on a 1-rank group as well (the GPU box's check that the probe's collectives work
+    over RCCL).  Returns ``(name, info)`` with ``info`` = what was measured and why, for the bench line."""
     import time
     names = [n for n in ("split", "single") if forms.get(n) is not None]
     if not names:
         return None, {"reason": "no captured form"}
     if forced in names:
         return forced, {"reason": f"forced by HSP_SPLIT_GRAPH ({forced})"}
-    if len(names) == 1 or world == 1 or not dist.is_initialized():
+    if len(names) == 1 or (world == 1 and not probe_single_rank) or not dist.is_initialized():
         pick = names[0] if world > 1 or len(names) == 1 else "single"
         return pick, {"reason": "only one form captured" if len(names) == 1 else "one rank: nothing to overlap"}
     sync = sync or (lambda: None)

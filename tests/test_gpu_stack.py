@@ -200,7 +200,7 @@ def test_cpu_input_fails_loudly(ref, flags):
         gcn3d.get_neighbor_index(torch.zeros(1, 32, 3), 4)
 
 
-@pytest.mark.parametrize("split", ["0", "1"])
+@pytest.mark.parametrize("split", ["0", "1", "probe"])
 def test_bench_data_parallel_path_smoke(dev, split):
     """bench.py with a forced 1-rank RCCL process group: hipGraph replay + the gradient exchange per step (the N>1 code
     path, minus the peers) -- one flat-buffer all-reduce, and the two-graph form with the first all-reduce issued
@@ -208,14 +208,19 @@ def test_bench_data_parallel_path_smoke(dev, split):
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSP_FORCE_DIST="1", HSP_SPLIT_GRAPH=split, MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(29533 + int(split)), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+               MASTER_PORT=str(29533 + {"0": 0, "1": 1, "probe": 2}[split]), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "2", "--batch", "2",
                           "--points", "256", "--no-cpu-baseline", "--no-gemm-tuning"], env=env, capture_output=True, text=True,
                          timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["config"]["hipgraph"] is True and line["value"] > 0 and line["n_gpus"] == 1
-    assert ("capture (split=True) failed" not in out.stderr) and line["config"]["split_graph"] is (split == "1")
+    assert "capture (split=True) failed" not in out.stderr
+    if split == "probe":           # both forms captured, the start-up probe's collectives (barrier, object gather / broadcast) over RCCL
+        assert set(line["config"]["grad_exchange_choice"]["probe_ms_per_step"]) == {"split", "single"}
+        assert line["config"]["process_group"]["backend"] == "nccl"
+    else:
+        assert line["config"]["split_graph"] is (split == "1")
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
 
 
