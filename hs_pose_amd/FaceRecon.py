@@ -103,7 +103,7 @@ class FaceRecon(nn.Module):
         # ``exact_train`` (HSP_EXACT_TRAIN=1, or set the attribute): the reference-order arithmetic under train-mode BatchNorm too.
         # Measured in round 6 (tools/exact_train_probe.py, fixture stack_refinit_trainbn_1028, free-running): every ordered neighbour
         # list of every HS layer equals the reference's and the six pose / size outputs agree to 9e-6 (fast products: 0.91 / 0.76 /
-        # 0.63 / 0.86 of the rows, 4e-2) -- for 2.12 instead of 1.71 ms per training step of the HS stack (fp32 matrix cores instead
+        # 0.63 / 0.86 of the rows, 4e-2) -- for 2.02 instead of 1.71 ms per training step of the HS stack (fp32 matrix cores instead
         # of the bf16 x3 products, BatchNorm's first pass not fused into the layer's out product).  Off by default: the step that is
         # timed is the fast one; tests/test_gpu_stack.py holds the switched-on form to 1e-4.
         exact = (not self.training or self.exact_train) and self.feature_dtype == torch.float32

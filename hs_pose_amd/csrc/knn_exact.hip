@@ -187,8 +187,13 @@ extern "C" int hsp_knn_xyz_f32(const float* xyz, int B, int N, int k, int k2, in
 }
 
 // the selection kernel leaves the (B, N, N) distances for the tie pass while that is a small buffer (an image's instances at
-// N = 1028: 4 MB each); beyond 64 MB a flagged row's distances are recomputed
-static bool knn_exact_keeps_distances(int B, int N) { return (size_t)B * N * N * sizeof(float) <= ((size_t)64 << 20); }
+// N = 1028: 4 MB each); beyond 512 MB a flagged row's distances are recomputed
+// (64 MB until round 6: at B = 16, N = 1028 -- 67.6 MB, the exact_train step -- the replay then recomputed 1028 dot products per
+// flagged row: 2.127 -> 2.015 ms per training step with the matrix kept)
+#ifndef HSP_KNN_DMAT_MB
+#define HSP_KNN_DMAT_MB 512
+#endif
+static bool knn_exact_keeps_distances(int B, int N) { return (size_t)B * N * N * sizeof(float) <= ((size_t)HSP_KNN_DMAT_MB << 20); }
 
 extern "C" size_t hsp_knn_exact_workspace_bytes(int B, int N, int C, int k, int drop_first) {
     if (B <= 0 || N <= 0 || C <= 0 || k <= 0) return 0;

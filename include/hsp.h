@@ -64,7 +64,7 @@ int hsp_knn_f32(const float *x, int B, int N, int C, int k, int drop_first, int3
  * vectorised row sum), 1: x is the transposed VIEW of a (B,C,N) tensor, which is what FaceRecon.py:94-95 hands conv_3 (ATen then
  * sums the channels as an outer reduction: cascade for the first 32 floor(N/32) points, four interleaved cascades for the rest).
  * The search flags the rows that hold two equal distances among their k + drop_first + 1 nearest and a fixed-grid pass replays only
- * those (round 5; while B N N floats stay below 64 MB the search also leaves the distance matrix in ws, so a replayed row reads its
+ * those (round 5; while B N N floats stay below 512 MB the search also leaves the distance matrix in ws, so a replayed row reads its
  * distances instead of recomputing ~0.5 MB of feature rows).
  * ws: hsp_knn_exact_workspace_bytes; tie_rows (may be NULL): a device int that is incremented once per row that held a tie. */
 size_t hsp_knn_exact_workspace_bytes(int B, int N, int C, int k, int drop_first);
