@@ -189,42 +189,6 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_kernel(const float* __restr
 // start of the interval.  Same arithmetic, same results bit for bit (tests/test_gpu_layers.py compares the schedules).
 // dynamic LDS: 2 * (S*C + 6 k) floats.  Needs S*C/4 - (NCH-1)*256 + k <= 256.
 // ------------------------------------------------------------------------------------------------
-// a buffer descriptor over a wave-uniform base: every per-point stream of the pipelined forward (winning rows, winners' support values,
-// the layer's output, the centre columns of fm) is addressed as  descriptor(cloud) + scalar offset(point) + loop-invariant lane offset,
-// so a point costs no vector address arithmetic (the pointer form spent ~80 of its ~150 per-point VALU instructions on 64-bit
-// multiply-adds and moves; the kernel is bound by VALU issue).  One 16-byte / 8-byte non-temporal store per stream instead of four / two.
-template <typename T>
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t rf_uniform_rsrc(T* p, size_t bytes) {
-    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
-    T* u = reinterpret_cast<T*>(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
-                                (unsigned)__builtin_amdgcn_readfirstlane((unsigned)a));
-    return __builtin_amdgcn_make_buffer_rsrc(u, 0, (int)bytes, 0x00020000);
-}
-using rf_u32x2 = __attribute__((ext_vector_type(2))) unsigned;
-using rf_u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-#define RF_NT 2      // cache-policy bits of the raw buffer stores: nt (write-once streams, see the pointer form's comments)
-__device__ __forceinline__ void rf_store4_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff, float4 v, float) {
-    rf_u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-    __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)voff, soff, RF_NT);
-}
-__device__ __forceinline__ void rf_store4_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff, float4 v, bf16_t) {
-    const uint2 p2 = Feat<bf16_t>::pack4(v);
-    rf_u32x2 u = {p2.x, p2.y};
-    __builtin_amdgcn_raw_buffer_store_b64(u, r, (int)voff, soff, RF_NT);
-}
-__device__ __forceinline__ void rf_store1_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff, float v, float) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)voff, soff, RF_NT);
-}
-__device__ __forceinline__ void rf_store1_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff, float v, bf16_t) {
-    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)f32_to_bf16_bits(v), r, (int)voff, soff, RF_NT);
-}
-__device__ __forceinline__ float rf_load1(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff, float) {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
-}
-__device__ __forceinline__ float rf_load1(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff, bf16_t) {
-    return __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, (int)voff, soff, 0) << 16);
-}
-
 template <bool SURFACE, int NCH, bool WF, typename FT>
 __global__ __launch_bounds__(RF_THREADS) void rf_fwd_pipe_kernel(const float* __restrict__ xyz,
                                                                  const int32_t* __restrict__ idx,
@@ -262,19 +226,13 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_pipe_kernel(const float* __
             sR2[buf * k + t] = make_float4(r.x, r.y, r.z, 0.f);
         }
     };
-    auto mean_phase = [&](int pb, int pi, const float* smax) {
-        // (descriptors of the PREVIOUS point's cloud: it may differ from the current one)
-        const __amdgpu_buffer_rsrc_t outR = rf_uniform_rsrc(out + (size_t)pb * N * C, (size_t)N * C * sizeof(FT));
-        const __amdgpu_buffer_rsrc_t fmR = rf_uniform_rsrc(SURFACE ? out : const_cast<FT*>(fm) + (size_t)pb * N * fstride,
-                                                           SURFACE ? 0 : (size_t)N * fstride * sizeof(FT));
-        const int so_out = __builtin_amdgcn_readfirstlane(pi * C * (int)sizeof(FT));
-        const int so_fm = __builtin_amdgcn_readfirstlane(pi * fstride * (int)sizeof(FT));
+    auto mean_phase = [&](size_t pt, const float* smax) {
         for (int c = tid; c < C; c += RF_THREADS) {
             float s = smax[c];
             for (int sp = 1; sp < S; ++sp) s = add_rn(s, smax[sp * C + c]);
             float v = __fdiv_rn(s, invS_div);
-            if (!SURFACE) v = add_rn(rf_load1(fmR, (unsigned)c * (unsigned)sizeof(FT), so_fm, FT()), v);
-            rf_store1_nt(outR, (unsigned)c * (unsigned)sizeof(FT), so_out, v, FT());
+            if (!SURFACE) v = add_rn(Feat<FT>::ld(fm + pt * fstride + c), v);
+            Feat<FT>::st_nt(out + pt * C + c, v);
         }
     };
     int b = it.b0, i = it.i0;
@@ -282,19 +240,15 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_pipe_kernel(const float* __
     if (have) dirs_phase(b, i, 0);
     int cur = 0;
     bool have_prev = false;
-    int prev_b = 0, prev_i = 0;
+    size_t prev_pt = 0;
     while (have) {
         int nb = b, ni = i + it.istep;
         if (ni >= N) { nb = b + it.bstep; ni = it.i0; }
         const bool have_next = nb < B;
+        const size_t pt = (size_t)b * N + i;
         __syncthreads();        // directions of this point are in place; the previous point's maxima are complete
-        if (have_prev) mean_phase(prev_b, prev_i, smax2 + (cur ^ 1) * SC);
+        if (have_prev) mean_phase(prev_pt, smax2 + (cur ^ 1) * SC);
         if (have_next) dirs_phase(nb, ni, cur ^ 1);
-        // this point's output streams: descriptor of the cloud + scalar offset of the point
-        const __amdgpu_buffer_rsrc_t argR = rf_uniform_rsrc(argrow + (size_t)b * N * SC, (size_t)N * SC * sizeof(uint16_t));
-        const __amdgpu_buffer_rsrc_t fwinR = rf_uniform_rsrc(WF ? fwin + (size_t)b * N * SC : out, WF ? (size_t)N * SC * sizeof(FT) : 0);
-        const int so_arg = __builtin_amdgcn_readfirstlane(i * SC * (int)sizeof(uint16_t));
-        const int so_fwin = __builtin_amdgcn_readfirstlane(i * SC * (int)sizeof(FT));
         float* smax = smax2 + cur * SC;
         const float4* sR = sR2 + cur * k;
         const int* sIdx = sIdx2 + cur * k;
@@ -368,18 +322,20 @@ __global__ __launch_bounds__(RF_THREADS) void rf_fwd_pipe_kernel(const float* __
                 }
                 *reinterpret_cast<float4*>(smax + j) = best;
                 {
-                    rf_u32x2 rows = {(unsigned)sIdx[a0] | ((unsigned)sIdx[a1] << 16), (unsigned)sIdx[a2] | ((unsigned)sIdx[a3] << 16)};
-                    __builtin_amdgcn_raw_buffer_store_b64(rows, argR, j * (int)sizeof(uint16_t), so_arg, RF_NT);
+                    const unsigned lo = (unsigned)sIdx[a0] | ((unsigned)sIdx[a1] << 16);
+                    const unsigned hi = (unsigned)sIdx[a2] | ((unsigned)sIdx[a3] << 16);
+                    unsigned* ap = reinterpret_cast<unsigned*>(argrow + pt * SC + j);
+                    __builtin_nontemporal_store(lo, ap); __builtin_nontemporal_store(hi, ap + 1);
                 }
-                if (WF) rf_store4_nt(fwinR, (unsigned)j * (unsigned)sizeof(FT), so_fwin, wf, FT());
+                if (WF) Feat<FT>::st4_nt(fwin + pt * SC + j, wf);
             }
         }
-        have_prev = true; prev_b = b; prev_i = i;
+        have_prev = true; prev_pt = pt;
         cur ^= 1;
         b = nb; i = ni; have = have_next;
     }
     __syncthreads();
-    if (have_prev) mean_phase(prev_b, prev_i, smax2 + (cur ^ 1) * SC);
+    if (have_prev) mean_phase(prev_pt, smax2 + (cur ^ 1) * SC);
 }
 
 // ------------------------------------------------------------------------------------------------
