@@ -252,8 +252,7 @@ __device__ __forceinline__ void knn3_wave_body(char* smem, const float* __restri
         // (the bound only has to be >= the ms-th smallest minimum: the descent stops after the sign, the exponent and five mantissa
         // bits and fills the rest with ones -- tau up to 3 % high, a survivor or two more for the ranking, 18 ballot rounds fewer)
         for (int bit = 31; bit >= KNN_TAU_LOW_BIT; --bit) {
-            const unsigned hi = bit == 31 ? 0u : (0xffffffffu << (bit + 1));
-            const bool zero = ((key ^ prefix) & hi) == 0 && ((key >> bit) & 1u) == 0;
+            const bool zero = (key ^ prefix) < (1u << bit);       // bits 31..bit+1 equal the prefix (whose lower bits are 0), bit `bit` is 0
             const int c0 = __popcll(__ballot(zero));
             if (need > c0) { need -= c0; prefix |= 1u << bit; }
         }
@@ -525,8 +524,7 @@ __device__ __forceinline__ void knn_select_wave(const float* dl, int2* sv, int N
     unsigned prefix = 0;
     int need = ms;
     for (int bit = 31; bit >= KNN_TAU_LOW_BIT; --bit) {     // (a bound, not the exact value: see knn3_wave_body)
-        const unsigned hi = bit == 31 ? 0u : (0xffffffffu << (bit + 1));
-        const bool zero = ((key ^ prefix) & hi) == 0 && ((key >> bit) & 1u) == 0;
+        const bool zero = (key ^ prefix) < (1u << bit);
         const int c0 = __popcll(__ballot(zero));
         if (need > c0) { need -= c0; prefix |= 1u << bit; }
     }
